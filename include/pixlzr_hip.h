@@ -1,0 +1,173 @@
+/*
+ * pixlzr_hip.h — C ABI of libpixlzr_hip.so, the MI355X (gfx950) implementation of
+ * the pixlzr encode hot path: per-tile level-of-detail detection + power-of-two
+ * down-sampling over the regular tile grid, and the .pixlzr bitstream writer.
+ *
+ * The reference (guiga-zalu/pixlzr-rust 0.3.1) has no FFI of its own; these are
+ * the entry points a Rust `extern "C"` block inside `Pixlzr::shrink_by` /
+ * `Pixlzr::shrink_directionally` / `Pixlzr::encode_to_vec` would bind (see
+ * INTEGRATION.md for that binding).  Each declaration cites the reference
+ * interface it replaces (paths relative to the reference repo).
+ *
+ * Conventions
+ *  - every function returns PXZ_OK (0) or a negative pxz_status; nothing aborts.
+ *    (The reference panics on the same conditions: unwrap() inside the path.)
+ *  - plain pointers and sizes only; "device" pointers are HIP device addresses
+ *    on the handle's GPU.  *_device entry points are asynchronous on the
+ *    handle's stream (pxz_set_stream); host-buffer entry points synchronise.
+ *  - a handle is bound to one GPU and may be used by one thread at a time;
+ *    distinct handles are independent (mirrors: concurrent calls on different
+ *    `Pixlzr` objects are legal, src/data_types/pixlzr.rs:17-25).
+ *  - tile order is the reference's: row-major, tile = ty*cols + tx
+ *    (src/data_types/iter.rs:64-76); grid = ceil(w/bw) x ceil(h/bh).
+ *  - there is no CPU fallback: without a gfx950 device pxz_create fails.
+ */
+#ifndef PIXLZR_HIP_H
+#define PIXLZR_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct pxz_handle pxz_handle;
+
+typedef enum pxz_status {
+	PXZ_OK = 0,
+	PXZ_ERR_INVALID_ARG = -1,   /* null pointer, channels not 3|4, zero sizes, non-finite factor */
+	PXZ_ERR_NO_DEVICE = -2,     /* no HIP device / not gfx950 */
+	PXZ_ERR_HIP = -3,           /* a HIP runtime call failed; see pxz_last_error */
+	PXZ_ERR_TILE_TOO_SMALL = -4,/* directional mode with a tile narrower/lower than 2 px:
+	                               the reference underflows usize and panics (operations.rs:220-221) */
+	PXZ_ERR_UNSUPPORTED = -5,   /* tile does not fit LDS residency (block_w*block_h too large) */
+	PXZ_ERR_NOMEM = -6,
+	PXZ_ERR_BUFFER_TOO_SMALL = -7
+} pxz_status;
+
+/* FilterType, repr(u8): src/data_types/mod.rs:10-30 */
+typedef enum pxz_filter {
+	PXZ_FILTER_NEAREST = 0,
+	PXZ_FILTER_TRIANGLE = 1,    /* down-scales with fir Hamming (mod.rs:298-300) */
+	PXZ_FILTER_CATMULLROM = 2,
+	PXZ_FILTER_GAUSSIAN = 3,
+	PXZ_FILTER_LANCZOS3 = 4
+} pxz_filter;
+
+/* which caller of the hot path is replaced */
+typedef enum pxz_mode {
+	PXZ_MODE_SHRINK_BY = 0,            /* Pixlzr::shrink_by, pixlzr.rs:155-185 (Oklab MAD, isotropic) */
+	PXZ_MODE_SHRINK_DIRECTIONALLY = 1  /* Pixlzr::shrink_directionally, pixlzr.rs:187-205 */
+} pxz_mode;
+
+/* ---- library / handle ------------------------------------------------- */
+const char *pxz_version(void);
+/* number of usable gfx950 devices (0 if none / no HIP runtime) */
+int pxz_device_count(void);
+int pxz_create(int device_id, pxz_handle **out);
+void pxz_destroy(pxz_handle *h);
+/* text of the last error on this handle ("" if none) */
+const char *pxz_last_error(const pxz_handle *h);
+/* run device entry points on the caller's hipStream_t (NULL = default stream) */
+int pxz_set_stream(pxz_handle *h, void *hip_stream);
+int pxz_synchronize(pxz_handle *h);
+
+/* ---- geometry --------------------------------------------------------- */
+/* ImageBlockIterator::new grid math, src/data_types/iter.rs:38-41 / src/split.rs:45-46 */
+int pxz_grid(uint32_t width, uint32_t height, uint32_t block_w, uint32_t block_h,
+             uint32_t *cols, uint32_t *rows);
+
+/* A batch of equally sized, pitch-linear, interleaved 8-bit frames
+ * (what `image::DynamicImage::ImageRgba8|ImageRgb8` holds, src/split.rs:10-27). */
+typedef struct pxz_frames {
+	uint32_t width, height;
+	uint32_t channels;          /* 3 (RGB8) or 4 (RGBA8) */
+	uint32_t pitch_bytes;       /* >= width*channels */
+	uint32_t n_frames;          /* >= 1 */
+	uint32_t reserved;          /* 0 */
+	uint64_t frame_stride_bytes;/* distance between frames (ignored when n_frames==1) */
+} pxz_frames;
+
+typedef struct pxz_params {
+	uint32_t block_w, block_h;  /* CLI -b / --block-height, src/bin/main.rs:19-24 */
+	uint32_t mode;              /* pxz_mode */
+	uint32_t filter;            /* pxz_filter (filter_downscale) */
+	float factor;               /* shrinking factor, src/bin/main.rs:26-29 */
+	uint32_t reserved;          /* 0 */
+} pxz_params;
+
+/* ---- the hot path ----------------------------------------------------- */
+
+/* Pixlzr::from_image (pixlzr_image.rs:6-22) + shrink_by | shrink_directionally
+ * (pixlzr.rs:155-205) for ALL tiles of one host-resident image:
+ * get_block_variance[_directionally] (operations.rs:26-126,192-259) ->
+ * reduce_image_section (operations.rs:140-156) -> PixlzrBlock::resize
+ * (block.rs:273-334, fast_image_resize convolution / nearest).
+ * Outputs (caller-allocated, tile order):
+ *   block_value[t]  Some(value) of the shrunk tile = hypot(v0,v1) (operations.rs:154)
+ *   out_w/out_h[t]  reduced tile dimensions
+ *   out_pixels      fixed slots of block_w*block_h*channels bytes per tile, of
+ *                   which out_w*out_h*channels are valid (tightly packed rows).
+ *                   May be NULL: LOD + dimensions only. */
+int pxz_shrink_image(pxz_handle *h, const uint8_t *pixels, uint32_t width, uint32_t height,
+                     uint32_t channels, uint32_t pitch_bytes, uint32_t block_w, uint32_t block_h,
+                     uint32_t mode, uint32_t filter, float factor,
+                     float *block_value, uint32_t *out_w, uint32_t *out_h, uint8_t *out_pixels);
+
+/* Same over a batch of device-resident frames: the measured path (frames come
+ * from a GPU decoder / stay in HBM).  All pointers are device pointers; outputs
+ * are frame-major: index = frame*tiles + tile; out_pixels slot stride as above.
+ * Asynchronous on the handle's stream; one kernel launch for the whole batch. */
+int pxz_shrink_frames_device(pxz_handle *h, const pxz_frames *frames, const pxz_params *params,
+                             const uint8_t *d_pixels, float *d_block_value, uint32_t *d_out_w,
+                             uint32_t *d_out_h, uint8_t *d_out_pixels);
+
+/* Detector only: get_block_variance_directionally (operations.rs:192-259) ->
+ * lod0 = hz, lod1 = vr (raw, before `* factor`); get_block_variance with the
+ * shrink_by closures (operations.rs:26-126, pixlzr.rs:160-162) -> lod0 = lod1 =
+ * value (params->factor applied).  Device pointers, frame-major. */
+int pxz_lod_frames_device(pxz_handle *h, const pxz_frames *frames, const pxz_params *params,
+                          const uint8_t *d_pixels, float *d_lod0, float *d_lod1);
+
+/* ---- bitstream: Pixlzr::encode_to_vec, src/encoding/mod.rs:40-89,168-200 ---- */
+/* Tiles given as produced by pxz_shrink_image (slots + dims + values).
+ * has_value may be NULL (all Some); has_value[t]==0 writes 0.0 (mod.rs:173-178).
+ * filter_byte = `self.filter.unwrap_or_default() as u8` (mod.rs:53): 0 after from_image.
+ * Returns the number of bytes written into `out`, or a negative pxz_status;
+ * call with out==NULL to obtain an upper bound. */
+int64_t pxz_encode_container(uint32_t width, uint32_t height, uint32_t block_w, uint32_t block_h,
+                             uint32_t channels, uint32_t filter_byte, const float *block_value,
+                             const uint8_t *has_value, const uint32_t *tile_w, const uint32_t *tile_h,
+                             const uint8_t *slots, uint8_t *out, size_t out_capacity);
+
+/* qoi::Encoder::new(data,w,h).encode_to_vec() as called at mod.rs:181-189
+ * (qoi crate 0.4.1 semantics incl. its run-of-one INDEX substitution).
+ * Writes the full stream incl. "qoif"; returns its length or a negative status. */
+int64_t pxz_qoi_encode(const uint8_t *data, uint32_t w, uint32_t h, uint32_t channels,
+                       uint8_t *out, size_t out_capacity);
+size_t pxz_qoi_bound(uint32_t w, uint32_t h, uint32_t channels);
+
+/* ---- utilities -------------------------------------------------------- */
+/* Deterministic synthetic frames for benchmarks/tests (integer-only generator,
+ * DESIGN.md "Synthetic frames"); dist: 0 opaque, 1 alpha, 2 flat, 3 noise.
+ * frame f of the batch uses seed 0x5049584C + first_frame_index + f. */
+int pxz_synth_frames_device(pxz_handle *h, const pxz_frames *frames, uint8_t *d_pixels,
+                            uint32_t first_frame_index, uint32_t dist);
+
+/* Down-scaling tables the kernels use for one axis (for cross-checks):
+ * fast_image_resize coefficient windows in i16 fixed point.  coeffs has room for
+ * out_size*window entries; any output pointer may be NULL. */
+int pxz_axis_table(uint32_t in_size, uint32_t out_size, uint32_t filter,
+                   int32_t *starts, int32_t *sizes, int16_t *coeffs, int32_t *window, int32_t *precision);
+
+/* Average device time (milliseconds) of the kernels launched by the last
+ * *_device call on this handle, measured with HIP events on the handle's
+ * stream; blocks until that work is done.  Enabled by pxz_enable_timing(h,1). */
+int pxz_enable_timing(pxz_handle *h, int on);
+int pxz_last_kernel_ms(pxz_handle *h, float *ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PIXLZR_HIP_H */

@@ -1,0 +1,442 @@
+// pxz_api.cpp — host runtime behind the C ABI of include/pixlzr_hip.h:
+// handle, per-configuration table cache, HBM staging for the host-buffer entry
+// point, kernel launches on the caller's stream, HIP-event timing.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <tuple>
+#include <vector>
+
+#include "../../include/pixlzr_hip.h"
+#include "pxz_internal.h"
+#include "pxz_tables.h"
+
+namespace pxz {
+hipError_t launch_shrink(const ShrinkArgs &a, uint32_t channels, hipStream_t stream);
+hipError_t launch_synth(const SynthArgs &s, hipStream_t stream);
+uint32_t waves_per_tile(uint32_t bw, uint32_t bh);
+}  // namespace pxz
+
+namespace {
+
+using pxz::AxisTab;
+using pxz::kMaxLevel;
+
+// device copy of the down-scaling tables for one (tile geometry, filter)
+struct TableSet {
+	AxisTab *d_tabs = nullptr;
+	uint16_t *d_bounds = nullptr;
+	int16_t *d_coeffs = nullptr;
+};
+
+struct DeviceBuffer {
+	void *ptr = nullptr;
+	size_t cap = 0;
+};
+
+}  // namespace
+
+struct pxz_handle {
+	int device = 0;
+	hipStream_t stream = nullptr;
+	std::string error;
+	float thresholds[pxz::kNumThresholds];
+	std::map<std::tuple<uint32_t, uint32_t, uint32_t, uint32_t, uint32_t>, TableSet> tables;
+	DeviceBuffer in, val, ow, oh, out;
+	bool timing = false;
+	std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+	size_t events_used = 0;
+};
+
+namespace {
+
+int fail(pxz_handle *h, int code, const char *fmt, ...)
+{
+	if (h) {
+		char buf[512];
+		va_list ap;
+		va_start(ap, fmt);
+		vsnprintf(buf, sizeof buf, fmt, ap);
+		va_end(ap);
+		h->error = buf;
+	}
+	return code;
+}
+
+#define PXZ_HIP(h, call)                                                                      \
+	do {                                                                                      \
+		hipError_t e_ = (call);                                                               \
+		if (e_ != hipSuccess) return fail((h), PXZ_ERR_HIP, "%s: %s", #call, hipGetErrorString(e_)); \
+	} while (0)
+
+int ensure(pxz_handle *h, DeviceBuffer &b, size_t bytes)
+{
+	if (b.cap >= bytes) return PXZ_OK;
+	if (b.ptr) (void)hipFree(b.ptr);
+	b.ptr = nullptr;
+	b.cap = 0;
+	if (hipMalloc(&b.ptr, bytes) != hipSuccess) return fail(h, PXZ_ERR_NOMEM, "hipMalloc(%zu) failed", bytes);
+	b.cap = bytes;
+	return PXZ_OK;
+}
+
+uint32_t ceil_div(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
+
+// reduced size for level exponent m (reference operations.rs:150-151)
+uint32_t reduced(uint32_t size, uint32_t m)
+{
+	if (m >= 31) return 1;
+	uint64_t r = ((uint64_t)size + ((1ull << m) - 1ull)) >> m;
+	return r < 1 ? 1u : (uint32_t)r;
+}
+
+int get_tables(pxz_handle *h, uint32_t bw, uint32_t bh, uint32_t edge_w, uint32_t edge_h, uint32_t filter,
+               TableSet *out)
+{
+	auto key = std::make_tuple(bw, bh, edge_w, edge_h, filter);
+	auto it = h->tables.find(key);
+	if (it != h->tables.end()) {
+		*out = it->second;
+		return PXZ_OK;
+	}
+	std::vector<AxisTab> tabs(2 * 2 * kMaxLevel);
+	std::vector<uint16_t> bounds;
+	std::vector<int16_t> coeffs;
+	const uint32_t sizes[2][2] = {{bw, edge_w}, {bh, edge_h}};
+	for (int axis = 0; axis < 2; ++axis) {
+		for (int cls = 0; cls < 2; ++cls) {
+			const uint32_t in = sizes[axis][cls];
+			for (int m = 0; m < kMaxLevel; ++m) {
+				AxisTab &t = tabs[(axis * 2 + cls) * kMaxLevel + m];
+				const uint32_t outsz = reduced(in, (uint32_t)m);
+				t = AxisTab{0, 0, (uint16_t)outsz, 0, 0, (uint16_t)in};
+				if (outsz == in) continue;  // identity: never looked up
+				pxz::AxisWindows win;
+				if (!pxz::build_axis(in, outsz, filter, &win)) return fail(h, PXZ_ERR_INVALID_ARG, "unknown filter %u", filter);
+				t.bounds_off = (uint32_t)bounds.size();
+				t.coeff_off = (uint32_t)coeffs.size();
+				t.window = (uint16_t)win.window;
+				t.precision = (uint16_t)win.precision;
+				if (filter == PXZ_FILTER_NEAREST) {
+					for (uint32_t o = 0; o < outsz; ++o) bounds.push_back((uint16_t)win.starts[o]);
+				} else {
+					for (uint32_t o = 0; o < outsz; ++o) {
+						bounds.push_back((uint16_t)win.starts[o]);
+						bounds.push_back((uint16_t)win.sizes[o]);
+					}
+					coeffs.insert(coeffs.end(), win.coeffs.begin(), win.coeffs.end());
+				}
+			}
+		}
+	}
+	if (bounds.empty()) bounds.push_back(0);
+	if (coeffs.empty()) coeffs.push_back(0);
+	TableSet ts;
+	PXZ_HIP(h, hipMalloc((void **)&ts.d_tabs, tabs.size() * sizeof(AxisTab)));
+	PXZ_HIP(h, hipMalloc((void **)&ts.d_bounds, bounds.size() * sizeof(uint16_t)));
+	PXZ_HIP(h, hipMalloc((void **)&ts.d_coeffs, coeffs.size() * sizeof(int16_t)));
+	PXZ_HIP(h, hipMemcpy(ts.d_tabs, tabs.data(), tabs.size() * sizeof(AxisTab), hipMemcpyHostToDevice));
+	PXZ_HIP(h, hipMemcpy(ts.d_bounds, bounds.data(), bounds.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+	PXZ_HIP(h, hipMemcpy(ts.d_coeffs, coeffs.data(), coeffs.size() * sizeof(int16_t), hipMemcpyHostToDevice));
+	h->tables[key] = ts;
+	*out = ts;
+	return PXZ_OK;
+}
+
+int check_frames(pxz_handle *h, const pxz_frames *f, const pxz_params *p)
+{
+	if (!h) return PXZ_ERR_INVALID_ARG;
+	if (!f || !p) return fail(h, PXZ_ERR_INVALID_ARG, "null descriptor");
+	if (f->width == 0 || f->height == 0 || f->n_frames == 0) return fail(h, PXZ_ERR_INVALID_ARG, "empty frame batch");
+	if (f->channels != 3 && f->channels != 4) return fail(h, PXZ_ERR_INVALID_ARG, "channels must be 3 or 4, got %u", f->channels);
+	if ((uint64_t)f->pitch_bytes < (uint64_t)f->width * f->channels) return fail(h, PXZ_ERR_INVALID_ARG, "pitch smaller than a row");
+	if (f->n_frames > 1 && f->frame_stride_bytes < (uint64_t)f->pitch_bytes * f->height)
+		return fail(h, PXZ_ERR_INVALID_ARG, "frame stride smaller than a frame");
+	if (p->block_w == 0 || p->block_h == 0) return fail(h, PXZ_ERR_INVALID_ARG, "zero block size");
+	if (p->mode > 1) return fail(h, PXZ_ERR_INVALID_ARG, "mode must be 0 or 1");
+	if (p->filter > 4) return fail(h, PXZ_ERR_INVALID_ARG, "filter must be 0..4");
+	if (!std::isfinite(p->factor)) return fail(h, PXZ_ERR_INVALID_ARG, "factor must be finite");
+	return PXZ_OK;
+}
+
+// Fills the kernel arguments for a batch; returns the LDS bytes needed per block.
+int prepare(pxz_handle *h, const pxz_frames *f, const pxz_params *p, bool want_pixels, pxz::ShrinkArgs *a)
+{
+	int rc = check_frames(h, f, p);
+	if (rc != PXZ_OK) return rc;
+	uint32_t cols, rows;
+	pxz_grid(f->width, f->height, p->block_w, p->block_h, &cols, &rows);
+	const uint32_t bw = p->block_w, bh = p->block_h;
+	const uint32_t edge_w = f->width - (cols - 1) * bw, edge_h = f->height - (rows - 1) * bh;
+	if (p->mode == PXZ_MODE_SHRINK_DIRECTIONALLY && (edge_w < 2 || edge_h < 2 || bw < 2 || bh < 2))
+		return fail(h, PXZ_ERR_TILE_TOO_SMALL,
+		            "directional detector needs tiles of at least 2x2 px (edge tile is %ux%u); the reference panics here",
+		            edge_w, edge_h);
+	if ((uint64_t)cols * rows * f->n_frames > 0xffffffffull) return fail(h, PXZ_ERR_UNSUPPORTED, "too many tiles");
+	if (bw > 0xffffu || bh > 0xffffu) return fail(h, PXZ_ERR_UNSUPPORTED, "block side above 65535");
+
+	auto round4 = [](uint32_t v) { return (v + 3u) & ~3u; };
+	a->lds_src_dw = round4(bw * bh);
+	a->lds_tmp_dw = want_pixels && p->filter != PXZ_FILTER_NEAREST ? round4(ceil_div(bw, 2) * bh) : 0;
+	a->lds_lab_dw = p->mode == PXZ_MODE_SHRINK_BY ? round4(3 * bw * bh) : 0;
+	const uint32_t nw = pxz::waves_per_tile(bw, bh);
+	const uint64_t per_tile = ((uint64_t)a->lds_src_dw + a->lds_tmp_dw + a->lds_lab_dw) * 4u;
+	const uint64_t lds_bytes = per_tile * (nw == 1 ? 4u : 1u) + (nw > 1 ? 4u * 4u * nw : 0u);
+	if (lds_bytes > 160u * 1024u)
+		return fail(h, PXZ_ERR_UNSUPPORTED, "a %ux%u tile needs %llu B of LDS (limit 163840)", bw, bh,
+		            (unsigned long long)lds_bytes);
+
+	a->frame_stride = f->n_frames > 1 ? f->frame_stride_bytes : (uint64_t)f->pitch_bytes * f->height;
+	a->pitch = f->pitch_bytes;
+	a->width = f->width;
+	a->height = f->height;
+	a->bw = bw;
+	a->bh = bh;
+	a->cols = cols;
+	a->rows = rows;
+	a->tiles_per_frame = cols * rows;
+	a->n_tiles = cols * rows * f->n_frames;
+	a->edge_w = edge_w;
+	a->edge_h = edge_h;
+	a->mode = p->mode;
+	a->filter = p->filter;
+	a->factor = p->factor;
+	a->slot_bytes = bw * bh * f->channels;
+	std::memcpy(a->thresholds, h->thresholds, sizeof a->thresholds);
+	a->tabs = nullptr;
+	a->bounds = nullptr;
+	a->coeffs = nullptr;
+	if (want_pixels) {
+		TableSet ts;
+		rc = get_tables(h, bw, bh, edge_w, edge_h, p->filter, &ts);
+		if (rc != PXZ_OK) return rc;
+		a->tabs = ts.d_tabs;
+		a->bounds = ts.d_bounds;
+		a->coeffs = ts.d_coeffs;
+	}
+	return PXZ_OK;
+}
+
+int timed_launch(pxz_handle *h, const pxz::ShrinkArgs &a, uint32_t channels)
+{
+	hipEvent_t e0 = nullptr, e1 = nullptr;
+	if (h->timing) {
+		if (h->events_used == h->events.size()) {
+			PXZ_HIP(h, hipEventCreate(&e0));
+			PXZ_HIP(h, hipEventCreate(&e1));
+			h->events.emplace_back(e0, e1);
+		}
+		e0 = h->events[h->events_used].first;
+		e1 = h->events[h->events_used].second;
+		++h->events_used;
+		PXZ_HIP(h, hipEventRecord(e0, h->stream));
+	}
+	PXZ_HIP(h, pxz::launch_shrink(a, channels, h->stream));
+	if (h->timing) PXZ_HIP(h, hipEventRecord(e1, h->stream));
+	return PXZ_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *pxz_version(void) { return "pixlzr-hip 0.1.0 (gfx950)"; }
+
+int pxz_device_count(void)
+{
+	int n = 0;
+	if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+	return n;
+}
+
+int pxz_create(int device_id, pxz_handle **out)
+{
+	if (!out) return PXZ_ERR_INVALID_ARG;
+	*out = nullptr;
+	int n = 0;
+	if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device_id < 0 || device_id >= n) return PXZ_ERR_NO_DEVICE;
+	hipDeviceProp_t prop;
+	if (hipGetDeviceProperties(&prop, device_id) != hipSuccess) return PXZ_ERR_NO_DEVICE;
+	if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) return PXZ_ERR_NO_DEVICE;  // kernels are gfx950 only
+	if (hipSetDevice(device_id) != hipSuccess) return PXZ_ERR_HIP;
+	pxz_handle *h = new (std::nothrow) pxz_handle();
+	if (!h) return PXZ_ERR_NOMEM;
+	h->device = device_id;
+	if (!pxz::build_level_thresholds(h->thresholds, pxz::kNumThresholds)) {
+		delete h;
+		return PXZ_ERR_UNSUPPORTED;  // platform log2f is not a clean step around 2^(k+1/2)
+	}
+	*out = h;
+	return PXZ_OK;
+}
+
+void pxz_destroy(pxz_handle *h)
+{
+	if (!h) return;
+	(void)hipSetDevice(h->device);
+	for (auto &kv : h->tables) {
+		(void)hipFree(kv.second.d_tabs);
+		(void)hipFree(kv.second.d_bounds);
+		(void)hipFree(kv.second.d_coeffs);
+	}
+	for (DeviceBuffer *b : {&h->in, &h->val, &h->ow, &h->oh, &h->out})
+		if (b->ptr) (void)hipFree(b->ptr);
+	for (auto &ev : h->events) {
+		(void)hipEventDestroy(ev.first);
+		(void)hipEventDestroy(ev.second);
+	}
+	delete h;
+}
+
+const char *pxz_last_error(const pxz_handle *h) { return h ? h->error.c_str() : "null handle"; }
+
+int pxz_set_stream(pxz_handle *h, void *hip_stream)
+{
+	if (!h) return PXZ_ERR_INVALID_ARG;
+	h->stream = static_cast<hipStream_t>(hip_stream);
+	return PXZ_OK;
+}
+
+int pxz_synchronize(pxz_handle *h)
+{
+	if (!h) return PXZ_ERR_INVALID_ARG;
+	PXZ_HIP(h, hipStreamSynchronize(h->stream));
+	return PXZ_OK;
+}
+
+int pxz_grid(uint32_t width, uint32_t height, uint32_t block_w, uint32_t block_h, uint32_t *cols, uint32_t *rows)
+{
+	if (!cols || !rows || block_w == 0 || block_h == 0) return PXZ_ERR_INVALID_ARG;
+	// ceil in f64 like iter.rs:38-41; exact for u32 operands
+	*cols = (uint32_t)std::ceil((double)width / (double)block_w);
+	*rows = (uint32_t)std::ceil((double)height / (double)block_h);
+	return PXZ_OK;
+}
+
+int pxz_shrink_frames_device(pxz_handle *h, const pxz_frames *frames, const pxz_params *params,
+                             const uint8_t *d_pixels, float *d_block_value, uint32_t *d_out_w, uint32_t *d_out_h,
+                             uint8_t *d_out_pixels)
+{
+	if (!h) return PXZ_ERR_INVALID_ARG;
+	if (!d_pixels || !d_block_value || !d_out_w || !d_out_h) return fail(h, PXZ_ERR_INVALID_ARG, "null device pointer");
+	PXZ_HIP(h, hipSetDevice(h->device));
+	pxz::ShrinkArgs a{};
+	int rc = prepare(h, frames, params, d_out_pixels != nullptr, &a);
+	if (rc != PXZ_OK) return rc;
+	a.src = d_pixels;
+	a.value = d_block_value;
+	a.out_w = d_out_w;
+	a.out_h = d_out_h;
+	a.out_px = d_out_pixels;
+	return timed_launch(h, a, frames->channels);
+}
+
+int pxz_lod_frames_device(pxz_handle *h, const pxz_frames *frames, const pxz_params *params,
+                          const uint8_t *d_pixels, float *d_lod0, float *d_lod1)
+{
+	if (!h) return PXZ_ERR_INVALID_ARG;
+	if (!d_pixels || !d_lod0 || !d_lod1) return fail(h, PXZ_ERR_INVALID_ARG, "null device pointer");
+	PXZ_HIP(h, hipSetDevice(h->device));
+	pxz::ShrinkArgs a{};
+	int rc = prepare(h, frames, params, false, &a);
+	if (rc != PXZ_OK) return rc;
+	a.src = d_pixels;
+	a.lod0 = d_lod0;
+	a.lod1 = d_lod1;
+	return timed_launch(h, a, frames->channels);
+}
+
+int pxz_shrink_image(pxz_handle *h, const uint8_t *pixels, uint32_t width, uint32_t height, uint32_t channels,
+                     uint32_t pitch_bytes, uint32_t block_w, uint32_t block_h, uint32_t mode, uint32_t filter,
+                     float factor, float *block_value, uint32_t *out_w, uint32_t *out_h, uint8_t *out_pixels)
+{
+	if (!h) return PXZ_ERR_INVALID_ARG;
+	if (!pixels || !block_value || !out_w || !out_h) return fail(h, PXZ_ERR_INVALID_ARG, "null pointer");
+	pxz_frames f{width, height, channels, pitch_bytes, 1, 0, 0};
+	pxz_params p{block_w, block_h, mode, filter, factor, 0};
+	int rc = check_frames(h, &f, &p);
+	if (rc != PXZ_OK) return rc;
+	PXZ_HIP(h, hipSetDevice(h->device));
+	uint32_t cols, rows;
+	pxz_grid(width, height, block_w, block_h, &cols, &rows);
+	const size_t tiles = (size_t)cols * rows;
+	const size_t in_bytes = (size_t)pitch_bytes * (height - 1) + (size_t)width * channels;
+	const size_t slot = (size_t)block_w * block_h * channels;
+	if ((rc = ensure(h, h->in, in_bytes)) != PXZ_OK) return rc;
+	if ((rc = ensure(h, h->val, tiles * 4)) != PXZ_OK) return rc;
+	if ((rc = ensure(h, h->ow, tiles * 4)) != PXZ_OK) return rc;
+	if ((rc = ensure(h, h->oh, tiles * 4)) != PXZ_OK) return rc;
+	if (out_pixels && (rc = ensure(h, h->out, tiles * slot)) != PXZ_OK) return rc;
+	PXZ_HIP(h, hipMemcpyAsync(h->in.ptr, pixels, in_bytes, hipMemcpyHostToDevice, h->stream));
+	rc = pxz_shrink_frames_device(h, &f, &p, (const uint8_t *)h->in.ptr, (float *)h->val.ptr, (uint32_t *)h->ow.ptr,
+	                              (uint32_t *)h->oh.ptr, out_pixels ? (uint8_t *)h->out.ptr : nullptr);
+	if (rc != PXZ_OK) return rc;
+	PXZ_HIP(h, hipMemcpyAsync(block_value, h->val.ptr, tiles * 4, hipMemcpyDeviceToHost, h->stream));
+	PXZ_HIP(h, hipMemcpyAsync(out_w, h->ow.ptr, tiles * 4, hipMemcpyDeviceToHost, h->stream));
+	PXZ_HIP(h, hipMemcpyAsync(out_h, h->oh.ptr, tiles * 4, hipMemcpyDeviceToHost, h->stream));
+	if (out_pixels) PXZ_HIP(h, hipMemcpyAsync(out_pixels, h->out.ptr, tiles * slot, hipMemcpyDeviceToHost, h->stream));
+	PXZ_HIP(h, hipStreamSynchronize(h->stream));
+	return PXZ_OK;
+}
+
+int pxz_synth_frames_device(pxz_handle *h, const pxz_frames *frames, uint8_t *d_pixels, uint32_t first_frame_index,
+                            uint32_t dist)
+{
+	if (!h) return PXZ_ERR_INVALID_ARG;
+	if (!frames || !d_pixels || dist > 3) return fail(h, PXZ_ERR_INVALID_ARG, "bad synth arguments");
+	if (frames->channels != 3 && frames->channels != 4) return fail(h, PXZ_ERR_INVALID_ARG, "channels must be 3 or 4");
+	if (frames->height > 65535u || frames->n_frames > 65535u) return fail(h, PXZ_ERR_UNSUPPORTED, "frame too tall for the synth grid");
+	PXZ_HIP(h, hipSetDevice(h->device));
+	pxz::SynthArgs s{d_pixels,
+	                 frames->n_frames > 1 ? frames->frame_stride_bytes : (uint64_t)frames->pitch_bytes * frames->height,
+	                 frames->pitch_bytes, frames->width, frames->height, frames->channels, frames->n_frames,
+	                 first_frame_index, dist};
+	PXZ_HIP(h, pxz::launch_synth(s, h->stream));
+	return PXZ_OK;
+}
+
+int pxz_axis_table(uint32_t in_size, uint32_t out_size, uint32_t filter, int32_t *starts, int32_t *sizes,
+                   int16_t *coeffs, int32_t *window, int32_t *precision)
+{
+	if (in_size == 0 || out_size == 0 || filter > 4) return PXZ_ERR_INVALID_ARG;
+	pxz::AxisWindows w;
+	if (!pxz::build_axis(in_size, out_size, filter, &w)) return PXZ_ERR_INVALID_ARG;
+	if (window) *window = w.window;
+	if (precision) *precision = w.precision;
+	if (starts) std::memcpy(starts, w.starts.data(), sizeof(int32_t) * out_size);
+	if (sizes) std::memcpy(sizes, w.sizes.data(), sizeof(int32_t) * out_size);
+	if (coeffs && !w.coeffs.empty()) std::memcpy(coeffs, w.coeffs.data(), sizeof(int16_t) * w.coeffs.size());
+	return PXZ_OK;
+}
+
+int pxz_enable_timing(pxz_handle *h, int on)
+{
+	if (!h) return PXZ_ERR_INVALID_ARG;
+	h->timing = on != 0;
+	h->events_used = 0;
+	return PXZ_OK;
+}
+
+// average over the launches recorded since the last call (or since enable)
+int pxz_last_kernel_ms(pxz_handle *h, float *ms)
+{
+	if (!h || !ms) return PXZ_ERR_INVALID_ARG;
+	if (!h->timing || h->events_used == 0) return fail(h, PXZ_ERR_INVALID_ARG, "no timed launches recorded");
+	PXZ_HIP(h, hipEventSynchronize(h->events[h->events_used - 1].second));
+	double total = 0.0;
+	for (size_t i = 0; i < h->events_used; ++i) {
+		float t = 0.f;
+		PXZ_HIP(h, hipEventElapsedTime(&t, h->events[i].first, h->events[i].second));
+		total += t;
+	}
+	*ms = (float)(total / (double)h->events_used);
+	h->events_used = 0;
+	return PXZ_OK;
+}
+
+}  // extern "C"

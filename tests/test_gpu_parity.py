@@ -1,0 +1,201 @@
+"""GPU parity: the HIP path (through the C ABI) against the oracle on the same inputs.
+Bit-exact everywhere: block values are compared as u32 bit patterns, pixels as bytes."""
+import os
+
+import numpy as np
+import pytest
+from PIL import Image
+
+pytestmark = pytest.mark.gpu
+
+FILTERS = {"nearest": 0, "triangle": 1, "catmullrom": 2, "gaussian": 3, "lanczos3": 4}
+
+
+@pytest.fixture(scope="module")
+def gpu(product):
+    import torch
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    h = product.Handle(0)
+    yield h
+    h.close()
+
+
+def assert_same_tiles(got, exp, channels, what=""):
+    gv, gw, gh, gs = got
+    ev, ew, eh, es = exp
+    assert (gw == ew).all() and (gh == eh).all(), f"{what}: reduced dims differ on {int(((gw != ew) | (gh != eh)).sum())} tiles"
+    gb, eb = gv.view(np.uint32), ev.view(np.uint32)
+    assert (gb == eb).all(), f"{what}: block values differ on {int((gb != eb).sum())} tiles, e.g. {gv[gb != eb][:3]} vs {ev[gb != eb][:3]}"
+    if es is not None:
+        valid = (ew.astype(np.int64) * eh * channels)
+        idx = np.arange(es.shape[1])[None, :] < valid[:, None]
+        diff = (gs != es) & idx
+        assert not diff.any(), f"{what}: {int(diff.sum())} payload bytes differ in {int(diff.any(axis=1).sum())} tiles"
+
+
+def histogram(ow, oh):
+    out = {}
+    for w, h in zip(ow.tolist(), oh.tolist()):
+        out[(w, h)] = out.get((w, h), 0) + 1
+    return out
+
+
+def test_synth_generator_matches_oracle(gpu, oracle):
+    for channels in (4, 3):
+        for dist in range(4):
+            d = gpu.synth_frames_device(2, 70, 100, channels, first_frame=5, dist=dist).cpu().numpy()
+            for f in range(2):
+                assert (d[f] == oracle.synth_frame(100, 70, channels, 5 + f, dist)).all(), (channels, dist, f)
+
+
+@pytest.mark.parametrize("name,block", [("Big-Ruscher.png", 32), ("base.png", 64), ("base.png", 32), ("image.png", 8)])
+def test_directional_detector_on_reference_images(gpu, oracle, golden_dir, name, block):
+    """get_block_variance_directionally over every tile of the reference's own images (RGB and RGBA,
+    edge tiles 24-high / 56x17 / 2-wide) — includes the SURVEY §8(c) KAT tiles."""
+    import torch
+    img = np.ascontiguousarray(np.asarray(Image.open(os.path.join(golden_dir, name))))
+    H, W, C = img.shape
+    l0, l1 = gpu.lod_frames_device(torch.from_numpy(img)[None].cuda(), block, block, 1)
+    l0, l1 = l0.cpu().numpy()[0], l1.cpu().numpy()[0]
+    cols, rows = oracle.grid(W, H, block, block)
+    for t in range(cols * rows):
+        x, y, w, h = oracle.tile_rect(W, H, block, block, t)
+        hz, vr, _, _ = oracle.lod_directional(img[y:y + h, x:x + w])
+        assert np.array([hz, vr], np.float32).tobytes() == np.array([l0[t], l1[t]], np.float32).tobytes(), (t, hz, l0[t])
+
+
+def test_oklab_detector_on_big_ruscher(gpu, oracle, golden_dir):
+    """get_block_variance (+shrink_by closures, factor 0.125) on the image behind Big-Ruscher.pix: values
+    bit-equal to the oracle and reduced sizes equal to the 2040 decisions stored in the reference's file."""
+    img = np.ascontiguousarray(np.asarray(Image.open(os.path.join(golden_dir, "Big-Ruscher.png"))))
+    got = gpu.shrink_image(img, 32, 32, 0, 4, 0.125)
+    exp = oracle.shrink_image(img, 32, 32, 0, 4, 0.125)
+    assert_same_tiles(got, exp, 3, "Big-Ruscher shrink_by")
+    d = oracle.decode_container(open(os.path.join(golden_dir, "Big-Ruscher.pix"), "rb").read())
+    assert (got[1] == d["tw"]).all() and (got[2] == d["th"]).all()
+
+
+CASES_1080P = [
+    # (dist, mode, filter, factor)
+    ("opaque", 1, "lanczos3", 16.0), ("opaque", 1, "lanczos3", 1.0), ("opaque", 0, "lanczos3", 1.0),
+    ("opaque", 0, "lanczos3", 0.125), ("alpha", 1, "lanczos3", 16.0), ("alpha", 0, "lanczos3", 1.0),
+    ("opaque", 1, "nearest", 16.0), ("alpha", 1, "catmullrom", 16.0), ("alpha", 0, "triangle", 0.5),
+    ("opaque", 1, "gaussian", 8.0), ("alpha", 1, "nearest", 4.0), ("opaque", 1, "lanczos3", -0.5),
+]
+
+
+@pytest.mark.parametrize("dist,mode,filt,factor", CASES_1080P)
+def test_shrink_1080p_rgba_32(gpu, oracle, dist, mode, filt, factor):
+    """BASELINE config: 1920x1080 RGBA8 synthetic, 32x32 tiles (last tile row 24 px high)."""
+    img = oracle.synth_frame(1920, 1080, 4, 0, {"opaque": 0, "alpha": 1}[dist])
+    got = gpu.shrink_image(img, 32, 32, mode, FILTERS[filt], factor)
+    exp = oracle.shrink_image(img, 32, 32, mode, FILTERS[filt], factor, nthreads=8)
+    assert_same_tiles(got, exp, 4, f"{dist} mode{mode} {filt} k={factor}")
+    if factor in (16.0, 1.0) and filt == "lanczos3" and dist == "opaque":
+        assert len(histogram(got[1], got[2])) >= 4  # the workload spans the levels
+
+
+@pytest.mark.parametrize("w,h,bw,bh,c", [
+    (64, 64, 64, 64, 4), (65, 33, 32, 32, 4), (100, 37, 48, 20, 4), (1920, 1170, 8, 8, 3), (257, 130, 16, 16, 4),
+    (180, 180, 90, 90, 4), (130, 70, 128, 64, 3), (34, 34, 32, 32, 4), (35, 35, 32, 32, 3), (31, 9, 64, 64, 4),
+    (3, 3, 32, 32, 4), (2, 2, 2, 2, 4), (640, 360, 64, 64, 4), (96, 96, 24, 24, 3)])
+@pytest.mark.parametrize("mode", [0, 1])
+def test_shrink_ragged_grids_and_block_sizes(gpu, oracle, w, h, bw, bh, c, mode):
+    """Edge tiles (clamped, split.rs:18-19), non-power-of-two tiles, multi-wave tiles (64x64 .. 128x64),
+    2-px tiles (directional 0/0 -> 1x1), RGB and RGBA."""
+    rng = np.random.default_rng(w * 131 + h)
+    img = oracle.synth_frame(w, h, c, 3, 1 if c == 4 else 0)
+    if mode == 1 and (w % bw == 1 or h % bh == 1):
+        # a 1-px edge tile: the reference underflows `width - 2` and panics (operations.rs:220-221)
+        with pytest.raises(Exception) as e:
+            gpu.shrink_image(img, bw, bh, mode, 4, 1.0)
+        assert getattr(e.value, "code", None) == -4
+        with pytest.raises(RuntimeError):
+            oracle.shrink_image(img, bw, bh, mode, 4, 1.0)
+        return
+    img[: h // 2] = (img[: h // 2].astype(np.int32) + rng.integers(-40, 40, size=img[: h // 2].shape)).clip(0, 255).astype(np.uint8)
+    for filt, factor in ((4, 8.0 if mode == 1 else 0.7), (2, 2.0 if mode == 1 else 0.2), (0, 4.0 if mode == 1 else 0.4)):
+        got = gpu.shrink_image(img, bw, bh, mode, filt, factor)
+        exp = oracle.shrink_image(img, bw, bh, mode, filt, factor)
+        assert_same_tiles(got, exp, c, f"{w}x{h} b{bw}x{bh} c{c} mode{mode} f{filt}")
+
+
+def test_pitch_and_unaligned_rows(gpu, oracle):
+    """Pitch larger than a row and rows that are not 16-byte aligned (scalar staging path)."""
+    base = oracle.synth_frame(203, 77, 4, 1, 1)
+    padded = np.zeros((77, 203 * 4 + 12), np.uint8)
+    padded[:, : 203 * 4] = base.reshape(77, -1)
+    view = padded[:, : 203 * 4].reshape(77, 203, 4)
+    assert view.strides[0] == 203 * 4 + 12
+    for mode, factor in ((1, 8.0), (0, 0.5)):
+        got = gpu.shrink_image(view, 32, 32, mode, 4, factor)
+        exp = oracle.shrink_image(base, 32, 32, mode, 4, factor)
+        assert_same_tiles(got, exp, 4, "pitched")
+
+
+def test_error_behaviour(gpu, product, oracle):
+    img = oracle.synth_frame(33, 40, 4, 0, 0)  # 33 = 32 + 1: a 1-px-wide edge tile
+    with pytest.raises(product.PxzError) as e:
+        gpu.shrink_image(img, 32, 32, 1, 4, 1.0)   # reference: usize underflow panic (operations.rs:221)
+    assert e.value.code == -4
+    gpu.shrink_image(img, 32, 32, 0, 4, 1.0)        # shrink_by has no such restriction
+    with pytest.raises(product.PxzError) as e:
+        gpu.shrink_image(img, 32, 32, 1, 9, 1.0)
+    assert e.value.code == -1
+    with pytest.raises(product.PxzError) as e:
+        gpu.shrink_image(img, 0, 32, 1, 4, 1.0)
+    assert e.value.code == -1
+    with pytest.raises(product.PxzError) as e:
+        gpu.shrink_image(img, 32, 32, 1, 4, float("nan"))
+    assert e.value.code == -1
+    with pytest.raises(product.PxzError) as e:
+        gpu.shrink_image(oracle.synth_frame(512, 512, 4, 0, 0), 256, 256, 1, 4, 1.0)  # tile beyond LDS residency
+    assert e.value.code == -5
+
+
+@pytest.mark.parametrize("mode,factor", [(1, 16.0), (0, 1.0)])
+def test_full_file_bit_exact(gpu, product, oracle, mode, factor):
+    """image -> shrink on the GPU -> product's container writer  ==  oracle shrink -> oracle writer."""
+    for c in (4, 3):
+        img = oracle.synth_frame(640, 360, c, 2, 1 if c == 4 else 0)
+        gv, gw, gh, gs = gpu.shrink_image(img, 32, 32, mode, 4, factor)
+        ev, ew, eh, es = oracle.shrink_image(img, 32, 32, mode, 4, factor)
+        mine = product.encode_container(640, 360, 32, 32, c, 0, gv, None, gw, gh, gs)
+        ref = oracle.encode_container(640, 360, 32, 32, c, 0, ev, None, ew, eh, es)
+        assert mine == ref
+        d = oracle.decode_container(mine)
+        assert (d["tw"] == gw).all() and (d["values"].view(np.uint32) == gv.view(np.uint32)).all()
+
+
+def test_8k_batch_against_oracle_and_properties(gpu, oracle):
+    """BASELINE headline size: 7680x4320 RGBA8, 32x32 tiles, device-resident batch.
+    Frame 0 is compared with the oracle in full; the rest through size-independent properties."""
+    import torch
+    frames = gpu.synth_frames_device(3, 4320, 7680, 4, first_frame=0, dist=0)
+    for mode, factor in ((1, 16.0), (0, 1.0)):
+        vals, ow, oh, slots = gpu.shrink_frames_device(frames, 32, 32, mode, 4, factor)
+        torch.cuda.synchronize()
+        img0 = frames[0].cpu().numpy()
+        assert (img0 == oracle.synth_frame(7680, 4320, 4, 0, 0)).all()
+        exp = oracle.shrink_image(img0, 32, 32, mode, 4, factor, nthreads=16)
+        got = (vals[0].cpu().numpy(), ow[0].cpu().numpy().astype(np.uint32), oh[0].cpu().numpy().astype(np.uint32),
+               slots[0].cpu().numpy())
+        assert_same_tiles(got, exp, 4, f"8K mode{mode}")
+        # determinism / idempotence: same launch again gives the same bytes
+        vals2, ow2, oh2, slots2 = gpu.shrink_frames_device(frames, 32, 32, mode, 4, factor)
+        assert torch.equal(vals.view(torch.int32), vals2.view(torch.int32)) and torch.equal(ow, ow2) and torch.equal(oh, oh2)
+        # batch independence: frame 2 alone == frame 2 inside the batch
+        v1, w1, h1, s1 = gpu.shrink_frames_device(frames[2:3], 32, 32, mode, 4, factor)
+        assert torch.equal(v1[0].view(torch.int32), vals[2].view(torch.int32)) and torch.equal(w1[0], ow[2])
+        valid = (w1[0].long() * h1[0].long() * 4)[:, None] > torch.arange(4096, device=s1.device)[None, :]
+        assert torch.equal(s1[0][valid], slots[2][valid])
+    # "noise": nothing shrinks and the slots are the source tiles (clone, block.rs:279-281)
+    noise = gpu.synth_frames_device(1, 4320, 7680, 4, first_frame=9, dist=3)
+    vals, ow, oh, slots = gpu.shrink_frames_device(noise, 32, 32, 1, 4, 16.0)
+    assert int((ow != 32).sum()) == 0 and int((oh != 32).sum()) == 0
+    tiles = noise[0].view(135, 32, 240, 32, 4).permute(0, 2, 1, 3, 4).reshape(135 * 240, 4096)
+    assert torch.equal(tiles, slots[0])
+    # "flat": every tile collapses to 1x1
+    flat = gpu.synth_frames_device(1, 4320, 7680, 4, first_frame=9, dist=2)
+    vals, ow, oh, slots = gpu.shrink_frames_device(flat, 32, 32, 1, 4, 1.0)
+    assert int((ow != 1).sum()) == 0 and int((oh != 1).sum()) == 0

@@ -1,0 +1,101 @@
+"""Product host code without a GPU: the C-ABI library loads and exports every symbol of
+include/pixlzr_hip.h, its bitstream writer reproduces the reference fixtures, and its
+down-scaling tables equal the oracle's.  (No compute calls: there is no GPU here.)"""
+import os
+import re
+
+import numpy as np
+import pytest
+from PIL import Image
+
+
+def test_library_exports_every_declared_symbol(product):
+    L = product.load_library()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    header = open(os.path.join(root, "include", "pixlzr_hip.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)  # declarations only, not prose
+    declared = set(re.findall(r"\b(pxz_[a-z0-9_]+)\s*\(", header))
+    assert declared == set(product.EXPORTED_SYMBOLS)
+    for name in declared:
+        assert hasattr(L, name), name
+    assert b"gfx950" in L.pxz_version()
+
+
+def test_no_cpu_fallback_without_device(product):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(product.PxzError) as e:
+        product.Handle(0)
+    assert e.value.code == -2  # PXZ_ERR_NO_DEVICE
+
+
+def test_product_never_touches_the_oracle():
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pkg = os.path.join(root, "pixlzr-rust_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h", ".hpp", "Makefile")):
+                text = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "liboracle" not in text and "oracle/" not in text and "import oracle" not in text, f
+
+
+def test_grid_matches_reference_math(product, oracle):
+    for (w, h, bw, bh) in [(1080, 1617, 64, 64), (1920, 1080, 32, 32), (7680, 4320, 32, 32), (1, 1, 64, 64),
+                           (65, 64, 64, 64), (1920, 1170, 8, 8), (100, 37, 48, 20)]:
+        assert product.grid(w, h, bw, bh) == oracle.grid(w, h, bw, bh)
+
+
+def test_container_writer_reproduces_base_pixlzr(product, oracle, golden_dir):
+    """encode_to_vec replacement vs the reference's own file (benches/base.pixlzr), byte for byte."""
+    img = np.asarray(Image.open(os.path.join(golden_dir, "base.png")))
+    gold = open(os.path.join(golden_dir, "base.pixlzr"), "rb").read()
+    H, W, C = img.shape
+    cols, rows = product.grid(W, H, 64, 64)
+    n = cols * rows
+    tw = np.zeros(n, np.uint32)
+    th = np.zeros(n, np.uint32)
+    slots = np.zeros((n, 64 * 64 * C), np.uint8)
+    for t in range(n):
+        x, y, w, h = oracle.tile_rect(W, H, 64, 64, t)
+        tw[t], th[t] = w, h
+        slots[t, : w * h * C] = img[y:y + h, x:x + w].reshape(-1)
+    out = product.encode_container(W, H, 64, 64, C, 0, np.zeros(n, np.float32), np.zeros(n, np.uint8), tw, th, slots)
+    assert out == gold
+
+
+def test_container_writer_reproduces_big_ruscher_pix(product, oracle, golden_dir):
+    raw = open(os.path.join(golden_dir, "Big-Ruscher.pix"), "rb").read()
+    d = oracle.decode_container(raw)
+    n = len(d["tw"])
+    slots = np.zeros((n, 32 * 32 * 3), np.uint8)
+    for t in range(n):
+        k = int(d["tw"][t]) * int(d["th"][t]) * 3
+        slots[t, :k] = d["slots"][t, :k]
+    out = product.encode_container(1920, 1080, 32, 32, 3, d["filter"], d["values"], None, d["tw"], d["th"], slots)
+    assert out == raw
+
+
+def test_qoi_encoder_equals_oracle_on_random_tiles(product, oracle):
+    rng = np.random.default_rng(3)
+    for c in (3, 4):
+        for shape in ((1, 1), (1, 2), (2, 1), (7, 5), (32, 32), (17, 56), (64, 64)):
+            for levels in (2, 5, 256):
+                tile = (rng.integers(0, levels, size=(shape[0], shape[1], c)) * (255 // max(levels - 1, 1))).astype(np.uint8)
+                if c == 4 and levels != 256:
+                    tile[..., 3] = 255
+                tile[0, 0, :3] = 0  # start on the initial "previous pixel" now and then
+                assert product.qoi_encode(tile) == oracle.qoi_encode(tile)
+    # long runs: the 62-cap and end-of-image flushes
+    tile = np.full((10, 100, 4), 9, np.uint8)
+    assert product.qoi_encode(tile) == oracle.qoi_encode(tile)
+
+
+def test_axis_tables_equal_oracle(product, oracle):
+    sizes = [(32, 16), (32, 8), (32, 4), (32, 2), (32, 1), (24, 12), (24, 6), (24, 3), (24, 2), (24, 1),
+             (17, 9), (17, 5), (17, 3), (64, 32), (64, 1), (56, 28), (56, 7), (16, 8), (16, 1), (100, 10), (3, 2)]
+    for filt in (1, 2, 3, 4):
+        for i, o in sizes:
+            a = product.axis_table(i, o, filt)
+            b = oracle.fir_coeffs(i, o, filt)
+            assert (a[0] == b[0]).all() and (a[1] == b[1]).all() and (a[2] == b[2]).all() and a[3] == b[3], (filt, i, o)
