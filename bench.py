@@ -1,0 +1,197 @@
+#!/usr/bin/env python3
+"""bench.py — pixlzr encode hot path on MI355X: megapixels/s + achieved HBM GB/s vs roofline.
+
+A "step" = one pass of the hot path (per-tile LOD detection + power-of-two down-sampling,
+Pixlzr::from_image + shrink_* of the reference) over one batch of synthetic 8K RGBA frames that
+is already resident in HBM: ONE fused kernel launch per step and per GPU.
+
+  python bench.py --gpus 1 --steps K --warmup W            # single GPU
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   # one rank per GPU
+
+Workload (BASELINE.json configs[2] / configs[4]): 7680x4320 RGBA8, 32x32 tiles, 8 frames per GPU
+(64 frames over 8 GPUs; 1.06 GB of source per GPU per step, well past the 256 MiB Infinity Cache),
+"opaque" synthetic distribution, filter Lanczos3.  Weak scaling: per-GPU work is fixed.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 measured achievable
+
+MODES = {"shrink_directionally": (1, 16.0), "shrink_by": (0, 1.0)}  # (pxz_mode, factor) per BASELINE.md §3
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--width", type=int, default=7680)
+    ap.add_argument("--height", type=int, default=4320)
+    ap.add_argument("--block", type=int, default=32)
+    ap.add_argument("--frames-per-gpu", type=int, default=8)
+    ap.add_argument("--mode", choices=list(MODES) + ["both"], default="both",
+                    help="`value` is quoted for --primary; `both` also measures the other detector")
+    ap.add_argument("--primary", choices=list(MODES), default="shrink_directionally")
+    ap.add_argument("--filter", type=int, default=4)
+    ap.add_argument("--dist", type=int, default=0, help="0 opaque, 1 alpha, 2 flat, 3 noise")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-gather", action="store_true", help="N>1: skip the block-stream gather to rank 0")
+    return ap.parse_args()
+
+
+def histogram(ow, oh):
+    import torch
+    key = ow.long() * 100000 + oh.long()
+    uniq, counts = torch.unique(key, return_counts=True)
+    return {f"{int(k) // 100000}x{int(k) % 100000}": int(c) for k, c in zip(uniq.tolist(), counts.tolist())}
+
+
+def run_mode(args, handle, frames, mode_name, rank, world, dist_mod):
+    """Times K steps of one detector mode; returns a dict of measurements (max over ranks)."""
+    import torch
+    pxz_mode, factor = MODES[mode_name]
+    N, H, W, C = frames.shape
+    bw = bh = args.block
+    out = None
+    vals, ow, oh, slots = handle.shrink_frames_device(frames, bw, bh, pxz_mode, args.filter, factor)
+    out = (vals, ow, oh, slots)
+    for _ in range(args.warmup):
+        handle.shrink_frames_device(frames, bw, bh, pxz_mode, args.filter, factor, out=out)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist_mod.barrier()
+    torch.cuda.synchronize()
+    handle.enable_timing(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        handle.shrink_frames_device(frames, bw, bh, pxz_mode, args.filter, factor, out=out)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist_mod.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    kernel_ms = handle.last_kernel_ms()  # HIP events on the launch stream, averaged over the K launches
+    handle.enable_timing(False)
+    if world > 1:
+        t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=frames.device)
+        dist_mod.all_reduce(t, op=dist_mod.ReduceOp.MAX)
+        elapsed, kernel_ms = float(t[0]), float(t[1])
+
+    tiles = ow.numel()
+    out_bytes = int((ow.long() * oh.long()).sum().item()) * C
+    read_bytes = N * H * W * C
+    algo_bytes = read_bytes + out_bytes + 12 * tiles  # source once + shrunk pixels + value/w/h
+    mp = N * H * W / 1e6
+    return {
+        "mode": mode_name, "factor": factor,
+        "elapsed_s": elapsed, "ms_per_step": elapsed / args.steps * 1e3,
+        "mp_per_s_per_gpu": mp * args.steps / elapsed,
+        "kernel_ms": kernel_ms,
+        "algo_bytes_per_launch": algo_bytes, "read_bytes": read_bytes, "write_bytes": out_bytes + 12 * tiles,
+        "achieved_gbps": algo_bytes / (kernel_ms * 1e-3) / 1e9,
+        "histogram": histogram(ow[0], oh[0]),
+    }
+
+
+def cpu_baseline(args, mode_name):
+    """The oracle (CPU restatement of the reference path) timed on this box's host cores on a bounded
+    sample: ONE frame of the batch.  kind="port": the Rust reference itself cannot be built here."""
+    from oracle import binding as oracle
+    oracle.build()
+    pxz_mode, factor = MODES[mode_name]
+    img = oracle.synth_frame(args.width, args.height, 4, 0, args.dist)
+    cores = os.cpu_count() or 1
+    mp = args.width * args.height / 1e6
+    best_all = best_one = None
+    for _ in range(2):
+        t0 = time.perf_counter()
+        oracle.shrink_image(img, args.block, args.block, pxz_mode, args.filter, factor, nthreads=cores)
+        dt = time.perf_counter() - t0
+        best_all = dt if best_all is None else min(best_all, dt)
+    t0 = time.perf_counter()
+    oracle.shrink_image(img, args.block, args.block, pxz_mode, args.filter, factor, nthreads=1)
+    best_one = time.perf_counter() - t0
+    return {"value": mp / best_all, "unit": "MP/s", "cores": cores, "kind": "port",
+            "sample": f"1 frame {args.width}x{args.height} RGBA8, {mode_name}, best of 2, {cores} threads over tile rows",
+            "single_thread_value": mp / best_one,
+            "reference_published": "88.4 ms / 1.746 MP = 19.8 MP/s single thread, hardware unstated (log_24-09-26.txt:6)"}
+
+
+def load_traffic(mode_name):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes of this same command, if present."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        with open(path) as f:
+            return json.load(f).get(mode_name)
+    except Exception:
+        return None
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local_rank)
+
+    from __graft_entry__ import load_product
+    product = load_product()
+    handle = product.Handle(local_rank)  # raises if the HIP library / device is missing: no fallback
+    nf = args.frames_per_gpu
+    frames = handle.synth_frames_device(nf, args.height, args.width, 4, first_frame=rank * nf, dist=args.dist)
+    torch.cuda.synchronize()
+
+    names = list(MODES) if args.mode == "both" else [args.mode]
+    primary = args.primary if args.primary in names else names[0]
+    results = {}
+    for name in names:
+        results[name] = run_mode(args, handle, frames, name, rank, world, dist)
+
+    if rank == 0:
+        r = results[primary]
+        total_mp = world * nf * args.width * args.height / 1e6
+        line = {
+            "metric": "encode megapixels/sec (per-tile LOD detection + block-wise downsample), 8K RGBA",
+            "value": total_mp * args.steps / r["elapsed_s"],
+            "unit": "MP/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": r["ms_per_step"],
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u8" if primary == "shrink_directionally" else "u8/f32",
+            "data": "synthetic",
+            "config": {"workload": f"{nf}x {args.width}x{args.height} RGBA8 frames per GPU, {args.block}x{args.block} tiles, "
+                                   f"{primary} factor {r['factor']}, filter {args.filter} (Lanczos3=4), dist {args.dist}, "
+                                   f"device-resident, one fused launch per step",
+                       "mode": primary, "frames_per_gpu": nf, "tile": args.block,
+                       "tile_size_histogram_frame0": r["histogram"]},
+            "roofline": {"bound": "hbm", "achieved": r["achieved_gbps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": r["achieved_gbps"] / HBM_PEAK_GBPS, "traffic": load_traffic(primary),
+                         "kernel_ms": r["kernel_ms"], "algorithmic_bytes_per_launch": r["algo_bytes_per_launch"],
+                         "kernel": "pxz::shrink_kernel"},
+            "modes": {k: {kk: v[kk] for kk in ("ms_per_step", "mp_per_s_per_gpu", "kernel_ms", "achieved_gbps",
+                                                "algo_bytes_per_launch", "histogram")} for k, v in results.items()},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args, primary)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
