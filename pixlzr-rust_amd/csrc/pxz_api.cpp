@@ -19,6 +19,7 @@
 namespace pxz {
 hipError_t launch_shrink(const ShrinkArgs &a, uint32_t channels, hipStream_t stream);
 hipError_t launch_synth(const SynthArgs &s, hipStream_t stream);
+hipError_t launch_finish(const FinishArgs &f, hipStream_t stream);
 uint32_t waves_per_tile(uint32_t bw, uint32_t bh);
 }  // namespace pxz
 
@@ -31,7 +32,8 @@ using pxz::kMaxLevel;
 struct TableSet {
 	AxisTab *d_tabs = nullptr;
 	uint16_t *d_bounds = nullptr;
-	int16_t *d_coeffs = nullptr;
+	uint32_t *d_coeffs = nullptr;
+	int32_t *d_ksums = nullptr;
 };
 
 struct DeviceBuffer {
@@ -47,7 +49,10 @@ struct pxz_handle {
 	std::string error;
 	float thresholds[pxz::kNumThresholds];
 	std::map<std::tuple<uint32_t, uint32_t, uint32_t, uint32_t, uint32_t>, TableSet> tables;
-	DeviceBuffer in, val, ow, oh, out;
+	// level breakpoints per (mode, factor bits, bw, bh, edge_w, edge_h)
+	struct Breaks { uint32_t b[4][pxz::kMaxLevel]; uint32_t asc[4]; };
+	std::map<std::tuple<uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t>, Breaks> breaks;
+	DeviceBuffer in, val, ow, oh, out, sums;
 	bool timing = false;
 	std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
 	size_t events_used = 0;
@@ -106,7 +111,8 @@ int get_tables(pxz_handle *h, uint32_t bw, uint32_t bh, uint32_t edge_w, uint32_
 	}
 	std::vector<AxisTab> tabs(2 * 2 * kMaxLevel);
 	std::vector<uint16_t> bounds;
-	std::vector<int16_t> coeffs;
+	std::vector<uint32_t> coeffs;
+	std::vector<int32_t> ksums;
 	const uint32_t sizes[2][2] = {{bw, edge_w}, {bh, edge_h}};
 	for (int axis = 0; axis < 2; ++axis) {
 		for (int cls = 0; cls < 2; ++cls) {
@@ -114,38 +120,143 @@ int get_tables(pxz_handle *h, uint32_t bw, uint32_t bh, uint32_t edge_w, uint32_
 			for (int m = 0; m < kMaxLevel; ++m) {
 				AxisTab &t = tabs[(axis * 2 + cls) * kMaxLevel + m];
 				const uint32_t outsz = reduced(in, (uint32_t)m);
-				t = AxisTab{0, 0, (uint16_t)outsz, 0, 0, (uint16_t)in};
+				t = AxisTab{0, 0, 0, (uint16_t)outsz, 0, 0, (uint16_t)in};
 				if (outsz == in) continue;  // identity: never looked up
 				pxz::AxisWindows win;
 				if (!pxz::build_axis(in, outsz, filter, &win)) return fail(h, PXZ_ERR_INVALID_ARG, "unknown filter %u", filter);
 				t.bounds_off = (uint32_t)bounds.size();
 				t.coeff_off = (uint32_t)coeffs.size();
-				t.window = (uint16_t)win.window;
+				t.ksum_off = (uint32_t)ksums.size();
 				t.precision = (uint16_t)win.precision;
 				if (filter == PXZ_FILTER_NEAREST) {
 					for (uint32_t o = 0; o < outsz; ++o) bounds.push_back((uint16_t)win.starts[o]);
-				} else {
-					for (uint32_t o = 0; o < outsz; ++o) {
-						bounds.push_back((uint16_t)win.starts[o]);
-						bounds.push_back((uint16_t)win.sizes[o]);
+					continue;
+				}
+				// pad every window to whole quads of 4 source samples (8-byte aligned LDS reads)
+				uint32_t wquads = 1;
+				for (uint32_t o = 0; o < outsz; ++o) {
+					const uint32_t lead = (uint32_t)win.starts[o] & 3u;
+					const uint32_t nq = (lead + (uint32_t)win.sizes[o] + 3u) / 4u;
+					if (nq > wquads) wquads = nq;
+				}
+				t.wquads = (uint16_t)wquads;
+				for (uint32_t o = 0; o < outsz; ++o) {
+					const uint32_t first = (uint32_t)win.starts[o], n = (uint32_t)win.sizes[o];
+					const uint32_t lead = first & 3u, nq = (lead + n + 3u) / 4u;
+					bounds.push_back((uint16_t)(first / 4u));
+					bounds.push_back((uint16_t)nq);
+					std::vector<int16_t> k(wquads * 4u, 0);
+					int32_t total = 0;
+					for (uint32_t i = 0; i < n; ++i) {
+						k[lead + i] = win.coeffs[(size_t)o * win.window + i];
+						total += k[lead + i];
 					}
-					coeffs.insert(coeffs.end(), win.coeffs.begin(), win.coeffs.end());
+					for (uint32_t d = 0; d < wquads * 2u; ++d)
+						coeffs.push_back((uint32_t)(uint16_t)k[2 * d] | ((uint32_t)(uint16_t)k[2 * d + 1] << 16));
+					ksums.push_back(total);
 				}
 			}
 		}
 	}
 	if (bounds.empty()) bounds.push_back(0);
 	if (coeffs.empty()) coeffs.push_back(0);
+	if (ksums.empty()) ksums.push_back(0);
 	TableSet ts;
 	PXZ_HIP(h, hipMalloc((void **)&ts.d_tabs, tabs.size() * sizeof(AxisTab)));
 	PXZ_HIP(h, hipMalloc((void **)&ts.d_bounds, bounds.size() * sizeof(uint16_t)));
-	PXZ_HIP(h, hipMalloc((void **)&ts.d_coeffs, coeffs.size() * sizeof(int16_t)));
+	PXZ_HIP(h, hipMalloc((void **)&ts.d_coeffs, coeffs.size() * sizeof(uint32_t)));
+	PXZ_HIP(h, hipMalloc((void **)&ts.d_ksums, ksums.size() * sizeof(int32_t)));
 	PXZ_HIP(h, hipMemcpy(ts.d_tabs, tabs.data(), tabs.size() * sizeof(AxisTab), hipMemcpyHostToDevice));
 	PXZ_HIP(h, hipMemcpy(ts.d_bounds, bounds.data(), bounds.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
-	PXZ_HIP(h, hipMemcpy(ts.d_coeffs, coeffs.data(), coeffs.size() * sizeof(int16_t), hipMemcpyHostToDevice));
+	PXZ_HIP(h, hipMemcpy(ts.d_coeffs, coeffs.data(), coeffs.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+	PXZ_HIP(h, hipMemcpy(ts.d_ksums, ksums.data(), ksums.size() * sizeof(int32_t), hipMemcpyHostToDevice));
 	h->tables[key] = ts;
 	*out = ts;
 	return PXZ_OK;
+}
+
+// ---- level decision tables ---------------------------------------------------
+// reference src/operations.rs:128-138
+float parse_value_host(float value)
+{
+	uint32_t bits;
+	std::memcpy(&bits, &value, 4);
+	if ((bits >> 31) == 0) return value;
+	float t = 1.0f + value;
+	return (t != t) ? 0.0f : (t > 0.0f ? t : 0.0f);
+}
+
+// level exponent of one tile of (w,h) whose directional gradient sum is `sum`
+// (operations.rs:253-258 -> pixlzr.rs:199 -> operations.rs:145-148)
+uint32_t level_of_sum(const pxz_handle *h, uint64_t sum, uint32_t w, uint32_t hh, float factor)
+{
+	const uint64_t fac = (uint64_t)(w - 2) * (uint64_t)(hh - 2) * 4096ull;
+	const float raw = (float)((double)sum / (double)fac);
+	const float v = parse_value_host(raw * factor);
+	uint32_t m = 0;
+	for (int j = 0; j < kMaxLevel; ++j) m += (v < h->thresholds[j]) ? 1u : 0u;
+	return m;
+}
+
+// Fills a->breaks / a->breaks_asc.  Oklab mode: the key is the bit pattern of the (non-negative)
+// parsed value, compared against the float thresholds' bit patterns.  Directional mode: the key is
+// the integer gradient sum; the float pipeline sum -> value -> level is monotone in the sum, so each
+// threshold becomes one integer breakpoint per tile class, found by bisection with the exact formula.
+void build_breaks(pxz_handle *h, pxz::ShrinkArgs *a)
+{
+	uint32_t fbits;
+	std::memcpy(&fbits, &a->factor, 4);
+	const auto key = std::make_tuple(a->mode, fbits, a->bw, a->bh, a->edge_w, a->edge_h);
+	auto it = h->breaks.find(key);
+	if (it != h->breaks.end()) {
+		std::memcpy(a->breaks, it->second.b, sizeof a->breaks);
+		std::memcpy(a->breaks_asc, it->second.asc, sizeof a->breaks_asc);
+		return;
+	}
+	struct Saver {
+		pxz_handle *h; pxz::ShrinkArgs *a; decltype(key) k;
+		~Saver() {
+			pxz_handle::Breaks br;
+			std::memcpy(br.b, a->breaks, sizeof br.b);
+			std::memcpy(br.asc, a->breaks_asc, sizeof br.asc);
+			h->breaks[k] = br;
+		}
+	} saver{h, a, key};
+	for (int cls = 0; cls < 4; ++cls) {
+		a->breaks_asc[cls] = 0;
+		for (int j = 0; j < kMaxLevel; ++j) std::memcpy(&a->breaks[cls][j], &h->thresholds[j], 4);
+	}
+	if (a->mode != PXZ_MODE_SHRINK_DIRECTIONALLY) return;
+	for (int cls = 0; cls < 4; ++cls) {
+		const uint32_t w = (cls & 1) ? a->edge_w : a->bw, hh = (cls & 2) ? a->edge_h : a->bh;
+		if (w <= 2 || hh <= 2) {  // 0/0 tiles are special-cased in the kernel
+			for (int j = 0; j < kMaxLevel; ++j) a->breaks[cls][j] = 0xffffffffu;
+			continue;
+		}
+		const uint64_t max_sum = (uint64_t)(w - 2) * (hh - 2) * 3u * 1020u;
+		const uint32_t m_lo = level_of_sum(h, 0, w, hh, a->factor), m_hi = level_of_sum(h, max_sum, w, hh, a->factor);
+		const bool asc = m_hi > m_lo;  // level exponent grows with the sum (negative factors)
+		a->breaks_asc[cls] = asc ? 1u : 0u;
+		for (int j = 0; j < kMaxLevel; ++j) {
+			// predicate "v < T[j]"  <=>  level exponent > j
+			auto below = [&](uint64_t s) { return level_of_sum(h, s, w, hh, a->factor) > (uint32_t)j; };
+			const bool at0 = below(0), atmax = below(max_sum);
+			uint32_t brk;
+			if (at0 == atmax) {
+				// constant: encode always-true / never for the class' comparison direction
+				const bool always = at0;
+				brk = asc ? (always ? 0u : 0xffffffffu) : (always ? 0xffffffffu : 0u);
+			} else {
+				uint64_t lo = 0, hi = max_sum;  // below(lo) == at0, below(hi) == atmax
+				while (hi - lo > 1) {
+					const uint64_t mid = lo + (hi - lo) / 2;
+					if (below(mid) == at0) lo = mid; else hi = mid;
+				}
+				brk = (uint32_t)hi;  // first sum on the far side
+			}
+			a->breaks[cls][j] = brk;
+		}
+	}
 }
 
 int check_frames(pxz_handle *h, const pxz_frames *f, const pxz_params *p)
@@ -180,13 +291,18 @@ int prepare(pxz_handle *h, const pxz_frames *f, const pxz_params *p, bool want_p
 	if ((uint64_t)cols * rows * f->n_frames > 0xffffffffull) return fail(h, PXZ_ERR_UNSUPPORTED, "too many tiles");
 	if (bw > 0xffffu || bh > 0xffffu) return fail(h, PXZ_ERR_UNSUPPORTED, "block side above 65535");
 
-	auto round4 = [](uint32_t v) { return (v + 3u) & ~3u; };
-	a->lds_src_dw = round4(bw * bh);
-	a->lds_tmp_dw = want_pixels && p->filter != PXZ_FILTER_NEAREST ? round4(ceil_div(bw, 2) * bh) : 0;
-	a->lds_lab_dw = p->mode == PXZ_MODE_SHRINK_BY ? round4(3 * bw * bh) : 0;
+	auto round2 = [](uint32_t v) { return (v + 1u) & ~1u; };
+	const bool conv = want_pixels && p->filter != PXZ_FILTER_NEAREST;
+	a->rs = round2(ceil_div(bw, 2));
+	a->plane_dw = a->rs * bh;
+	a->hps = round2(ceil_div(bh, 2));
+	a->tmp_dw = conv ? ceil_div(bw, 2) * a->hps : 0;
+	a->lab_dw = p->mode == PXZ_MODE_SHRINK_BY ? 3 * bw * bh : 0;
+	// planes | max(transposed planes, Oklab scratch) | slack for zero-weight over-reads past the last row
+	const uint32_t scratch = 4 * a->tmp_dw > a->lab_dw ? 4 * a->tmp_dw : a->lab_dw;
+	a->tile_dw = (4 * a->plane_dw + scratch + 4 * a->rs + 4 * a->hps + 3u) & ~3u;
 	const uint32_t nw = pxz::waves_per_tile(bw, bh);
-	const uint64_t per_tile = ((uint64_t)a->lds_src_dw + a->lds_tmp_dw + a->lds_lab_dw) * 4u;
-	const uint64_t lds_bytes = per_tile * (nw == 1 ? 4u : 1u) + (nw > 1 ? 4u * 4u * nw : 0u);
+	const uint64_t lds_bytes = (uint64_t)a->tile_dw * 4u * (nw == 1 ? 4u : 1u) + (nw > 1 ? 16u * nw : 0u);
 	if (lds_bytes > 160u * 1024u)
 		return fail(h, PXZ_ERR_UNSUPPORTED, "a %ux%u tile needs %llu B of LDS (limit 163840)", bw, bh,
 		            (unsigned long long)lds_bytes);
@@ -207,10 +323,11 @@ int prepare(pxz_handle *h, const pxz_frames *f, const pxz_params *p, bool want_p
 	a->filter = p->filter;
 	a->factor = p->factor;
 	a->slot_bytes = bw * bh * f->channels;
-	std::memcpy(a->thresholds, h->thresholds, sizeof a->thresholds);
+	build_breaks(h, a);
 	a->tabs = nullptr;
 	a->bounds = nullptr;
 	a->coeffs = nullptr;
+	a->ksums = nullptr;
 	if (want_pixels) {
 		TableSet ts;
 		rc = get_tables(h, bw, bh, edge_w, edge_h, p->filter, &ts);
@@ -218,12 +335,19 @@ int prepare(pxz_handle *h, const pxz_frames *f, const pxz_params *p, bool want_p
 		a->tabs = ts.d_tabs;
 		a->bounds = ts.d_bounds;
 		a->coeffs = ts.d_coeffs;
+		a->ksums = ts.d_ksums;
 	}
 	return PXZ_OK;
 }
 
-int timed_launch(pxz_handle *h, const pxz::ShrinkArgs &a, uint32_t channels)
+// fused kernel + finishing kernel (stored value / raw detector outputs), timed together
+int timed_launch(pxz_handle *h, pxz::ShrinkArgs &a, uint32_t channels, float *value, float *lod0, float *lod1)
 {
+	int rc = ensure(h, h->sums, (size_t)a.n_tiles * 8u);
+	if (rc != PXZ_OK) return rc;
+	a.sums = (uint32_t *)h->sums.ptr;
+	const pxz::FinishArgs fin{a.sums, value, lod0, lod1, a.n_tiles, a.tiles_per_frame, a.cols, a.rows,
+	                          a.bw, a.bh, a.edge_w, a.edge_h, a.mode, a.factor};
 	hipEvent_t e0 = nullptr, e1 = nullptr;
 	if (h->timing) {
 		if (h->events_used == h->events.size()) {
@@ -237,6 +361,7 @@ int timed_launch(pxz_handle *h, const pxz::ShrinkArgs &a, uint32_t channels)
 		PXZ_HIP(h, hipEventRecord(e0, h->stream));
 	}
 	PXZ_HIP(h, pxz::launch_shrink(a, channels, h->stream));
+	PXZ_HIP(h, pxz::launch_finish(fin, h->stream));
 	if (h->timing) PXZ_HIP(h, hipEventRecord(e1, h->stream));
 	return PXZ_OK;
 }
@@ -283,8 +408,9 @@ void pxz_destroy(pxz_handle *h)
 		(void)hipFree(kv.second.d_tabs);
 		(void)hipFree(kv.second.d_bounds);
 		(void)hipFree(kv.second.d_coeffs);
+		(void)hipFree(kv.second.d_ksums);
 	}
-	for (DeviceBuffer *b : {&h->in, &h->val, &h->ow, &h->oh, &h->out})
+	for (DeviceBuffer *b : {&h->in, &h->val, &h->ow, &h->oh, &h->out, &h->sums})
 		if (b->ptr) (void)hipFree(b->ptr);
 	for (auto &ev : h->events) {
 		(void)hipEventDestroy(ev.first);
@@ -329,11 +455,10 @@ int pxz_shrink_frames_device(pxz_handle *h, const pxz_frames *frames, const pxz_
 	int rc = prepare(h, frames, params, d_out_pixels != nullptr, &a);
 	if (rc != PXZ_OK) return rc;
 	a.src = d_pixels;
-	a.value = d_block_value;
 	a.out_w = d_out_w;
 	a.out_h = d_out_h;
 	a.out_px = d_out_pixels;
-	return timed_launch(h, a, frames->channels);
+	return timed_launch(h, a, frames->channels, d_block_value, nullptr, nullptr);
 }
 
 int pxz_lod_frames_device(pxz_handle *h, const pxz_frames *frames, const pxz_params *params,
@@ -346,9 +471,7 @@ int pxz_lod_frames_device(pxz_handle *h, const pxz_frames *frames, const pxz_par
 	int rc = prepare(h, frames, params, false, &a);
 	if (rc != PXZ_OK) return rc;
 	a.src = d_pixels;
-	a.lod0 = d_lod0;
-	a.lod1 = d_lod1;
-	return timed_launch(h, a, frames->channels);
+	return timed_launch(h, a, frames->channels, nullptr, d_lod0, d_lod1);
 }
 
 int pxz_shrink_image(pxz_handle *h, const uint8_t *pixels, uint32_t width, uint32_t height, uint32_t channels,

@@ -5,18 +5,22 @@
 namespace pxz {
 
 constexpr int kMaxLevel = 18;        // level exponents 0..17 (2^17 > any LDS-resident tile side)
-constexpr int kNumThresholds = 32;   // thresholds for round(log2f(v)) >= -k, k = 0..31
+constexpr int kNumThresholds = 32;   // float thresholds for round(log2f(v)) >= -k, k = 0..31
 constexpr int kWave = 64;
 
 // One down-scaling table along one axis: in_size -> out_size.
-// Convolution: bounds[bounds_off + 2*o] = first source index, [+1] = tap count;
-//              coeffs[coeff_off + o*window + i] = i16 fixed-point weight.
-// Nearest:     bounds[bounds_off + o] = source index.
+// Convolution (windows padded to whole quads of 4 source samples, zero weights in the padding):
+//   bounds[bounds_off + 2*o]     first quad (source index / 4) of output o
+//   bounds[bounds_off + 2*o + 1] number of quads
+//   coeffs[coeff_off + o*wquads*2 + 2*q + {0,1}]  packed i16 pairs (k0 | k1<<16), (k2 | k3<<16)
+//   ksums[ksum_off + o]          sum of the window's weights (constant-input shortcut)
+// Nearest: bounds[bounds_off + o] = source index.
 struct AxisTab {
 	uint32_t bounds_off;
 	uint32_t coeff_off;
+	uint32_t ksum_off;
 	uint16_t out_size;
-	uint16_t window;
+	uint16_t wquads;
 	uint16_t precision;
 	uint16_t in_size;
 };
@@ -33,23 +37,37 @@ struct ShrinkArgs {
 	uint32_t edge_w, edge_h; // size of the last column / row of tiles
 	uint32_t mode, filter;
 	float factor;
-	// outputs (device); out_px may be null (no resample), lod0/lod1 may be null
-	float *value;
+	// outputs (device); out_px may be null (no resample), out_w/out_h may be null
+	uint32_t *sums;          // 2 per tile: gradient sums (directional) | f32 value bits (Oklab); -> finish_kernel
 	uint32_t *out_w;
 	uint32_t *out_h;
 	uint8_t *out_px;
-	float *lod0;
-	float *lod1;
 	uint32_t slot_bytes;     // bw*bh*channels
 	// tables (device)
 	const AxisTab *tabs;     // [axis 0=x,1=y][cls 0=full,1=edge][kMaxLevel]
 	const uint16_t *bounds;
-	const int16_t *coeffs;
-	float thresholds[kNumThresholds];
-	// LDS carve-up (in dwords, per tile)
-	uint32_t lds_src_dw;     // bw*bh
-	uint32_t lds_tmp_dw;     // ceil(bw/2)*bh
-	uint32_t lds_lab_dw;     // 3*bw*bh in Oklab mode, else 0
+	const uint32_t *coeffs;
+	const int32_t *ksums;
+	// Level decision: m = #{j < kMaxLevel : key < breaks[cls][j]} (or key >= ... when breaks_asc[cls]),
+	// cls = ycls*2 + xcls.  directional: key = integer gradient sum; Oklab: key = bits of the parsed value.
+	uint32_t breaks[4][kMaxLevel];
+	uint32_t breaks_asc[4];
+	// LDS carve-up (dwords per tile): 4 planes of u16 pairs [y][x], 4 transposed planes [ox][y], Oklab scratch
+	uint32_t rs;             // plane row stride: round_up(ceil(bw/2), 2)
+	uint32_t plane_dw;       // rs * bh
+	uint32_t hps;            // transposed row stride: round_up(ceil(bh/2), 2)
+	uint32_t tmp_dw;         // ceil(bw/2) * hps   (0 when no convolution)
+	uint32_t lab_dw;         // Oklab mode: 3*bw*bh floats (aliases the transposed planes), else 0
+	uint32_t tile_dw;        // total dwords per tile incl. over-read slack
+};
+
+struct FinishArgs {
+	const uint32_t *sums;
+	float *value;            // may be null
+	float *lod0;             // may be null
+	float *lod1;             // may be null
+	uint32_t n_tiles, tiles_per_frame, cols, rows, bw, bh, edge_w, edge_h, mode;
+	float factor;
 };
 
 struct SynthArgs {
