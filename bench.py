@@ -107,7 +107,11 @@ def cpu_baseline(args, mode_name):
     oracle.build()
     pxz_mode, factor = MODES[mode_name]
     img = oracle.synth_frame(args.width, args.height, 4, 0, args.dist)
-    cores = os.cpu_count() or 1
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    cores = max(1, min(avail, 16))  # the GPU box grants ~16 host cores per GPU
     mp = args.width * args.height / 1e6
     best_all = best_one = None
     for _ in range(2):

@@ -17,7 +17,7 @@
 #include "pxz_tables.h"
 
 namespace pxz {
-hipError_t launch_shrink(const ShrinkArgs &a, uint32_t channels, hipStream_t stream);
+hipError_t launch_shrink(const ShrinkArgs &a, uint32_t channels, uint32_t n_cus, hipStream_t stream);
 hipError_t launch_synth(const SynthArgs &s, hipStream_t stream);
 hipError_t launch_finish(const FinishArgs &f, hipStream_t stream);
 uint32_t waves_per_tile(uint32_t bw, uint32_t bh);
@@ -30,10 +30,12 @@ using pxz::kMaxLevel;
 
 // device copy of the down-scaling tables for one (tile geometry, filter)
 struct TableSet {
-	AxisTab *d_tabs = nullptr;
+	std::vector<AxisTab> tabs;  // host copy, passed by value in the kernel arguments
 	uint16_t *d_bounds = nullptr;
 	uint32_t *d_coeffs = nullptr;
 	int32_t *d_ksums = nullptr;
+	uint32_t *d_rows = nullptr;
+	uint32_t rows_dw = 0;
 };
 
 struct DeviceBuffer {
@@ -45,6 +47,7 @@ struct DeviceBuffer {
 
 struct pxz_handle {
 	int device = 0;
+	uint32_t n_cus = 256;
 	hipStream_t stream = nullptr;
 	std::string error;
 	float thresholds[pxz::kNumThresholds];
@@ -92,6 +95,15 @@ int ensure(pxz_handle *h, DeviceBuffer &b, size_t bytes)
 
 uint32_t ceil_div(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
 
+// magic number for unsigned division by d >= 1 (exact for every 32-bit dividend)
+pxz::FastDiv make_fastdiv(uint32_t d)
+{
+	uint32_t l = 0;
+	while ((1ull << l) < d) ++l;  // ceil(log2 d)
+	const uint64_t m = ((1ull << 32) * ((1ull << l) - d)) / d + 1;
+	return pxz::FastDiv{(uint32_t)m, l < 1 ? l : 1u, l < 1 ? 0u : l - 1};
+}
+
 // reduced size for level exponent m (reference operations.rs:150-151)
 uint32_t reduced(uint32_t size, uint32_t m)
 {
@@ -101,18 +113,19 @@ uint32_t reduced(uint32_t size, uint32_t m)
 }
 
 int get_tables(pxz_handle *h, uint32_t bw, uint32_t bh, uint32_t edge_w, uint32_t edge_h, uint32_t filter,
-               TableSet *out)
+               const TableSet **out)
 {
 	auto key = std::make_tuple(bw, bh, edge_w, edge_h, filter);
 	auto it = h->tables.find(key);
 	if (it != h->tables.end()) {
-		*out = it->second;
+		*out = &it->second;
 		return PXZ_OK;
 	}
 	std::vector<AxisTab> tabs(2 * 2 * kMaxLevel);
 	std::vector<uint16_t> bounds;
 	std::vector<uint32_t> coeffs;
 	std::vector<int32_t> ksums;
+	std::vector<uint32_t> rows;
 	const uint32_t sizes[2][2] = {{bw, edge_w}, {bh, edge_h}};
 	for (int axis = 0; axis < 2; ++axis) {
 		for (int cls = 0; cls < 2; ++cls) {
@@ -120,8 +133,19 @@ int get_tables(pxz_handle *h, uint32_t bw, uint32_t bh, uint32_t edge_w, uint32_
 			for (int m = 0; m < kMaxLevel; ++m) {
 				AxisTab &t = tabs[(axis * 2 + cls) * kMaxLevel + m];
 				const uint32_t outsz = reduced(in, (uint32_t)m);
-				t = AxisTab{0, 0, 0, (uint16_t)outsz, 0, 0, (uint16_t)in};
+				t = AxisTab{0, 0, 0, 0, 0, (uint16_t)outsz, 0, 0, (uint16_t)in};
 				if (outsz == in) continue;  // identity: never looked up
+				// identical (in, out) pairs share one table: the edge class of a grid without ragged
+				// edge, and every level past the first that reaches 1 px
+				if (cls == 1 && sizes[axis][1] == sizes[axis][0]) {
+					t = tabs[(axis * 2 + 0) * kMaxLevel + m];
+					continue;
+				}
+				if (m > 0 && tabs[(axis * 2 + cls) * kMaxLevel + m - 1].out_size == outsz &&
+				    tabs[(axis * 2 + cls) * kMaxLevel + m - 1].in_size == in && reduced(in, (uint32_t)m - 1) != in) {
+					t = tabs[(axis * 2 + cls) * kMaxLevel + m - 1];
+					continue;
+				}
 				pxz::AxisWindows win;
 				if (!pxz::build_axis(in, outsz, filter, &win)) return fail(h, PXZ_ERR_INVALID_ARG, "unknown filter %u", filter);
 				t.bounds_off = (uint32_t)bounds.size();
@@ -140,6 +164,8 @@ int get_tables(pxz_handle *h, uint32_t bw, uint32_t bh, uint32_t edge_w, uint32_
 					if (nq > wquads) wquads = nq;
 				}
 				t.wquads = (uint16_t)wquads;
+				t.rows_off = (uint32_t)rows.size();
+				t.row_stride = (4u + wquads * 2u + 3u) & ~3u;
 				for (uint32_t o = 0; o < outsz; ++o) {
 					const uint32_t first = (uint32_t)win.starts[o], n = (uint32_t)win.sizes[o];
 					const uint32_t lead = first & 3u, nq = (lead + n + 3u) / 4u;
@@ -151,8 +177,16 @@ int get_tables(pxz_handle *h, uint32_t bw, uint32_t bh, uint32_t edge_w, uint32_
 						k[lead + i] = win.coeffs[(size_t)o * win.window + i];
 						total += k[lead + i];
 					}
-					for (uint32_t d = 0; d < wquads * 2u; ++d)
-						coeffs.push_back((uint32_t)(uint16_t)k[2 * d] | ((uint32_t)(uint16_t)k[2 * d + 1] << 16));
+					const size_t row0 = rows.size();
+					rows.resize(row0 + t.row_stride, 0u);
+					rows[row0 + 0] = first / 4u;
+					rows[row0 + 1] = nq;
+					rows[row0 + 2] = (uint32_t)total;
+					for (uint32_t d = 0; d < wquads * 2u; ++d) {
+						const uint32_t pr = (uint32_t)(uint16_t)k[2 * d] | ((uint32_t)(uint16_t)k[2 * d + 1] << 16);
+						coeffs.push_back(pr);
+						rows[row0 + 4 + d] = pr;
+					}
 					ksums.push_back(total);
 				}
 			}
@@ -161,17 +195,20 @@ int get_tables(pxz_handle *h, uint32_t bw, uint32_t bh, uint32_t edge_w, uint32_
 	if (bounds.empty()) bounds.push_back(0);
 	if (coeffs.empty()) coeffs.push_back(0);
 	if (ksums.empty()) ksums.push_back(0);
+	rows.resize(rows.size() + 32, 0u);  // the fast path always fetches 4+16 dwords per row
 	TableSet ts;
-	PXZ_HIP(h, hipMalloc((void **)&ts.d_tabs, tabs.size() * sizeof(AxisTab)));
+	ts.tabs = tabs;
 	PXZ_HIP(h, hipMalloc((void **)&ts.d_bounds, bounds.size() * sizeof(uint16_t)));
 	PXZ_HIP(h, hipMalloc((void **)&ts.d_coeffs, coeffs.size() * sizeof(uint32_t)));
 	PXZ_HIP(h, hipMalloc((void **)&ts.d_ksums, ksums.size() * sizeof(int32_t)));
-	PXZ_HIP(h, hipMemcpy(ts.d_tabs, tabs.data(), tabs.size() * sizeof(AxisTab), hipMemcpyHostToDevice));
 	PXZ_HIP(h, hipMemcpy(ts.d_bounds, bounds.data(), bounds.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
 	PXZ_HIP(h, hipMemcpy(ts.d_coeffs, coeffs.data(), coeffs.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
 	PXZ_HIP(h, hipMemcpy(ts.d_ksums, ksums.data(), ksums.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+	ts.rows_dw = (uint32_t)rows.size();
+	PXZ_HIP(h, hipMalloc((void **)&ts.d_rows, rows.size() * sizeof(uint32_t)));
+	PXZ_HIP(h, hipMemcpy(ts.d_rows, rows.data(), rows.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
 	h->tables[key] = ts;
-	*out = ts;
+	*out = &h->tables[key];
 	return PXZ_OK;
 }
 
@@ -293,16 +330,17 @@ int prepare(pxz_handle *h, const pxz_frames *f, const pxz_params *p, bool want_p
 
 	auto round2 = [](uint32_t v) { return (v + 1u) & ~1u; };
 	const bool conv = want_pixels && p->filter != PXZ_FILTER_NEAREST;
-	a->rs = round2(ceil_div(bw, 2));
+	auto skew = [](uint32_t v) { return (v & 15u) == 0 ? v + 2u : v; };  // keep rows off a common LDS bank
+	a->rs = skew(round2(ceil_div(bw, 2)));
 	a->plane_dw = a->rs * bh;
-	a->hps = round2(ceil_div(bh, 2));
+	a->hps = skew(round2(ceil_div(bh, 2)));
 	a->tmp_dw = conv ? ceil_div(bw, 2) * a->hps : 0;
 	a->lab_dw = p->mode == PXZ_MODE_SHRINK_BY ? 3 * bw * bh : 0;
 	// planes | max(transposed planes, Oklab scratch) | slack for zero-weight over-reads past the last row
 	const uint32_t scratch = 4 * a->tmp_dw > a->lab_dw ? 4 * a->tmp_dw : a->lab_dw;
 	a->tile_dw = (4 * a->plane_dw + scratch + 4 * a->rs + 4 * a->hps + 3u) & ~3u;
 	const uint32_t nw = pxz::waves_per_tile(bw, bh);
-	const uint64_t lds_bytes = (uint64_t)a->tile_dw * 4u * (nw == 1 ? 4u : 1u) + (nw > 1 ? 16u * nw : 0u);
+	const uint64_t lds_bytes = (uint64_t)a->tile_dw * 4u + (nw > 1 ? 16u * nw : 0u);
 	if (lds_bytes > 160u * 1024u)
 		return fail(h, PXZ_ERR_UNSUPPORTED, "a %ux%u tile needs %llu B of LDS (limit 163840)", bw, bh,
 		            (unsigned long long)lds_bytes);
@@ -316,6 +354,8 @@ int prepare(pxz_handle *h, const pxz_frames *f, const pxz_params *p, bool want_p
 	a->cols = cols;
 	a->rows = rows;
 	a->tiles_per_frame = cols * rows;
+	a->div_tpf = make_fastdiv(cols * rows);
+	a->div_cols = make_fastdiv(cols);
 	a->n_tiles = cols * rows * f->n_frames;
 	a->edge_w = edge_w;
 	a->edge_h = edge_h;
@@ -324,18 +364,23 @@ int prepare(pxz_handle *h, const pxz_frames *f, const pxz_params *p, bool want_p
 	a->factor = p->factor;
 	a->slot_bytes = bw * bh * f->channels;
 	build_breaks(h, a);
-	a->tabs = nullptr;
+	std::memset(a->tabs, 0, sizeof a->tabs);
 	a->bounds = nullptr;
 	a->coeffs = nullptr;
 	a->ksums = nullptr;
+	a->trows = nullptr;
+	a->tab_dw = 0;
 	if (want_pixels) {
-		TableSet ts;
-		rc = get_tables(h, bw, bh, edge_w, edge_h, p->filter, &ts);
+		const TableSet *tsp = nullptr;
+		rc = get_tables(h, bw, bh, edge_w, edge_h, p->filter, &tsp);
 		if (rc != PXZ_OK) return rc;
-		a->tabs = ts.d_tabs;
+		const TableSet &ts = *tsp;
+		std::memcpy(a->tabs, ts.tabs.data(), sizeof a->tabs);
 		a->bounds = ts.d_bounds;
 		a->coeffs = ts.d_coeffs;
 		a->ksums = ts.d_ksums;
+		a->trows = ts.d_rows;
+		a->tab_dw = ts.rows_dw * 4u <= 48u * 1024u ? (ts.rows_dw + 3u) & ~3u : 0u;
 	}
 	return PXZ_OK;
 }
@@ -360,7 +405,7 @@ int timed_launch(pxz_handle *h, pxz::ShrinkArgs &a, uint32_t channels, float *va
 		++h->events_used;
 		PXZ_HIP(h, hipEventRecord(e0, h->stream));
 	}
-	PXZ_HIP(h, pxz::launch_shrink(a, channels, h->stream));
+	PXZ_HIP(h, pxz::launch_shrink(a, channels, h->n_cus, h->stream));
 	PXZ_HIP(h, pxz::launch_finish(fin, h->stream));
 	if (h->timing) PXZ_HIP(h, hipEventRecord(e1, h->stream));
 	return PXZ_OK;
@@ -392,6 +437,7 @@ int pxz_create(int device_id, pxz_handle **out)
 	pxz_handle *h = new (std::nothrow) pxz_handle();
 	if (!h) return PXZ_ERR_NOMEM;
 	h->device = device_id;
+	h->n_cus = prop.multiProcessorCount > 0 ? (uint32_t)prop.multiProcessorCount : 256u;
 	if (!pxz::build_level_thresholds(h->thresholds, pxz::kNumThresholds)) {
 		delete h;
 		return PXZ_ERR_UNSUPPORTED;  // platform log2f is not a clean step around 2^(k+1/2)
@@ -405,10 +451,10 @@ void pxz_destroy(pxz_handle *h)
 	if (!h) return;
 	(void)hipSetDevice(h->device);
 	for (auto &kv : h->tables) {
-		(void)hipFree(kv.second.d_tabs);
 		(void)hipFree(kv.second.d_bounds);
 		(void)hipFree(kv.second.d_coeffs);
 		(void)hipFree(kv.second.d_ksums);
+		(void)hipFree(kv.second.d_rows);
 	}
 	for (DeviceBuffer *b : {&h->in, &h->val, &h->ow, &h->oh, &h->out, &h->sums})
 		if (b->ptr) (void)hipFree(b->ptr);

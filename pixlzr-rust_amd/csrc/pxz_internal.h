@@ -19,10 +19,17 @@ struct AxisTab {
 	uint32_t bounds_off;
 	uint32_t coeff_off;
 	uint32_t ksum_off;
+	uint32_t rows_off;       // unified rows (fast path): per output row_stride dwords =
+	uint32_t row_stride;     //   {first quad, quads, weight sum, 0} + wquads*2 packed pairs, 16-B aligned
 	uint16_t out_size;
 	uint16_t wquads;
 	uint16_t precision;
 	uint16_t in_size;
+};
+
+// q = n / d as (t + ((n - t) >> sh1)) >> sh2 with t = mulhi(n, mul)  (Granlund-Montgomery)
+struct FastDiv {
+	uint32_t mul, sh1, sh2;
 };
 
 struct ShrinkArgs {
@@ -34,6 +41,7 @@ struct ShrinkArgs {
 	uint32_t cols, rows;
 	uint32_t tiles_per_frame;
 	uint32_t n_tiles;        // n_frames * tiles_per_frame
+	FastDiv div_tpf, div_cols;
 	uint32_t edge_w, edge_h; // size of the last column / row of tiles
 	uint32_t mode, filter;
 	float factor;
@@ -44,21 +52,29 @@ struct ShrinkArgs {
 	uint8_t *out_px;
 	uint32_t slot_bytes;     // bw*bh*channels
 	// tables (device)
-	const AxisTab *tabs;     // [axis 0=x,1=y][cls 0=full,1=edge][kMaxLevel]
+	AxisTab tabs[4 * kMaxLevel];  // [axis 0=x,1=y][cls 0=full,1=edge][kMaxLevel], in the kernarg segment:
+	                              // scalar loads, never behind the vector-memory counter
 	const uint16_t *bounds;
 	const uint32_t *coeffs;
 	const int32_t *ksums;
+	const uint32_t *trows;   // unified table rows, padded by 32 dwords
+	uint32_t tab_dw;         // dwords of trows to keep in LDS (multiple of 4), 0 = too large / unused
 	// Level decision: m = #{j < kMaxLevel : key < breaks[cls][j]} (or key >= ... when breaks_asc[cls]),
 	// cls = ycls*2 + xcls.  directional: key = integer gradient sum; Oklab: key = bits of the parsed value.
 	uint32_t breaks[4][kMaxLevel];
 	uint32_t breaks_asc[4];
 	// LDS carve-up (dwords per tile): 4 planes of u16 pairs [y][x], 4 transposed planes [ox][y], Oklab scratch
-	uint32_t rs;             // plane row stride: round_up(ceil(bw/2), 2)
+	uint32_t rs;             // plane row stride: round_up(ceil(bw/2), 2), +2 of bank skew when a multiple of 16
 	uint32_t plane_dw;       // rs * bh
-	uint32_t hps;            // transposed row stride: round_up(ceil(bh/2), 2)
+	uint32_t hps;            // transposed row stride: round_up(ceil(bh/2), 2), +2 of bank skew likewise
 	uint32_t tmp_dw;         // ceil(bw/2) * hps   (0 when no convolution)
 	uint32_t lab_dw;         // Oklab mode: 3*bw*bh floats (aliases the transposed planes), else 0
 	uint32_t tile_dw;        // total dwords per tile incl. over-read slack
+};
+
+struct LaunchGeom {
+	uint32_t blocks, threads, lds_bytes;
+	bool fast32;
 };
 
 struct FinishArgs {

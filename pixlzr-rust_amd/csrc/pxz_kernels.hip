@@ -13,6 +13,7 @@
 // written into the bitstream, and the reference (Rust) never fuses a*b+c.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "pxz_internal.h"
 
@@ -44,6 +45,14 @@ __constant__ RecipAlphaTable kRecipAlpha = RecipAlphaTable();
 
 // Walks i = first, first+step, ... while tracking (row, col) = (i / width, i % width)
 // without a division per element.
+// n / d for a host-prepared divisor (round-up magic number): stays on the scalar unit for
+// wave-uniform n, where a plain `/` would expand to ~25 VALU instructions.
+__device__ __forceinline__ uint32_t fastdiv(uint32_t n, const FastDiv &d)
+{
+	const uint32_t t = __umulhi(n, d.mul);
+	return (t + ((n - t) >> d.sh1)) >> d.sh2;
+}
+
 struct RowWalker {
 	uint32_t row, col, drow, dcol, width;
 	__device__ RowWalker(uint32_t first, uint32_t step, uint32_t width_) : width(width_)
@@ -275,6 +284,224 @@ __device__ __forceinline__ uint32_t level_count(uint32_t key, const uint32_t *br
 }
 
 // ---------------------------------------------------------------------------
+// resample fast path: full, opaque 32x32 RGBA tile, both passes needed.
+// Compile-time geometry (plane row stride 18 dwords -- 16 + 2 of bank skew --, plane 576
+// dwords, transposed plane [ox][18 dwords] = 288 dwords) turns every LDS address into
+// base+immediate and keeps the row groups / output columns on distinct banks.
+// Work items are spread over all 64 lanes: when there are fewer than 64 outputs the
+// filter window itself is split over 2..8 lanes and summed with DPP.
+// ---------------------------------------------------------------------------
+constexpr uint32_t kRS32 = 18, kPD32 = 18 * 32, kHS32 = 18, kTD32 = 16 * 18;
+
+template <int LPI>
+__device__ __forceinline__ int32_t group_sum(int32_t v)
+{
+	if constexpr (LPI == 8) v += (int32_t)dpp_mov<0x141>((uint32_t)v);  // row_half_mirror: i <-> 7-i
+	if constexpr (LPI >= 4) v += (int32_t)dpp_mov<0x4E>((uint32_t)v);   // quad_perm [2,3,0,1]
+	if constexpr (LPI >= 2) v += (int32_t)dpp_mov<0xB1>((uint32_t)v);   // quad_perm [1,0,3,2]
+	return v;
+}
+
+// A lane's table row: header {first quad, quads, weight sum} + up to 8 quads of packed weights,
+// fetched as independent 16-byte loads (one memory latency instead of one per window step).
+struct RowRegs {
+	uint32_t fq, nq;
+	int32_t ksum;
+	uint32_t k[16];
+};
+__device__ __forceinline__ void load_row(const uint32_t *rowp, RowRegs &r)
+{
+	const uint4 h = *reinterpret_cast<const uint4 *>(rowp);
+	const uint4 c0 = *reinterpret_cast<const uint4 *>(rowp + 4), c1 = *reinterpret_cast<const uint4 *>(rowp + 8);
+	const uint4 c2 = *reinterpret_cast<const uint4 *>(rowp + 12), c3 = *reinterpret_cast<const uint4 *>(rowp + 16);
+	r.fq = h.x;
+	r.nq = h.y;
+	r.ksum = (int32_t)h.z;
+	r.k[0] = c0.x; r.k[1] = c0.y; r.k[2] = c0.z; r.k[3] = c0.w;
+	r.k[4] = c1.x; r.k[5] = c1.y; r.k[6] = c1.z; r.k[7] = c1.w;
+	r.k[8] = c2.x; r.k[9] = c2.y; r.k[10] = c2.z; r.k[11] = c2.w;
+	r.k[12] = c3.x; r.k[13] = c3.y; r.k[14] = c3.z; r.k[15] = c3.w;
+}
+
+// horizontal pass, one source row per item: item = (ox, y), the window split over LPI lanes
+// (each lane takes quads part, part+LPI, ...; weights beyond the window are zero in the table)
+template <int LPI>
+__device__ __forceinline__ void fast32_h_rows(const uint32_t *trows, const AxisTab &tx, const uint32_t *s_pl, uint32_t *s_tmp,
+                                              uint32_t lane, uint32_t nw, uint32_t lgx)
+{
+	// outputs this narrow (nw <= 2) always see the whole 32-px row: 8 quads, all taken
+	constexpr int QPL = 8 / LPI;  // quads per lane
+	const uint32_t item = lane / LPI, part = lane % LPI;
+	const bool live = item < nw * 32u;
+	const uint32_t ox = item & (nw - 1u), y = live ? item >> lgx : 0u;
+	const uint32_t *rowp = trows + tx.rows_off + ox * tx.row_stride;
+	const uint4 hdr = *reinterpret_cast<const uint4 *>(rowp);
+	uint2 kk[QPL];
+#pragma unroll
+	for (int j = 0; j < QPL; ++j) kk[j] = *reinterpret_cast<const uint2 *>(rowp + 4 + 2 * (part + j * LPI));
+	const uint32_t *row = s_pl + y * kRS32 + hdr.x * 2u + part * 2u;
+	int32_t a0 = 0, a1 = 0, a2 = 0;
+#pragma unroll
+	for (int j = 0; j < QPL; ++j) {
+		const uint2 d0 = *reinterpret_cast<const uint2 *>(row + j * LPI * 2);
+		const uint2 d1 = *reinterpret_cast<const uint2 *>(row + kPD32 + j * LPI * 2);
+		const uint2 d2 = *reinterpret_cast<const uint2 *>(row + 2 * kPD32 + j * LPI * 2);
+		a0 = dot2(d0.y, kk[j].y, dot2(d0.x, kk[j].x, a0));
+		a1 = dot2(d1.y, kk[j].y, dot2(d1.x, kk[j].x, a1));
+		a2 = dot2(d2.y, kk[j].y, dot2(d2.x, kk[j].x, a2));
+	}
+	a0 = group_sum<LPI>(a0);
+	a1 = group_sum<LPI>(a1);
+	a2 = group_sum<LPI>(a2);
+	if (live && part == 0) {
+		const int prec = tx.precision;
+		const int32_t init = 1 << (prec - 1);
+		uint16_t *t16 = reinterpret_cast<uint16_t *>(s_tmp) + ox * (2 * kHS32) + y;
+		t16[0] = (uint16_t)clip8(a0 + init, prec);
+		t16[2 * kTD32] = (uint16_t)clip8(a1 + init, prec);
+		t16[4 * kTD32] = (uint16_t)clip8(a2 + init, prec);
+	}
+}
+
+// vertical pass over the transposed planes, window split over LPI lanes; item = (oy fastest, ox),
+// so that a lane keeps the same output row (= the same table row) across iterations
+template <int LPI>
+__device__ __forceinline__ void fast32_v(const uint32_t *trows, const AxisTab &tx, const AxisTab &ty, const uint32_t *s_tmp,
+                                         uint32_t lane, uint32_t nw, uint32_t nh, uint8_t *dst)
+{
+	constexpr int QPL = 8 / LPI;
+	const uint32_t items = nw * nh;
+	const uint32_t lgy = 31u - (uint32_t)__builtin_clz(nh);
+	const uint32_t part = lane % LPI, item0 = lane / LPI;
+	const uint32_t oy = item0 & (nh - 1u);  // invariant: the item step (64/LPI) is a multiple of nh
+	const uint32_t *rowp = trows + ty.rows_off + oy * ty.row_stride;
+	const uint4 hdr = *reinterpret_cast<const uint4 *>(rowp);
+	uint2 kk[QPL];
+#pragma unroll
+	for (int j = 0; j < QPL; ++j) kk[j] = *reinterpret_cast<const uint2 *>(rowp + 4 + 2 * (part + j * LPI));
+	const uint32_t wq = ty.wquads;
+	const int px_ = tx.precision, py = ty.precision;
+	const int32_t ix = 1 << (px_ - 1), iy = 1 << (py - 1);
+	for (uint32_t item = item0; item < ((items + 63u / LPI) & ~(64u / LPI - 1u)); item += 64u / LPI) {
+		const bool live = item < items;
+		const uint32_t ox = live ? item >> lgy : 0u;
+		const uint32_t *colp = s_tmp + ox * kHS32 + hdr.x * 2u + part * 2u;
+		int32_t a0 = 0, a1 = 0, a2 = 0;
+#pragma unroll
+		for (int j = 0; j < QPL; ++j) {
+			if (LPI > 1 || (uint32_t)j < wq) {  // LPI == 1: wave-uniform trim of the zero-weight tail
+				const uint2 d0 = *reinterpret_cast<const uint2 *>(colp + j * LPI * 2);
+				const uint2 d1 = *reinterpret_cast<const uint2 *>(colp + kTD32 + j * LPI * 2);
+				const uint2 d2 = *reinterpret_cast<const uint2 *>(colp + 2 * kTD32 + j * LPI * 2);
+				a0 = dot2(d0.y, kk[j].y, dot2(d0.x, kk[j].x, a0));
+				a1 = dot2(d1.y, kk[j].y, dot2(d1.x, kk[j].x, a1));
+				a2 = dot2(d2.y, kk[j].y, dot2(d2.x, kk[j].x, a2));
+			}
+		}
+		a0 = group_sum<LPI>(a0);
+		a1 = group_sum<LPI>(a1);
+		a2 = group_sum<LPI>(a2);
+		if (live && part == 0) {
+			// opaque tile: alpha is the convolution of the constant 255 = the windows' weight sums
+			const int32_t ksx = (int32_t)trows[tx.rows_off + ox * tx.row_stride + 2];
+			const int32_t ah = (int32_t)clip8(ix + 255 * ksx, px_);
+			const uint32_t al = clip8(iy + ah * (int32_t)hdr.z, py);
+			uint32_t px = clip8(a0 + iy, py) | (clip8(a1 + iy, py) << 8) | (clip8(a2 + iy, py) << 16) | (al << 24);
+			if (al != 255u) px = unpremultiply(px);
+			reinterpret_cast<uint32_t *>(dst)[oy * nw + ox] = px;
+		}
+	}
+}
+
+// horizontal pass, item = (ox, pair of rows): nw*16 items, nw/4 per lane, the same ox (table row)
+// every time; WQ = quads per window (weights past a lane's own window are zero in the table)
+template <int WQ>
+__device__ __forceinline__ void fast32_h_pairs(const uint32_t *trows, const AxisTab &tx, const uint32_t *s_pl, uint32_t *s_tmp,
+                                               uint32_t lane, uint32_t nw, uint32_t lgx)
+{
+	const uint32_t ox = lane & (nw - 1u);
+	RowRegs r;
+	load_row(trows + tx.rows_off + ox * tx.row_stride, r);
+	const int prec = tx.precision;
+	const int32_t init = 1 << (prec - 1);
+	for (uint32_t i = lane; i < nw * 16u; i += 64u) {
+		const uint32_t yp = i >> lgx;
+		const uint32_t *row = s_pl + yp * (2 * kRS32) + r.fq * 2u;
+		int32_t a0 = init, a1 = init, a2 = init, b0 = init, b1 = init, b2 = init;
+#pragma unroll
+		for (int q = 0; q < WQ; ++q) {
+			const uint2 d0 = *reinterpret_cast<const uint2 *>(row + q * 2);
+			const uint2 e0 = *reinterpret_cast<const uint2 *>(row + kRS32 + q * 2);
+			const uint2 d1 = *reinterpret_cast<const uint2 *>(row + kPD32 + q * 2);
+			const uint2 e1 = *reinterpret_cast<const uint2 *>(row + kPD32 + kRS32 + q * 2);
+			const uint2 d2 = *reinterpret_cast<const uint2 *>(row + 2 * kPD32 + q * 2);
+			const uint2 e2 = *reinterpret_cast<const uint2 *>(row + 2 * kPD32 + kRS32 + q * 2);
+			const uint32_t k01 = r.k[2 * q], k23 = r.k[2 * q + 1];
+			a0 = dot2(d0.y, k23, dot2(d0.x, k01, a0));
+			b0 = dot2(e0.y, k23, dot2(e0.x, k01, b0));
+			a1 = dot2(d1.y, k23, dot2(d1.x, k01, a1));
+			b1 = dot2(e1.y, k23, dot2(e1.x, k01, b1));
+			a2 = dot2(d2.y, k23, dot2(d2.x, k01, a2));
+			b2 = dot2(e2.y, k23, dot2(e2.x, k01, b2));
+		}
+		uint32_t *t = s_tmp + ox * kHS32 + yp;
+		t[0] = clip8(a0, prec) | (clip8(b0, prec) << 16);
+		t[kTD32] = clip8(a1, prec) | (clip8(b1, prec) << 16);
+		t[2 * kTD32] = clip8(a2, prec) | (clip8(b2, prec) << 16);
+	}
+}
+
+__device__ __forceinline__ void resample_fast32_hv(const ShrinkArgs &a, const uint32_t *trows, const AxisTab &tx, const AxisTab &ty,
+                                                   uint32_t *s_pl, uint32_t *s_tmp, uint32_t lane, uint32_t nw,
+                                                   uint32_t nh, uint8_t *dst)
+{
+	const uint32_t lgx = 31u - (uint32_t)__builtin_clz(nw);  // nw is a power of two <= 16
+	if (nw >= 4) {
+		switch (tx.wquads) {  // straight-line window code per size: no branches between LDS reads and dot2s
+		case 4: fast32_h_pairs<4>(trows, tx, s_pl, s_tmp, lane, nw, lgx); break;
+		case 5: fast32_h_pairs<5>(trows, tx, s_pl, s_tmp, lane, nw, lgx); break;
+		case 6: fast32_h_pairs<6>(trows, tx, s_pl, s_tmp, lane, nw, lgx); break;
+		case 7: fast32_h_pairs<7>(trows, tx, s_pl, s_tmp, lane, nw, lgx); break;
+		default: fast32_h_pairs<8>(trows, tx, s_pl, s_tmp, lane, nw, lgx); break;
+		}
+	} else if (nw == 2) {
+		fast32_h_rows<1>(trows, tx, s_pl, s_tmp, lane, nw, lgx);
+	} else {
+		fast32_h_rows<2>(trows, tx, s_pl, s_tmp, lane, nw, lgx);
+	}
+	tile_sync<1>();
+	const uint32_t items = nw * nh;
+	if (items >= 64u) fast32_v<1>(trows, tx, ty, s_tmp, lane, nw, nh, dst);
+	else if (items >= 32u) fast32_v<2>(trows, tx, ty, s_tmp, lane, nw, nh, dst);
+	else if (items >= 16u) fast32_v<4>(trows, tx, ty, s_tmp, lane, nw, nh, dst);
+	else fast32_v<8>(trows, tx, ty, s_tmp, lane, nw, nh, dst);
+}
+
+// Fast-path eligibility of a tile (full 32x32 RGBA, 16-byte aligned rows) and its first byte.
+__device__ __forceinline__ bool fast32_tile_src(const ShrinkArgs &a, uint32_t tile_g, const uint8_t *&src)
+{
+	if (tile_g >= a.n_tiles) return false;
+	const uint32_t frame = fastdiv(tile_g, a.div_tpf);
+	const uint32_t t = tile_g - frame * a.tiles_per_frame;
+	const uint32_t ty = fastdiv(t, a.div_cols), tx = t - ty * a.cols;
+	const uint32_t w = (tx == a.cols - 1) ? a.edge_w : a.bw;
+	const uint32_t h = (ty == a.rows - 1) ? a.edge_h : a.bh;
+	src = a.src + (size_t)frame * a.frame_stride + (size_t)(ty * 32u) * a.pitch + (size_t)(tx * 32u) * 4u;
+	return w == 32 && h == 32 && ((reinterpret_cast<uintptr_t>(src) | a.pitch) & 15u) == 0;
+}
+// Issues the four 16-byte loads of a lane's share of a fast tile (rows l/8 + 8k, quad l%8).
+__device__ __forceinline__ void fast32_prefetch(const ShrinkArgs &a, uint32_t tile_g, uint32_t lane, uint4 (&pre)[4], bool &valid)
+{
+	const uint8_t *src;
+	valid = fast32_tile_src(a, tile_g, src);
+	if (valid) {
+		const uint8_t *p = src + (size_t)(lane >> 3) * a.pitch + (lane & 7u) * 16u;
+#pragma unroll
+		for (int k = 0; k < 4; ++k) pre[k] = *reinterpret_cast<const uint4 *>(p + (size_t)(8 * k) * a.pitch);
+	}
+}
+
+// ---------------------------------------------------------------------------
 // the fused shrink kernel
 // ---------------------------------------------------------------------------
 // NW   waves cooperating on one tile (1: four independent tiles per 256-thread
@@ -289,19 +516,14 @@ __device__ __forceinline__ uint32_t level_count(uint32_t key, const uint32_t *br
 // transposed ([ox][y], two rows per dword) so the vertical pass is dot2-shaped too.
 // TW   compile-time tile side (32) enabling the fast path for full RGBA tiles, 0 = none
 template <int NW, int C, int MODE, int TW>
-__global__ void __launch_bounds__(NW == 1 ? 256 : 64 * NW) shrink_kernel(const ShrinkArgs a)
+__device__ __forceinline__ void process_tile(const ShrinkArgs &a, const uint32_t tile_g, uint32_t *s_pl, uint32_t *s_red,
+                                             const uint32_t *s_tab, const uint32_t tid, uint4 (&pre)[4], bool &pre_valid,
+                                             const uint32_t next_tile)
 {
-	extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
 	constexpr uint32_t TPT = 64u * NW;                // threads per tile
-	constexpr uint32_t TPB = NW == 1 ? 4u : 1u;       // tiles per block
-	const uint32_t sub = NW == 1 ? threadIdx.x / 64u : 0u;
-	const uint32_t tid = NW == 1 ? threadIdx.x % 64u : threadIdx.x;
-	const uint32_t tile_g = blockIdx.x * TPB + sub;
-	if (tile_g >= a.n_tiles) return;  // whole wave (NW==1) or whole block (NW>1)
-
-	const uint32_t frame = tile_g / a.tiles_per_frame;
+	const uint32_t frame = fastdiv(tile_g, a.div_tpf);
 	const uint32_t t = tile_g - frame * a.tiles_per_frame;
-	const uint32_t ty = t / a.cols, tx = t - ty * a.cols;
+	const uint32_t ty = fastdiv(t, a.div_cols), tx = t - ty * a.cols;
 	const uint32_t w = (tx == a.cols - 1) ? a.edge_w : a.bw;  // split.rs:18
 	const uint32_t h = (ty == a.rows - 1) ? a.edge_h : a.bh;  // split.rs:19
 	const uint32_t n = w * h;
@@ -309,37 +531,35 @@ __global__ void __launch_bounds__(NW == 1 ? 256 : 64 * NW) shrink_kernel(const S
 	const uint8_t *src = a.src + (size_t)frame * a.frame_stride + (size_t)(ty * a.bh) * a.pitch + (size_t)(tx * a.bw) * C;
 
 	const uint32_t rs = a.rs, PD = a.plane_dw;
-	uint32_t *s_pl = lds + sub * a.tile_dw;
 	uint32_t *s_tmp = s_pl + 4 * PD;
 	uint16_t *pl16 = reinterpret_cast<uint16_t *>(s_pl);
 	float *s_lab = reinterpret_cast<float *>(s_tmp);
-	uint32_t *s_red = lds + TPB * a.tile_dw;  // 4*NW dwords, only carved (and used) when NW > 1
-	(void)s_red;
+	(void)s_red;  // 4*NW dwords, only carved (and used) when NW > 1
 	(void)s_lab;
+	(void)s_tab;
 
 	// ---- stage the tile: coalesced 16-B loads along image rows -> planar u16 pairs ----
 	uint32_t alpha_and = 0xffu;
-	uint4 raw[4];
 	const uint32_t qpr = w >> 2, nquad = qpr * h;
 	const bool vec = C == 4 && ((w & 3u) == 0) && ((reinterpret_cast<uintptr_t>(src) & 15u) == 0) &&
 	                 ((a.pitch & 15u) == 0) && nquad <= 4u * TPT;
-	// full 32x32 RGBA tile of the fast path: every index below is a shift/mask
-	const bool fast = TW == 32 && NW == 1 && C == 4 && vec && w == 32 && h == 32 && rs == 16;
+	// full 32x32 RGBA tile of the fast path: its pixels were requested one tile ago and are
+	// already in registers; every index below is a shift/mask
+	const bool fast = TW == 32 && NW == 1 && C == 4 && pre_valid;
 	if (fast) {
 #pragma unroll
 		for (int k = 0; k < 4; ++k) {
 			const uint32_t row = (tid >> 3) + 8u * (uint32_t)k, col = tid & 7u;
-			const uint4 v = *reinterpret_cast<const uint4 *>(src + (size_t)row * a.pitch + col * 16u);
-			raw[k] = v;
+			const uint4 v = pre[k];
 			alpha_and &= (v.x & v.y & v.z & v.w) >> 24;
-			uint32_t *d = s_pl + row * 16u + col * 2u;
+			uint32_t *d = s_pl + row * kRS32 + col * 2u;
 #pragma unroll
 			for (uint32_t c = 0; c < 4; ++c) {
 				const uint32_t sel = c | 0x0c000c00u | ((4u + c) << 16);
 				uint2 pr;
 				pr.x = __builtin_amdgcn_perm(v.y, v.x, sel);
 				pr.y = __builtin_amdgcn_perm(v.w, v.z, sel);
-				*reinterpret_cast<uint2 *>(d + c * PD) = pr;
+				*reinterpret_cast<uint2 *>(d + c * kPD32) = pr;
 			}
 		}
 	} else if (vec) {
@@ -349,7 +569,6 @@ __global__ void __launch_bounds__(NW == 1 ? 256 : 64 * NW) shrink_kernel(const S
 			const uint32_t i = tid + (uint32_t)k * TPT;
 			if (i < nquad) {
 				const uint4 v = *reinterpret_cast<const uint4 *>(src + (size_t)rw.row * a.pitch + rw.col * 16u);
-				raw[k] = v;
 				alpha_and &= (v.x & v.y & v.z & v.w) >> 24;
 				uint32_t *d = s_pl + rw.row * rs + rw.col * 2u;
 #pragma unroll
@@ -376,6 +595,10 @@ __global__ void __launch_bounds__(NW == 1 ? 256 : 64 * NW) shrink_kernel(const S
 			alpha_and &= al;
 		}
 	}
+	if constexpr (TW == 32 && NW == 1 && C == 4) {
+		// request the NEXT tile's pixels now: they land while this tile is being processed
+		fast32_prefetch(a, next_tile, tid, pre, pre_valid);
+	}
 	tile_sync<NW>();
 
 	// ---- level-of-detail value --------------------------------------------
@@ -392,36 +615,58 @@ __global__ void __launch_bounds__(NW == 1 ? 256 : 64 * NW) shrink_kernel(const S
 			// smoothing c = t(y)+t(y+1) (2 adds), the neighbour pair's c by DPP, |vr| (sad).
 			const uint32_t q = tid & 15u, g = tid >> 4;
 			const uint32_t y0 = g * 8u, steps = g == 3 ? 3u : 4u;  // two window rows per step
-			const uint32_t *p = s_pl + y0 * 16u + q;
+			const uint32_t *p = s_pl + y0 * kRS32 + q;
 			const uint32_t two = 0x00020002u;
 			uint32_t rA[3], rB[3], tP[3], dP[3];
 #pragma unroll
 			for (int c = 0; c < 3; ++c) {
-				const uint32_t a0 = p[c * PD], a1 = p[c * PD + 1], b0 = p[c * PD + 16], b1 = p[c * PD + 17];
+				const uint32_t a0 = p[c * kPD32], a1 = p[c * kPD32 + 1], b0 = p[c * kPD32 + kRS32], b1 = p[c * kPD32 + kRS32 + 1];
 				rA[c] = pk_mad_u16(__builtin_amdgcn_alignbit(a1, a0, 16), two, u32(us2(a0) + us2(a1)));
 				rB[c] = pk_mad_u16(__builtin_amdgcn_alignbit(b1, b0, 16), two, u32(us2(b0) + us2(b1)));
 				tP[c] = u32(us2(a0) + us2(b0));
 				dP[c] = b0;
 			}
-			p += 32;
-			for (uint32_t st = 0; st < steps; ++st, p += 32) {
+			p += 2 * kRS32;
+			// the two rows of step s+1 are requested before step s is computed (LDS latency hidden
+			// inside the wave; the last request reads past the group's rows and is discarded)
+			uint32_t n0[3], n1[3], o0[3], o1[3];
+#pragma unroll
+			for (int c = 0; c < 3; ++c) {
+				n0[c] = p[c * kPD32];
+				n1[c] = p[c * kPD32 + 1];
+				o0[c] = p[c * kPD32 + kRS32];
+				o1[c] = p[c * kPD32 + kRS32 + 1];
+			}
+			for (uint32_t st = 0; st < steps; ++st) {
+				p += 2 * kRS32;
+				uint32_t f0[3], f1[3], g0[3], g1[3];
 #pragma unroll
 				for (int c = 0; c < 3; ++c) {
-					const uint32_t n0 = p[c * PD], n1 = p[c * PD + 1], o0 = p[c * PD + 16], o1 = p[c * PD + 17];
-					const uint32_t rN = pk_mad_u16(__builtin_amdgcn_alignbit(n1, n0, 16), two, u32(us2(n0) + us2(n1)));
+					f0[c] = p[c * kPD32];
+					f1[c] = p[c * kPD32 + 1];
+					g0[c] = p[c * kPD32 + kRS32];
+					g1[c] = p[c * kPD32 + kRS32 + 1];
+				}
+#pragma unroll
+				for (int c = 0; c < 3; ++c) {
+					const uint32_t rN = pk_mad_u16(__builtin_amdgcn_alignbit(n1[c], n0[c], 16), two, u32(us2(n0[c]) + us2(n1[c])));
 					sum_hz = sad16(rN, rA[c], sum_hz);
-					const uint32_t tN = u32(us2(dP[c]) + us2(n0));
+					const uint32_t tN = u32(us2(dP[c]) + us2(n0[c]));
 					const uint32_t c0 = u32(us2(tP[c]) + us2(tN));
 					sum_vr = sad16(dpp_mov<0x101>(c0), c0, sum_vr);  // row_shl:1 = the pair to the right
-					const uint32_t rO = pk_mad_u16(__builtin_amdgcn_alignbit(o1, o0, 16), two, u32(us2(o0) + us2(o1)));
+					const uint32_t rO = pk_mad_u16(__builtin_amdgcn_alignbit(o1[c], o0[c], 16), two, u32(us2(o0[c]) + us2(o1[c])));
 					sum_hz = sad16(rO, rB[c], sum_hz);
-					const uint32_t tO = u32(us2(n0) + us2(o0));
+					const uint32_t tO = u32(us2(n0[c]) + us2(o0[c]));
 					const uint32_t e0 = u32(us2(tN) + us2(tO));
 					sum_vr = sad16(dpp_mov<0x101>(e0), e0, sum_vr);
 					rA[c] = rN;
 					rB[c] = rO;
 					tP[c] = tO;
-					dP[c] = o0;
+					dP[c] = o0[c];
+					n0[c] = f0[c];
+					n1[c] = f1[c];
+					o0[c] = g0[c];
+					o1[c] = g1[c];
 				}
 			}
 			if (q == 15u) sum_hz = sum_vr = 0;  // pair 15 starts no window (x = 30, 31)
@@ -590,11 +835,22 @@ __global__ void __launch_bounds__(NW == 1 ? 256 : 64 * NW) shrink_kernel(const S
 		       ((uint32_t)pl16[idx + 6u * PD] << 24);
 	};
 	if (nw == w && nh == h) {  // block.rs:279-281: clone
-		if (vec && (a.slot_bytes & 15u) == 0 && (reinterpret_cast<uintptr_t>(a.out_px) & 15u) == 0) {
+		if (fast && (a.slot_bytes & 15u) == 0 && (reinterpret_cast<uintptr_t>(a.out_px) & 15u) == 0) {
+			// re-interleave the planes: 4 pixels (one 16-byte store) per lane and step
 #pragma unroll
 			for (int k = 0; k < 4; ++k) {
-				const uint32_t i = tid + (uint32_t)k * TPT;
-				if (i < nquad) reinterpret_cast<uint4 *>(dst)[i] = raw[k];
+				const uint32_t i = tid + 64u * (uint32_t)k;  // quad index = row*8 + col
+				const uint32_t *p = s_pl + (i >> 3) * kRS32 + (i & 7u) * 2u;
+				const uint2 r = *reinterpret_cast<const uint2 *>(p), g = *reinterpret_cast<const uint2 *>(p + kPD32);
+				const uint2 b = *reinterpret_cast<const uint2 *>(p + 2 * kPD32), al = *reinterpret_cast<const uint2 *>(p + 3 * kPD32);
+				const uint32_t rg01 = __builtin_amdgcn_perm(g.x, r.x, 0x06020400u), ba01 = __builtin_amdgcn_perm(al.x, b.x, 0x06020400u);
+				const uint32_t rg23 = __builtin_amdgcn_perm(g.y, r.y, 0x06020400u), ba23 = __builtin_amdgcn_perm(al.y, b.y, 0x06020400u);
+				uint4 o;
+				o.x = __builtin_amdgcn_perm(ba01, rg01, 0x05040100u);
+				o.y = __builtin_amdgcn_perm(ba01, rg01, 0x07060302u);
+				o.z = __builtin_amdgcn_perm(ba23, rg23, 0x05040100u);
+				o.w = __builtin_amdgcn_perm(ba23, rg23, 0x07060302u);
+				reinterpret_cast<uint4 *>(dst)[i] = o;
 			}
 		} else {
 			RowWalker rw(tid, TPT, w);
@@ -652,6 +908,12 @@ __global__ void __launch_bounds__(NW == 1 ? 256 : 64 * NW) shrink_kernel(const S
 	const uint32_t nch = opaque ? 3u : 4u;  // channels that need taps
 
 	const bool need_h = nw != w, need_v = nh != h;
+	if constexpr (TW == 32 && NW == 1 && C == 4) {
+		if (fast && opaque && need_h && need_v) {
+			resample_fast32_hv(a, s_tab, tab_x, tab_y, s_pl, s_tmp, tid, nw, nh, dst);
+			return;
+		}
+	}
 	const int prec_x = tab_x.precision, prec_y = tab_y.precision;
 	const int32_t init_x = 1 << (prec_x - 1), init_y = 1 << (prec_y - 1);
 	const uint16_t *bnd_x = a.bounds + tab_x.bounds_off, *bnd_y = a.bounds + tab_y.bounds_off;
@@ -781,6 +1043,42 @@ __global__ void __launch_bounds__(NW == 1 ? 256 : 64 * NW) shrink_kernel(const S
 }
 
 // ---------------------------------------------------------------------------
+// kernel: persistent over tiles.  NW == 1: every wave of the block owns one LDS tile
+// image and walks tiles wave_id, wave_id + total_waves, ... (neighbouring waves take
+// neighbouring tiles, so a block reads contiguous spans of the image rows).  The
+// down-scaling table rows of the fast path are copied into LDS once per block.
+// ---------------------------------------------------------------------------
+template <int NW, int C, int MODE, int TW>
+__global__ void __launch_bounds__(NW == 1 ? 768 : 64 * NW) shrink_kernel(const ShrinkArgs a)
+{
+	extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+	if constexpr (NW == 1) {
+		const uint32_t wpb = blockDim.x / 64u, sub = threadIdx.x / 64u, tid = threadIdx.x % 64u;
+		if constexpr (TW != 0) {
+			for (uint32_t i = threadIdx.x; i < a.tab_dw / 4u; i += blockDim.x)
+				reinterpret_cast<uint4 *>(lds)[i] = reinterpret_cast<const uint4 *>(a.trows)[i];
+			__syncthreads();
+		}
+		uint32_t *s_pl = lds + (TW != 0 ? a.tab_dw : 0u) + sub * a.tile_dw;
+		const uint32_t stride = gridDim.x * wpb;
+		uint4 pre[4];
+		bool pre_valid = false;
+		if constexpr (TW == 32 && C == 4) fast32_prefetch(a, __builtin_amdgcn_readfirstlane(blockIdx.x * wpb + sub), tid, pre, pre_valid);
+		for (uint32_t tile_g = __builtin_amdgcn_readfirstlane(blockIdx.x * wpb + sub); tile_g < a.n_tiles; tile_g += stride) {
+			process_tile<NW, C, MODE, TW>(a, tile_g, s_pl, nullptr, lds, tid, pre, pre_valid, tile_g + stride);
+			tile_sync<1>();  // the next tile reuses this wave's LDS image
+		}
+	} else {
+		uint4 pre[4];
+		bool pre_valid = false;
+		for (uint32_t tile_g = blockIdx.x; tile_g < a.n_tiles; tile_g += gridDim.x) {
+			process_tile<NW, C, MODE, TW>(a, tile_g, lds, lds + a.tile_dw, nullptr, threadIdx.x, pre, pre_valid, 0xffffffffu);
+			__syncthreads();
+		}
+	}
+}
+
+// ---------------------------------------------------------------------------
 // finishing kernel: one lane per tile turns the detector result into the stored
 // block value (and the raw detector outputs for pxz_lod_*).  All f64 work lives here.
 // ---------------------------------------------------------------------------
@@ -866,31 +1164,28 @@ __global__ void __launch_bounds__(256) synth_kernel(const SynthArgs s)
 // launchers (called from pxz_api.cpp)
 // ---------------------------------------------------------------------------
 template <int NW, int C, int MODE, int TW>
-static hipError_t launch_one(const ShrinkArgs &a, uint32_t lds_bytes, hipStream_t stream)
+static hipError_t launch_one(const ShrinkArgs &a, const LaunchGeom &g, hipStream_t stream)
 {
-	constexpr uint32_t TPB = NW == 1 ? 4u : 1u;
-	const uint32_t blocks = (a.n_tiles + TPB - 1) / TPB;
-	const uint32_t threads = NW == 1 ? 256u : 64u * NW;
 	auto kernel = shrink_kernel<NW, C, MODE, TW>;
-	if (lds_bytes > 64u * 1024u) {
+	if (g.lds_bytes > 64u * 1024u) {
 		hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
-		                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+		                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds_bytes);
 		if (e != hipSuccess) return e;
 	}
-	hipLaunchKernelGGL(kernel, dim3(blocks), dim3(threads), lds_bytes, stream, a);
+	hipLaunchKernelGGL(kernel, dim3(g.blocks), dim3(g.threads), g.lds_bytes, stream, a);
 	return hipGetLastError();
 }
 
 template <int NW>
-static hipError_t launch_nw(const ShrinkArgs &a, uint32_t channels, uint32_t lds_bytes, hipStream_t stream)
+static hipError_t launch_nw(const ShrinkArgs &a, uint32_t channels, const LaunchGeom &g, hipStream_t stream)
 {
 	if constexpr (NW == 1) {
-		if (channels == 4 && a.bw == 32 && a.bh == 32)  // the headline geometry: compile-time fast path
-			return a.mode == 1 ? launch_one<1, 4, 1, 32>(a, lds_bytes, stream) : launch_one<1, 4, 0, 32>(a, lds_bytes, stream);
+		if (g.fast32)  // the headline geometry: compile-time fast path, table rows in LDS
+			return a.mode == 1 ? launch_one<1, 4, 1, 32>(a, g, stream) : launch_one<1, 4, 0, 32>(a, g, stream);
 	}
 	if (channels == 4)
-		return a.mode == 1 ? launch_one<NW, 4, 1, 0>(a, lds_bytes, stream) : launch_one<NW, 4, 0, 0>(a, lds_bytes, stream);
-	return a.mode == 1 ? launch_one<NW, 3, 1, 0>(a, lds_bytes, stream) : launch_one<NW, 3, 0, 0>(a, lds_bytes, stream);
+		return a.mode == 1 ? launch_one<NW, 4, 1, 0>(a, g, stream) : launch_one<NW, 4, 0, 0>(a, g, stream);
+	return a.mode == 1 ? launch_one<NW, 3, 1, 0>(a, g, stream) : launch_one<NW, 3, 0, 0>(a, g, stream);
 }
 
 // waves per tile: 1 up to 32x32, then one wave per 1024 px, capped at 16
@@ -904,16 +1199,50 @@ uint32_t waves_per_tile(uint32_t bw, uint32_t bh)
 	return 16;
 }
 
-hipError_t launch_shrink(const ShrinkArgs &a, uint32_t channels, hipStream_t stream)
+// Launch geometry.  NW == 1: persistent blocks of up to 12 waves (one LDS tile image each) sized to
+// the 160 KB of LDS, at most one resident set per CU; NW > 1: one tile per block, grid capped likewise.
+LaunchGeom plan_launch(const ShrinkArgs &a, uint32_t channels, uint32_t n_cus)
 {
+	LaunchGeom g{};
 	const uint32_t nw = waves_per_tile(a.bw, a.bh);
-	const uint32_t lds_bytes = a.tile_dw * 4u * (nw == 1 ? 4u : 1u) + (nw > 1 ? 16u * nw : 0u);
-	switch (nw) {
-	case 1: return launch_nw<1>(a, channels, lds_bytes, stream);
-	case 2: return launch_nw<2>(a, channels, lds_bytes, stream);
-	case 4: return launch_nw<4>(a, channels, lds_bytes, stream);
-	case 8: return launch_nw<8>(a, channels, lds_bytes, stream);
-	default: return launch_nw<16>(a, channels, lds_bytes, stream);
+	const uint32_t tile_bytes = a.tile_dw * 4u;
+	constexpr uint32_t kLds = 160u * 1024u;
+	if (nw == 1) {
+		g.fast32 = channels == 4 && a.bw == 32 && a.bh == 32 && (a.out_px == nullptr || a.filter == 0 || a.tab_dw != 0) &&
+		           a.tab_dw * 4u + tile_bytes <= kLds;
+		const uint32_t tab_bytes = g.fast32 ? a.tab_dw * 4u : 0u;
+		uint32_t wpb = (kLds - tab_bytes) / tile_bytes;
+		if (wpb > 12u) wpb = 12u;
+		if (const char *e = getenv("PXZ_WPB")) {  // tuning knob: waves per block
+			const uint32_t v = (uint32_t)atoi(e);
+			if (v >= 1 && v < wpb) wpb = v;
+		}
+		if (wpb < 1u) wpb = 1u;
+		g.threads = 64u * wpb;
+		g.lds_bytes = tab_bytes + wpb * tile_bytes;
+		const uint32_t per_cu = kLds / g.lds_bytes > 0 ? kLds / g.lds_bytes : 1u;
+		uint32_t resident = n_cus * (per_cu > 2u ? 2u : per_cu);
+		const uint32_t need = (a.n_tiles + wpb - 1u) / wpb;
+		g.blocks = need < resident ? need : resident;
+	} else {
+		g.threads = 64u * nw;
+		g.lds_bytes = tile_bytes + 16u * nw;
+		const uint32_t per_cu = kLds / g.lds_bytes > 0 ? kLds / g.lds_bytes : 1u;
+		const uint32_t resident = n_cus * per_cu * 2u;
+		g.blocks = a.n_tiles < resident ? a.n_tiles : resident;
+	}
+	return g;
+}
+
+hipError_t launch_shrink(const ShrinkArgs &a, uint32_t channels, uint32_t n_cus, hipStream_t stream)
+{
+	const LaunchGeom g = plan_launch(a, channels, n_cus);
+	switch (waves_per_tile(a.bw, a.bh)) {
+	case 1: return launch_nw<1>(a, channels, g, stream);
+	case 2: return launch_nw<2>(a, channels, g, stream);
+	case 4: return launch_nw<4>(a, channels, g, stream);
+	case 8: return launch_nw<8>(a, channels, g, stream);
+	default: return launch_nw<16>(a, channels, g, stream);
 	}
 }
 
