@@ -53,17 +53,31 @@ def histogram(ow, oh):
     return {f"{int(k) // 100000}x{int(k) % 100000}": int(c) for k, c in zip(uniq.tolist(), counts.tolist())}
 
 
-def run_mode(args, handle, frames, mode_name, rank, world, dist_mod):
-    """Times K steps of one detector mode; returns a dict of measurements (max over ranks)."""
+def run_mode(args, handle, frames, mode_name, rank, world, dist_mod, pdist):
+    """Times K steps of one detector mode; returns a dict of measurements (max over ranks).
+    N == 1: a step is the fused hot-path launch.  N > 1: every rank runs the same launch on its own
+    frames, then the one exchange step of the path: compact the block stream (pack kernels) and gather
+    it to the writer rank 0 over RCCL (unless --no-gather)."""
     import torch
     pxz_mode, factor = MODES[mode_name]
     N, H, W, C = frames.shape
     bw = bh = args.block
-    out = None
-    vals, ow, oh, slots = handle.shrink_frames_device(frames, bw, bh, pxz_mode, args.filter, factor)
-    out = (vals, ow, oh, slots)
-    for _ in range(args.warmup):
+    out = handle.shrink_frames_device(frames, bw, bh, pxz_mode, args.filter, factor)
+    vals, ow, oh, slots = out
+    gather = world > 1 and not args.no_gather
+    pack_out = handle.pack_tiles_device(ow, oh, slots, C) if gather else None
+    gather_state = {"error": None, "bytes": 0}
+
+    def step():
         handle.shrink_frames_device(frames, bw, bh, pxz_mode, args.filter, factor, out=out)
+        if gather:
+            offsets, packed = handle.pack_tiles_device(ow, oh, slots, C, out=pack_out)
+            got = pdist.gather_block_streams(vals, ow, oh, packed, offsets[-1], dst=0)
+            if got is not None:
+                gather_state["bytes"] = sum(int(g["packed"].numel()) for g in got)
+
+    for _ in range(args.warmup):
+        step()
     torch.cuda.synchronize()
     if world > 1:
         dist_mod.barrier()
@@ -71,7 +85,7 @@ def run_mode(args, handle, frames, mode_name, rank, world, dist_mod):
     handle.enable_timing(True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        handle.shrink_frames_device(frames, bw, bh, pxz_mode, args.filter, factor, out=out)
+        step()
     torch.cuda.synchronize()
     if world > 1:
         dist_mod.barrier()
@@ -97,6 +111,7 @@ def run_mode(args, handle, frames, mode_name, rank, world, dist_mod):
         "algo_bytes_per_launch": algo_bytes, "read_bytes": read_bytes, "write_bytes": out_bytes + 12 * tiles,
         "achieved_gbps": algo_bytes / (kernel_ms * 1e-3) / 1e9,
         "histogram": histogram(ow[0], oh[0]),
+        "gathered_stream_bytes_per_step": gather_state["bytes"] if gather else None,
     }
 
 
@@ -145,16 +160,23 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # rehearsal switch for a ONE-GPU box: all ranks on cuda:0, gloo instead of RCCL (RCCL refuses
+    # two ranks on one device).  Never set by the driver.
+    same_gpu = os.environ.get("PXZ_BENCH_SAME_GPU") == "1"
+    device_index = 0 if same_gpu else local_rank
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        torch.cuda.set_device(device_index)
+        if same_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device_index))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-    torch.cuda.set_device(local_rank)
+    torch.cuda.set_device(device_index)
 
     from __graft_entry__ import load_product
     product = load_product()
-    handle = product.Handle(local_rank)  # raises if the HIP library / device is missing: no fallback
+    handle = product.Handle(device_index)  # raises if the HIP library / device is missing: no fallback
     nf = args.frames_per_gpu
     frames = handle.synth_frames_device(nf, args.height, args.width, 4, first_frame=rank * nf, dist=args.dist)
     torch.cuda.synchronize()
@@ -163,7 +185,7 @@ def main():
     primary = args.primary if args.primary in names else names[0]
     results = {}
     for name in names:
-        results[name] = run_mode(args, handle, frames, name, rank, world, dist)
+        results[name] = run_mode(args, handle, frames, name, rank, world, dist, product.dist)
 
     if rank == 0:
         r = results[primary]
@@ -181,6 +203,10 @@ def main():
                                    f"{primary} factor {r['factor']}, filter {args.filter} (Lanczos3=4), dist {args.dist}, "
                                    f"device-resident, one fused launch per step",
                        "mode": primary, "frames_per_gpu": nf, "tile": args.block,
+                       "parallelism": f"{world} ranks x {nf} frames, no data-path collective; "
+                                      + ("block streams packed and gathered to rank 0 each step" if world > 1 and not args.no_gather
+                                         else "no exchange step"),
+                       "gathered_stream_bytes_per_step": r["gathered_stream_bytes_per_step"],
                        "tile_size_histogram_frame0": r["histogram"]},
             "roofline": {"bound": "hbm", "achieved": r["achieved_gbps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": r["achieved_gbps"] / HBM_PEAK_GBPS, "traffic": load_traffic(primary),

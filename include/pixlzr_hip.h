@@ -130,6 +130,16 @@ int pxz_shrink_frames_device(pxz_handle *h, const pxz_frames *frames, const pxz_
 int pxz_lod_frames_device(pxz_handle *h, const pxz_frames *frames, const pxz_params *params,
                           const uint8_t *d_pixels, float *d_lod0, float *d_lod1);
 
+/* Block-stream compaction (device): the valid out_w*out_h*channels bytes of every slot, in tile
+ * order, into one contiguous stream -- the payload `encode_block` (src/encoding/mod.rs:168-200)
+ * consumes tile after tile, and what one rank ships to the writer rank over RCCL.
+ * d_offsets gets n_tiles+1 byte offsets (u64; the last one is the stream length).  Tiles that
+ * would exceed packed_capacity are skipped (offsets stay valid, so the caller can detect it).
+ * Asynchronous on the handle's stream. */
+int pxz_pack_tiles_device(pxz_handle *h, uint32_t n_tiles, uint32_t channels, uint32_t slot_bytes,
+                          const uint32_t *d_tile_w, const uint32_t *d_tile_h, const uint8_t *d_slots,
+                          uint64_t *d_offsets, uint8_t *d_packed, uint64_t packed_capacity);
+
 /* ---- bitstream: Pixlzr::encode_to_vec, src/encoding/mod.rs:40-89,168-200 ---- */
 /* Tiles given as produced by pxz_shrink_image (slots + dims + values).
  * has_value may be NULL (all Some); has_value[t]==0 writes 0.0 (mod.rs:173-178).

@@ -13,3 +13,4 @@ from .binding import (  # noqa: F401
     PxzError, Handle, build_library, library_path, load_library, grid, encode_container, qoi_encode, axis_table,
     EXPORTED_SYMBOLS,
 )
+from . import dist  # noqa: E402,F401  (torch.distributed plumbing: frame sharding + block-stream gather)

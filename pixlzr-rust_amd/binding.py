@@ -17,7 +17,7 @@ DIST_OPAQUE, DIST_ALPHA, DIST_FLAT, DIST_NOISE = range(4)
 EXPORTED_SYMBOLS = [
     "pxz_version", "pxz_device_count", "pxz_create", "pxz_destroy", "pxz_last_error", "pxz_set_stream",
     "pxz_synchronize", "pxz_grid", "pxz_shrink_image", "pxz_shrink_frames_device", "pxz_lod_frames_device",
-    "pxz_encode_container", "pxz_qoi_encode", "pxz_qoi_bound", "pxz_synth_frames_device", "pxz_axis_table",
+    "pxz_pack_tiles_device", "pxz_encode_container", "pxz_qoi_encode", "pxz_qoi_bound", "pxz_synth_frames_device", "pxz_axis_table",
     "pxz_enable_timing", "pxz_last_kernel_ms",
 ]
 
@@ -97,6 +97,8 @@ def load_library():
     L.pxz_shrink_frames_device.argtypes = [vp, C.POINTER(Frames), C.POINTER(Params)] + [vp] * 5
     L.pxz_lod_frames_device.restype = C.c_int
     L.pxz_lod_frames_device.argtypes = [vp, C.POINTER(Frames), C.POINTER(Params)] + [vp] * 3
+    L.pxz_pack_tiles_device.restype = C.c_int
+    L.pxz_pack_tiles_device.argtypes = [vp, u32, u32, u32, vp, vp, vp, vp, vp, C.c_uint64]
     L.pxz_encode_container.restype = C.c_int64
     L.pxz_encode_container.argtypes = [u32] * 6 + [vp] * 5 + [vp, C.c_size_t]
     L.pxz_qoi_encode.restype = C.c_int64
@@ -270,6 +272,24 @@ class Handle:
         self._check(self._L.pxz_lod_frames_device(self._h, C.byref(fd), C.byref(pd), C.c_void_p(frames.data_ptr()),
                                                   C.c_void_p(l0.data_ptr()), C.c_void_p(l1.data_ptr())))
         return l0, l1
+
+    def pack_tiles_device(self, ow, oh, slots, channels, out=None):
+        """Compacts the valid bytes of the slots (any leading batch dims) into one stream.
+        Returns (offsets int64[n_tiles+1], packed uint8[capacity]); offsets[-1] is the stream length."""
+        import torch
+        n = ow.numel()
+        slot_bytes = slots.shape[-1]
+        if out is None:
+            offsets = torch.empty(n + 1, dtype=torch.int64, device=ow.device)
+            packed = torch.empty(n * slot_bytes, dtype=torch.uint8, device=ow.device)
+        else:
+            offsets, packed = out
+        self.use_torch_stream()
+        self._check(self._L.pxz_pack_tiles_device(
+            self._h, n, channels, slot_bytes, C.c_void_p(ow.data_ptr()), C.c_void_p(oh.data_ptr()),
+            C.c_void_p(slots.data_ptr()), C.c_void_p(offsets.data_ptr()), C.c_void_p(packed.data_ptr()),
+            packed.numel()))
+        return offsets, packed
 
     def synth_frames_device(self, n_frames, height, width, channels=4, first_frame=0, dist=DIST_OPAQUE, out=None):
         import torch

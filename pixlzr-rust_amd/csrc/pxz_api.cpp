@@ -20,6 +20,7 @@ namespace pxz {
 hipError_t launch_shrink(const ShrinkArgs &a, uint32_t channels, uint32_t n_cus, hipStream_t stream);
 hipError_t launch_synth(const SynthArgs &s, hipStream_t stream);
 hipError_t launch_finish(const FinishArgs &f, hipStream_t stream);
+hipError_t launch_pack(const PackArgs &a, hipStream_t stream);
 uint32_t waves_per_tile(uint32_t bw, uint32_t bh);
 }  // namespace pxz
 
@@ -55,7 +56,7 @@ struct pxz_handle {
 	// level breakpoints per (mode, factor bits, bw, bh, edge_w, edge_h)
 	struct Breaks { uint32_t b[4][pxz::kMaxLevel]; uint32_t asc[4]; };
 	std::map<std::tuple<uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t>, Breaks> breaks;
-	DeviceBuffer in, val, ow, oh, out, sums;
+	DeviceBuffer in, val, ow, oh, out, sums, chunks;
 	bool timing = false;
 	std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
 	size_t events_used = 0;
@@ -456,7 +457,7 @@ void pxz_destroy(pxz_handle *h)
 		(void)hipFree(kv.second.d_ksums);
 		(void)hipFree(kv.second.d_rows);
 	}
-	for (DeviceBuffer *b : {&h->in, &h->val, &h->ow, &h->oh, &h->out, &h->sums})
+	for (DeviceBuffer *b : {&h->in, &h->val, &h->ow, &h->oh, &h->out, &h->sums, &h->chunks})
 		if (b->ptr) (void)hipFree(b->ptr);
 	for (auto &ev : h->events) {
 		(void)hipEventDestroy(ev.first);
@@ -550,6 +551,25 @@ int pxz_shrink_image(pxz_handle *h, const uint8_t *pixels, uint32_t width, uint3
 	PXZ_HIP(h, hipMemcpyAsync(out_h, h->oh.ptr, tiles * 4, hipMemcpyDeviceToHost, h->stream));
 	if (out_pixels) PXZ_HIP(h, hipMemcpyAsync(out_pixels, h->out.ptr, tiles * slot, hipMemcpyDeviceToHost, h->stream));
 	PXZ_HIP(h, hipStreamSynchronize(h->stream));
+	return PXZ_OK;
+}
+
+int pxz_pack_tiles_device(pxz_handle *h, uint32_t n_tiles, uint32_t channels, uint32_t slot_bytes,
+                          const uint32_t *d_tile_w, const uint32_t *d_tile_h, const uint8_t *d_slots,
+                          uint64_t *d_offsets, uint8_t *d_packed, uint64_t packed_capacity)
+{
+	if (!h) return PXZ_ERR_INVALID_ARG;
+	if (!d_tile_w || !d_tile_h || !d_slots || !d_offsets || !d_packed || n_tiles == 0)
+		return fail(h, PXZ_ERR_INVALID_ARG, "null pointer / no tiles");
+	if (channels != 3 && channels != 4) return fail(h, PXZ_ERR_INVALID_ARG, "channels must be 3 or 4");
+	PXZ_HIP(h, hipSetDevice(h->device));
+	const uint32_t n_chunks = (n_tiles + 4095u) / 4096u;
+	if ((uint64_t)slot_bytes * 4096ull > 0xffffffffull) return fail(h, PXZ_ERR_UNSUPPORTED, "slot too large for the chunked scan");
+	int rc = ensure(h, h->chunks, (size_t)n_chunks * 8u);
+	if (rc != PXZ_OK) return rc;
+	pxz::PackArgs a{d_tile_w, d_tile_h, d_slots, (unsigned long long *)d_offsets, (unsigned long long *)h->chunks.ptr,
+	                d_packed, packed_capacity, n_tiles, n_chunks, channels, slot_bytes};
+	PXZ_HIP(h, pxz::launch_pack(a, h->stream));
 	return PXZ_OK;
 }
 

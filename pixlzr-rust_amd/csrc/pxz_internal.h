@@ -86,6 +86,16 @@ struct FinishArgs {
 	float factor;
 };
 
+struct PackArgs {
+	const uint32_t *w, *h;        // per tile
+	const uint8_t *slots;
+	unsigned long long *offsets;  // n_tiles + 1
+	unsigned long long *chunk_totals;
+	uint8_t *packed;
+	unsigned long long capacity;
+	uint32_t n_tiles, n_chunks, channels, slot_bytes;
+};
+
 struct SynthArgs {
 	uint8_t *dst;
 	uint64_t frame_stride;

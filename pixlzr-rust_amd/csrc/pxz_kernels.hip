@@ -1116,6 +1116,102 @@ __global__ void __launch_bounds__(256) finish_kernel(const FinishArgs f)
 }
 
 // ---------------------------------------------------------------------------
+// block-stream compaction: the valid bytes of the fixed output slots, tile order,
+// into one contiguous stream (what a writer / the RCCL gather consumes).
+//   offsets[t] = sum_{u<t} w[u]*h[u]*C  (exclusive scan, u64), offsets[n] = total
+// Three launches: per-chunk scan (4096 tiles per block), scan of the chunk totals,
+// copy (one wave per tile, 16-byte reads from the slot, dword or byte writes).
+// ---------------------------------------------------------------------------
+constexpr uint32_t kPackChunk = 4096;  // tiles per block in the scan: 256 threads x 16
+
+__global__ void __launch_bounds__(256) pack_scan_local_kernel(const PackArgs a)
+{
+	__shared__ uint32_t s_wave[4];
+	const uint32_t base = blockIdx.x * kPackChunk + threadIdx.x * 16u;
+	uint32_t sz[16], run = 0;
+#pragma unroll
+	for (uint32_t i = 0; i < 16; ++i) {
+		const uint32_t t = base + i;
+		sz[i] = t < a.n_tiles ? a.w[t] * a.h[t] * a.channels : 0u;
+		run += sz[i];
+	}
+	// exclusive scan of the per-thread totals inside the block
+	uint32_t incl = run;
+#pragma unroll
+	for (int off = 1; off < 64; off <<= 1) {
+		const uint32_t v = __shfl_up(incl, off, 64);
+		if ((threadIdx.x & 63u) >= (uint32_t)off) incl += v;
+	}
+	if ((threadIdx.x & 63u) == 63u) s_wave[threadIdx.x >> 6] = incl;
+	__syncthreads();
+	uint32_t wave_off = 0;
+	for (uint32_t q = 0; q < (threadIdx.x >> 6); ++q) wave_off += s_wave[q];
+	uint32_t excl = wave_off + incl - run;
+#pragma unroll
+	for (uint32_t i = 0; i < 16; ++i) {
+		const uint32_t t = base + i;
+		if (t < a.n_tiles) a.offsets[t] = excl;  // chunk-local for now (a chunk holds < 2^32 bytes)
+		excl += sz[i];
+	}
+	if (threadIdx.x == 255) a.chunk_totals[blockIdx.x] = excl;
+}
+
+__global__ void __launch_bounds__(1024) pack_scan_chunks_kernel(const PackArgs a)
+{
+	// one block: exclusive scan of the chunk totals (u64), in place
+	__shared__ unsigned long long s_wave[16];
+	__shared__ unsigned long long s_carry;
+	if (threadIdx.x == 0) s_carry = 0;
+	__syncthreads();
+	for (uint32_t base = 0; base < a.n_chunks; base += 1024u) {
+		const uint32_t i = base + threadIdx.x;
+		const unsigned long long v = i < a.n_chunks ? a.chunk_totals[i] : 0ull;
+		unsigned long long incl = v;
+#pragma unroll
+		for (int off = 1; off < 64; off <<= 1) {
+			const unsigned long long u = __shfl_up(incl, off, 64);
+			if ((threadIdx.x & 63u) >= (uint32_t)off) incl += u;
+		}
+		if ((threadIdx.x & 63u) == 63u) s_wave[threadIdx.x >> 6] = incl;
+		__syncthreads();
+		unsigned long long wave_off = s_carry;
+		for (uint32_t q = 0; q < (threadIdx.x >> 6); ++q) wave_off += s_wave[q];
+		if (i < a.n_chunks) a.chunk_totals[i] = wave_off + incl - v;
+		__syncthreads();
+		if (threadIdx.x == 1023) s_carry = wave_off + incl;
+		__syncthreads();
+	}
+	if (threadIdx.x == 0) a.offsets[a.n_tiles] = s_carry;  // grand total
+}
+
+__global__ void __launch_bounds__(256) pack_copy_kernel(const PackArgs a)
+{
+	const uint32_t t = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+	if (t >= a.n_tiles) return;
+	const unsigned long long off = a.chunk_totals[t / kPackChunk] + a.offsets[t];
+	const uint32_t bytes = a.w[t] * a.h[t] * a.channels;
+	const uint8_t *src = a.slots + (size_t)t * a.slot_bytes;
+	uint8_t *dst = a.packed + off;
+	if (lane == 0) a.offsets[t] = off;  // chunk-local -> global (each tile is owned by exactly one wave)
+	if (off + bytes > a.capacity) return;
+	if (((off | bytes) & 3ull) == 0 && (a.slot_bytes & 3u) == 0) {
+		const uint32_t *s4 = reinterpret_cast<const uint32_t *>(src);
+		uint32_t *d4 = reinterpret_cast<uint32_t *>(dst);
+		for (uint32_t i = lane; i < (bytes >> 2); i += 64u) d4[i] = s4[i];
+	} else {
+		for (uint32_t i = lane; i < bytes; i += 64u) dst[i] = src[i];
+	}
+}
+
+hipError_t launch_pack(const PackArgs &a, hipStream_t stream)
+{
+	hipLaunchKernelGGL(pack_scan_local_kernel, dim3(a.n_chunks), dim3(256), 0, stream, a);
+	hipLaunchKernelGGL(pack_scan_chunks_kernel, dim3(1), dim3(1024), 0, stream, a);
+	hipLaunchKernelGGL(pack_copy_kernel, dim3((a.n_tiles + 3) / 4), dim3(256), 0, stream, a);
+	return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
 // synthetic frames (DESIGN.md "Synthetic frames"): integer-only, one pixel per thread
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t fmix32(uint32_t h)

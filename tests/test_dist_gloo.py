@@ -1,0 +1,94 @@
+"""N>1 path on CPU: world_size 2 over gloo.  Each rank shrinks its shard of frames (with the oracle
+standing in for the GPU kernel, which needs no GPU-side exchange), the block streams are gathered
+to rank 0 with the product's dist plumbing, and the writer rank's .pixlzr files must equal the
+single-process result byte for byte."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+W, H, B, NF = 160, 96, 32, 5
+
+
+def _shrink_frames(oracle, frame_ids, mode, factor):
+    vals, ws, hs, chunks = [], [], [], []
+    for f in frame_ids:
+        img = oracle.synth_frame(W, H, 4, f, 1)
+        v, ow, oh, slots = oracle.shrink_image(img, B, B, mode, 4, factor)
+        vals.append(v)
+        ws.append(ow)
+        hs.append(oh)
+        for t in range(len(ow)):
+            chunks.append(slots[t, : int(ow[t]) * int(oh[t]) * 4])
+    packed = np.concatenate(chunks) if chunks else np.zeros(0, np.uint8)
+    return np.concatenate(vals), np.concatenate(ws), np.concatenate(hs), packed
+
+
+def _files_from_stream(product, values, tw, th, packed, n_frames):
+    """Writer rank: cut the gathered stream back into frames and write the containers."""
+    tiles = len(values) // n_frames
+    files, off = [], 0
+    for f in range(n_frames):
+        sl = slice(f * tiles, (f + 1) * tiles)
+        slots = np.zeros((tiles, B * B * 4), np.uint8)
+        for i, (w, h) in enumerate(zip(tw[sl], th[sl])):
+            nb = int(w) * int(h) * 4
+            slots[i, :nb] = packed[off:off + nb]
+            off += nb
+        files.append(product.encode_container(W, H, B, B, 4, 0, values[sl], None, tw[sl].astype(np.uint32),
+                                              th[sl].astype(np.uint32), slots))
+    assert off == len(packed)
+    return files
+
+
+def _worker(rank, world, port, mode, factor, result_path):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from tests.conftest import load_product
+    from oracle import binding as oracle
+    product = load_product()
+    from pixlzr_rust_amd import dist as pdist
+    mine = pdist.shard_frames(NF, world, rank)
+    v, tw, th, packed = _shrink_frames(oracle, mine, mode, factor)
+    got = pdist.gather_block_streams(torch.from_numpy(v), torch.from_numpy(tw.astype(np.int32)),
+                                     torch.from_numpy(th.astype(np.int32)), torch.from_numpy(packed.copy()),
+                                     len(packed), dst=0)
+    if rank == 0:
+        files = []
+        for r, part in enumerate(got):
+            nfr = len(pdist.shard_frames(NF, world, r))
+            files += _files_from_stream(product, part["values"].numpy(), part["tile_w"].numpy(), part["tile_h"].numpy(),
+                                        part["packed"].numpy(), nfr)
+        np.save(result_path, np.array([len(f) for f in files]))
+        with open(result_path + ".bin", "wb") as fh:
+            fh.write(b"".join(files))
+    else:
+        assert got is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode,factor", [(1, 8.0), (0, 0.5)])
+def test_two_ranks_gather_equals_single_process(tmp_path, product, oracle, mode, factor):
+    assert list(product.dist.shard_frames(5, 2, 0)) == [0, 1] and list(product.dist.shard_frames(5, 2, 1)) == [2, 3, 4]
+    assert [len(product.dist.shard_frames(64, 8, r)) for r in range(8)] == [8] * 8
+    result = str(tmp_path / "sizes.npy")
+    port = 29500 + (os.getpid() % 2000)
+    mp.spawn(_worker, args=(2, port, mode, factor, result), nprocs=2, join=True)
+    sizes = np.load(result)
+    blob = open(result + ".bin", "rb").read()
+    assert len(sizes) == NF
+    off = 0
+    for f in range(NF):
+        img = oracle.synth_frame(W, H, 4, f, 1)
+        v, ow, oh, slots = oracle.shrink_image(img, B, B, mode, 4, factor)
+        ref = oracle.encode_container(W, H, B, B, 4, 0, v, None, ow, oh, slots)
+        assert blob[off:off + int(sizes[f])] == ref, f"frame {f}"
+        off += int(sizes[f])

@@ -201,3 +201,22 @@ def test_8k_batch_against_oracle_and_properties(gpu, oracle):
     flat = gpu.synth_frames_device(1, 4320, 7680, 4, first_frame=9, dist=2)
     vals, ow, oh, slots = gpu.shrink_frames_device(flat, 32, 32, 1, 4, 1.0)
     assert int((ow != 1).sum()) == 0 and int((oh != 1).sum()) == 0
+
+
+def test_pack_tiles_matches_numpy(gpu, oracle):
+    """pxz_pack_tiles_device: exclusive scan of tile byte sizes + compaction of the slots (RGBA and RGB,
+    more tiles than one scan chunk of 4096)."""
+    import torch
+    for c, (w, h) in ((4, (3072, 1568)), (3, (200, 96))):
+        img = oracle.synth_frame(w, h, c, 4, 1 if c == 4 else 0)
+        frames = torch.from_numpy(img)[None].cuda()
+        vals, ow, oh, slots = gpu.shrink_frames_device(frames, 32, 32, 1, 4, 12.0)
+        offsets, packed = gpu.pack_tiles_device(ow, oh, slots, c)
+        torch.cuda.synchronize()
+        sizes = (ow.long() * oh.long() * c).reshape(-1).cpu().numpy()
+        exp_off = np.concatenate([[0], np.cumsum(sizes)])
+        assert (offsets.cpu().numpy() == exp_off).all()
+        assert ow.numel() > 4096 or c == 3
+        sl = slots.reshape(-1, slots.shape[-1]).cpu().numpy()
+        exp = np.concatenate([sl[t, : sizes[t]] for t in range(len(sizes))])
+        assert (packed[: exp_off[-1]].cpu().numpy() == exp).all()
