@@ -6,6 +6,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -21,6 +22,7 @@ hipError_t launch_shrink(const ShrinkArgs &a, uint32_t channels, uint32_t n_cus,
 hipError_t launch_synth(const SynthArgs &s, hipStream_t stream);
 hipError_t launch_finish(const FinishArgs &f, hipStream_t stream);
 hipError_t launch_pack(const PackArgs &a, hipStream_t stream);
+hipError_t launch_oklab32(const ShrinkArgs &a, uint32_t n_cus, hipStream_t stream);
 uint32_t waves_per_tile(uint32_t bw, uint32_t bh);
 }  // namespace pxz
 
@@ -405,6 +407,13 @@ int timed_launch(pxz_handle *h, pxz::ShrinkArgs &a, uint32_t channels, float *va
 		e1 = h->events[h->events_used].second;
 		++h->events_used;
 		PXZ_HIP(h, hipEventRecord(e0, h->stream));
+	}
+	// shrink_by on the headline geometry: the block-cooperative Oklab detector first, then the
+	// fused kernel only stages + resamples (it still runs the generic detector on ragged-edge tiles)
+	a.oklab_given = 0;
+	if (a.mode == PXZ_MODE_SHRINK_BY && channels == 4 && a.bw == 32 && a.bh == 32 && !getenv("PXZ_NO_OKLAB32")) {
+		a.oklab_given = 1;
+		PXZ_HIP(h, pxz::launch_oklab32(a, h->n_cus, h->stream));
 	}
 	PXZ_HIP(h, pxz::launch_shrink(a, channels, h->n_cus, h->stream));
 	PXZ_HIP(h, pxz::launch_finish(fin, h->stream));

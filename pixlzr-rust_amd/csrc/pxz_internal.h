@@ -46,6 +46,7 @@ struct ShrinkArgs {
 	uint32_t mode, filter;
 	float factor;
 	// outputs (device); out_px may be null (no resample), out_w/out_h may be null
+	uint32_t oklab_given;    // 1: full 32x32 RGBA tiles already carry their Oklab value in sums[] (oklab32_kernel)
 	uint32_t *sums;          // 2 per tile: gradient sums (directional) | f32 value bits (Oklab); -> finish_kernel
 	uint32_t *out_w;
 	uint32_t *out_h;

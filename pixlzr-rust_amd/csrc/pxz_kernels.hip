@@ -595,6 +595,11 @@ __device__ __forceinline__ void process_tile(const ShrinkArgs &a, const uint32_t
 			alpha_and &= al;
 		}
 	}
+	uint32_t given_bits = 0;
+	if constexpr (TW == 32 && NW == 1 && C == 4 && MODE == 0) {
+		// issued before the prefetch below, so waiting for it later does not drain the prefetch
+		if (a.oklab_given && fast) given_bits = a.sums[2 * tile_g];
+	}
 	if constexpr (TW == 32 && NW == 1 && C == 4) {
 		// request the NEXT tile's pixels now: they land while this tile is being processed
 		fast32_prefetch(a, next_tile, tid, pre, pre_valid);
@@ -761,6 +766,11 @@ __device__ __forceinline__ void process_tile(const ShrinkArgs &a, const uint32_t
 			m0 = level_count(sum_hz, a.breaks[cls], a.breaks_asc[cls]);
 			m1 = level_count(sum_vr, a.breaks[cls], a.breaks_asc[cls]);
 		}
+	} else if (TW == 32 && NW == 1 && C == 4 && a.oklab_given && fast) {
+		// the block-cooperative detector (oklab32_kernel) already left this tile's value in sums[]
+		const uint32_t vb = __builtin_amdgcn_readfirstlane(given_bits);
+		key0 = key1 = vb;
+		m0 = m1 = level_count(__float_as_uint(parse_value(__uint_as_float(vb))), a.breaks[cls], a.breaks_asc[cls]);
 	} else {
 		// get_block_variance, operations.rs:26-126 with shrink_by's closures
 		// (pixlzr.rs:160-162).  Colours are computed once, in parallel, into LDS
@@ -1076,6 +1086,179 @@ __global__ void __launch_bounds__(NW == 1 ? 768 : 64 * NW) shrink_kernel(const S
 			__syncthreads();
 		}
 	}
+}
+
+// ---------------------------------------------------------------------------
+// Oklab-MAD detector, block-cooperative (full 32x32 RGBA tiles): get_block_variance
+// (reference src/operations.rs:26-126) with shrink_by's closures (pixlzr.rs:160-162).
+//
+// The two f32 accumulations of the reference are sequential over the tile's pixels and
+// end up in the bitstream, so they are replayed in exactly that order.  To keep the chip
+// busy anyway, a block of 16 waves works on 15 tiles at once: waves 0..14 ("producers")
+// each convert one tile to Oklab (f32 + the glibc-cbrtf double-precision steps) and keep
+// the 16 pixels x 3 values of every lane in registers; wave 15 walks 15 x 4 chains
+// (channels a, b, l, alpha of every tile) in lock-step, 60 lanes wide, reading the values
+// from double-buffered LDS bands of 8 tile rows that the producers fill one step ahead.
+// Pass 1 sums, pass 2 (after the means are known) sums |x - mean|; the producers re-stage
+// the bands from registers for pass 2.
+// ---------------------------------------------------------------------------
+constexpr uint32_t kOkTiles = 15;           // tiles per block and batch (one per producer wave)
+constexpr uint32_t kOkPlane = 256 + 4;      // floats per (tile, channel) band: 8 rows x 32 px + bank skew
+constexpr uint32_t kOkBand = kOkTiles * 4 * kOkPlane;  // floats per band buffer
+
+// Correctly rounded f64 quotient for operands far from overflow/underflow: the same
+// rcp + Newton + residual steps the compiler emits for `/`, minus the range scaling.
+__device__ __forceinline__ double div_f64_inrange(double n, double d)
+{
+	double r = __builtin_amdgcn_rcp(d);
+	double e = __builtin_fma(-d, r, 1.0);
+	r = __builtin_fma(r, e, r);
+	e = __builtin_fma(-d, r, 1.0);
+	r = __builtin_fma(r, e, r);
+	const double q = n * r;
+	const double res = __builtin_fma(-d, q, n);
+	return __builtin_fma(res, r, q);
+}
+
+// glibc 2.35 cbrtf for x in [0, 4): same arithmetic as cbrt_f32 above, table + in-range division
+__device__ __forceinline__ float cbrt_f32_lut(float x, const double *third)
+{
+	int xe;
+	const float xm = frexpf(x, &xe);
+	const float u = (float)(0.492659620528969547 + (0.697570460207922770 - 0.191502161678719066 * (double)xm) * (double)xm);
+	const float t2 = u * u * u;
+	const int q3 = xe / 3, r3 = xe - 3 * q3;  // C semantics: remainder carries the sign of xe
+	const double num = (double)u * ((double)t2 + 2.0 * (double)xm);
+	const double den = 2.0 * (double)t2 + (double)xm;
+	const float ym = (float)(div_f64_inrange(num, den) * third[2 + r3]);
+	const float y = ldexpf(ym, q3);
+	return x == 0.0f ? 0.0f : y;
+}
+
+template <int MODE_UNUSED>
+__global__ void __launch_bounds__(1024) oklab32_kernel(const ShrinkArgs a)
+{
+	extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+	float *s_srgb = reinterpret_cast<float *>(lds);          // 256: sRGB u8 -> linear
+	float *s_alpha = s_srgb + 256;                           // 256: a / 255
+	double *s_third = reinterpret_cast<double *>(s_alpha + 256);  // 5 (+3 pad): 2^(k/3)
+	float *s_band = reinterpret_cast<float *>(s_third + 8);  // 2 x kOkBand
+	const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+	if (threadIdx.x < 256) {
+		s_srgb[threadIdx.x] = __uint_as_float(kSrgbToLinearBits[threadIdx.x]);
+		s_alpha[threadIdx.x] = __fdiv_rn((float)threadIdx.x, 255.0f);
+	}
+	if (threadIdx.x == 0) {
+		s_third[0] = 1.0 / 1.5874010519681994748;
+		s_third[1] = 1.0 / 1.2599210498948731648;
+		s_third[2] = 1.0;
+		s_third[3] = 1.2599210498948731648;
+		s_third[4] = 1.5874010519681994748;
+	}
+	__syncthreads();
+
+	const uint32_t n_batches = (a.n_tiles + kOkTiles - 1) / kOkTiles;
+	for (uint32_t batch = blockIdx.x; batch < n_batches; batch += gridDim.x) {
+		const uint32_t tile_g = batch * kOkTiles + wave;  // producers: their tile; chain wave: unused
+		const uint8_t *src = nullptr;
+		const bool producer = wave < kOkTiles;
+		const bool eligible = producer && fast32_tile_src(a, tile_g, src);
+		float lab[4][4][3];  // [quad][pixel][a, b, l]
+		uint32_t alpha_px[4];  // the 4 alpha bytes of every quad
+		if (eligible) {
+			const uint8_t *p = src + (size_t)(lane >> 3) * a.pitch + (lane & 7u) * 16u;
+			uint4 px[4];
+#pragma unroll
+			for (int k = 0; k < 4; ++k) px[k] = *reinterpret_cast<const uint4 *>(p + (size_t)(8 * k) * a.pitch);
+#pragma unroll
+			for (int k = 0; k < 4; ++k) {
+				const uint32_t v[4] = {px[k].x, px[k].y, px[k].z, px[k].w};
+				alpha_px[k] = (v[0] >> 24) | ((v[1] >> 24) << 8) | ((v[2] >> 24) << 16) | ((v[3] >> 24) << 24);
+#pragma unroll
+				for (int j = 0; j < 4; ++j) {
+					// palette 0.7.6: LUT, then Ottosson's matrices with left-to-right f32 sums
+					const float r = s_srgb[v[j] & 255u], g = s_srgb[(v[j] >> 8) & 255u], b = s_srgb[(v[j] >> 16) & 255u];
+					const float l = 0.4122214708f * r + 0.5363325363f * g + 0.0514459929f * b;
+					const float m = 0.2119034982f * r + 0.6806995451f * g + 0.1073969566f * b;
+					const float s3 = 0.0883024619f * r + 0.2817188376f * g + 0.6299787005f * b;
+					const float l_ = cbrt_f32_lut(l, s_third), m_ = cbrt_f32_lut(m, s_third), s_ = cbrt_f32_lut(s3, s_third);
+					lab[k][j][2] = 0.2104542553f * l_ + 0.7936177850f * m_ - 0.0040720468f * s_;  // L
+					lab[k][j][0] = 1.9779984951f * l_ - 2.4285922050f * m_ + 0.4505937099f * s_;  // a
+					lab[k][j][1] = 0.0259040371f * l_ + 0.7827717662f * m_ - 0.8086757660f * s_;  // b
+				}
+			}
+		}
+		// chain wave state: lane = tile*4 + channel (a, b, l, alpha)
+		const uint32_t ct = lane >> 2, cc = lane & 3u;
+		float acc = 0.0f, mean = 0.0f;
+#pragma unroll
+		for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+			for (int k = 0; k < 4; ++k) {
+				float *buf = s_band + (uint32_t)(k & 1) * kOkBand;
+				if (eligible) {
+					float *d = buf + (wave * 4u) * kOkPlane + lane * 4u;  // 4 consecutive pixels of this lane
+#pragma unroll
+					for (int c = 0; c < 3; ++c)
+						*reinterpret_cast<float4 *>(d + c * kOkPlane) =
+						    make_float4(lab[k][0][c], lab[k][1][c], lab[k][2][c], lab[k][3][c]);
+					*reinterpret_cast<float4 *>(d + 3 * kOkPlane) =
+					    make_float4(s_alpha[alpha_px[k] & 255u], s_alpha[(alpha_px[k] >> 8) & 255u],
+					                s_alpha[(alpha_px[k] >> 16) & 255u], s_alpha[alpha_px[k] >> 24]);
+				}
+				__syncthreads();  // band k is complete; band k-1 has been consumed
+				if (wave == kOkTiles && ct < kOkTiles) {
+					const float *x = buf + (ct * 4u + cc) * kOkPlane;
+					if (pass == 0) {
+#pragma unroll 4
+						for (uint32_t i = 0; i < 256; i += 4) {
+							const float4 v = *reinterpret_cast<const float4 *>(x + i);
+							acc += v.x;  // operations.rs:60-63, row-major pixel order
+							acc += v.y;
+							acc += v.z;
+							acc += v.w;
+						}
+					} else {
+#pragma unroll 4
+						for (uint32_t i = 0; i < 256; i += 4) {
+							const float4 v = *reinterpret_cast<const float4 *>(x + i);
+							acc += fabsf(v.x - mean);  // :80-83
+							acc += fabsf(v.y - mean);
+							acc += fabsf(v.z - mean);
+							acc += fabsf(v.w - mean);
+						}
+					}
+				}
+			}
+			if (pass == 0) {
+				mean = __fdiv_rn(acc, 1024.0f);  // :65-68, count = 32*32
+				acc = 0.0f;
+			}
+		}
+		__syncthreads();  // the last band has been consumed before the next batch overwrites buffer 1... and 0
+		if (wave == kOkTiles && ct < kOkTiles) {
+			const float d0 = __shfl(acc, (int)(lane & ~3u) + 0, 64), d1 = __shfl(acc, (int)(lane & ~3u) + 1, 64);
+			const float d2 = __shfl(acc, (int)(lane & ~3u) + 2, 64), d3 = __shfl(acc, (int)(lane & ~3u) + 3, 64);
+			const float total = d0 + d1 + d2 + d3;  // :89
+			const float value = __fdiv_rn(total, 1024.0f) * a.factor * 10.0f;  // pixlzr.rs:162
+			const uint32_t tg = batch * kOkTiles + ct;
+			const uint8_t *unused;
+			if (cc == 0 && fast32_tile_src(a, tg, unused))
+				reinterpret_cast<uint2 *>(a.sums)[tg] = make_uint2(__float_as_uint(value), __float_as_uint(value));
+		}
+	}
+}
+
+hipError_t launch_oklab32(const ShrinkArgs &a, uint32_t n_cus, hipStream_t stream)
+{
+	const uint32_t lds_bytes = (512u + 16u) * 4u + 2u * kOkBand * 4u;
+	auto kernel = oklab32_kernel<0>;
+	hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+	if (e != hipSuccess) return e;
+	const uint32_t n_batches = (a.n_tiles + kOkTiles - 1) / kOkTiles;
+	const uint32_t blocks = n_batches < n_cus ? n_batches : n_cus;
+	hipLaunchKernelGGL(kernel, dim3(blocks), dim3(1024), lds_bytes, stream, a);
+	return hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------
