@@ -222,7 +222,7 @@ size_t orc_encode_container(uint32_t width, uint32_t height, uint32_t bw, uint32
 		uint32_t line_len = 0;
 		for (uint32_t cx = 0; cx < cols; cx++) {
 			size_t t = (size_t)r * cols + cx;
-			if ((size_t)(p - out) + 13 + orc_qoi_bound(tw[t], th[t], channels) > out_cap)
+			if ((size_t)(p - out) + 9 + orc_qoi_bound(tw[t], th[t], channels) > out_cap)  /* stream starts 4 B early */
 				return 0;
 			memcpy(p, "block", 5);
 			float v = (has_value && !has_value[t]) ? 0.0f : block_value[t];

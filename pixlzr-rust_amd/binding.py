@@ -52,10 +52,11 @@ def build_library(force=False):
     srcs = [os.path.join(_CSRC, f) for f in os.listdir(_CSRC)
             if f.endswith((".hip", ".cpp", ".h", ".inc")) or f == "Makefile"]
     srcs.append(os.path.join(os.path.dirname(_HERE), "include", "pixlzr_hip.h"))
+    srcs.append(os.path.join(os.path.dirname(_HERE), "include", "pixlzr.hpp"))
     if (not force and os.path.exists(_LIB_PATH)
             and all(os.path.getmtime(_LIB_PATH) >= os.path.getmtime(s) for s in srcs)):
         return _LIB_PATH
-    r = subprocess.run(["make", "-C", _CSRC, "libpixlzr_hip.so"], capture_output=True, text=True)
+    r = subprocess.run(["make", "-C", _CSRC, "all"], capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("building libpixlzr_hip.so failed:\n" + r.stdout + r.stderr)
     return _LIB_PATH
