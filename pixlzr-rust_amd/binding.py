@@ -7,7 +7,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, "csrc")
-_LIB_PATH = os.path.join(_CSRC, "libpixlzr_hip.so")
+_LIB_PATH = os.environ.get("PXZ_LIB") or os.path.join(_CSRC, "libpixlzr_hip.so")  # PXZ_LIB: diagnostic builds
 
 FILTER_NEAREST, FILTER_TRIANGLE, FILTER_CATMULLROM, FILTER_GAUSSIAN, FILTER_LANCZOS3 = range(5)
 MODE_SHRINK_BY, MODE_SHRINK_DIRECTIONALLY = 0, 1

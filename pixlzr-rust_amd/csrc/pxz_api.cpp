@@ -58,7 +58,7 @@ struct pxz_handle {
 	// level breakpoints per (mode, factor bits, bw, bh, edge_w, edge_h)
 	struct Breaks { uint32_t b[4][pxz::kMaxLevel]; uint32_t asc[4]; };
 	std::map<std::tuple<uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t>, Breaks> breaks;
-	DeviceBuffer in, val, ow, oh, out, sums, chunks;
+	DeviceBuffer in, val, ow, oh, out, sums, chunks, work;
 	bool timing = false;
 	std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
 	size_t events_used = 0;
@@ -394,6 +394,8 @@ int timed_launch(pxz_handle *h, pxz::ShrinkArgs &a, uint32_t channels, float *va
 	int rc = ensure(h, h->sums, (size_t)a.n_tiles * 8u);
 	if (rc != PXZ_OK) return rc;
 	a.sums = (uint32_t *)h->sums.ptr;
+	if ((rc = ensure(h, h->work, ((size_t)a.n_tiles + 4u) * 4u + 64u)) != PXZ_OK) return rc;  // + 8 u64 of diagnostic stamps
+	a.work = (uint32_t *)h->work.ptr;
 	const pxz::FinishArgs fin{a.sums, value, lod0, lod1, a.n_tiles, a.tiles_per_frame, a.cols, a.rows,
 	                          a.bw, a.bh, a.edge_w, a.edge_h, a.mode, a.factor};
 	hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -466,7 +468,7 @@ void pxz_destroy(pxz_handle *h)
 		(void)hipFree(kv.second.d_ksums);
 		(void)hipFree(kv.second.d_rows);
 	}
-	for (DeviceBuffer *b : {&h->in, &h->val, &h->ow, &h->oh, &h->out, &h->sums, &h->chunks})
+	for (DeviceBuffer *b : {&h->in, &h->val, &h->ow, &h->oh, &h->out, &h->sums, &h->chunks, &h->work})
 		if (b->ptr) (void)hipFree(b->ptr);
 	for (auto &ev : h->events) {
 		(void)hipEventDestroy(ev.first);
@@ -609,6 +611,14 @@ int pxz_axis_table(uint32_t in_size, uint32_t out_size, uint32_t filter, int32_t
 	if (starts) std::memcpy(starts, w.starts.data(), sizeof(int32_t) * out_size);
 	if (sizes) std::memcpy(sizes, w.sizes.data(), sizeof(int32_t) * out_size);
 	if (coeffs && !w.coeffs.empty()) std::memcpy(coeffs, w.coeffs.data(), sizeof(int16_t) * w.coeffs.size());
+	return PXZ_OK;
+}
+
+// diagnostic builds only: copy bytes out of the handle's worklist/stamp buffer
+int pxz_debug_read_work(pxz_handle *h, void *dst, size_t offset, size_t bytes)
+{
+	if (!h || !dst || !h->work.ptr || offset + bytes > h->work.cap) return PXZ_ERR_INVALID_ARG;
+	PXZ_HIP(h, hipMemcpy(dst, (const uint8_t *)h->work.ptr + offset, bytes, hipMemcpyDeviceToHost));
 	return PXZ_OK;
 }
 

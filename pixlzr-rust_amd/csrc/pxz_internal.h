@@ -47,6 +47,7 @@ struct ShrinkArgs {
 	float factor;
 	// outputs (device); out_px may be null (no resample), out_w/out_h may be null
 	uint32_t oklab_given;    // 1: full 32x32 RGBA tiles already carry their Oklab value in sums[] (oklab32_kernel)
+	uint32_t *work;          // worklist: [0] = count, [1..] = tile ids (null: all tiles)
 	uint32_t *sums;          // 2 per tile: gradient sums (directional) | f32 value bits (Oklab); -> finish_kernel
 	uint32_t *out_w;
 	uint32_t *out_h;
@@ -71,6 +72,26 @@ struct ShrinkArgs {
 	uint32_t tmp_dw;         // ceil(bw/2) * hps   (0 when no convolution)
 	uint32_t lab_dw;         // Oklab mode: 3*bw*bh floats (aliases the transposed planes), else 0
 	uint32_t tile_dw;        // total dwords per tile incl. over-read slack
+};
+
+// Arguments of shrink32_kernel (full 32x32 RGBA tiles only): the subset of ShrinkArgs it needs
+struct Fast32Args {
+	const uint8_t *src;
+	uint64_t frame_stride;
+	uint32_t pitch, cols, rows, tiles_per_frame, n_tiles;
+	FastDiv div_tpf, div_cols;
+	uint32_t edge_w, edge_h, bw, bh;
+	uint32_t filter;
+	uint32_t *sums;
+	uint32_t *out_w;
+	uint32_t *out_h;
+	uint8_t *out_px;
+	uint32_t *work;
+	const uint32_t *trows;
+	uint32_t tab_dw, tile_dw;
+	uint32_t breaks[kMaxLevel];
+	uint32_t breaks_asc;
+	AxisTab tabs[kMaxLevel];
 };
 
 struct LaunchGeom {

@@ -451,7 +451,7 @@ __device__ __forceinline__ void fast32_h_pairs(const uint32_t *trows, const Axis
 	}
 }
 
-__device__ __forceinline__ void resample_fast32_hv(const ShrinkArgs &a, const uint32_t *trows, const AxisTab &tx, const AxisTab &ty,
+__device__ __forceinline__ void resample_fast32_hv(const uint32_t *trows, const AxisTab &tx, const AxisTab &ty,
                                                    uint32_t *s_pl, uint32_t *s_tmp, uint32_t lane, uint32_t nw,
                                                    uint32_t nh, uint8_t *dst)
 {
@@ -478,7 +478,8 @@ __device__ __forceinline__ void resample_fast32_hv(const ShrinkArgs &a, const ui
 }
 
 // Fast-path eligibility of a tile (full 32x32 RGBA, 16-byte aligned rows) and its first byte.
-__device__ __forceinline__ bool fast32_tile_src(const ShrinkArgs &a, uint32_t tile_g, const uint8_t *&src)
+template <class Args>
+__device__ __forceinline__ bool fast32_tile_src(const Args &a, uint32_t tile_g, const uint8_t *&src)
 {
 	if (tile_g >= a.n_tiles) return false;
 	const uint32_t frame = fastdiv(tile_g, a.div_tpf);
@@ -490,7 +491,8 @@ __device__ __forceinline__ bool fast32_tile_src(const ShrinkArgs &a, uint32_t ti
 	return w == 32 && h == 32 && ((reinterpret_cast<uintptr_t>(src) | a.pitch) & 15u) == 0;
 }
 // Issues the four 16-byte loads of a lane's share of a fast tile (rows l/8 + 8k, quad l%8).
-__device__ __forceinline__ void fast32_prefetch(const ShrinkArgs &a, uint32_t tile_g, uint32_t lane, uint4 (&pre)[4], bool &valid)
+template <class Args>
+__device__ __forceinline__ void fast32_prefetch(const Args &a, uint32_t tile_g, uint32_t lane, uint4 (&pre)[4], bool &valid)
 {
 	const uint8_t *src;
 	valid = fast32_tile_src(a, tile_g, src);
@@ -920,7 +922,7 @@ __device__ __forceinline__ void process_tile(const ShrinkArgs &a, const uint32_t
 	const bool need_h = nw != w, need_v = nh != h;
 	if constexpr (TW == 32 && NW == 1 && C == 4) {
 		if (fast && opaque && need_h && need_v) {
-			resample_fast32_hv(a, s_tab, tab_x, tab_y, s_pl, s_tmp, tid, nw, nh, dst);
+			resample_fast32_hv(s_tab, tab_x, tab_y, s_pl, s_tmp, tid, nw, nh, dst);
 			return;
 		}
 	}
@@ -1052,6 +1054,212 @@ __device__ __forceinline__ void process_tile(const ShrinkArgs &a, const uint32_t
 	}
 }
 
+// ---- diagnostic build only (-DPXZ_STAMPS): per-phase wave-cycle shares of shrink32_kernel.
+// Stamp values leave through a buffer of their own (a.work, past the worklist); no output depends on them.
+#ifdef PXZ_STAMPS
+__device__ __forceinline__ unsigned long long stamp_now()
+{
+	unsigned long long t;
+	__builtin_amdgcn_sched_barrier(0);
+	asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+	__builtin_amdgcn_sched_barrier(0);
+	return t;
+}
+#define PXZ_STAMP(i)                                   \
+	do {                                               \
+		const unsigned long long now_ = stamp_now();   \
+		st_acc[i] += now_ - st_last;                   \
+		st_last = now_;                                \
+	} while (0)
+#else
+#define PXZ_STAMP(i) \
+	do {             \
+	} while (0)
+#endif
+
+// ---------------------------------------------------------------------------
+// shrink32_kernel: the common case on its own — full, 16-byte-aligned 32x32 RGBA tiles whose
+// resample is a clone, a nearest pick, or a two-pass convolution of an opaque tile.  Everything
+// else (ragged-edge tiles, tiles with transparency, one-pass resamples) is appended to a device
+// worklist that the generic kernel processes afterwards.  Persistent waves, one LDS tile image
+// each, next tile's pixels prefetched into registers, table rows in LDS, lookups in kernarg.
+// MODE 1: directional detector here; MODE 0: value already in sums[] (oklab32_kernel).
+// ---------------------------------------------------------------------------
+template <int MODE>
+__global__ void __launch_bounds__(768) shrink32_kernel(const Fast32Args a)
+{
+	extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+	const uint32_t wpb = blockDim.x / 64u, sub = threadIdx.x / 64u, tid = threadIdx.x % 64u;
+	for (uint32_t i = threadIdx.x; i < a.tab_dw / 4u; i += blockDim.x)
+		reinterpret_cast<uint4 *>(lds)[i] = reinterpret_cast<const uint4 *>(a.trows)[i];
+	__syncthreads();
+	const uint32_t *s_tab = lds;
+	uint32_t *s_pl = lds + a.tab_dw + sub * a.tile_dw;
+	uint32_t *s_tmp = s_pl + 4 * kPD32;
+	const uint32_t stride = gridDim.x * wpb;
+	// two register sets of prefetched pixels: while tile k is processed, tiles k+1 and k+2 are in flight
+	// (one 4 KB tile per wave does not keep enough bytes outstanding to cover HBM latency)
+	uint4 preA[4], preB[4];
+	bool validA = false, validB = false;
+	const uint32_t first = __builtin_amdgcn_readfirstlane(blockIdx.x * wpb + sub);
+	fast32_prefetch(a, first, tid, preA, validA);
+	fast32_prefetch(a, first + stride, tid, preB, validB);
+#ifdef PXZ_STAMPS
+	unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+	unsigned long long st_last = stamp_now();
+#endif
+	auto one_tile = [&](const uint32_t tile_g, uint4 (&pre)[4], bool &pre_valid) {
+		auto defer = [&]() {
+			if (tid == 0) a.work[1 + atomicAdd(&a.work[0], 1u)] = tile_g;
+		};
+		if (!pre_valid) {  // ragged edge / unaligned rows: generic kernel
+			defer();
+			fast32_prefetch(a, tile_g + 2u * stride, tid, pre, pre_valid);
+			return;
+		}
+		uint32_t given_bits = 0;
+		if constexpr (MODE == 0) given_bits = a.sums[2 * tile_g];  // issued before the prefetch: its wait leaves the prefetch in flight
+		// ---- stage: prefetched registers -> planar u16 pairs
+		uint32_t alpha_and = 0xffu;
+#pragma unroll
+		for (int k = 0; k < 4; ++k) {
+			const uint32_t row = (tid >> 3) + 8u * (uint32_t)k, col = tid & 7u;
+			const uint4 v = pre[k];
+			alpha_and &= (v.x & v.y & v.z & v.w) >> 24;
+			uint32_t *d = s_pl + row * kRS32 + col * 2u;
+#pragma unroll
+			for (uint32_t c = 0; c < 4; ++c) {
+				const uint32_t sel = c | 0x0c000c00u | ((4u + c) << 16);
+				uint2 pr;
+				pr.x = __builtin_amdgcn_perm(v.y, v.x, sel);
+				pr.y = __builtin_amdgcn_perm(v.w, v.z, sel);
+				*reinterpret_cast<uint2 *>(d + c * kPD32) = pr;
+			}
+		}
+		PXZ_STAMP(0);  // wait for the prefetched pixels + staging
+		fast32_prefetch(a, tile_g + 2u * stride, tid, pre, pre_valid);  // two tiles ahead: lands during the next tile
+		tile_sync<1>();
+		PXZ_STAMP(1);  // prefetch issue
+
+		// ---- detector + level decision
+		uint32_t m0, m1;
+		if constexpr (MODE == 1) {
+			uint32_t sum_hz = 0, sum_vr = 0;
+			// 16 lanes (pixel pairs) per row group, 4 groups of 8 window rows (the last one 6).  Per
+			// channel and window row: r = 1-2-1 along x (perm, add, mad), |hz| (sad), column smoothing
+			// c = t(y)+t(y+1) (2 adds), the neighbour pair's c by DPP, |vr| (sad).  Fully unrolled:
+			// every LDS address is a per-channel base + immediate, no loop-carried register moves.
+			const uint32_t q = tid & 15u, g = tid >> 4;
+			const uint32_t two = 0x00020002u;
+			const uint32_t *pc[3];
+			pc[0] = s_pl + g * (8u * kRS32) + q;
+			pc[1] = pc[0] + kPD32;
+			pc[2] = pc[1] + kPD32;
+			uint32_t rA[3], rB[3], tP[3], dP[3];
+#pragma unroll
+			for (int c = 0; c < 3; ++c) {
+				const uint32_t a0 = pc[c][0], a1 = pc[c][1], b0 = pc[c][kRS32], b1 = pc[c][kRS32 + 1];
+				rA[c] = pk_mad_u16(__builtin_amdgcn_alignbit(a1, a0, 16), two, u32(us2(a0) + us2(a1)));
+				rB[c] = pk_mad_u16(__builtin_amdgcn_alignbit(b1, b0, 16), two, u32(us2(b0) + us2(b1)));
+				tP[c] = u32(us2(a0) + us2(b0));
+				dP[c] = b0;
+			}
+#pragma unroll
+			for (int st = 0; st < 4; ++st) {
+				if (st < 3 || g != 3u) {  // the last group has 6 window rows = 3 steps
+#pragma unroll
+					for (int c = 0; c < 3; ++c) {
+						const uint32_t *pr = pc[c] + (2 + 2 * st) * (int)kRS32;
+						const uint32_t n0 = pr[0], n1 = pr[1], o0 = pr[kRS32], o1 = pr[kRS32 + 1];
+						const uint32_t rN = pk_mad_u16(__builtin_amdgcn_alignbit(n1, n0, 16), two, u32(us2(n0) + us2(n1)));
+						sum_hz = sad16(rN, rA[c], sum_hz);
+						const uint32_t tN = u32(us2(dP[c]) + us2(n0));
+						const uint32_t c0 = u32(us2(tP[c]) + us2(tN));
+						sum_vr = sad16(dpp_mov<0x101>(c0), c0, sum_vr);  // row_shl:1 = the pair to the right
+						const uint32_t rO = pk_mad_u16(__builtin_amdgcn_alignbit(o1, o0, 16), two, u32(us2(o0) + us2(o1)));
+						sum_hz = sad16(rO, rB[c], sum_hz);
+						const uint32_t tO = u32(us2(n0) + us2(o0));
+						const uint32_t e0 = u32(us2(tN) + us2(tO));
+						sum_vr = sad16(dpp_mov<0x101>(e0), e0, sum_vr);
+						rA[c] = rN;
+						rB[c] = rO;
+						tP[c] = tO;
+						dP[c] = o0;
+					}
+				}
+			}
+			if (q == 15u) sum_hz = sum_vr = 0;  // pair 15 starts no window (x = 30, 31)
+			sum_hz = wave_sum_sgpr(sum_hz);
+			sum_vr = wave_sum_sgpr(sum_vr);
+			m0 = level_count(sum_hz, a.breaks, a.breaks_asc);
+			m1 = level_count(sum_vr, a.breaks, a.breaks_asc);
+			if (tid == 0) reinterpret_cast<uint2 *>(a.sums)[tile_g] = make_uint2(sum_hz, sum_vr);
+		} else {
+			const uint32_t vb = __builtin_amdgcn_readfirstlane(given_bits);
+			m0 = m1 = level_count(__float_as_uint(parse_value(__uint_as_float(vb))), a.breaks, a.breaks_asc);
+		}
+		const uint32_t nw = reduced_size(32u, m0), nh = reduced_size(32u, m1);
+		if (tid == 0) {
+			if (a.out_w) a.out_w[tile_g] = nw;
+			if (a.out_h) a.out_h[tile_g] = nh;
+		}
+		PXZ_STAMP(2);  // detector + reduction + level decision + metadata
+		if (a.out_px != nullptr) {
+			uint8_t *dst = a.out_px + (size_t)tile_g * 4096u;
+			if (nw == 32u && nh == 32u) {
+				// clone (block.rs:279-281): re-interleave the planes, one 16-byte store per 4 pixels
+#pragma unroll
+				for (int k = 0; k < 4; ++k) {
+					const uint32_t i = tid + 64u * (uint32_t)k;
+					const uint32_t *p = s_pl + (i >> 3) * kRS32 + (i & 7u) * 2u;
+					const uint2 r = *reinterpret_cast<const uint2 *>(p), g = *reinterpret_cast<const uint2 *>(p + kPD32);
+					const uint2 b = *reinterpret_cast<const uint2 *>(p + 2 * kPD32), al = *reinterpret_cast<const uint2 *>(p + 3 * kPD32);
+					const uint32_t rg01 = __builtin_amdgcn_perm(g.x, r.x, 0x06020400u), ba01 = __builtin_amdgcn_perm(al.x, b.x, 0x06020400u);
+					const uint32_t rg23 = __builtin_amdgcn_perm(g.y, r.y, 0x06020400u), ba23 = __builtin_amdgcn_perm(al.y, b.y, 0x06020400u);
+					uint4 o;
+					o.x = __builtin_amdgcn_perm(ba01, rg01, 0x05040100u);
+					o.y = __builtin_amdgcn_perm(ba01, rg01, 0x07060302u);
+					o.z = __builtin_amdgcn_perm(ba23, rg23, 0x05040100u);
+					o.w = __builtin_amdgcn_perm(ba23, rg23, 0x07060302u);
+					reinterpret_cast<uint4 *>(dst)[i] = o;
+				}
+			} else if (nw != 32u && nh != 32u && a.filter != 0 && wave_and_sgpr(alpha_and) == 0xffu) {
+				const uint32_t lx = m0 < (uint32_t)kMaxLevel ? m0 : (uint32_t)kMaxLevel - 1;
+				const uint32_t ly = m1 < (uint32_t)kMaxLevel ? m1 : (uint32_t)kMaxLevel - 1;
+				resample_fast32_hv(s_tab, a.tabs[lx], a.tabs[ly], s_pl, s_tmp, tid, nw, nh, dst);
+			} else if (a.filter == 0) {
+				// ResizeAlg::Nearest (mod.rs:277): source index = floor((o + 0.5) * 2^m), no alpha handling
+				const uint32_t lgx = 31u - (uint32_t)__builtin_clz(nw);
+				const uint32_t hx = m0 ? (1u << (m0 < 6u ? m0 - 1u : 4u)) : 0u, hy = m1 ? (1u << (m1 < 6u ? m1 - 1u : 4u)) : 0u;
+				const uint16_t *pl16 = reinterpret_cast<const uint16_t *>(s_pl);
+				for (uint32_t i = tid; i < nw * nh; i += 64u) {
+					const uint32_t ox = i & (nw - 1u), oy = i >> lgx;
+					// 32 -> nw = 32 >> m (m <= 5): index (2o+1) * 2^(m-1); m >= 5 gives the single index 16
+					const uint32_t x = m0 == 0 ? ox : (m0 < 6u ? (2u * ox + 1u) * hx : 16u);
+					const uint32_t y = m1 == 0 ? oy : (m1 < 6u ? (2u * oy + 1u) * hy : 16u);
+					const uint32_t idx = y * (2u * kRS32) + x;
+					reinterpret_cast<uint32_t *>(dst)[i] = (uint32_t)pl16[idx] | ((uint32_t)pl16[idx + 2u * kPD32] << 8) |
+					                                       ((uint32_t)pl16[idx + 4u * kPD32] << 16) | ((uint32_t)pl16[idx + 6u * kPD32] << 24);
+				}
+			} else {
+				defer();  // transparency or a single-pass resample: generic kernel
+			}
+		}
+		tile_sync<1>();  // the next tile reuses this wave's LDS image
+		PXZ_STAMP(3);  // clone / resample / defer
+	};
+	for (uint32_t tile_g = first; tile_g < a.n_tiles; tile_g += 2u * stride) {
+		one_tile(tile_g, preA, validA);
+		if (tile_g + stride < a.n_tiles) one_tile(tile_g + stride, preB, validB);
+	}
+#ifdef PXZ_STAMPS
+	if (tid == 0) {
+		unsigned long long *out = reinterpret_cast<unsigned long long *>(a.work + ((a.n_tiles + 2u + 1u) & ~1u));
+		for (int i = 0; i < 8; ++i) atomicAdd(out + i, st_acc[i]);
+	}
+#endif
+}
+
 // ---------------------------------------------------------------------------
 // kernel: persistent over tiles.  NW == 1: every wave of the block owns one LDS tile
 // image and walks tiles wave_id, wave_id + total_waves, ... (neighbouring waves take
@@ -1074,7 +1282,10 @@ __global__ void __launch_bounds__(NW == 1 ? 768 : 64 * NW) shrink_kernel(const S
 		uint4 pre[4];
 		bool pre_valid = false;
 		if constexpr (TW == 32 && C == 4) fast32_prefetch(a, __builtin_amdgcn_readfirstlane(blockIdx.x * wpb + sub), tid, pre, pre_valid);
-		for (uint32_t tile_g = __builtin_amdgcn_readfirstlane(blockIdx.x * wpb + sub); tile_g < a.n_tiles; tile_g += stride) {
+		// with a worklist (left by shrink32_kernel) only the listed tiles are processed
+		const uint32_t count = a.work ? __builtin_amdgcn_readfirstlane(a.work[0]) : a.n_tiles;
+		for (uint32_t i = __builtin_amdgcn_readfirstlane(blockIdx.x * wpb + sub); i < count; i += stride) {
+			const uint32_t tile_g = a.work ? __builtin_amdgcn_readfirstlane(a.work[1 + i]) : i;
 			process_tile<NW, C, MODE, TW>(a, tile_g, s_pl, nullptr, lds, tid, pre, pre_valid, tile_g + stride);
 			tile_sync<1>();  // the next tile reuses this wave's LDS image
 		}
@@ -1458,10 +1669,6 @@ static hipError_t launch_one(const ShrinkArgs &a, const LaunchGeom &g, hipStream
 template <int NW>
 static hipError_t launch_nw(const ShrinkArgs &a, uint32_t channels, const LaunchGeom &g, hipStream_t stream)
 {
-	if constexpr (NW == 1) {
-		if (g.fast32)  // the headline geometry: compile-time fast path, table rows in LDS
-			return a.mode == 1 ? launch_one<1, 4, 1, 32>(a, g, stream) : launch_one<1, 4, 0, 32>(a, g, stream);
-	}
 	if (channels == 4)
 		return a.mode == 1 ? launch_one<NW, 4, 1, 0>(a, g, stream) : launch_one<NW, 4, 0, 0>(a, g, stream);
 	return a.mode == 1 ? launch_one<NW, 3, 1, 0>(a, g, stream) : launch_one<NW, 3, 0, 0>(a, g, stream);
@@ -1487,8 +1694,7 @@ LaunchGeom plan_launch(const ShrinkArgs &a, uint32_t channels, uint32_t n_cus)
 	const uint32_t tile_bytes = a.tile_dw * 4u;
 	constexpr uint32_t kLds = 160u * 1024u;
 	if (nw == 1) {
-		g.fast32 = channels == 4 && a.bw == 32 && a.bh == 32 && (a.out_px == nullptr || a.filter == 0 || a.tab_dw != 0) &&
-		           a.tab_dw * 4u + tile_bytes <= kLds;
+		g.fast32 = false;
 		const uint32_t tab_bytes = g.fast32 ? a.tab_dw * 4u : 0u;
 		uint32_t wpb = (kLds - tab_bytes) / tile_bytes;
 		if (wpb > 12u) wpb = 12u;
@@ -1513,15 +1719,83 @@ LaunchGeom plan_launch(const ShrinkArgs &a, uint32_t channels, uint32_t n_cus)
 	return g;
 }
 
+bool fast32_applicable(const ShrinkArgs &a, uint32_t channels)
+{
+	return channels == 4 && a.bw == 32 && a.bh == 32 && a.work != nullptr &&
+	       (a.out_px == nullptr || a.filter == 0 || a.tab_dw != 0) && !(a.mode == 0 && !a.oklab_given);
+}
+
 hipError_t launch_shrink(const ShrinkArgs &a, uint32_t channels, uint32_t n_cus, hipStream_t stream)
 {
-	const LaunchGeom g = plan_launch(a, channels, n_cus);
-	switch (waves_per_tile(a.bw, a.bh)) {
-	case 1: return launch_nw<1>(a, channels, g, stream);
-	case 2: return launch_nw<2>(a, channels, g, stream);
-	case 4: return launch_nw<4>(a, channels, g, stream);
-	case 8: return launch_nw<8>(a, channels, g, stream);
-	default: return launch_nw<16>(a, channels, g, stream);
+	ShrinkArgs ga = a;
+	if (fast32_applicable(a, channels)) {
+		// 1) the lean kernel for full opaque tiles; it leaves the rest in the worklist
+		Fast32Args f{};
+		f.src = a.src;
+		f.frame_stride = a.frame_stride;
+		f.pitch = a.pitch;
+		f.cols = a.cols;
+		f.rows = a.rows;
+		f.tiles_per_frame = a.tiles_per_frame;
+		f.n_tiles = a.n_tiles;
+		f.div_tpf = a.div_tpf;
+		f.div_cols = a.div_cols;
+		f.edge_w = a.edge_w;
+		f.edge_h = a.edge_h;
+		f.bw = 32;
+		f.bh = 32;
+		f.filter = a.filter;
+		f.sums = a.sums;
+		f.out_w = a.out_w;
+		f.out_h = a.out_h;
+		f.out_px = a.out_px;
+		f.work = a.work;
+		f.trows = a.trows;
+		f.tab_dw = a.out_px && a.filter != 0 ? a.tab_dw : 0u;
+		for (int j = 0; j < kMaxLevel; ++j) {
+			f.breaks[j] = a.breaks[0][j];
+			f.tabs[j] = a.tabs[j];  // x axis, full class; identical to the y axis for 32x32
+		}
+		f.breaks_asc = a.breaks_asc[0];
+		// planes 4 x 576 dwords, transposed planes 3 x 288, slack for zero-weight over-reads
+		f.tile_dw = (f.out_px && f.filter != 0) ? 4u * kPD32 + 3u * kTD32 + 2u * kRS32 : 4u * kPD32 + 2u * kRS32;
+		f.tile_dw = (f.tile_dw + 3u) & ~3u;
+		constexpr uint32_t kLds = 160u * 1024u;
+		uint32_t wpb = (kLds - f.tab_dw * 4u) / (f.tile_dw * 4u);
+		if (wpb > 12u) wpb = 12u;
+		if (const char *e = getenv("PXZ_WPB")) {
+			const uint32_t v = (uint32_t)atoi(e);
+			if (v >= 1 && v < wpb) wpb = v;
+		}
+		const uint32_t lds_bytes = f.tab_dw * 4u + wpb * f.tile_dw * 4u;
+		const uint32_t per_cu = kLds / lds_bytes > 0 ? kLds / lds_bytes : 1u;
+		const uint32_t resident = n_cus * (per_cu > 2u ? 2u : per_cu);
+		const uint32_t need = (a.n_tiles + wpb - 1u) / wpb;
+		const uint32_t blocks = need < resident ? need : resident;
+		hipError_t e = hipMemsetAsync(a.work, 0, 4, stream);
+		if (e != hipSuccess) return e;
+		if (a.mode == 1) {
+			auto k = shrink32_kernel<1>;
+			if (lds_bytes > 64u * 1024u && (e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)) != hipSuccess) return e;
+			hipLaunchKernelGGL(k, dim3(blocks), dim3(64u * wpb), lds_bytes, stream, f);
+		} else {
+			auto k = shrink32_kernel<0>;
+			if (lds_bytes > 64u * 1024u && (e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)) != hipSuccess) return e;
+			hipLaunchKernelGGL(k, dim3(blocks), dim3(64u * wpb), lds_bytes, stream, f);
+		}
+		if ((e = hipGetLastError()) != hipSuccess) return e;
+		// 2) the generic kernel walks the worklist (usually empty or a few percent of the tiles)
+	} else {
+		ga.work = nullptr;
+	}
+	ga.oklab_given = 0;  // the generic path computes its own Oklab values
+	const LaunchGeom g = plan_launch(ga, channels, n_cus);
+	switch (waves_per_tile(ga.bw, ga.bh)) {
+	case 1: return launch_nw<1>(ga, channels, g, stream);
+	case 2: return launch_nw<2>(ga, channels, g, stream);
+	case 4: return launch_nw<4>(ga, channels, g, stream);
+	case 8: return launch_nw<8>(ga, channels, g, stream);
+	default: return launch_nw<16>(ga, channels, g, stream);
 	}
 }
 

@@ -1,0 +1,34 @@
+"""Diagnostic: phase shares of shrink32_kernel from the -DPXZ_STAMPS build (PXZ_LIB=...stamps.so)."""
+import os, sys, ctypes as C
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+from __graft_entry__ import load_product
+P = load_product()
+h = P.Handle(0)
+dist = int(os.environ.get("DIST", "0"))
+frames = h.synth_frames_device(8, 4320, 7680, 4, 0, dist)
+LOD = os.environ.get("LOD") == "1"
+run = (lambda o=None: h.lod_frames_device(frames, 32, 32, 1, 16.0)) if LOD else (lambda o=None: h.shrink_frames_device(frames, 32, 32, 1, 4, 16.0, out=o))
+out = run()
+torch.cuda.synchronize()
+# the stamps live behind the worklist inside the handle's private buffer: read via a second launch's side effect
+# -> expose through hipMemcpy using torch: find the buffer by re-running and copying from the known layout
+L = P.load_library()
+L.pxz_debug_read_work.restype = C.c_int
+L.pxz_debug_read_work.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t]
+n_tiles = out[1].numel() if not LOD else out[0].numel()
+def read():
+    buf = (C.c_uint64 * 8)()
+    off = ((n_tiles + 3) & ~1) * 4
+    assert L.pxz_debug_read_work(h._h, buf, off, 64) == 0
+    return list(buf)
+before = read()
+for _ in range(5): run(None if LOD else out)
+torch.cuda.synchronize()
+after = read()
+d = [a - b for a, b in zip(after, before)]
+tot = sum(d[:4])
+names = ["wait prefetch + stage", "issue prefetch", "detector+decision+meta", "clone/resample"]
+for n, v in zip(names, d): print(f"{n:28s} {v/5/n_tiles:10.1f} cycles/tile  {100*v/tot:5.1f}%")
+print("total per tile (wave cycles):", tot / 5 / n_tiles)
