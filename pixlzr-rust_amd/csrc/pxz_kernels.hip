@@ -329,16 +329,16 @@ template <int LPI>
 __device__ __forceinline__ void fast32_h_rows(const uint32_t *trows, const AxisTab &tx, const uint32_t *s_pl, uint32_t *s_tmp,
                                               uint32_t lane, uint32_t nw, uint32_t lgx)
 {
-	// outputs this narrow (nw <= 2) always see the whole 32-px row: 8 quads, all taken
 	constexpr int QPL = 8 / LPI;  // quads per lane
 	const uint32_t item = lane / LPI, part = lane % LPI;
 	const bool live = item < nw * 32u;
 	const uint32_t ox = item & (nw - 1u), y = live ? item >> lgx : 0u;
 	const uint32_t *rowp = trows + tx.rows_off + ox * tx.row_stride;
 	const uint4 hdr = *reinterpret_cast<const uint4 *>(rowp);
-	uint2 kk[QPL];
+	uint2 kk[QPL];  // quads past the table's window width carry no weight (the row ends there)
 #pragma unroll
-	for (int j = 0; j < QPL; ++j) kk[j] = *reinterpret_cast<const uint2 *>(rowp + 4 + 2 * (part + j * LPI));
+	for (int j = 0; j < QPL; ++j)
+		kk[j] = part + (uint32_t)(j * LPI) < tx.wquads ? *reinterpret_cast<const uint2 *>(rowp + 4 + 2 * (part + j * LPI)) : make_uint2(0u, 0u);
 	const uint32_t *row = s_pl + y * kRS32 + hdr.x * 2u + part * 2u;
 	int32_t a0 = 0, a1 = 0, a2 = 0;
 #pragma unroll
@@ -376,10 +376,11 @@ __device__ __forceinline__ void fast32_v(const uint32_t *trows, const AxisTab &t
 	const uint32_t oy = item0 & (nh - 1u);  // invariant: the item step (64/LPI) is a multiple of nh
 	const uint32_t *rowp = trows + ty.rows_off + oy * ty.row_stride;
 	const uint4 hdr = *reinterpret_cast<const uint4 *>(rowp);
-	uint2 kk[QPL];
-#pragma unroll
-	for (int j = 0; j < QPL; ++j) kk[j] = *reinterpret_cast<const uint2 *>(rowp + 4 + 2 * (part + j * LPI));
 	const uint32_t wq = ty.wquads;
+	uint2 kk[QPL];  // quads past the table's window width carry no weight (the row ends there)
+#pragma unroll
+	for (int j = 0; j < QPL; ++j)
+		kk[j] = part + (uint32_t)(j * LPI) < wq ? *reinterpret_cast<const uint2 *>(rowp + 4 + 2 * (part + j * LPI)) : make_uint2(0u, 0u);
 	const int px_ = tx.precision, py = ty.precision;
 	const int32_t ix = 1 << (px_ - 1), iy = 1 << (py - 1);
 	for (uint32_t item = item0; item < ((items + 63u / LPI) & ~(64u / LPI - 1u)); item += 64u / LPI) {
@@ -409,6 +410,90 @@ __device__ __forceinline__ void fast32_v(const uint32_t *trows, const AxisTab &t
 			uint32_t px = clip8(a0 + iy, py) | (clip8(a1 + iy, py) << 8) | (clip8(a2 + iy, py) << 16) | (al << 24);
 			if (al != 255u) px = unpremultiply(px);
 			reinterpret_cast<uint32_t *>(dst)[oy * nw + ox] = px;
+		}
+	}
+}
+
+// single-pass cases of the fast path (one axis keeps its 32 samples), opaque tile.
+// Vertical only: item = (pair of columns, output row) straight on the [y][x] planes; the (row j,
+// row j+1) sample pairs dot2 needs are built with two perms per column pair and row pair.
+__device__ __forceinline__ void fast32_v_only(const uint32_t *trows, const AxisTab &ty, const uint32_t *s_pl, uint32_t lane,
+                                              uint32_t nh, uint8_t *dst)
+{
+	const uint32_t lgy = 31u - (uint32_t)__builtin_clz(nh);
+	const uint32_t oy = lane & (nh - 1u);  // invariant per lane: 64 is a multiple of nh
+	RowRegs r;
+	load_row(trows + ty.rows_off + oy * ty.row_stride, r);
+	const int prec = ty.precision;
+	const int32_t init = 1 << (prec - 1);
+	const uint32_t al = clip8(init + 255 * r.ksum, prec);  // constant-255 alpha through the same window
+	const uint32_t wq = ty.wquads;
+	for (uint32_t i = lane; i < 16u * nh; i += 64u) {
+		const uint32_t qx = i >> lgy;  // column pair
+		const uint32_t *colp = s_pl + (r.fq * 4u) * kRS32 + qx;
+		int32_t acc[3][2];
+#pragma unroll
+		for (int c = 0; c < 3; ++c) acc[c][0] = acc[c][1] = init;
+#pragma unroll
+		for (int q = 0; q < 8; ++q) {
+			if ((uint32_t)q < wq) {
+#pragma unroll
+				for (int c = 0; c < 3; ++c) {
+					const uint32_t *p = colp + c * kPD32 + (q * 4) * (int)kRS32;
+					const uint32_t r0 = p[0], r1 = p[kRS32], r2 = p[2 * kRS32], r3 = p[3 * kRS32];
+					const uint32_t l01 = __builtin_amdgcn_perm(r1, r0, 0x05040100u), l23 = __builtin_amdgcn_perm(r3, r2, 0x05040100u);
+					const uint32_t h01 = __builtin_amdgcn_perm(r1, r0, 0x07060302u), h23 = __builtin_amdgcn_perm(r3, r2, 0x07060302u);
+					acc[c][0] = dot2(l23, r.k[2 * q + 1], dot2(l01, r.k[2 * q], acc[c][0]));
+					acc[c][1] = dot2(h23, r.k[2 * q + 1], dot2(h01, r.k[2 * q], acc[c][1]));
+				}
+			}
+		}
+		uint2 o;
+		o.x = clip8(acc[0][0], prec) | (clip8(acc[1][0], prec) << 8) | (clip8(acc[2][0], prec) << 16) | (al << 24);
+		o.y = clip8(acc[0][1], prec) | (clip8(acc[1][1], prec) << 8) | (clip8(acc[2][1], prec) << 16) | (al << 24);
+		if (al != 255u) {
+			o.x = unpremultiply(o.x);
+			o.y = unpremultiply(o.y);
+		}
+		reinterpret_cast<uint2 *>(dst)[oy * 16u + qx] = o;  // pixels (2qx, 2qx+1) of output row oy, row length 32
+	}
+}
+
+// Horizontal only: item = (output column, pair of rows), results go straight to the slot.
+__device__ __forceinline__ void fast32_h_only(const uint32_t *trows, const AxisTab &tx, const uint32_t *s_pl, uint32_t lane,
+                                              uint32_t nw, uint8_t *dst)
+{
+	const uint32_t lgx = 31u - (uint32_t)__builtin_clz(nw);
+	const uint32_t ox = lane & (nw - 1u);
+	RowRegs r;
+	load_row(trows + tx.rows_off + ox * tx.row_stride, r);
+	const int prec = tx.precision;
+	const int32_t init = 1 << (prec - 1);
+	const uint32_t al = clip8(init + 255 * r.ksum, prec);
+	const uint32_t wq = tx.wquads;
+	for (uint32_t i = lane; i < nw * 16u; i += 64u) {
+		const uint32_t yp = i >> lgx;
+		const uint32_t *row = s_pl + yp * (2 * kRS32) + r.fq * 2u;
+		int32_t acc[3][2];
+#pragma unroll
+		for (int c = 0; c < 3; ++c) acc[c][0] = acc[c][1] = init;
+#pragma unroll
+		for (int q = 0; q < 8; ++q) {
+			if ((uint32_t)q < wq) {
+#pragma unroll
+				for (int c = 0; c < 3; ++c) {
+					const uint2 d = *reinterpret_cast<const uint2 *>(row + c * kPD32 + q * 2);
+					const uint2 e = *reinterpret_cast<const uint2 *>(row + c * kPD32 + kRS32 + q * 2);
+					acc[c][0] = dot2(d.y, r.k[2 * q + 1], dot2(d.x, r.k[2 * q], acc[c][0]));
+					acc[c][1] = dot2(e.y, r.k[2 * q + 1], dot2(e.x, r.k[2 * q], acc[c][1]));
+				}
+			}
+		}
+#pragma unroll
+		for (uint32_t rr = 0; rr < 2; ++rr) {
+			uint32_t px = clip8(acc[0][rr], prec) | (clip8(acc[1][rr], prec) << 8) | (clip8(acc[2][rr], prec) << 16) | (al << 24);
+			if (al != 255u) px = unpremultiply(px);
+			reinterpret_cast<uint32_t *>(dst)[(2u * yp + rr) * nw + ox] = px;
 		}
 	}
 }
@@ -458,6 +543,9 @@ __device__ __forceinline__ void resample_fast32_hv(const uint32_t *trows, const 
 	const uint32_t lgx = 31u - (uint32_t)__builtin_clz(nw);  // nw is a power of two <= 16
 	if (nw >= 4) {
 		switch (tx.wquads) {  // straight-line window code per size: no branches between LDS reads and dot2s
+		case 1: fast32_h_pairs<1>(trows, tx, s_pl, s_tmp, lane, nw, lgx); break;
+		case 2: fast32_h_pairs<2>(trows, tx, s_pl, s_tmp, lane, nw, lgx); break;
+		case 3: fast32_h_pairs<3>(trows, tx, s_pl, s_tmp, lane, nw, lgx); break;
 		case 4: fast32_h_pairs<4>(trows, tx, s_pl, s_tmp, lane, nw, lgx); break;
 		case 5: fast32_h_pairs<5>(trows, tx, s_pl, s_tmp, lane, nw, lgx); break;
 		case 6: fast32_h_pairs<6>(trows, tx, s_pl, s_tmp, lane, nw, lgx); break;
@@ -1086,7 +1174,7 @@ __device__ __forceinline__ unsigned long long stamp_now()
 // MODE 1: directional detector here; MODE 0: value already in sums[] (oklab32_kernel).
 // ---------------------------------------------------------------------------
 template <int MODE>
-__global__ void __launch_bounds__(768) shrink32_kernel(const Fast32Args a)
+__global__ void __launch_bounds__(1024) shrink32_kernel(const Fast32Args a)
 {
 	extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
 	const uint32_t wpb = blockDim.x / 64u, sub = threadIdx.x / 64u, tid = threadIdx.x % 64u;
@@ -1094,8 +1182,16 @@ __global__ void __launch_bounds__(768) shrink32_kernel(const Fast32Args a)
 		reinterpret_cast<uint4 *>(lds)[i] = reinterpret_cast<const uint4 *>(a.trows)[i];
 	__syncthreads();
 	const uint32_t *s_tab = lds;
+	// level breakpoints, one per lane (lanes >= kMaxLevel never count): the level exponent of a key is
+	// one lane-parallel compare + ballot + popcount instead of a scalar compare chain
+	const uint32_t brk_lane = tid < (uint32_t)kMaxLevel ? a.breaks[tid] : (a.breaks_asc ? 0xffffffffu : 0u);
+	auto level_of = [&](uint32_t key) -> uint32_t {
+		const unsigned long long lt = __builtin_amdgcn_ballot_w64(key < brk_lane);
+		const unsigned long long live = (1ull << kMaxLevel) - 1ull;
+		return (uint32_t)__builtin_popcountll((a.breaks_asc ? ~lt : lt) & live);
+	};
 	uint32_t *s_pl = lds + a.tab_dw + sub * a.tile_dw;
-	uint32_t *s_tmp = s_pl + 4 * kPD32;
+	uint32_t *s_tmp = s_pl + 3 * kPD32;  // R, G, B planes only: tiles with transparency go to the worklist
 	const uint32_t stride = gridDim.x * wpb;
 	// two register sets of prefetched pixels: while tile k is processed, tiles k+1 and k+2 are in flight
 	// (one 4 KB tile per wave does not keep enough bytes outstanding to cover HBM latency)
@@ -1128,7 +1224,7 @@ __global__ void __launch_bounds__(768) shrink32_kernel(const Fast32Args a)
 			alpha_and &= (v.x & v.y & v.z & v.w) >> 24;
 			uint32_t *d = s_pl + row * kRS32 + col * 2u;
 #pragma unroll
-			for (uint32_t c = 0; c < 4; ++c) {
+			for (uint32_t c = 0; c < 3; ++c) {
 				const uint32_t sel = c | 0x0c000c00u | ((4u + c) << 16);
 				uint2 pr;
 				pr.x = __builtin_amdgcn_perm(v.y, v.x, sel);
@@ -1138,6 +1234,11 @@ __global__ void __launch_bounds__(768) shrink32_kernel(const Fast32Args a)
 		}
 		PXZ_STAMP(0);  // wait for the prefetched pixels + staging
 		fast32_prefetch(a, tile_g + 2u * stride, tid, pre, pre_valid);  // two tiles ahead: lands during the next tile
+		if (__builtin_amdgcn_ballot_w64(alpha_and != 0xffu) != 0ull) {
+			// transparency: premultiplied convolution and the alpha plane live in the generic kernel
+			defer();
+			return;
+		}
 		tile_sync<1>();
 		PXZ_STAMP(1);  // prefetch issue
 
@@ -1191,12 +1292,12 @@ __global__ void __launch_bounds__(768) shrink32_kernel(const Fast32Args a)
 			if (q == 15u) sum_hz = sum_vr = 0;  // pair 15 starts no window (x = 30, 31)
 			sum_hz = wave_sum_sgpr(sum_hz);
 			sum_vr = wave_sum_sgpr(sum_vr);
-			m0 = level_count(sum_hz, a.breaks, a.breaks_asc);
-			m1 = level_count(sum_vr, a.breaks, a.breaks_asc);
+			m0 = level_of(sum_hz);
+			m1 = level_of(sum_vr);
 			if (tid == 0) reinterpret_cast<uint2 *>(a.sums)[tile_g] = make_uint2(sum_hz, sum_vr);
 		} else {
 			const uint32_t vb = __builtin_amdgcn_readfirstlane(given_bits);
-			m0 = m1 = level_count(__float_as_uint(parse_value(__uint_as_float(vb))), a.breaks, a.breaks_asc);
+			m0 = m1 = level_of(__float_as_uint(parse_value(__uint_as_float(vb))));
 		}
 		const uint32_t nw = reduced_size(32u, m0), nh = reduced_size(32u, m1);
 		if (tid == 0) {
@@ -1213,9 +1314,10 @@ __global__ void __launch_bounds__(768) shrink32_kernel(const Fast32Args a)
 					const uint32_t i = tid + 64u * (uint32_t)k;
 					const uint32_t *p = s_pl + (i >> 3) * kRS32 + (i & 7u) * 2u;
 					const uint2 r = *reinterpret_cast<const uint2 *>(p), g = *reinterpret_cast<const uint2 *>(p + kPD32);
-					const uint2 b = *reinterpret_cast<const uint2 *>(p + 2 * kPD32), al = *reinterpret_cast<const uint2 *>(p + 3 * kPD32);
-					const uint32_t rg01 = __builtin_amdgcn_perm(g.x, r.x, 0x06020400u), ba01 = __builtin_amdgcn_perm(al.x, b.x, 0x06020400u);
-					const uint32_t rg23 = __builtin_amdgcn_perm(g.y, r.y, 0x06020400u), ba23 = __builtin_amdgcn_perm(al.y, b.y, 0x06020400u);
+					const uint2 b = *reinterpret_cast<const uint2 *>(p + 2 * kPD32);
+					const uint32_t opq = 0x00ff00ffu;  // the tile is opaque: alpha pair (255, 255)
+					const uint32_t rg01 = __builtin_amdgcn_perm(g.x, r.x, 0x06020400u), ba01 = __builtin_amdgcn_perm(opq, b.x, 0x06020400u);
+					const uint32_t rg23 = __builtin_amdgcn_perm(g.y, r.y, 0x06020400u), ba23 = __builtin_amdgcn_perm(opq, b.y, 0x06020400u);
 					uint4 o;
 					o.x = __builtin_amdgcn_perm(ba01, rg01, 0x05040100u);
 					o.y = __builtin_amdgcn_perm(ba01, rg01, 0x07060302u);
@@ -1223,7 +1325,7 @@ __global__ void __launch_bounds__(768) shrink32_kernel(const Fast32Args a)
 					o.w = __builtin_amdgcn_perm(ba23, rg23, 0x07060302u);
 					reinterpret_cast<uint4 *>(dst)[i] = o;
 				}
-			} else if (nw != 32u && nh != 32u && a.filter != 0 && wave_and_sgpr(alpha_and) == 0xffu) {
+			} else if (nw != 32u && nh != 32u && a.filter != 0) {
 				const uint32_t lx = m0 < (uint32_t)kMaxLevel ? m0 : (uint32_t)kMaxLevel - 1;
 				const uint32_t ly = m1 < (uint32_t)kMaxLevel ? m1 : (uint32_t)kMaxLevel - 1;
 				resample_fast32_hv(s_tab, a.tabs[lx], a.tabs[ly], s_pl, s_tmp, tid, nw, nh, dst);
@@ -1239,10 +1341,14 @@ __global__ void __launch_bounds__(768) shrink32_kernel(const Fast32Args a)
 					const uint32_t y = m1 == 0 ? oy : (m1 < 6u ? (2u * oy + 1u) * hy : 16u);
 					const uint32_t idx = y * (2u * kRS32) + x;
 					reinterpret_cast<uint32_t *>(dst)[i] = (uint32_t)pl16[idx] | ((uint32_t)pl16[idx + 2u * kPD32] << 8) |
-					                                       ((uint32_t)pl16[idx + 4u * kPD32] << 16) | ((uint32_t)pl16[idx + 6u * kPD32] << 24);
+					                                       ((uint32_t)pl16[idx + 4u * kPD32] << 16) | 0xff000000u;
 				}
+			} else if (nh != 32u) {
+				const uint32_t ly = m1 < (uint32_t)kMaxLevel ? m1 : (uint32_t)kMaxLevel - 1;
+				fast32_v_only(s_tab, a.tabs[ly], s_pl, tid, nh, dst);  // width kept
 			} else {
-				defer();  // transparency or a single-pass resample: generic kernel
+				const uint32_t lx = m0 < (uint32_t)kMaxLevel ? m0 : (uint32_t)kMaxLevel - 1;
+				fast32_h_only(s_tab, a.tabs[lx], s_pl, tid, nw, dst);  // height kept
 			}
 		}
 		tile_sync<1>();  // the next tile reuses this wave's LDS image
@@ -1752,17 +1858,21 @@ hipError_t launch_shrink(const ShrinkArgs &a, uint32_t channels, uint32_t n_cus,
 		f.work = a.work;
 		f.trows = a.trows;
 		f.tab_dw = a.out_px && a.filter != 0 ? a.tab_dw : 0u;
+		// only the x-axis tables of full tiles are used (the y axis of a 32x32 tile is identical): they
+		// are the first rows of the blob, up to where the y axis begins
+		const uint32_t y_begin = a.tabs[2 * kMaxLevel + 1].rows_off;
+		if (f.tab_dw != 0 && y_begin != 0 && y_begin < f.tab_dw) f.tab_dw = (y_begin + 3u) & ~3u;
 		for (int j = 0; j < kMaxLevel; ++j) {
 			f.breaks[j] = a.breaks[0][j];
 			f.tabs[j] = a.tabs[j];  // x axis, full class; identical to the y axis for 32x32
 		}
 		f.breaks_asc = a.breaks_asc[0];
-		// planes 4 x 576 dwords, transposed planes 3 x 288, slack for zero-weight over-reads
-		f.tile_dw = (f.out_px && f.filter != 0) ? 4u * kPD32 + 3u * kTD32 + 2u * kRS32 : 4u * kPD32 + 2u * kRS32;
+		// planes 3 x 576 dwords (R, G, B), transposed planes 3 x 288, slack for zero-weight over-reads
+		f.tile_dw = (f.out_px && f.filter != 0) ? 3u * kPD32 + 3u * kTD32 + 2u * kRS32 : 3u * kPD32 + 4u * kRS32;
 		f.tile_dw = (f.tile_dw + 3u) & ~3u;
 		constexpr uint32_t kLds = 160u * 1024u;
 		uint32_t wpb = (kLds - f.tab_dw * 4u) / (f.tile_dw * 4u);
-		if (wpb > 12u) wpb = 12u;
+		if (wpb > 16u) wpb = 16u;
 		if (const char *e = getenv("PXZ_WPB")) {
 			const uint32_t v = (uint32_t)atoi(e);
 			if (v >= 1 && v < wpb) wpb = v;

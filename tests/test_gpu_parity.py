@@ -220,3 +220,44 @@ def test_pack_tiles_matches_numpy(gpu, oracle):
         sl = slots.reshape(-1, slots.shape[-1]).cpu().numpy()
         exp = np.concatenate([sl[t, : sizes[t]] for t in range(len(sizes))])
         assert (packed[: exp_off[-1]].cpu().numpy() == exp).all()
+
+
+@pytest.mark.parametrize("axis", [0, 1])
+def test_single_pass_resamples(gpu, oracle, axis):
+    """Tiles that keep one axis at full size (width level from hz, height level from vr): strong variation
+    along one axis plus a weak one along the other gives horizontal-only / vertical-only resamples at
+    several levels (32x16, 32x8, ... or 16x32, 8x32, ...)."""
+    rng = np.random.default_rng(11 + axis)
+    h, w = 256, 512
+    strong = rng.integers(0, 256, size=(h if axis == 0 else w, 3)).astype(np.int32)
+    weak = rng.integers(0, 12, size=(w if axis == 0 else h, 3)).astype(np.int32)
+    img = np.empty((h, w, 4), np.uint8)
+    img[..., 3] = 255
+    if axis == 0:
+        img[..., :3] = np.clip(strong[:, None, :] + weak[None, :, :] - 6, 0, 255)
+    else:
+        img[..., :3] = np.clip(strong[None, :, :] + weak[:, None, :] - 6, 0, 255)
+    seen = set()
+    for factor in (256.0, 128.0, 64.0, 32.0, 16.0, 8.0):
+        for filt in (4, 3, 2, 1, 0):
+            got = gpu.shrink_image(img, 32, 32, 1, filt, factor)
+            exp = oracle.shrink_image(img, 32, 32, 1, filt, factor)
+            assert_same_tiles(got, exp, 4, f"axis{axis} k={factor} f{filt}")
+            seen |= set(histogram(got[1], got[2]))
+    one_pass = {k for k in seen if (k[0] == 32) != (k[1] == 32)}
+    assert len(one_pass) >= 3, seen
+
+
+@pytest.mark.parametrize("filt", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("mode,factors", [(1, (64.0, 16.0, 4.0, 1.0)), (0, (2.0, 0.5))])
+def test_every_filter_on_opaque_fast_path(gpu, oracle, filt, mode, factors):
+    """All five FilterTypes (narrow Hamming windows .. wide Lanczos3) through the 32x32 fast kernels,
+    every level from 32x32 down to 1x1, opaque RGBA."""
+    img = oracle.synth_frame(1024, 512, 4, 7, 0)
+    seen = set()
+    for factor in factors:
+        got = gpu.shrink_image(img, 32, 32, mode, filt, factor)
+        exp = oracle.shrink_image(img, 32, 32, mode, filt, factor, nthreads=8)
+        assert_same_tiles(got, exp, 4, f"filter {filt} mode {mode} k={factor}")
+        seen |= set(histogram(got[1], got[2]))
+    assert len(seen) >= (5 if mode == 1 else 3), seen
