@@ -1437,18 +1437,20 @@ __device__ __forceinline__ double div_f64_inrange(double n, double d)
 	return __builtin_fma(res, r, q);
 }
 
-// glibc 2.35 cbrtf for x in [0, 4): same arithmetic as cbrt_f32 above, table + in-range division
-__device__ __forceinline__ float cbrt_f32_lut(float x, const double *third)
+// glibc 2.35 cbrtf for x in [0, 4): same arithmetic as cbrt_f32 above with the in-range division.
+// The tail `(float)(q * third[2 + xe % 3])` followed by `ldexpf(.., xe / 3)` is folded into ONE
+// multiplication by 2^(xe/3) * third[..]: scaling a double by a power of two is exact and commutes
+// with the rounding to float (no underflow in this range), so the bits are unchanged.  `scale` is the
+// LDS table of those 132 doubles indexed by xe + 130 (xe in [-130, 1]).
+__device__ __forceinline__ float cbrt_f32_lut(float x, const double *scale)
 {
 	int xe;
 	const float xm = frexpf(x, &xe);
 	const float u = (float)(0.492659620528969547 + (0.697570460207922770 - 0.191502161678719066 * (double)xm) * (double)xm);
 	const float t2 = u * u * u;
-	const int q3 = xe / 3, r3 = xe - 3 * q3;  // C semantics: remainder carries the sign of xe
 	const double num = (double)u * ((double)t2 + 2.0 * (double)xm);
 	const double den = 2.0 * (double)t2 + (double)xm;
-	const float ym = (float)(div_f64_inrange(num, den) * third[2 + r3]);
-	const float y = ldexpf(ym, q3);
+	const float y = (float)(div_f64_inrange(num, den) * scale[xe + 130]);
 	return x == 0.0f ? 0.0f : y;
 }
 
@@ -1458,35 +1460,46 @@ __global__ void __launch_bounds__(1024) oklab32_kernel(const ShrinkArgs a)
 	extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
 	float *s_srgb = reinterpret_cast<float *>(lds);          // 256: sRGB u8 -> linear
 	float *s_alpha = s_srgb + 256;                           // 256: a / 255
-	double *s_third = reinterpret_cast<double *>(s_alpha + 256);  // 5 (+3 pad): 2^(k/3)
-	float *s_band = reinterpret_cast<float *>(s_third + 8);  // 2 x kOkBand
+	double *s_scale = reinterpret_cast<double *>(s_alpha + 256);  // 132: 2^(xe/3) * 2^((xe%3)/3), xe = i - 130
+	float *s_mean = reinterpret_cast<float *>(s_scale + 132);     // 64: per (tile, channel) means
+	float *s_band = s_mean + 64;                             // 2 x kOkBand
 	const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
 	if (threadIdx.x < 256) {
 		s_srgb[threadIdx.x] = __uint_as_float(kSrgbToLinearBits[threadIdx.x]);
 		s_alpha[threadIdx.x] = __fdiv_rn((float)threadIdx.x, 255.0f);
 	}
-	if (threadIdx.x == 0) {
-		s_third[0] = 1.0 / 1.5874010519681994748;
-		s_third[1] = 1.0 / 1.2599210498948731648;
-		s_third[2] = 1.0;
-		s_third[3] = 1.2599210498948731648;
-		s_third[4] = 1.5874010519681994748;
+	if (threadIdx.x < 132) {
+		const int xe = (int)threadIdx.x - 130;
+		const int q3 = xe / 3, r3 = xe - 3 * q3;  // C semantics: the remainder carries the sign of xe
+		const double third = r3 == 0 ? 1.0
+		                   : r3 == 1 ? 1.2599210498948731648
+		                   : r3 == 2 ? 1.5874010519681994748
+		                   : r3 == -1 ? 1.0 / 1.2599210498948731648
+		                              : 1.0 / 1.5874010519681994748;
+		s_scale[threadIdx.x] = ldexp(third, q3);  // exact
 	}
 	__syncthreads();
 
 	const uint32_t n_batches = (a.n_tiles + kOkTiles - 1) / kOkTiles;
-	for (uint32_t batch = blockIdx.x; batch < n_batches; batch += gridDim.x) {
-		const uint32_t tile_g = batch * kOkTiles + wave;  // producers: their tile; chain wave: unused
+	const bool producer = wave < kOkTiles;
+	// producers keep the NEXT batch's pixels in flight while they work on the current one
+	uint4 px[4];
+	bool eligible = false;
+	auto fetch = [&](uint32_t batch) {
 		const uint8_t *src = nullptr;
-		const bool producer = wave < kOkTiles;
-		const bool eligible = producer && fast32_tile_src(a, tile_g, src);
-		float lab[4][4][3];  // [quad][pixel][a, b, l]
-		uint32_t alpha_px[4];  // the 4 alpha bytes of every quad
+		eligible = producer && batch < n_batches && fast32_tile_src(a, batch * kOkTiles + wave, src);
 		if (eligible) {
 			const uint8_t *p = src + (size_t)(lane >> 3) * a.pitch + (lane & 7u) * 16u;
-			uint4 px[4];
 #pragma unroll
 			for (int k = 0; k < 4; ++k) px[k] = *reinterpret_cast<const uint4 *>(p + (size_t)(8 * k) * a.pitch);
+		}
+	};
+	fetch(blockIdx.x);
+	for (uint32_t batch = blockIdx.x; batch < n_batches; batch += gridDim.x) {
+		const bool have = eligible;
+		float lab[4][4][3];     // [quad][pixel][a, b, l]
+		uint32_t alpha_px[4];   // the 4 alpha bytes of every quad
+		if (have) {
 #pragma unroll
 			for (int k = 0; k < 4; ++k) {
 				const uint32_t v[4] = {px[k].x, px[k].y, px[k].z, px[k].w};
@@ -1498,30 +1511,43 @@ __global__ void __launch_bounds__(1024) oklab32_kernel(const ShrinkArgs a)
 					const float l = 0.4122214708f * r + 0.5363325363f * g + 0.0514459929f * b;
 					const float m = 0.2119034982f * r + 0.6806995451f * g + 0.1073969566f * b;
 					const float s3 = 0.0883024619f * r + 0.2817188376f * g + 0.6299787005f * b;
-					const float l_ = cbrt_f32_lut(l, s_third), m_ = cbrt_f32_lut(m, s_third), s_ = cbrt_f32_lut(s3, s_third);
+					const float l_ = cbrt_f32_lut(l, s_scale), m_ = cbrt_f32_lut(m, s_scale), s_ = cbrt_f32_lut(s3, s_scale);
 					lab[k][j][2] = 0.2104542553f * l_ + 0.7936177850f * m_ - 0.0040720468f * s_;  // L
 					lab[k][j][0] = 1.9779984951f * l_ - 2.4285922050f * m_ + 0.4505937099f * s_;  // a
 					lab[k][j][1] = 0.0259040371f * l_ + 0.7827717662f * m_ - 0.8086757660f * s_;  // b
 				}
 			}
 		}
+		fetch(batch + gridDim.x);  // px[] is consumed: request the next batch now
 		// chain wave state: lane = tile*4 + channel (a, b, l, alpha)
 		const uint32_t ct = lane >> 2, cc = lane & 3u;
-		float acc = 0.0f, mean = 0.0f;
+		float acc = 0.0f;
+		float mean4[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
 		for (int pass = 0; pass < 2; ++pass) {
+			if (pass == 1) {
+				// the chain wave publishes the means (operations.rs:65-68); producers subtract them in
+				// parallel, so the second chain walk is one add of |d| per element (:80-83)
+				if (wave == kOkTiles) s_mean[lane] = __fdiv_rn(acc, 1024.0f);
+				acc = 0.0f;
+				__syncthreads();
+				if (have) {
+#pragma unroll
+					for (int c = 0; c < 4; ++c) mean4[c] = s_mean[wave * 4u + (uint32_t)c];
+				}
+			}
 #pragma unroll
 			for (int k = 0; k < 4; ++k) {
 				float *buf = s_band + (uint32_t)(k & 1) * kOkBand;
-				if (eligible) {
+				if (have) {
 					float *d = buf + (wave * 4u) * kOkPlane + lane * 4u;  // 4 consecutive pixels of this lane
 #pragma unroll
 					for (int c = 0; c < 3; ++c)
 						*reinterpret_cast<float4 *>(d + c * kOkPlane) =
-						    make_float4(lab[k][0][c], lab[k][1][c], lab[k][2][c], lab[k][3][c]);
+						    make_float4(lab[k][0][c] - mean4[c], lab[k][1][c] - mean4[c], lab[k][2][c] - mean4[c], lab[k][3][c] - mean4[c]);
 					*reinterpret_cast<float4 *>(d + 3 * kOkPlane) =
-					    make_float4(s_alpha[alpha_px[k] & 255u], s_alpha[(alpha_px[k] >> 8) & 255u],
-					                s_alpha[(alpha_px[k] >> 16) & 255u], s_alpha[alpha_px[k] >> 24]);
+					    make_float4(s_alpha[alpha_px[k] & 255u] - mean4[3], s_alpha[(alpha_px[k] >> 8) & 255u] - mean4[3],
+					                s_alpha[(alpha_px[k] >> 16) & 255u] - mean4[3], s_alpha[alpha_px[k] >> 24] - mean4[3]);
 				}
 				__syncthreads();  // band k is complete; band k-1 has been consumed
 				if (wave == kOkTiles && ct < kOkTiles) {
@@ -1539,20 +1565,16 @@ __global__ void __launch_bounds__(1024) oklab32_kernel(const ShrinkArgs a)
 #pragma unroll 4
 						for (uint32_t i = 0; i < 256; i += 4) {
 							const float4 v = *reinterpret_cast<const float4 *>(x + i);
-							acc += fabsf(v.x - mean);  // :80-83
-							acc += fabsf(v.y - mean);
-							acc += fabsf(v.z - mean);
-							acc += fabsf(v.w - mean);
+							acc += fabsf(v.x);
+							acc += fabsf(v.y);
+							acc += fabsf(v.z);
+							acc += fabsf(v.w);
 						}
 					}
 				}
 			}
-			if (pass == 0) {
-				mean = __fdiv_rn(acc, 1024.0f);  // :65-68, count = 32*32
-				acc = 0.0f;
-			}
 		}
-		__syncthreads();  // the last band has been consumed before the next batch overwrites buffer 1... and 0
+		__syncthreads();  // the last band has been consumed before the next batch refills the buffers
 		if (wave == kOkTiles && ct < kOkTiles) {
 			const float d0 = __shfl(acc, (int)(lane & ~3u) + 0, 64), d1 = __shfl(acc, (int)(lane & ~3u) + 1, 64);
 			const float d2 = __shfl(acc, (int)(lane & ~3u) + 2, 64), d3 = __shfl(acc, (int)(lane & ~3u) + 3, 64);
@@ -1568,7 +1590,7 @@ __global__ void __launch_bounds__(1024) oklab32_kernel(const ShrinkArgs a)
 
 hipError_t launch_oklab32(const ShrinkArgs &a, uint32_t n_cus, hipStream_t stream)
 {
-	const uint32_t lds_bytes = (512u + 16u) * 4u + 2u * kOkBand * 4u;
+	const uint32_t lds_bytes = (512u + 2u * 132u + 64u) * 4u + 2u * kOkBand * 4u;
 	auto kernel = oklab32_kernel<0>;
 	hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
 	if (e != hipSuccess) return e;
