@@ -140,6 +140,16 @@ int pxz_pack_tiles_device(pxz_handle *h, uint32_t n_tiles, uint32_t channels, ui
                           const uint32_t *d_tile_w, const uint32_t *d_tile_h, const uint8_t *d_slots,
                           uint64_t *d_offsets, uint8_t *d_packed, uint64_t packed_capacity);
 
+/* Pixlzr::encode_to_vec (src/encoding/mod.rs:40-89) + encode_block (:168-200) + the `qoi` crate 0.4.1
+ * encoder it calls (:181-189), entirely on the device: the tiles of a batch of frames (as left by
+ * pxz_shrink_frames_device: values, dims, slots) become the complete .pixlzr files, back to back in
+ * d_out.  d_file_offsets gets n_frames+1 byte offsets (file f = [off[f], off[f+1])).  filter_byte as in
+ * pxz_encode_container.  If out_capacity is too small the files are truncated but the offsets are
+ * still exact (retry with off[n_frames] bytes).  Asynchronous on the handle's stream. */
+int pxz_encode_frames_device(pxz_handle *h, const pxz_frames *frames, const pxz_params *params, uint32_t filter_byte,
+                             const float *d_block_value, const uint32_t *d_tile_w, const uint32_t *d_tile_h,
+                             const uint8_t *d_slots, uint8_t *d_out, uint64_t out_capacity, uint64_t *d_file_offsets);
+
 /* ---- bitstream: Pixlzr::encode_to_vec, src/encoding/mod.rs:40-89,168-200 ---- */
 /* Tiles given as produced by pxz_shrink_image (slots + dims + values).
  * has_value may be NULL (all Some); has_value[t]==0 writes 0.0 (mod.rs:173-178).

@@ -17,7 +17,7 @@ DIST_OPAQUE, DIST_ALPHA, DIST_FLAT, DIST_NOISE = range(4)
 EXPORTED_SYMBOLS = [
     "pxz_version", "pxz_device_count", "pxz_create", "pxz_destroy", "pxz_last_error", "pxz_set_stream",
     "pxz_synchronize", "pxz_grid", "pxz_shrink_image", "pxz_shrink_frames_device", "pxz_lod_frames_device",
-    "pxz_pack_tiles_device", "pxz_encode_container", "pxz_qoi_encode", "pxz_qoi_bound", "pxz_synth_frames_device", "pxz_axis_table",
+    "pxz_pack_tiles_device", "pxz_encode_frames_device", "pxz_encode_container", "pxz_qoi_encode", "pxz_qoi_bound", "pxz_synth_frames_device", "pxz_axis_table",
     "pxz_enable_timing", "pxz_last_kernel_ms",
 ]
 
@@ -100,6 +100,8 @@ def load_library():
     L.pxz_lod_frames_device.argtypes = [vp, C.POINTER(Frames), C.POINTER(Params)] + [vp] * 3
     L.pxz_pack_tiles_device.restype = C.c_int
     L.pxz_pack_tiles_device.argtypes = [vp, u32, u32, u32, vp, vp, vp, vp, vp, C.c_uint64]
+    L.pxz_encode_frames_device.restype = C.c_int
+    L.pxz_encode_frames_device.argtypes = [vp, C.POINTER(Frames), C.POINTER(Params), u32, vp, vp, vp, vp, vp, C.c_uint64, vp]
     L.pxz_encode_container.restype = C.c_int64
     L.pxz_encode_container.argtypes = [u32] * 6 + [vp] * 5 + [vp, C.c_size_t]
     L.pxz_qoi_encode.restype = C.c_int64
@@ -291,6 +293,27 @@ class Handle:
             C.c_void_p(slots.data_ptr()), C.c_void_p(offsets.data_ptr()), C.c_void_p(packed.data_ptr()),
             packed.numel()))
         return offsets, packed
+
+    def encode_frames_device(self, shape, bw, bh, vals, ow, oh, slots, filter_byte=0, out=None):
+        """GPU bitstream: tiles of a batch -> the .pixlzr files, back to back.  shape = (N, H, W, C) of the frames.
+        Returns (file_offsets int64[N+1], bytes uint8[capacity])."""
+        import torch
+        N, H, W, Cc = shape
+        fd = Frames(W, H, Cc, W * Cc, N, 0, W * Cc * H)
+        pd = Params(bw, bh, 0, 0, 1.0, 0)
+        if out is None:
+            cols, rows = grid(W, H, bw, bh)
+            cap = N * (26 + rows * 4) + N * cols * rows * (13 + 10 + bw * bh * (Cc + 1) + 8)
+            offs = torch.empty(N + 1, dtype=torch.int64, device=vals.device)
+            buf = torch.empty(cap, dtype=torch.uint8, device=vals.device)
+        else:
+            offs, buf = out
+        self.use_torch_stream()
+        self._check(self._L.pxz_encode_frames_device(
+            self._h, C.byref(fd), C.byref(pd), filter_byte, C.c_void_p(vals.data_ptr()), C.c_void_p(ow.data_ptr()),
+            C.c_void_p(oh.data_ptr()), C.c_void_p(slots.data_ptr()), C.c_void_p(buf.data_ptr()), buf.numel(),
+            C.c_void_p(offs.data_ptr())))
+        return offs, buf
 
     def synth_frames_device(self, n_frames, height, width, channels=4, first_frame=0, dist=DIST_OPAQUE, out=None):
         import torch

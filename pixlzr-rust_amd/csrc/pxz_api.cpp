@@ -23,6 +23,7 @@ hipError_t launch_synth(const SynthArgs &s, hipStream_t stream);
 hipError_t launch_finish(const FinishArgs &f, hipStream_t stream);
 hipError_t launch_pack(const PackArgs &a, hipStream_t stream);
 hipError_t launch_oklab32(const ShrinkArgs &a, uint32_t n_cus, hipStream_t stream);
+hipError_t launch_qoi(const QoiArgs &a, hipStream_t stream);
 uint32_t waves_per_tile(uint32_t bw, uint32_t bh);
 }  // namespace pxz
 
@@ -58,7 +59,7 @@ struct pxz_handle {
 	// level breakpoints per (mode, factor bits, bw, bh, edge_w, edge_h)
 	struct Breaks { uint32_t b[4][pxz::kMaxLevel]; uint32_t asc[4]; };
 	std::map<std::tuple<uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t>, Breaks> breaks;
-	DeviceBuffer in, val, ow, oh, out, sums, chunks, work;
+	DeviceBuffer in, val, ow, oh, out, sums, chunks, work, qscratch, qmeta;
 	bool timing = false;
 	std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
 	size_t events_used = 0;
@@ -468,7 +469,7 @@ void pxz_destroy(pxz_handle *h)
 		(void)hipFree(kv.second.d_ksums);
 		(void)hipFree(kv.second.d_rows);
 	}
-	for (DeviceBuffer *b : {&h->in, &h->val, &h->ow, &h->oh, &h->out, &h->sums, &h->chunks, &h->work})
+	for (DeviceBuffer *b : {&h->in, &h->val, &h->ow, &h->oh, &h->out, &h->sums, &h->chunks, &h->work, &h->qscratch, &h->qmeta})
 		if (b->ptr) (void)hipFree(b->ptr);
 	for (auto &ev : h->events) {
 		(void)hipEventDestroy(ev.first);
@@ -578,9 +579,71 @@ int pxz_pack_tiles_device(pxz_handle *h, uint32_t n_tiles, uint32_t channels, ui
 	if ((uint64_t)slot_bytes * 4096ull > 0xffffffffull) return fail(h, PXZ_ERR_UNSUPPORTED, "slot too large for the chunked scan");
 	int rc = ensure(h, h->chunks, (size_t)n_chunks * 8u);
 	if (rc != PXZ_OK) return rc;
-	pxz::PackArgs a{d_tile_w, d_tile_h, d_slots, (unsigned long long *)d_offsets, (unsigned long long *)h->chunks.ptr,
+	pxz::PackArgs a{d_tile_w, d_tile_h, nullptr, d_slots, (unsigned long long *)d_offsets, (unsigned long long *)h->chunks.ptr,
 	                d_packed, packed_capacity, n_tiles, n_chunks, channels, slot_bytes};
 	PXZ_HIP(h, pxz::launch_pack(a, h->stream));
+	return PXZ_OK;
+}
+
+int pxz_encode_frames_device(pxz_handle *h, const pxz_frames *frames, const pxz_params *params, uint32_t filter_byte,
+                             const float *d_block_value, const uint32_t *d_tile_w, const uint32_t *d_tile_h,
+                             const uint8_t *d_slots, uint8_t *d_out, uint64_t out_capacity, uint64_t *d_file_offsets)
+{
+	if (!h) return PXZ_ERR_INVALID_ARG;
+	if (!frames || !params || !d_block_value || !d_tile_w || !d_tile_h || !d_slots || !d_out || !d_file_offsets)
+		return fail(h, PXZ_ERR_INVALID_ARG, "null pointer");
+	if (frames->channels != 3 && frames->channels != 4) return fail(h, PXZ_ERR_INVALID_ARG, "channels must be 3 or 4");
+	if (params->block_w == 0 || params->block_h == 0 || frames->n_frames == 0) return fail(h, PXZ_ERR_INVALID_ARG, "bad geometry");
+	PXZ_HIP(h, hipSetDevice(h->device));
+	// grid in f32 like the container code (pixlzr.rs:36-46)
+	const uint32_t cols = (uint32_t)std::ceil((float)frames->width / (float)params->block_w);
+	const uint32_t rows = (uint32_t)std::ceil((float)frames->height / (float)params->block_h);
+	const uint64_t tiles64 = (uint64_t)cols * rows * frames->n_frames;
+	if (tiles64 > 0xffffffffull) return fail(h, PXZ_ERR_UNSUPPORTED, "too many tiles");
+	const uint32_t n_tiles = (uint32_t)tiles64, c = frames->channels;
+	const uint32_t slot = params->block_w * params->block_h * c;
+	if ((slot & 15u) != 0 && c == 4) return fail(h, PXZ_ERR_UNSUPPORTED, "RGBA slots must be 16-byte multiples");
+	// record = 13 + 10 + at most (channels+1) bytes per pixel + 8, rounded up for the 8-byte appends
+	const uint32_t stride = (31u + params->block_w * params->block_h * (c + 1u) + 8u + 7u) & ~7u;
+	const uint32_t n_chunks = (n_tiles + 4095u) / 4096u;
+	if ((uint64_t)stride * 4096ull > 0xffffffffull) return fail(h, PXZ_ERR_UNSUPPORTED, "tile too large for the chunked scan");
+	int rc;
+	if ((rc = ensure(h, h->qscratch, (size_t)n_tiles * stride)) != PXZ_OK) return rc;
+	// perm | rec_len | bins(64) as u32, then offsets (n+1) and chunk totals as u64
+	const size_t meta_u32 = (size_t)n_tiles * 2 + 64;
+	const size_t meta_bytes = ((meta_u32 * 4 + 7) & ~(size_t)7) + ((size_t)n_tiles + 1 + n_chunks) * 8;
+	if ((rc = ensure(h, h->qmeta, meta_bytes)) != PXZ_OK) return rc;
+	uint32_t *m32 = (uint32_t *)h->qmeta.ptr;
+	unsigned long long *m64 = (unsigned long long *)((uint8_t *)h->qmeta.ptr + ((meta_u32 * 4 + 7) & ~(size_t)7));
+	pxz::QoiArgs a{};
+	a.slots = d_slots;
+	a.w = d_tile_w;
+	a.h = d_tile_h;
+	a.value = d_block_value;
+	a.perm = m32;
+	a.rec_len = m32 + n_tiles;
+	a.bins = m32 + 2 * (size_t)n_tiles;
+	a.scratch = (uint8_t *)h->qscratch.ptr;
+	a.offsets = m64;
+	a.chunk_totals = m64 + n_tiles + 1;
+	a.out = d_out;
+	a.file_offsets = (unsigned long long *)d_file_offsets;
+	a.capacity = out_capacity;
+	a.n_tiles = n_tiles;
+	a.n_chunks = n_chunks;
+	a.tiles_per_frame = cols * rows;
+	a.cols = cols;
+	a.rows = rows;
+	a.channels = c;
+	a.slot_bytes = slot;
+	a.stride = stride;
+	a.hdr_bytes = 26u + rows * 4u;
+	a.width = frames->width;
+	a.height = frames->height;
+	a.bw = params->block_w;
+	a.bh = params->block_h;
+	a.filter_byte = filter_byte;
+	PXZ_HIP(h, pxz::launch_qoi(a, h->stream));
 	return PXZ_OK;
 }
 

@@ -110,12 +110,31 @@ struct FinishArgs {
 
 struct PackArgs {
 	const uint32_t *w, *h;        // per tile
+	const uint32_t *sizes;        // optional: explicit byte sizes per tile (else w*h*channels)
 	const uint8_t *slots;
 	unsigned long long *offsets;  // n_tiles + 1
 	unsigned long long *chunk_totals;
 	uint8_t *packed;
 	unsigned long long capacity;
 	uint32_t n_tiles, n_chunks, channels, slot_bytes;
+};
+
+struct QoiArgs {
+	const uint8_t *slots;
+	const uint32_t *w, *h;
+	const float *value;
+	uint32_t *perm;               // tiles ordered by pixel count (largest first)
+	uint32_t *bins;               // 64: histogram + cursors
+	uint8_t *scratch;             // per-tile records, `stride` bytes apart
+	uint32_t *rec_len;
+	unsigned long long *offsets;  // n_tiles + 1
+	unsigned long long *chunk_totals;
+	uint8_t *out;
+	unsigned long long *file_offsets;  // n_frames + 1
+	unsigned long long capacity;
+	uint32_t n_tiles, n_chunks, tiles_per_frame, cols, rows;
+	uint32_t channels, slot_bytes, stride, hdr_bytes;
+	uint32_t width, height, bw, bh, filter_byte;
 };
 
 struct SynthArgs {

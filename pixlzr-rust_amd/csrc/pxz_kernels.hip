@@ -1654,7 +1654,7 @@ __global__ void __launch_bounds__(256) pack_scan_local_kernel(const PackArgs a)
 #pragma unroll
 	for (uint32_t i = 0; i < 16; ++i) {
 		const uint32_t t = base + i;
-		sz[i] = t < a.n_tiles ? a.w[t] * a.h[t] * a.channels : 0u;
+		sz[i] = t < a.n_tiles ? (a.sizes ? a.sizes[t] : a.w[t] * a.h[t] * a.channels) : 0u;
 		run += sz[i];
 	}
 	// exclusive scan of the per-thread totals inside the block
@@ -1730,6 +1730,249 @@ hipError_t launch_pack(const PackArgs &a, hipStream_t stream)
 	hipLaunchKernelGGL(pack_scan_local_kernel, dim3(a.n_chunks), dim3(256), 0, stream, a);
 	hipLaunchKernelGGL(pack_scan_chunks_kernel, dim3(1), dim3(1024), 0, stream, a);
 	hipLaunchKernelGGL(pack_copy_kernel, dim3((a.n_tiles + 3) / 4), dim3(256), 0, stream, a);
+	return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// .pixlzr bitstream on the GPU: Pixlzr::encode_to_vec (reference src/encoding/mod.rs:40-89) with
+// encode_block (:168-200) and the `qoi` crate 0.4.1 encoder it calls (:181-189).
+//
+// QOI is sequential per tile (previous pixel, run length, 64-entry index), tiles are independent:
+// one lane encodes one tile.  Tiles are first binned by pixel count (counting sort) so that the 64
+// tiles of a wave have the same length and the lanes stay busy together.  Each lane keeps its index
+// in LDS as table[slot][lane] (consecutive lanes -> consecutive banks), reads 4 pixels per 16-byte
+// load from its slot and appends bytes through a 64-bit accumulator (aligned 8-byte stores) into a
+// per-tile scratch record:  "block" | f32 BE value | u32 BE len | w,h BE | channels | 0 | ops | 0x00*7 0x01.
+// Then: scan of the record lengths, splice into the final files, header + per-row length table.
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) qoi_bin_count_kernel(const QoiArgs a)
+{
+	// per-block histogram in LDS, then one global atomic per non-empty class and block
+	__shared__ uint32_t s_hist[32];
+	if (threadIdx.x < 32) s_hist[threadIdx.x] = 0;
+	__syncthreads();
+	const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+	if (t < a.n_tiles) atomicAdd(&s_hist[31u - (uint32_t)__builtin_clz((a.w[t] * a.h[t]) | 1u)], 1u);
+	__syncthreads();
+	if (threadIdx.x < 32 && s_hist[threadIdx.x]) atomicAdd(&a.bins[threadIdx.x], s_hist[threadIdx.x]);
+}
+
+__global__ void qoi_bin_scan_kernel(const QoiArgs a)
+{
+	// largest tiles first (they set the tail): cursor[c] = start of class c in the permutation
+	uint32_t run = 0;
+	for (int c = 31; c >= 0; --c) {
+		const uint32_t n = a.bins[c];
+		a.bins[32 + c] = run;
+		run += n;
+	}
+}
+
+__global__ void __launch_bounds__(256) qoi_bin_scatter_kernel(const QoiArgs a)
+{
+	// the block reserves one range per class (one global atomic each), threads take slots inside it
+	__shared__ uint32_t s_hist[32], s_base[32];
+	if (threadIdx.x < 32) s_hist[threadIdx.x] = 0;
+	__syncthreads();
+	const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+	uint32_t cls = 0, local = 0;
+	if (t < a.n_tiles) {
+		cls = 31u - (uint32_t)__builtin_clz((a.w[t] * a.h[t]) | 1u);
+		local = atomicAdd(&s_hist[cls], 1u);
+	}
+	__syncthreads();
+	if (threadIdx.x < 32 && s_hist[threadIdx.x]) s_base[threadIdx.x] = atomicAdd(&a.bins[32u + threadIdx.x], s_hist[threadIdx.x]);
+	__syncthreads();
+	if (t < a.n_tiles) a.perm[s_base[cls] + local] = t;
+}
+
+struct ByteSink {
+	unsigned long long acc;
+	uint32_t cnt;        // bytes in acc
+	unsigned long long *out;
+	__device__ __forceinline__ void put(uint32_t b)
+	{
+		acc |= (unsigned long long)(b & 255u) << (8u * cnt);
+		if (++cnt == 8u) {
+			*out++ = acc;
+			acc = 0;
+			cnt = 0;
+		}
+	}
+};
+
+template <int C>
+__global__ void __launch_bounds__(256) qoi_tiles_kernel(const QoiArgs a)
+{
+	__shared__ uint32_t s_index[4][64][64];  // [wave][slot][lane]
+	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+	const bool live = i < a.n_tiles;
+	const uint32_t t = live ? a.perm[i] : 0u;
+	uint32_t(*index)[64] = s_index[wave];
+#pragma unroll 8
+	for (int sidx = 0; sidx < 64; ++sidx) index[sidx][lane] = 0u;  // qoi: index starts as zero pixels
+	if (!live) return;
+	const uint32_t w = a.w[t], h = a.h[t], n = w * h;
+	const uint8_t *src = a.slots + (size_t)t * a.slot_bytes;
+	uint8_t *rec = a.scratch + (size_t)t * a.stride;
+	ByteSink s{0ull, 0u, reinterpret_cast<unsigned long long *>(rec)};
+	// encode_block: magic, value, length placeholder (mod.rs:172-178,195)
+	const uint32_t vb = __float_as_uint(a.value[t]);
+	s.put('b'); s.put('l'); s.put('o'); s.put('c'); s.put('k');
+	s.put(vb >> 24); s.put(vb >> 16); s.put(vb >> 8); s.put(vb);
+	s.put(0); s.put(0); s.put(0); s.put(0);
+	// qoi header minus its 4-byte magic (mod.rs:191): width, height BE, channels, colourspace 0
+	s.put(w >> 24); s.put(w >> 16); s.put(w >> 8); s.put(w);
+	s.put(h >> 24); s.put(h >> 16); s.put(h >> 8); s.put(h);
+	s.put((uint32_t)C); s.put(0);
+
+	uint32_t prev = 0xff000000u, run = 0, last_slot = 0;
+	bool seen_op = false;
+	const bool aligned = C == 4 ? true : ((a.slot_bytes & 3u) == 0);
+	for (uint32_t base = 0; base < n; base += 4u) {
+		uint32_t px4[4];
+		if constexpr (C == 4) {
+			const uint4 v = *reinterpret_cast<const uint4 *>(src + (size_t)base * 4u);  // slots are 16-byte aligned
+			px4[0] = v.x; px4[1] = v.y; px4[2] = v.z; px4[3] = v.w;
+		} else {
+			if (aligned) {
+				const uint32_t *p = reinterpret_cast<const uint32_t *>(src + (size_t)base * 3u);
+				const uint32_t d0 = p[0], d1 = p[1], d2 = p[2];
+				px4[0] = d0 & 0xffffffu;
+				px4[1] = (d0 >> 24) | ((d1 & 0xffffu) << 8);
+				px4[2] = (d1 >> 16) | ((d2 & 0xffu) << 16);
+				px4[3] = d2 >> 8;
+			} else {
+				for (int j = 0; j < 4; ++j) {
+					const uint8_t *p = src + (size_t)(base + j) * 3u;
+					px4[j] = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16);
+				}
+			}
+#pragma unroll
+			for (int j = 0; j < 4; ++j) px4[j] |= 0xff000000u;
+		}
+#pragma unroll
+		for (int j = 0; j < 4; ++j) {
+			const uint32_t pi = base + (uint32_t)j;
+			if (pi >= n) break;
+			const uint32_t px = px4[j];
+			if (px == prev) {
+				if (++run == 62u || pi + 1u == n) {
+					s.put(0xc0u | (run - 1u));
+					run = 0;
+				}
+				continue;
+			}
+			if (run) {
+				// the crate writes a pending run of ONE as INDEX of the repeated pixel once any op was written
+				s.put(run == 1u && seen_op ? last_slot : (0xc0u | (run - 1u)));
+				run = 0;
+			}
+			seen_op = true;
+			last_slot = ((px & 255u) * 3u + ((px >> 8) & 255u) * 5u + ((px >> 16) & 255u) * 7u + (px >> 24) * 11u) & 63u;
+			if (index[last_slot][lane] == px) {
+				s.put(last_slot);  // QOI_OP_INDEX
+			} else {
+				index[last_slot][lane] = px;
+				const uint32_t dr = ((px & 255u) - (prev & 255u)) & 255u;
+				const uint32_t dg = (((px >> 8) & 255u) - ((prev >> 8) & 255u)) & 255u;
+				const uint32_t db = (((px >> 16) & 255u) - ((prev >> 16) & 255u)) & 255u;
+				if (C == 4 && (px >> 24) != (prev >> 24)) {
+					s.put(0xff); s.put(px); s.put(px >> 8); s.put(px >> 16); s.put(px >> 24);  // QOI_OP_RGBA
+				} else if (((dr + 2u) & 255u) < 4u && ((dg + 2u) & 255u) < 4u && ((db + 2u) & 255u) < 4u) {
+					s.put(0x40u | (((dr + 2u) & 3u) << 4) | (((dg + 2u) & 3u) << 2) | ((db + 2u) & 3u));  // QOI_OP_DIFF
+				} else if (((dg + 32u) & 255u) < 64u && ((dr - dg + 8u) & 255u) < 16u && ((db - dg + 8u) & 255u) < 16u) {
+					s.put(0x80u | ((dg + 32u) & 63u));  // QOI_OP_LUMA
+					s.put((((dr - dg + 8u) & 15u) << 4) | ((db - dg + 8u) & 15u));
+				} else {
+					s.put(0xfe); s.put(px); s.put(px >> 8); s.put(px >> 16);  // QOI_OP_RGB
+				}
+			}
+			prev = px;
+		}
+	}
+	s.put(0); s.put(0); s.put(0); s.put(0); s.put(0); s.put(0); s.put(0); s.put(1);  // QOI end marker
+	const uint32_t total = (uint32_t)(reinterpret_cast<uint8_t *>(s.out) - rec) + s.cnt;
+	if (s.cnt) *s.out = s.acc;  // partial tail (the record stride leaves room)
+	const uint32_t qlen = total - 13u;  // mod.rs:193-195
+	rec[9] = (uint8_t)(qlen >> 24);
+	rec[10] = (uint8_t)(qlen >> 16);
+	rec[11] = (uint8_t)(qlen >> 8);
+	rec[12] = (uint8_t)qlen;
+	a.rec_len[t] = total;
+}
+
+// splice: one wave per tile copies its record to (frame+1)*hdr + offset[t]
+__global__ void __launch_bounds__(256) qoi_splice_kernel(const QoiArgs a)
+{
+	const uint32_t t = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+	if (t >= a.n_tiles) return;
+	const unsigned long long off = a.chunk_totals[t / kPackChunk] + a.offsets[t];
+	if (lane == 0) a.offsets[t] = off;
+	const uint32_t frame = t / a.tiles_per_frame;
+	const unsigned long long dstoff = (unsigned long long)(frame + 1u) * a.hdr_bytes + off;
+	const uint32_t len = a.rec_len[t];
+	if (dstoff + len > a.capacity) return;
+	const uint8_t *src = a.scratch + (size_t)t * a.stride;
+	uint8_t *dst = a.out + dstoff;
+	for (uint32_t i = lane; i < len; i += 64u) dst[i] = src[i];
+}
+
+// file header + line-length table (mod.rs:50-57,77-82): one thread per (frame, tile row)
+__global__ void __launch_bounds__(256) qoi_headers_kernel(const QoiArgs a)
+{
+	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+	const uint32_t frames = a.n_tiles / a.tiles_per_frame;
+	if (i >= frames * a.rows) return;
+	const uint32_t f = i / a.rows, r = i - f * a.rows;
+	const uint32_t t0 = f * a.tiles_per_frame + r * a.cols;
+	// offsets[] already hold global record offsets (splice ran first); a row's length is a difference
+	const unsigned long long lo = a.offsets[t0];
+	const unsigned long long hi = (t0 + a.cols == a.n_tiles) ? a.offsets[a.n_tiles] : a.offsets[t0 + a.cols];
+	const unsigned long long file0 = (unsigned long long)f * a.hdr_bytes + a.offsets[f * a.tiles_per_frame];
+	if (file0 + a.hdr_bytes > a.capacity) return;
+	uint8_t *hd = a.out + file0;
+	const uint32_t len = (uint32_t)(hi - lo);
+	uint8_t *lt = hd + 26 + 4 * r;
+	lt[0] = (uint8_t)(len >> 24); lt[1] = (uint8_t)(len >> 16); lt[2] = (uint8_t)(len >> 8); lt[3] = (uint8_t)len;
+	if (r == 0) {
+		const uint8_t magic[10] = {'P', 'I', 'X', 'L', 'Z', 'R', 0, 0, 2, (uint8_t)a.filter_byte};
+		for (int k = 0; k < 10; ++k) hd[k] = magic[k];
+		const uint32_t v[4] = {a.width, a.height, a.bw, a.bh};
+		for (int k = 0; k < 4; ++k) {
+			hd[10 + 4 * k] = (uint8_t)(v[k] >> 24);
+			hd[11 + 4 * k] = (uint8_t)(v[k] >> 16);
+			hd[12 + 4 * k] = (uint8_t)(v[k] >> 8);
+			hd[13 + 4 * k] = (uint8_t)v[k];
+		}
+		a.file_offsets[f] = file0;
+		if (f + 1 == frames) a.file_offsets[frames] = (unsigned long long)frames * a.hdr_bytes + a.offsets[a.n_tiles];
+	}
+}
+
+hipError_t launch_qoi(const QoiArgs &a, hipStream_t stream)
+{
+	hipError_t e = hipMemsetAsync(a.bins, 0, 64 * sizeof(uint32_t), stream);
+	if (e != hipSuccess) return e;
+	const uint32_t tb = (a.n_tiles + 255u) / 256u;
+	hipLaunchKernelGGL(qoi_bin_count_kernel, dim3(tb), dim3(256), 0, stream, a);
+	hipLaunchKernelGGL(qoi_bin_scan_kernel, dim3(1), dim3(1), 0, stream, a);
+	hipLaunchKernelGGL(qoi_bin_scatter_kernel, dim3(tb), dim3(256), 0, stream, a);
+	if (a.channels == 4) hipLaunchKernelGGL(qoi_tiles_kernel<4>, dim3(tb), dim3(256), 0, stream, a);
+	else hipLaunchKernelGGL(qoi_tiles_kernel<3>, dim3(tb), dim3(256), 0, stream, a);
+	// exclusive scan of the record lengths (same chunked scan as the pixel pack, sizes given)
+	PackArgs p{};
+	p.sizes = a.rec_len;
+	p.offsets = a.offsets;
+	p.chunk_totals = a.chunk_totals;
+	p.n_tiles = a.n_tiles;
+	p.n_chunks = a.n_chunks;
+	hipLaunchKernelGGL(pack_scan_local_kernel, dim3(a.n_chunks), dim3(256), 0, stream, p);
+	hipLaunchKernelGGL(pack_scan_chunks_kernel, dim3(1), dim3(1024), 0, stream, p);
+	hipLaunchKernelGGL(qoi_splice_kernel, dim3((a.n_tiles + 3u) / 4u), dim3(256), 0, stream, a);
+	const uint32_t frames = a.n_tiles / a.tiles_per_frame;
+	hipLaunchKernelGGL(qoi_headers_kernel, dim3((frames * a.rows + 255u) / 256u), dim3(256), 0, stream, a);
 	return hipGetLastError();
 }
 

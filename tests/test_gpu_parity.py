@@ -261,3 +261,47 @@ def test_every_filter_on_opaque_fast_path(gpu, oracle, filt, mode, factors):
         assert_same_tiles(got, exp, 4, f"filter {filt} mode {mode} k={factor}")
         seen |= set(histogram(got[1], got[2]))
     assert len(seen) >= (5 if mode == 1 else 3), seen
+
+
+def test_device_bitstream_reproduces_base_pixlzr(gpu, oracle, golden_dir):
+    """GPU QOI + container on the un-shrunk tiles of benches/base.png (64x64, edge tiles 56x64/64x17/56x17):
+    must be the reference's own file byte for byte (bench-00.rs:55,66)."""
+    import torch
+    img = np.ascontiguousarray(np.asarray(Image.open(os.path.join(golden_dir, "base.png"))))
+    gold = open(os.path.join(golden_dir, "base.pixlzr"), "rb").read()
+    H, W, C = img.shape
+    cols, rows = oracle.grid(W, H, 64, 64)
+    n = cols * rows
+    tw = np.zeros(n, np.int32)
+    th = np.zeros(n, np.int32)
+    slots = np.zeros((n, 64 * 64 * C), np.uint8)
+    for t in range(n):
+        x, y, w, h = oracle.tile_rect(W, H, 64, 64, t)
+        tw[t], th[t] = w, h
+        slots[t, : w * h * C] = img[y:y + h, x:x + w].reshape(-1)
+    offs, buf = gpu.encode_frames_device((1, H, W, C), 64, 64, torch.zeros(n, device="cuda"),
+                                         torch.from_numpy(tw).cuda(), torch.from_numpy(th).cuda(), torch.from_numpy(slots).cuda())
+    torch.cuda.synchronize()
+    offs = offs.cpu().numpy()
+    assert offs[0] == 0 and offs[1] == len(gold)
+    assert buf[: offs[1]].cpu().numpy().tobytes() == gold
+
+
+@pytest.mark.parametrize("c,mode,factor", [(4, 1, 16.0), (4, 0, 1.0), (3, 1, 8.0), (4, 1, 1.0)])
+def test_device_bitstream_equals_oracle_writer(gpu, oracle, c, mode, factor):
+    """shrink on the GPU -> GPU QOI + container == oracle shrink -> oracle writer, for a batch of frames
+    (all tile sizes 32x32 .. 1x1, opaque and transparent RGBA, RGB)."""
+    import torch
+    frames = []
+    for f in range(3):
+        frames.append(oracle.synth_frame(672, 416, c, 20 + f, (f % 2) if c == 4 else 0))
+    dev = torch.from_numpy(np.stack(frames)).cuda()
+    vals, ow, oh, slots = gpu.shrink_frames_device(dev, 32, 32, mode, 4, factor)
+    offs, buf = gpu.encode_frames_device(tuple(dev.shape), 32, 32, vals, ow, oh, slots)
+    torch.cuda.synchronize()
+    offs = offs.cpu().numpy()
+    data = buf[: offs[-1]].cpu().numpy().tobytes()
+    for f in range(3):
+        v, w, h, s = oracle.shrink_image(frames[f], 32, 32, mode, 4, factor)
+        ref = oracle.encode_container(672, 416, 32, 32, c, 0, v, None, w, h, s)
+        assert data[offs[f]:offs[f + 1]] == ref, f"frame {f}"
