@@ -43,6 +43,8 @@ def parse():
     ap.add_argument("--dist", type=int, default=0, help="0 opaque, 1 alpha, 2 flat, 3 noise")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip the block-stream gather to rank 0")
+    ap.add_argument("--with-bitstream", action="store_true",
+                    help="N=1: also run the device QOI + container writer inside every step (always on when gathering)")
     return ap.parse_args()
 
 
@@ -65,16 +67,19 @@ def run_mode(args, handle, frames, mode_name, rank, world, dist_mod, pdist):
     out = handle.shrink_frames_device(frames, bw, bh, pxz_mode, args.filter, factor)
     vals, ow, oh, slots = out
     gather = world > 1 and not args.no_gather
-    pack_out = handle.pack_tiles_device(ow, oh, slots, C) if gather else None
-    gather_state = {"error": None, "bytes": 0}
+    bitstream = gather or args.with_bitstream
+    enc_out = handle.encode_frames_device(tuple(frames.shape), bw, bh, vals, ow, oh, slots) if bitstream else None
+    gather_state = {"bytes": 0}
 
     def step():
         handle.shrink_frames_device(frames, bw, bh, pxz_mode, args.filter, factor, out=out)
-        if gather:
-            offsets, packed = handle.pack_tiles_device(ow, oh, slots, C, out=pack_out)
-            got = pdist.gather_block_streams(vals, ow, oh, packed, offsets[-1], dst=0)
-            if got is not None:
-                gather_state["bytes"] = sum(int(g["packed"].numel()) for g in got)
+        if bitstream:
+            # encode_to_vec on the device: QOI tiles + container -> finished .pixlzr files
+            offs, buf = handle.encode_frames_device(tuple(frames.shape), bw, bh, vals, ow, oh, slots, out=enc_out)
+            if gather:
+                got = pdist.gather_files(offs, buf, dst=0)  # the one exchange step: file bytes to the writer rank
+                if got is not None:
+                    gather_state["bytes"] = sum(int(g[1].numel()) for g in got)
 
     for _ in range(args.warmup):
         step()
@@ -112,6 +117,7 @@ def run_mode(args, handle, frames, mode_name, rank, world, dist_mod, pdist):
         "achieved_gbps": algo_bytes / (kernel_ms * 1e-3) / 1e9,
         "histogram": histogram(ow[0], oh[0]),
         "gathered_stream_bytes_per_step": gather_state["bytes"] if gather else None,
+        "bitstream_in_step": bool(bitstream),
     }
 
 
@@ -204,7 +210,7 @@ def main():
                                    f"device-resident, one fused launch per step",
                        "mode": primary, "frames_per_gpu": nf, "tile": args.block,
                        "parallelism": f"{world} ranks x {nf} frames, no data-path collective; "
-                                      + ("block streams packed and gathered to rank 0 each step" if world > 1 and not args.no_gather
+                                      + ("device-encoded .pixlzr files gathered to rank 0 each step" if world > 1 and not args.no_gather
                                          else "no exchange step"),
                        "gathered_stream_bytes_per_step": r["gathered_stream_bytes_per_step"],
                        "tile_size_histogram_frame0": r["histogram"]},

@@ -64,3 +64,42 @@ def gather_block_streams(values, tile_w, tile_h, packed, packed_len, dst=0, grou
     for req in dist.batch_isend_irecv(ops):
         req.wait()
     return None
+
+
+def gather_files(file_offsets, buf, dst=0, group=None):
+    """Variable-length gather of finished .pixlzr files (pxz_encode_frames_device output) to `dst`.
+
+    file_offsets int64[n+1] and buf u8[>= file_offsets[-1]] live on this rank's device.  Returns on dst a
+    list (rank order) of (offsets int64[n_r+1] on CPU, bytes u8 tensor on the device); None elsewhere."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    dev = buf.device
+    n = file_offsets.numel()
+    sizes = torch.stack([file_offsets[-1].to(torch.int64), torch.tensor(n, dtype=torch.int64, device=dev)])
+    all_sizes = torch.empty(2 * world, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(all_sizes, sizes, group=group)
+    all_sizes = all_sizes.view(world, 2).cpu()  # the one host sync of the step
+    my_len = int(all_sizes[rank, 0])
+    if rank == dst:
+        out, ops = [None] * world, []
+        for r in range(world):
+            blen, rn = int(all_sizes[r, 0]), int(all_sizes[r, 1])
+            if r == rank:
+                out[r] = (file_offsets, buf[:my_len])
+                continue
+            roffs = torch.empty(rn, dtype=torch.int64, device=dev)
+            rbuf = torch.empty(blen, dtype=torch.uint8, device=dev)
+            out[r] = (roffs, rbuf)
+            ops.append(dist.P2POp(dist.irecv, roffs, r, group))
+            if blen:
+                ops.append(dist.P2POp(dist.irecv, rbuf, r, group))
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+        return out
+    ops = [dist.P2POp(dist.isend, file_offsets.contiguous(), dst, group)]
+    if my_len:
+        ops.append(dist.P2POp(dist.isend, buf[:my_len].contiguous(), dst, group))
+    for req in dist.batch_isend_irecv(ops):
+        req.wait()
+    return None

@@ -92,3 +92,52 @@ def test_two_ranks_gather_equals_single_process(tmp_path, product, oracle, mode,
         ref = oracle.encode_container(W, H, B, B, 4, 0, v, None, ow, oh, slots)
         assert blob[off:off + int(sizes[f])] == ref, f"frame {f}"
         off += int(sizes[f])
+
+
+def _worker_files(rank, world, port, result_path):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from tests.conftest import load_product
+    from oracle import binding as oracle
+    product = load_product()
+    from pixlzr_rust_amd import dist as pdist
+    files = []
+    for f in pdist.shard_frames(NF, world, rank):
+        img = oracle.synth_frame(W, H, 4, f, 1)
+        v, ow, oh, slots = oracle.shrink_image(img, B, B, 1, 4, 8.0)
+        files.append(product.encode_container(W, H, B, B, 4, 0, v, None, ow, oh, slots))  # product's writer, host side
+    offs = np.concatenate([[0], np.cumsum([len(x) for x in files])]).astype(np.int64)
+    buf = np.frombuffer(b"".join(files) + bytes(64), np.uint8).copy()  # capacity larger than the payload
+    got = pdist.gather_files(torch.from_numpy(offs), torch.from_numpy(buf), dst=0)
+    if rank == 0:
+        blob, sizes = b"", []
+        for roffs, rbuf in got:
+            roffs = roffs.numpy()
+            for i in range(len(roffs) - 1):
+                blob += rbuf.numpy()[roffs[i]:roffs[i + 1]].tobytes()
+                sizes.append(int(roffs[i + 1] - roffs[i]))
+        np.save(result_path, np.array(sizes))
+        open(result_path + ".bin", "wb").write(blob)
+    else:
+        assert got is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_gather_files(tmp_path, product, oracle):
+    """gather_files: each rank's finished .pixlzr files arrive on rank 0 in frame order, byte-exact."""
+    result = str(tmp_path / "fsizes.npy")
+    port = 31500 + (os.getpid() % 2000)
+    mp.spawn(_worker_files, args=(2, port, result), nprocs=2, join=True)
+    sizes = np.load(result)
+    blob = open(result + ".bin", "rb").read()
+    off = 0
+    for f in range(NF):
+        img = oracle.synth_frame(W, H, 4, f, 1)
+        v, ow, oh, slots = oracle.shrink_image(img, B, B, 1, 4, 8.0)
+        ref = oracle.encode_container(W, H, B, B, 4, 0, v, None, ow, oh, slots)
+        assert blob[off:off + int(sizes[f])] == ref
+        off += int(sizes[f])
+    assert off == len(blob)
