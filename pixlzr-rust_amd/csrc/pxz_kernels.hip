@@ -367,7 +367,7 @@ __device__ __forceinline__ void fast32_h_rows(const uint32_t *trows, const AxisT
 // so that a lane keeps the same output row (= the same table row) across iterations
 template <int LPI>
 __device__ __forceinline__ void fast32_v(const uint32_t *trows, const AxisTab &tx, const AxisTab &ty, const uint32_t *s_tmp,
-                                         uint32_t lane, uint32_t nw, uint32_t nh, uint8_t *dst)
+                                         uint32_t lane, uint32_t nw, uint32_t nh, uint32_t *out)
 {
 	constexpr int QPL = 8 / LPI;
 	const uint32_t items = nw * nh;
@@ -409,7 +409,7 @@ __device__ __forceinline__ void fast32_v(const uint32_t *trows, const AxisTab &t
 			const uint32_t al = clip8(iy + ah * (int32_t)hdr.z, py);
 			uint32_t px = clip8(a0 + iy, py) | (clip8(a1 + iy, py) << 8) | (clip8(a2 + iy, py) << 16) | (al << 24);
 			if (al != 255u) px = unpremultiply(px);
-			reinterpret_cast<uint32_t *>(dst)[oy * nw + ox] = px;
+			out[oy * nw + ox] = px;
 		}
 	}
 }
@@ -418,7 +418,7 @@ __device__ __forceinline__ void fast32_v(const uint32_t *trows, const AxisTab &t
 // Vertical only: item = (pair of columns, output row) straight on the [y][x] planes; the (row j,
 // row j+1) sample pairs dot2 needs are built with two perms per column pair and row pair.
 __device__ __forceinline__ void fast32_v_only(const uint32_t *trows, const AxisTab &ty, const uint32_t *s_pl, uint32_t lane,
-                                              uint32_t nh, uint8_t *dst)
+                                              uint32_t nh, uint32_t *out)
 {
 	const uint32_t lgy = 31u - (uint32_t)__builtin_clz(nh);
 	const uint32_t oy = lane & (nh - 1u);  // invariant per lane: 64 is a multiple of nh
@@ -455,13 +455,13 @@ __device__ __forceinline__ void fast32_v_only(const uint32_t *trows, const AxisT
 			o.x = unpremultiply(o.x);
 			o.y = unpremultiply(o.y);
 		}
-		reinterpret_cast<uint2 *>(dst)[oy * 16u + qx] = o;  // pixels (2qx, 2qx+1) of output row oy, row length 32
+		*reinterpret_cast<uint2 *>(out + (oy * 16u + qx) * 2u) = o;  // pixels (2qx, 2qx+1) of output row oy, row length 32
 	}
 }
 
 // Horizontal only: item = (output column, pair of rows), results go straight to the slot.
 __device__ __forceinline__ void fast32_h_only(const uint32_t *trows, const AxisTab &tx, const uint32_t *s_pl, uint32_t lane,
-                                              uint32_t nw, uint8_t *dst)
+                                              uint32_t nw, uint32_t *out)
 {
 	const uint32_t lgx = 31u - (uint32_t)__builtin_clz(nw);
 	const uint32_t ox = lane & (nw - 1u);
@@ -493,7 +493,7 @@ __device__ __forceinline__ void fast32_h_only(const uint32_t *trows, const AxisT
 		for (uint32_t rr = 0; rr < 2; ++rr) {
 			uint32_t px = clip8(acc[0][rr], prec) | (clip8(acc[1][rr], prec) << 8) | (clip8(acc[2][rr], prec) << 16) | (al << 24);
 			if (al != 255u) px = unpremultiply(px);
-			reinterpret_cast<uint32_t *>(dst)[(2u * yp + rr) * nw + ox] = px;
+			out[(2u * yp + rr) * nw + ox] = px;
 		}
 	}
 }
@@ -538,7 +538,7 @@ __device__ __forceinline__ void fast32_h_pairs(const uint32_t *trows, const Axis
 
 __device__ __forceinline__ void resample_fast32_hv(const uint32_t *trows, const AxisTab &tx, const AxisTab &ty,
                                                    uint32_t *s_pl, uint32_t *s_tmp, uint32_t lane, uint32_t nw,
-                                                   uint32_t nh, uint8_t *dst)
+                                                   uint32_t nh, uint32_t *out)
 {
 	const uint32_t lgx = 31u - (uint32_t)__builtin_clz(nw);  // nw is a power of two <= 16
 	if (nw >= 4) {
@@ -559,10 +559,10 @@ __device__ __forceinline__ void resample_fast32_hv(const uint32_t *trows, const 
 	}
 	tile_sync<1>();
 	const uint32_t items = nw * nh;
-	if (items >= 64u) fast32_v<1>(trows, tx, ty, s_tmp, lane, nw, nh, dst);
-	else if (items >= 32u) fast32_v<2>(trows, tx, ty, s_tmp, lane, nw, nh, dst);
-	else if (items >= 16u) fast32_v<4>(trows, tx, ty, s_tmp, lane, nw, nh, dst);
-	else fast32_v<8>(trows, tx, ty, s_tmp, lane, nw, nh, dst);
+	if (items >= 64u) fast32_v<1>(trows, tx, ty, s_tmp, lane, nw, nh, out);
+	else if (items >= 32u) fast32_v<2>(trows, tx, ty, s_tmp, lane, nw, nh, out);
+	else if (items >= 16u) fast32_v<4>(trows, tx, ty, s_tmp, lane, nw, nh, out);
+	else fast32_v<8>(trows, tx, ty, s_tmp, lane, nw, nh, out);
 }
 
 // Fast-path eligibility of a tile (full 32x32 RGBA, 16-byte aligned rows) and its first byte.
@@ -1010,7 +1010,7 @@ __device__ __forceinline__ void process_tile(const ShrinkArgs &a, const uint32_t
 	const bool need_h = nw != w, need_v = nh != h;
 	if constexpr (TW == 32 && NW == 1 && C == 4) {
 		if (fast && opaque && need_h && need_v) {
-			resample_fast32_hv(s_tab, tab_x, tab_y, s_pl, s_tmp, tid, nw, nh, dst);
+			resample_fast32_hv(s_tab, tab_x, tab_y, s_pl, s_tmp, tid, nw, nh, reinterpret_cast<uint32_t *>(dst));
 			return;
 		}
 	}
@@ -1193,35 +1193,77 @@ __global__ void __launch_bounds__(1024) shrink32_kernel(const Fast32Args a)
 	uint32_t *s_pl = lds + a.tab_dw + sub * a.tile_dw;
 	uint32_t *s_tmp = s_pl + 3 * kPD32;  // R, G, B planes only: tiles with transparency go to the worklist
 	const uint32_t stride = gridDim.x * wpb;
-	// two register sets of prefetched pixels: while tile k is processed, tiles k+1 and k+2 are in flight
-	// (one 4 KB tile per wave does not keep enough bytes outstanding to cover HBM latency)
-	uint4 preA[4], preB[4];
-	bool validA = false, validB = false;
+	// The pixels of the next tile are requested right after the current one has been staged, and a
+	// tile's output pixels are parked in LDS and stored at the START of the next iteration, before
+	// that prefetch: loads and stores share one in-order counter (vmcnt), so the wait for the
+	// prefetched registers must not find younger stores or loads behind it.
+	uint4 pre[4];
+	bool pre_valid = false;
 	const uint32_t first = __builtin_amdgcn_readfirstlane(blockIdx.x * wpb + sub);
-	fast32_prefetch(a, first, tid, preA, validA);
-	fast32_prefetch(a, first + stride, tid, preB, validB);
+	fast32_prefetch(a, first, tid, pre, pre_valid);
 #ifdef PXZ_STAMPS
 	unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 	unsigned long long st_last = stamp_now();
 #endif
-	auto one_tile = [&](const uint32_t tile_g, uint4 (&pre)[4], bool &pre_valid) {
+	uint32_t pend_kind = 0;       // 0 nothing, 1 linear pixels in LDS, 2 clone (re-interleave the planes)
+	uint32_t pend_px = 0;         // pixels parked in LDS (kind 1)
+	const uint32_t *pend_src = nullptr;
+	uint8_t *pend_dst = nullptr;
+	auto flush = [&]() {
+		if (pend_kind == 1) {
+			uint32_t *d = reinterpret_cast<uint32_t *>(pend_dst);
+			if (pend_px >= 4u) {  // whole 16-byte groups (pixel counts are powers of two)
+				for (uint32_t i = tid; i < (pend_px >> 2); i += 64u)
+					reinterpret_cast<uint4 *>(d)[i] = reinterpret_cast<const uint4 *>(pend_src)[i];
+			} else if (tid < pend_px) {
+				d[tid] = pend_src[tid];
+			}
+		} else if (pend_kind == 2) {
+			// clone (block.rs:279-281): re-interleave the planes, one 16-byte store per 4 pixels
+#pragma unroll
+			for (int k = 0; k < 4; ++k) {
+				const uint32_t i = tid + 64u * (uint32_t)k;
+				const uint32_t *p = s_pl + (i >> 3) * kRS32 + (i & 7u) * 2u;
+				const uint2 r = *reinterpret_cast<const uint2 *>(p), g = *reinterpret_cast<const uint2 *>(p + kPD32);
+				const uint2 b = *reinterpret_cast<const uint2 *>(p + 2 * kPD32);
+				const uint32_t opq = 0x00ff00ffu;  // the tile is opaque: alpha pair (255, 255)
+				const uint32_t rg01 = __builtin_amdgcn_perm(g.x, r.x, 0x06020400u), ba01 = __builtin_amdgcn_perm(opq, b.x, 0x06020400u);
+				const uint32_t rg23 = __builtin_amdgcn_perm(g.y, r.y, 0x06020400u), ba23 = __builtin_amdgcn_perm(opq, b.y, 0x06020400u);
+				uint4 o;
+				o.x = __builtin_amdgcn_perm(ba01, rg01, 0x05040100u);
+				o.y = __builtin_amdgcn_perm(ba01, rg01, 0x07060302u);
+				o.z = __builtin_amdgcn_perm(ba23, rg23, 0x05040100u);
+				o.w = __builtin_amdgcn_perm(ba23, rg23, 0x07060302u);
+				reinterpret_cast<uint4 *>(pend_dst)[i] = o;
+			}
+		}
+		pend_kind = 0;
+	};
+	auto one_tile = [&](const uint32_t tile_g) {
 		auto defer = [&]() {
 			if (tid == 0) a.work[1 + atomicAdd(&a.work[0], 1u)] = tile_g;
 		};
 		if (!pre_valid) {  // ragged edge / unaligned rows: generic kernel
+			flush();
 			defer();
-			fast32_prefetch(a, tile_g + 2u * stride, tid, pre, pre_valid);
+			fast32_prefetch(a, tile_g + stride, tid, pre, pre_valid);
 			return;
 		}
 		uint32_t given_bits = 0;
 		if constexpr (MODE == 0) given_bits = a.sums[2 * tile_g];  // issued before the prefetch: its wait leaves the prefetch in flight
-		// ---- stage: prefetched registers -> planar u16 pairs
+		// ---- wait for the prefetched registers (the opacity test is their first use), then emit the
+		// previous tile's parked pixels, then stage: registers -> planar u16 pairs
 		uint32_t alpha_and = 0xffu;
+#pragma unroll
+		for (int k = 0; k < 4; ++k) alpha_and &= (pre[k].x & pre[k].y & pre[k].z & pre[k].w) >> 24;
+		const bool transparent = __builtin_amdgcn_ballot_w64(alpha_and != 0xffu) != 0ull;
+		__builtin_amdgcn_sched_barrier(0);
+		flush();
+		__builtin_amdgcn_sched_barrier(0);
 #pragma unroll
 		for (int k = 0; k < 4; ++k) {
 			const uint32_t row = (tid >> 3) + 8u * (uint32_t)k, col = tid & 7u;
 			const uint4 v = pre[k];
-			alpha_and &= (v.x & v.y & v.z & v.w) >> 24;
 			uint32_t *d = s_pl + row * kRS32 + col * 2u;
 #pragma unroll
 			for (uint32_t c = 0; c < 3; ++c) {
@@ -1233,8 +1275,8 @@ __global__ void __launch_bounds__(1024) shrink32_kernel(const Fast32Args a)
 			}
 		}
 		PXZ_STAMP(0);  // wait for the prefetched pixels + staging
-		fast32_prefetch(a, tile_g + 2u * stride, tid, pre, pre_valid);  // two tiles ahead: lands during the next tile
-		if (__builtin_amdgcn_ballot_w64(alpha_and != 0xffu) != 0ull) {
+		fast32_prefetch(a, tile_g + stride, tid, pre, pre_valid);  // lands while this tile is processed
+		if (transparent) {
 			// transparency: premultiplied convolution and the alpha plane live in the generic kernel
 			defer();
 			return;
@@ -1306,29 +1348,17 @@ __global__ void __launch_bounds__(1024) shrink32_kernel(const Fast32Args a)
 		}
 		PXZ_STAMP(2);  // detector + reduction + level decision + metadata
 		if (a.out_px != nullptr) {
-			uint8_t *dst = a.out_px + (size_t)tile_g * 4096u;
+			pend_dst = a.out_px + (size_t)tile_g * 4096u;
+			pend_px = nw * nh;
 			if (nw == 32u && nh == 32u) {
-				// clone (block.rs:279-281): re-interleave the planes, one 16-byte store per 4 pixels
-#pragma unroll
-				for (int k = 0; k < 4; ++k) {
-					const uint32_t i = tid + 64u * (uint32_t)k;
-					const uint32_t *p = s_pl + (i >> 3) * kRS32 + (i & 7u) * 2u;
-					const uint2 r = *reinterpret_cast<const uint2 *>(p), g = *reinterpret_cast<const uint2 *>(p + kPD32);
-					const uint2 b = *reinterpret_cast<const uint2 *>(p + 2 * kPD32);
-					const uint32_t opq = 0x00ff00ffu;  // the tile is opaque: alpha pair (255, 255)
-					const uint32_t rg01 = __builtin_amdgcn_perm(g.x, r.x, 0x06020400u), ba01 = __builtin_amdgcn_perm(opq, b.x, 0x06020400u);
-					const uint32_t rg23 = __builtin_amdgcn_perm(g.y, r.y, 0x06020400u), ba23 = __builtin_amdgcn_perm(opq, b.y, 0x06020400u);
-					uint4 o;
-					o.x = __builtin_amdgcn_perm(ba01, rg01, 0x05040100u);
-					o.y = __builtin_amdgcn_perm(ba01, rg01, 0x07060302u);
-					o.z = __builtin_amdgcn_perm(ba23, rg23, 0x05040100u);
-					o.w = __builtin_amdgcn_perm(ba23, rg23, 0x07060302u);
-					reinterpret_cast<uint4 *>(dst)[i] = o;
-				}
+				pend_kind = 2;  // the planes themselves, re-interleaved by the flush
 			} else if (nw != 32u && nh != 32u && a.filter != 0) {
 				const uint32_t lx = m0 < (uint32_t)kMaxLevel ? m0 : (uint32_t)kMaxLevel - 1;
 				const uint32_t ly = m1 < (uint32_t)kMaxLevel ? m1 : (uint32_t)kMaxLevel - 1;
-				resample_fast32_hv(s_tab, a.tabs[lx], a.tabs[ly], s_pl, s_tmp, tid, nw, nh, dst);
+				// the vertical pass reads only the transposed planes: the R plane is free for the pixels
+				resample_fast32_hv(s_tab, a.tabs[lx], a.tabs[ly], s_pl, s_tmp, tid, nw, nh, s_pl);
+				pend_kind = 1;
+				pend_src = s_pl;
 			} else if (a.filter == 0) {
 				// ResizeAlg::Nearest (mod.rs:277): source index = floor((o + 0.5) * 2^m), no alpha handling
 				const uint32_t lgx = 31u - (uint32_t)__builtin_clz(nw);
@@ -1340,24 +1370,27 @@ __global__ void __launch_bounds__(1024) shrink32_kernel(const Fast32Args a)
 					const uint32_t x = m0 == 0 ? ox : (m0 < 6u ? (2u * ox + 1u) * hx : 16u);
 					const uint32_t y = m1 == 0 ? oy : (m1 < 6u ? (2u * oy + 1u) * hy : 16u);
 					const uint32_t idx = y * (2u * kRS32) + x;
-					reinterpret_cast<uint32_t *>(dst)[i] = (uint32_t)pl16[idx] | ((uint32_t)pl16[idx + 2u * kPD32] << 8) |
-					                                       ((uint32_t)pl16[idx + 4u * kPD32] << 16) | 0xff000000u;
+					s_tmp[i] = (uint32_t)pl16[idx] | ((uint32_t)pl16[idx + 2u * kPD32] << 8) | ((uint32_t)pl16[idx + 4u * kPD32] << 16) | 0xff000000u;
 				}
+				pend_kind = 1;
+				pend_src = s_tmp;
 			} else if (nh != 32u) {
 				const uint32_t ly = m1 < (uint32_t)kMaxLevel ? m1 : (uint32_t)kMaxLevel - 1;
-				fast32_v_only(s_tab, a.tabs[ly], s_pl, tid, nh, dst);  // width kept
+				fast32_v_only(s_tab, a.tabs[ly], s_pl, tid, nh, s_tmp);  // width kept; the transposed planes are unused here
+				pend_kind = 1;
+				pend_src = s_tmp;
 			} else {
 				const uint32_t lx = m0 < (uint32_t)kMaxLevel ? m0 : (uint32_t)kMaxLevel - 1;
-				fast32_h_only(s_tab, a.tabs[lx], s_pl, tid, nw, dst);  // height kept
+				fast32_h_only(s_tab, a.tabs[lx], s_pl, tid, nw, s_tmp);  // height kept
+				pend_kind = 1;
+				pend_src = s_tmp;
 			}
 		}
 		tile_sync<1>();  // the next tile reuses this wave's LDS image
 		PXZ_STAMP(3);  // clone / resample / defer
 	};
-	for (uint32_t tile_g = first; tile_g < a.n_tiles; tile_g += 2u * stride) {
-		one_tile(tile_g, preA, validA);
-		if (tile_g + stride < a.n_tiles) one_tile(tile_g + stride, preB, validB);
-	}
+	for (uint32_t tile_g = first; tile_g < a.n_tiles; tile_g += stride) one_tile(tile_g);
+	flush();  // the last tile's pixels
 #ifdef PXZ_STAMPS
 	if (tid == 0) {
 		unsigned long long *out = reinterpret_cast<unsigned long long *>(a.work + ((a.n_tiles + 2u + 1u) & ~1u));
@@ -2133,7 +2166,8 @@ hipError_t launch_shrink(const ShrinkArgs &a, uint32_t channels, uint32_t n_cus,
 		}
 		f.breaks_asc = a.breaks_asc[0];
 		// planes 3 x 576 dwords (R, G, B), transposed planes 3 x 288, slack for zero-weight over-reads
-		f.tile_dw = (f.out_px && f.filter != 0) ? 3u * kPD32 + 3u * kTD32 + 2u * kRS32 : 3u * kPD32 + 4u * kRS32;
+		// (the transposed-plane region also parks the pixels of nearest / one-pass outputs: always there with out_px)
+		f.tile_dw = f.out_px ? 3u * kPD32 + 3u * kTD32 + 2u * kRS32 : 3u * kPD32 + 4u * kRS32;
 		f.tile_dw = (f.tile_dw + 3u) & ~3u;
 		constexpr uint32_t kLds = 160u * 1024u;
 		uint32_t wpb = (kLds - f.tab_dw * 4u) / (f.tile_dw * 4u);
