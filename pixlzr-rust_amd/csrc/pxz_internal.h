@@ -96,7 +96,6 @@ struct Fast32Args {
 
 struct LaunchGeom {
 	uint32_t blocks, threads, lds_bytes;
-	bool fast32;
 };
 
 struct FinishArgs {

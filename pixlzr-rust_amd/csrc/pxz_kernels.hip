@@ -604,11 +604,9 @@ __device__ __forceinline__ void fast32_prefetch(const Args &a, uint32_t tile_g, 
 // process two pixels per instruction (detector) and v_dot2_i32_i16 two filter
 // taps per instruction (resample).  The horizontal pass writes its u8 results
 // transposed ([ox][y], two rows per dword) so the vertical pass is dot2-shaped too.
-// TW   compile-time tile side (32) enabling the fast path for full RGBA tiles, 0 = none
-template <int NW, int C, int MODE, int TW>
+template <int NW, int C, int MODE>
 __device__ __forceinline__ void process_tile(const ShrinkArgs &a, const uint32_t tile_g, uint32_t *s_pl, uint32_t *s_red,
-                                             const uint32_t *s_tab, const uint32_t tid, uint4 (&pre)[4], bool &pre_valid,
-                                             const uint32_t next_tile)
+                                             const uint32_t tid)
 {
 	constexpr uint32_t TPT = 64u * NW;                // threads per tile
 	const uint32_t frame = fastdiv(tile_g, a.div_tpf);
@@ -626,33 +624,13 @@ __device__ __forceinline__ void process_tile(const ShrinkArgs &a, const uint32_t
 	float *s_lab = reinterpret_cast<float *>(s_tmp);
 	(void)s_red;  // 4*NW dwords, only carved (and used) when NW > 1
 	(void)s_lab;
-	(void)s_tab;
 
 	// ---- stage the tile: coalesced 16-B loads along image rows -> planar u16 pairs ----
 	uint32_t alpha_and = 0xffu;
 	const uint32_t qpr = w >> 2, nquad = qpr * h;
 	const bool vec = C == 4 && ((w & 3u) == 0) && ((reinterpret_cast<uintptr_t>(src) & 15u) == 0) &&
 	                 ((a.pitch & 15u) == 0) && nquad <= 4u * TPT;
-	// full 32x32 RGBA tile of the fast path: its pixels were requested one tile ago and are
-	// already in registers; every index below is a shift/mask
-	const bool fast = TW == 32 && NW == 1 && C == 4 && pre_valid;
-	if (fast) {
-#pragma unroll
-		for (int k = 0; k < 4; ++k) {
-			const uint32_t row = (tid >> 3) + 8u * (uint32_t)k, col = tid & 7u;
-			const uint4 v = pre[k];
-			alpha_and &= (v.x & v.y & v.z & v.w) >> 24;
-			uint32_t *d = s_pl + row * kRS32 + col * 2u;
-#pragma unroll
-			for (uint32_t c = 0; c < 4; ++c) {
-				const uint32_t sel = c | 0x0c000c00u | ((4u + c) << 16);
-				uint2 pr;
-				pr.x = __builtin_amdgcn_perm(v.y, v.x, sel);
-				pr.y = __builtin_amdgcn_perm(v.w, v.z, sel);
-				*reinterpret_cast<uint2 *>(d + c * kPD32) = pr;
-			}
-		}
-	} else if (vec) {
+	if (vec) {
 		RowWalker rw(tid, TPT, qpr);
 #pragma unroll
 		for (int k = 0; k < 4; ++k) {
@@ -685,15 +663,6 @@ __device__ __forceinline__ void process_tile(const ShrinkArgs &a, const uint32_t
 			alpha_and &= al;
 		}
 	}
-	uint32_t given_bits = 0;
-	if constexpr (TW == 32 && NW == 1 && C == 4 && MODE == 0) {
-		// issued before the prefetch below, so waiting for it later does not drain the prefetch
-		if (a.oklab_given && fast) given_bits = a.sums[2 * tile_g];
-	}
-	if constexpr (TW == 32 && NW == 1 && C == 4) {
-		// request the NEXT tile's pixels now: they land while this tile is being processed
-		fast32_prefetch(a, next_tile, tid, pre, pre_valid);
-	}
 	tile_sync<NW>();
 
 	// ---- level-of-detail value --------------------------------------------
@@ -704,68 +673,7 @@ __device__ __forceinline__ void process_tile(const ShrinkArgs &a, const uint32_t
 		// operators: hz = r(y+2) - r(y) with r = 1-2-1 smoothing along x; vr = c(x+2) - c(x) with
 		// c = 1-2-1 smoothing along y.  Two windows per lane and instruction (packed u16).
 		uint32_t sum_hz = 0, sum_vr = 0;
-		if (fast) {
-			// 16 lanes (pixel pairs) per row group, 4 groups of 8 window rows (the last one 6).
-			// Per channel and row step: r = 1-2-1 along x (perm, add, mad), |hz| (sad), column
-			// smoothing c = t(y)+t(y+1) (2 adds), the neighbour pair's c by DPP, |vr| (sad).
-			const uint32_t q = tid & 15u, g = tid >> 4;
-			const uint32_t y0 = g * 8u, steps = g == 3 ? 3u : 4u;  // two window rows per step
-			const uint32_t *p = s_pl + y0 * kRS32 + q;
-			const uint32_t two = 0x00020002u;
-			uint32_t rA[3], rB[3], tP[3], dP[3];
-#pragma unroll
-			for (int c = 0; c < 3; ++c) {
-				const uint32_t a0 = p[c * kPD32], a1 = p[c * kPD32 + 1], b0 = p[c * kPD32 + kRS32], b1 = p[c * kPD32 + kRS32 + 1];
-				rA[c] = pk_mad_u16(__builtin_amdgcn_alignbit(a1, a0, 16), two, u32(us2(a0) + us2(a1)));
-				rB[c] = pk_mad_u16(__builtin_amdgcn_alignbit(b1, b0, 16), two, u32(us2(b0) + us2(b1)));
-				tP[c] = u32(us2(a0) + us2(b0));
-				dP[c] = b0;
-			}
-			p += 2 * kRS32;
-			// the two rows of step s+1 are requested before step s is computed (LDS latency hidden
-			// inside the wave; the last request reads past the group's rows and is discarded)
-			uint32_t n0[3], n1[3], o0[3], o1[3];
-#pragma unroll
-			for (int c = 0; c < 3; ++c) {
-				n0[c] = p[c * kPD32];
-				n1[c] = p[c * kPD32 + 1];
-				o0[c] = p[c * kPD32 + kRS32];
-				o1[c] = p[c * kPD32 + kRS32 + 1];
-			}
-			for (uint32_t st = 0; st < steps; ++st) {
-				p += 2 * kRS32;
-				uint32_t f0[3], f1[3], g0[3], g1[3];
-#pragma unroll
-				for (int c = 0; c < 3; ++c) {
-					f0[c] = p[c * kPD32];
-					f1[c] = p[c * kPD32 + 1];
-					g0[c] = p[c * kPD32 + kRS32];
-					g1[c] = p[c * kPD32 + kRS32 + 1];
-				}
-#pragma unroll
-				for (int c = 0; c < 3; ++c) {
-					const uint32_t rN = pk_mad_u16(__builtin_amdgcn_alignbit(n1[c], n0[c], 16), two, u32(us2(n0[c]) + us2(n1[c])));
-					sum_hz = sad16(rN, rA[c], sum_hz);
-					const uint32_t tN = u32(us2(dP[c]) + us2(n0[c]));
-					const uint32_t c0 = u32(us2(tP[c]) + us2(tN));
-					sum_vr = sad16(dpp_mov<0x101>(c0), c0, sum_vr);  // row_shl:1 = the pair to the right
-					const uint32_t rO = pk_mad_u16(__builtin_amdgcn_alignbit(o1[c], o0[c], 16), two, u32(us2(o0[c]) + us2(o1[c])));
-					sum_hz = sad16(rO, rB[c], sum_hz);
-					const uint32_t tO = u32(us2(n0[c]) + us2(o0[c]));
-					const uint32_t e0 = u32(us2(tN) + us2(tO));
-					sum_vr = sad16(dpp_mov<0x101>(e0), e0, sum_vr);
-					rA[c] = rN;
-					rB[c] = rO;
-					tP[c] = tO;
-					dP[c] = o0[c];
-					n0[c] = f0[c];
-					n1[c] = f1[c];
-					o0[c] = g0[c];
-					o1[c] = g1[c];
-				}
-			}
-			if (q == 15u) sum_hz = sum_vr = 0;  // pair 15 starts no window (x = 30, 31)
-		} else if (w > 2 && h > 2) {
+		if (w > 2 && h > 2) {
 			const uint32_t WR = h - 2;
 			const uint32_t VP = (w >> 1) - 1;  // pixel pairs that start a valid window pair (w even)
 			uint32_t G = ((w & 1u) == 0 && VP >= 1) ? TPT / VP : 0u;
@@ -856,11 +764,6 @@ __device__ __forceinline__ void process_tile(const ShrinkArgs &a, const uint32_t
 			m0 = level_count(sum_hz, a.breaks[cls], a.breaks_asc[cls]);
 			m1 = level_count(sum_vr, a.breaks[cls], a.breaks_asc[cls]);
 		}
-	} else if (TW == 32 && NW == 1 && C == 4 && a.oklab_given && fast) {
-		// the block-cooperative detector (oklab32_kernel) already left this tile's value in sums[]
-		const uint32_t vb = __builtin_amdgcn_readfirstlane(given_bits);
-		key0 = key1 = vb;
-		m0 = m1 = level_count(__float_as_uint(parse_value(__uint_as_float(vb))), a.breaks[cls], a.breaks_asc[cls]);
 	} else {
 		// get_block_variance, operations.rs:26-126 with shrink_by's closures
 		// (pixlzr.rs:160-162).  Colours are computed once, in parallel, into LDS
@@ -935,22 +838,18 @@ __device__ __forceinline__ void process_tile(const ShrinkArgs &a, const uint32_t
 		       ((uint32_t)pl16[idx + 6u * PD] << 24);
 	};
 	if (nw == w && nh == h) {  // block.rs:279-281: clone
-		if (fast && (a.slot_bytes & 15u) == 0 && (reinterpret_cast<uintptr_t>(a.out_px) & 15u) == 0) {
-			// re-interleave the planes: 4 pixels (one 16-byte store) per lane and step
-#pragma unroll
-			for (int k = 0; k < 4; ++k) {
-				const uint32_t i = tid + 64u * (uint32_t)k;  // quad index = row*8 + col
-				const uint32_t *p = s_pl + (i >> 3) * kRS32 + (i & 7u) * 2u;
-				const uint2 r = *reinterpret_cast<const uint2 *>(p), g = *reinterpret_cast<const uint2 *>(p + kPD32);
-				const uint2 b = *reinterpret_cast<const uint2 *>(p + 2 * kPD32), al = *reinterpret_cast<const uint2 *>(p + 3 * kPD32);
-				const uint32_t rg01 = __builtin_amdgcn_perm(g.x, r.x, 0x06020400u), ba01 = __builtin_amdgcn_perm(al.x, b.x, 0x06020400u);
-				const uint32_t rg23 = __builtin_amdgcn_perm(g.y, r.y, 0x06020400u), ba23 = __builtin_amdgcn_perm(al.y, b.y, 0x06020400u);
-				uint4 o;
-				o.x = __builtin_amdgcn_perm(ba01, rg01, 0x05040100u);
-				o.y = __builtin_amdgcn_perm(ba01, rg01, 0x07060302u);
-				o.z = __builtin_amdgcn_perm(ba23, rg23, 0x05040100u);
-				o.w = __builtin_amdgcn_perm(ba23, rg23, 0x07060302u);
-				reinterpret_cast<uint4 *>(dst)[i] = o;
+		if (C == 4 && (w & 1u) == 0 && (reinterpret_cast<uintptr_t>(dst) & 7u) == 0) {
+			// two pixels per step: one dword of each plane, re-interleaved with byte permutes
+			const uint32_t P2 = w >> 1;
+			RowWalker rw(tid, TPT, P2);
+			for (uint32_t i = tid; i < P2 * h; i += TPT, rw.next()) {
+				const uint32_t *p = s_pl + rw.row * rs + rw.col;
+				const uint32_t rg = __builtin_amdgcn_perm(p[PD], p[0], 0x06020400u);          // r0 g0 r1 g1
+				const uint32_t ba = __builtin_amdgcn_perm(p[3 * PD], p[2 * PD], 0x06020400u);  // b0 a0 b1 a1
+				uint2 o;
+				o.x = __builtin_amdgcn_perm(ba, rg, 0x05040100u);
+				o.y = __builtin_amdgcn_perm(ba, rg, 0x07060302u);
+				reinterpret_cast<uint2 *>(dst)[i] = o;
 			}
 		} else {
 			RowWalker rw(tid, TPT, w);
@@ -1008,12 +907,6 @@ __device__ __forceinline__ void process_tile(const ShrinkArgs &a, const uint32_t
 	const uint32_t nch = opaque ? 3u : 4u;  // channels that need taps
 
 	const bool need_h = nw != w, need_v = nh != h;
-	if constexpr (TW == 32 && NW == 1 && C == 4) {
-		if (fast && opaque && need_h && need_v) {
-			resample_fast32_hv(s_tab, tab_x, tab_y, s_pl, s_tmp, tid, nw, nh, reinterpret_cast<uint32_t *>(dst));
-			return;
-		}
-	}
 	const int prec_x = tab_x.precision, prec_y = tab_y.precision;
 	const int32_t init_x = 1 << (prec_x - 1), init_y = 1 << (prec_y - 1);
 	const uint16_t *bnd_x = a.bounds + tab_x.bounds_off, *bnd_y = a.bounds + tab_y.bounds_off;
@@ -1400,39 +1293,28 @@ __global__ void __launch_bounds__(1024) shrink32_kernel(const Fast32Args a)
 }
 
 // ---------------------------------------------------------------------------
-// kernel: persistent over tiles.  NW == 1: every wave of the block owns one LDS tile
-// image and walks tiles wave_id, wave_id + total_waves, ... (neighbouring waves take
-// neighbouring tiles, so a block reads contiguous spans of the image rows).  The
-// down-scaling table rows of the fast path are copied into LDS once per block.
+// generic kernel: persistent over tiles (or over the worklist left by shrink32_kernel).  NW == 1:
+// every wave of the block owns one LDS tile image and walks tiles wave_id, wave_id + total_waves, ...;
+// NW > 1: one tile per block iteration.
 // ---------------------------------------------------------------------------
-template <int NW, int C, int MODE, int TW>
+template <int NW, int C, int MODE>
 __global__ void __launch_bounds__(NW == 1 ? 768 : 64 * NW) shrink_kernel(const ShrinkArgs a)
 {
 	extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
 	if constexpr (NW == 1) {
 		const uint32_t wpb = blockDim.x / 64u, sub = threadIdx.x / 64u, tid = threadIdx.x % 64u;
-		if constexpr (TW != 0) {
-			for (uint32_t i = threadIdx.x; i < a.tab_dw / 4u; i += blockDim.x)
-				reinterpret_cast<uint4 *>(lds)[i] = reinterpret_cast<const uint4 *>(a.trows)[i];
-			__syncthreads();
-		}
-		uint32_t *s_pl = lds + (TW != 0 ? a.tab_dw : 0u) + sub * a.tile_dw;
+		uint32_t *s_pl = lds + sub * a.tile_dw;
 		const uint32_t stride = gridDim.x * wpb;
-		uint4 pre[4];
-		bool pre_valid = false;
-		if constexpr (TW == 32 && C == 4) fast32_prefetch(a, __builtin_amdgcn_readfirstlane(blockIdx.x * wpb + sub), tid, pre, pre_valid);
 		// with a worklist (left by shrink32_kernel) only the listed tiles are processed
 		const uint32_t count = a.work ? __builtin_amdgcn_readfirstlane(a.work[0]) : a.n_tiles;
 		for (uint32_t i = __builtin_amdgcn_readfirstlane(blockIdx.x * wpb + sub); i < count; i += stride) {
 			const uint32_t tile_g = a.work ? __builtin_amdgcn_readfirstlane(a.work[1 + i]) : i;
-			process_tile<NW, C, MODE, TW>(a, tile_g, s_pl, nullptr, lds, tid, pre, pre_valid, tile_g + stride);
+			process_tile<NW, C, MODE>(a, tile_g, s_pl, nullptr, tid);
 			tile_sync<1>();  // the next tile reuses this wave's LDS image
 		}
 	} else {
-		uint4 pre[4];
-		bool pre_valid = false;
 		for (uint32_t tile_g = blockIdx.x; tile_g < a.n_tiles; tile_g += gridDim.x) {
-			process_tile<NW, C, MODE, TW>(a, tile_g, lds, lds + a.tile_dw, nullptr, threadIdx.x, pre, pre_valid, 0xffffffffu);
+			process_tile<NW, C, MODE>(a, tile_g, lds, lds + a.tile_dw, threadIdx.x);
 			__syncthreads();
 		}
 	}
@@ -2057,10 +1939,10 @@ __global__ void __launch_bounds__(256) synth_kernel(const SynthArgs s)
 // ---------------------------------------------------------------------------
 // launchers (called from pxz_api.cpp)
 // ---------------------------------------------------------------------------
-template <int NW, int C, int MODE, int TW>
+template <int NW, int C, int MODE>
 static hipError_t launch_one(const ShrinkArgs &a, const LaunchGeom &g, hipStream_t stream)
 {
-	auto kernel = shrink_kernel<NW, C, MODE, TW>;
+	auto kernel = shrink_kernel<NW, C, MODE>;
 	if (g.lds_bytes > 64u * 1024u) {
 		hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
 		                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds_bytes);
@@ -2074,8 +1956,8 @@ template <int NW>
 static hipError_t launch_nw(const ShrinkArgs &a, uint32_t channels, const LaunchGeom &g, hipStream_t stream)
 {
 	if (channels == 4)
-		return a.mode == 1 ? launch_one<NW, 4, 1, 0>(a, g, stream) : launch_one<NW, 4, 0, 0>(a, g, stream);
-	return a.mode == 1 ? launch_one<NW, 3, 1, 0>(a, g, stream) : launch_one<NW, 3, 0, 0>(a, g, stream);
+		return a.mode == 1 ? launch_one<NW, 4, 1>(a, g, stream) : launch_one<NW, 4, 0>(a, g, stream);
+	return a.mode == 1 ? launch_one<NW, 3, 1>(a, g, stream) : launch_one<NW, 3, 0>(a, g, stream);
 }
 
 // waves per tile: 1 up to 32x32, then one wave per 1024 px, capped at 16
@@ -2098,9 +1980,7 @@ LaunchGeom plan_launch(const ShrinkArgs &a, uint32_t channels, uint32_t n_cus)
 	const uint32_t tile_bytes = a.tile_dw * 4u;
 	constexpr uint32_t kLds = 160u * 1024u;
 	if (nw == 1) {
-		g.fast32 = false;
-		const uint32_t tab_bytes = g.fast32 ? a.tab_dw * 4u : 0u;
-		uint32_t wpb = (kLds - tab_bytes) / tile_bytes;
+		uint32_t wpb = kLds / tile_bytes;
 		if (wpb > 12u) wpb = 12u;
 		if (const char *e = getenv("PXZ_WPB")) {  // tuning knob: waves per block
 			const uint32_t v = (uint32_t)atoi(e);
@@ -2108,7 +1988,7 @@ LaunchGeom plan_launch(const ShrinkArgs &a, uint32_t channels, uint32_t n_cus)
 		}
 		if (wpb < 1u) wpb = 1u;
 		g.threads = 64u * wpb;
-		g.lds_bytes = tab_bytes + wpb * tile_bytes;
+		g.lds_bytes = wpb * tile_bytes;
 		const uint32_t per_cu = kLds / g.lds_bytes > 0 ? kLds / g.lds_bytes : 1u;
 		uint32_t resident = n_cus * (per_cu > 2u ? 2u : per_cu);
 		const uint32_t need = (a.n_tiles + wpb - 1u) / wpb;
