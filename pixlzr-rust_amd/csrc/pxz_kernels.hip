@@ -1073,6 +1073,11 @@ __global__ void __launch_bounds__(1024) shrink32_kernel(const Fast32Args a)
 	const uint32_t wpb = blockDim.x / 64u, sub = threadIdx.x / 64u, tid = threadIdx.x % 64u;
 	for (uint32_t i = threadIdx.x; i < a.tab_dw / 4u; i += blockDim.x)
 		reinterpret_cast<uint4 *>(lds)[i] = reinterpret_cast<const uint4 *>(a.trows)[i];
+	// Tiles are dealt to the waves of a block on demand (an LDS ticket counter): tile costs differ by 2x
+	// between size classes, and a static stride leaves the unluckiest wave of the chip running alone.
+	// Block b owns tiles b, b + blocks, b + 2*blocks, ...; ticket t is tile b + t*blocks.
+	uint32_t *s_ticket = lds + a.tab_dw + wpb * a.tile_dw;
+	if (threadIdx.x == 0) *s_ticket = wpb;  // tickets 0..wpb-1 are the waves' first tiles
 	__syncthreads();
 	const uint32_t *s_tab = lds;
 	// level breakpoints, one per lane (lanes >= kMaxLevel never count): the level exponent of a key is
@@ -1085,14 +1090,22 @@ __global__ void __launch_bounds__(1024) shrink32_kernel(const Fast32Args a)
 	};
 	uint32_t *s_pl = lds + a.tab_dw + sub * a.tile_dw;
 	uint32_t *s_tmp = s_pl + 3 * kPD32;  // R, G, B planes only: tiles with transparency go to the worklist
-	const uint32_t stride = gridDim.x * wpb;
+	auto tile_of_ticket = [&](uint32_t t) -> uint32_t {
+		const unsigned long long g = (unsigned long long)blockIdx.x + (unsigned long long)t * gridDim.x;
+		return g < (unsigned long long)a.n_tiles ? (uint32_t)g : 0xffffffffu;
+	};
+	auto next_ticket = [&]() -> uint32_t {
+		uint32_t t = 0;
+		if (tid == 0) t = atomicAdd(s_ticket, 1u);
+		return tile_of_ticket(__builtin_amdgcn_readfirstlane(t));
+	};
 	// The pixels of the next tile are requested right after the current one has been staged, and a
 	// tile's output pixels are parked in LDS and stored at the START of the next iteration, before
 	// that prefetch: loads and stores share one in-order counter (vmcnt), so the wait for the
 	// prefetched registers must not find younger stores or loads behind it.
 	uint4 pre[4];
 	bool pre_valid = false;
-	const uint32_t first = __builtin_amdgcn_readfirstlane(blockIdx.x * wpb + sub);
+	const uint32_t first = tile_of_ticket(__builtin_amdgcn_readfirstlane(sub));
 	fast32_prefetch(a, first, tid, pre, pre_valid);
 #ifdef PXZ_STAMPS
 	unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -1132,14 +1145,14 @@ __global__ void __launch_bounds__(1024) shrink32_kernel(const Fast32Args a)
 		}
 		pend_kind = 0;
 	};
-	auto one_tile = [&](const uint32_t tile_g) {
+	auto one_tile = [&](const uint32_t tile_g, const uint32_t tile_next) {
 		auto defer = [&]() {
 			if (tid == 0) a.work[1 + atomicAdd(&a.work[0], 1u)] = tile_g;
 		};
 		if (!pre_valid) {  // ragged edge / unaligned rows: generic kernel
 			flush();
 			defer();
-			fast32_prefetch(a, tile_g + stride, tid, pre, pre_valid);
+			fast32_prefetch(a, tile_next, tid, pre, pre_valid);
 			return;
 		}
 		uint32_t given_bits = 0;
@@ -1168,7 +1181,7 @@ __global__ void __launch_bounds__(1024) shrink32_kernel(const Fast32Args a)
 			}
 		}
 		PXZ_STAMP(0);  // wait for the prefetched pixels + staging
-		fast32_prefetch(a, tile_g + stride, tid, pre, pre_valid);  // lands while this tile is processed
+		fast32_prefetch(a, tile_next, tid, pre, pre_valid);  // lands while this tile is processed
 		if (transparent) {
 			// transparency: premultiplied convolution and the alpha plane live in the generic kernel
 			defer();
@@ -1282,7 +1295,11 @@ __global__ void __launch_bounds__(1024) shrink32_kernel(const Fast32Args a)
 		tile_sync<1>();  // the next tile reuses this wave's LDS image
 		PXZ_STAMP(3);  // clone / resample / defer
 	};
-	for (uint32_t tile_g = first; tile_g < a.n_tiles; tile_g += stride) one_tile(tile_g);
+	for (uint32_t tile_g = first; tile_g < a.n_tiles;) {
+		const uint32_t tile_next = next_ticket();
+		one_tile(tile_g, tile_next);
+		tile_g = tile_next;
+	}
 	flush();  // the last tile's pixels
 #ifdef PXZ_STAMPS
 	if (tid == 0) {
@@ -1304,12 +1321,22 @@ __global__ void __launch_bounds__(NW == 1 ? 768 : 64 * NW) shrink_kernel(const S
 	if constexpr (NW == 1) {
 		const uint32_t wpb = blockDim.x / 64u, sub = threadIdx.x / 64u, tid = threadIdx.x % 64u;
 		uint32_t *s_pl = lds + sub * a.tile_dw;
-		const uint32_t stride = gridDim.x * wpb;
+		// tiles are dealt to the waves of a block on demand (LDS ticket counter, as in shrink32_kernel):
+		// block b owns items b, b + blocks, ...; ticket t is item b + t*blocks
+		uint32_t *s_ticket = lds + wpb * a.tile_dw;
+		if (threadIdx.x == 0) *s_ticket = wpb;
+		__syncthreads();
 		// with a worklist (left by shrink32_kernel) only the listed tiles are processed
 		const uint32_t count = a.work ? __builtin_amdgcn_readfirstlane(a.work[0]) : a.n_tiles;
-		for (uint32_t i = __builtin_amdgcn_readfirstlane(blockIdx.x * wpb + sub); i < count; i += stride) {
-			const uint32_t tile_g = a.work ? __builtin_amdgcn_readfirstlane(a.work[1 + i]) : i;
+		uint32_t ticket = sub;
+		for (;;) {
+			const unsigned long long i = (unsigned long long)blockIdx.x + (unsigned long long)ticket * gridDim.x;
+			if (i >= (unsigned long long)count) break;
+			const uint32_t tile_g = a.work ? __builtin_amdgcn_readfirstlane(a.work[1 + (uint32_t)i]) : (uint32_t)i;
 			process_tile<NW, C, MODE>(a, tile_g, s_pl, nullptr, tid);
+			uint32_t t = 0;
+			if (tid == 0) t = atomicAdd(s_ticket, 1u);
+			ticket = __builtin_amdgcn_readfirstlane(t);
 			tile_sync<1>();  // the next tile reuses this wave's LDS image
 		}
 	} else {
@@ -1980,7 +2007,7 @@ LaunchGeom plan_launch(const ShrinkArgs &a, uint32_t channels, uint32_t n_cus)
 	const uint32_t tile_bytes = a.tile_dw * 4u;
 	constexpr uint32_t kLds = 160u * 1024u;
 	if (nw == 1) {
-		uint32_t wpb = kLds / tile_bytes;
+		uint32_t wpb = (kLds - 16u) / tile_bytes;  // 16 bytes: the ticket counter
 		if (wpb > 12u) wpb = 12u;
 		if (const char *e = getenv("PXZ_WPB")) {  // tuning knob: waves per block
 			const uint32_t v = (uint32_t)atoi(e);
@@ -1988,7 +2015,7 @@ LaunchGeom plan_launch(const ShrinkArgs &a, uint32_t channels, uint32_t n_cus)
 		}
 		if (wpb < 1u) wpb = 1u;
 		g.threads = 64u * wpb;
-		g.lds_bytes = wpb * tile_bytes;
+		g.lds_bytes = wpb * tile_bytes + 16u;
 		const uint32_t per_cu = kLds / g.lds_bytes > 0 ? kLds / g.lds_bytes : 1u;
 		uint32_t resident = n_cus * (per_cu > 2u ? 2u : per_cu);
 		const uint32_t need = (a.n_tiles + wpb - 1u) / wpb;
@@ -2050,13 +2077,13 @@ hipError_t launch_shrink(const ShrinkArgs &a, uint32_t channels, uint32_t n_cus,
 		f.tile_dw = f.out_px ? 3u * kPD32 + 3u * kTD32 + 2u * kRS32 : 3u * kPD32 + 4u * kRS32;
 		f.tile_dw = (f.tile_dw + 3u) & ~3u;
 		constexpr uint32_t kLds = 160u * 1024u;
-		uint32_t wpb = (kLds - f.tab_dw * 4u) / (f.tile_dw * 4u);
+		uint32_t wpb = (kLds - f.tab_dw * 4u - 16u) / (f.tile_dw * 4u);
 		if (wpb > 16u) wpb = 16u;
 		if (const char *e = getenv("PXZ_WPB")) {
 			const uint32_t v = (uint32_t)atoi(e);
 			if (v >= 1 && v < wpb) wpb = v;
 		}
-		const uint32_t lds_bytes = f.tab_dw * 4u + wpb * f.tile_dw * 4u;
+		const uint32_t lds_bytes = f.tab_dw * 4u + wpb * f.tile_dw * 4u + 16u;  // + the ticket counter
 		const uint32_t per_cu = kLds / lds_bytes > 0 ? kLds / lds_bytes : 1u;
 		const uint32_t resident = n_cus * (per_cu > 2u ? 2u : per_cu);
 		const uint32_t need = (a.n_tiles + wpb - 1u) / wpb;

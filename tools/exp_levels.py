@@ -15,7 +15,7 @@ def timeit(fn, n=10):
     return ms
 lod = timeit(lambda: h.lod_frames_device(frames, 32, 32, 1, 16.0))
 print("lod only", round(lod, 4))
-for factor in (16.0, 0.7, 0.35, 0.18, 0.09, 0.045, 0.02):
+for factor in (16.0, 8.0, 5.6, 4.0, 2.8, 2.0, 1.4, 1.0, 0.7, 0.35, 0.09):
     out = h.shrink_frames_device(frames, 32, 32, 1, 4, factor)
     ms = timeit(lambda: h.shrink_frames_device(frames, 32, 32, 1, 4, factor, out=out))
     ow, oh = out[1], out[2]
