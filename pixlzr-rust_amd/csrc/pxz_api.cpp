@@ -137,7 +137,7 @@ int get_tables(pxz_handle *h, uint32_t bw, uint32_t bh, uint32_t edge_w, uint32_
 			for (int m = 0; m < kMaxLevel; ++m) {
 				AxisTab &t = tabs[(axis * 2 + cls) * kMaxLevel + m];
 				const uint32_t outsz = reduced(in, (uint32_t)m);
-				t = AxisTab{0, 0, 0, 0, 0, (uint16_t)outsz, 0, 0, (uint16_t)in};
+				t = AxisTab{0, 0, 0, 0, 0, (uint16_t)outsz, 0, 0, (uint16_t)in, 0};
 				if (outsz == in) continue;  // identity: never looked up
 				// identical (in, out) pairs share one table: the edge class of a grid without ragged
 				// edge, and every level past the first that reaches 1 px
@@ -192,6 +192,40 @@ int get_tables(pxz_handle *h, uint32_t bw, uint32_t bh, uint32_t edge_w, uint32_
 						rows[row0 + 4 + d] = pr;
 					}
 					ksums.push_back(total);
+				}
+				// 32x32 tiles: operands for the matrix-core form of the two-pass resample (x axis table,
+				// used for both axes of a full tile)
+				if (axis == 0 && cls == 0 && bw == 32 && bh == 32 && (outsz == 16 || outsz == 8)) {
+					std::vector<uint32_t> mf(pxz::kMfDwords, 0u);
+					bool fits = true, opaque_stays = true;
+					const int32_t half = 1 << (win.precision - 1);
+					for (uint32_t o = 0; o < outsz; ++o) {
+						int32_t k[32] = {0};
+						int32_t total = 0;
+						for (uint32_t i = 0; i < (uint32_t)win.sizes[o]; ++i) {
+							k[(uint32_t)win.starts[o] + i] = win.coeffs[(size_t)o * win.window + i];
+							total += k[(uint32_t)win.starts[o] + i];
+						}
+						for (uint32_t g = 0; g < 4; ++g) {
+							for (uint32_t j = 0; j < 8; ++j) {
+								const uint32_t src = j < 4 ? 4 * g + j : 16 + 4 * g + (j - 4);
+								const int32_t lo = ((k[src] + 128) & 255) - 128, hi = (k[src] - lo) / 256;
+								if (hi < -128 || hi > 127) fits = false;
+								const uint32_t lane = g * 16 + o, dw = 2 * lane + j / 4, sh = 8 * (j & 3);
+								mf[dw] |= (uint32_t)(uint8_t)lo << sh;
+								mf[128 + dw] |= (uint32_t)(uint8_t)hi << sh;
+							}
+						}
+						mf[256 + o] = (uint32_t)(128 * total + half);
+						mf[272 + o] = (uint32_t)total;
+						const int32_t al = (half + 255 * total) >> win.precision;
+						if (al < 255) opaque_stays = false;  // clip8: above 255 is clamped to 255
+					}
+					mf[288] = opaque_stays ? 1u : 0u;
+					if (fits) {
+						t.mf_off = (uint32_t)rows.size();
+						rows.insert(rows.end(), mf.begin(), mf.end());
+					}
 				}
 			}
 		}
@@ -395,7 +429,7 @@ int timed_launch(pxz_handle *h, pxz::ShrinkArgs &a, uint32_t channels, float *va
 	int rc = ensure(h, h->sums, (size_t)a.n_tiles * 8u);
 	if (rc != PXZ_OK) return rc;
 	a.sums = (uint32_t *)h->sums.ptr;
-	if ((rc = ensure(h, h->work, ((size_t)a.n_tiles + 4u) * 4u + 64u)) != PXZ_OK) return rc;  // + 8 u64 of diagnostic stamps
+	if ((rc = ensure(h, h->work, ((size_t)a.n_tiles + 4u) * 4u + 64u + 4096u * 8u)) != PXZ_OK) return rc;  // + 8 u64 of diagnostic stamps
 	a.work = (uint32_t *)h->work.ptr;
 	const pxz::FinishArgs fin{a.sums, value, lod0, lod1, a.n_tiles, a.tiles_per_frame, a.cols, a.rows,
 	                          a.bw, a.bh, a.edge_w, a.edge_h, a.mode, a.factor};

@@ -25,7 +25,18 @@ struct AxisTab {
 	uint16_t wquads;
 	uint16_t precision;
 	uint16_t in_size;
+	uint32_t mf_off;         // matrix-core operand table of a 32 -> 16|8 axis (dword offset in the rows blob, 0: none)
 };
+
+// Matrix-core operand table of one 32 -> out axis (out = 16 or 8), kMfDwords dwords, see resample_mfma32:
+//   [0, 128)    low bytes  of the weights: lane l = (o = l & 15, g = l >> 4), 8 x i8 = K_lo[o][src(g, j)]
+//   [128, 256)  high bytes of the weights, same arrangement (K = 256 * K_hi + K_lo, both signed 8-bit)
+//   [256, 272)  bias[o]  = 128 * sum_i K[o][i] + 2^(precision - 1)
+//   [272, 288)  ksum[o]  = sum_i K[o][i]
+//   [288]       1 if clip8(2^(precision-1) + 255 * ksum[o]) == 255 for every o (opaque stays opaque)
+// src(g, j) = 4g + j (j < 4), 16 + 4g + (j - 4) (j >= 4): the order in which the first product's
+// accumulator registers hand their rows to the second product.
+constexpr uint32_t kMfDwords = 292;
 
 // q = n / d as (t + ((n - t) >> sh1)) >> sh2 with t = mulhi(n, mul)  (Granlund-Montgomery)
 struct FastDiv {
@@ -89,6 +100,7 @@ struct Fast32Args {
 	uint32_t *work;
 	const uint32_t *trows;
 	uint32_t tab_dw, tile_dw;
+	uint32_t chunk_lg;       // tickets deal runs of 2^chunk_lg adjacent tiles
 	uint32_t breaks[kMaxLevel];
 	uint32_t breaks_asc;
 	AxisTab tabs[kMaxLevel];

@@ -565,6 +565,111 @@ __device__ __forceinline__ void resample_fast32_hv(const uint32_t *trows, const 
 	else fast32_v<8>(trows, tx, ty, s_tmp, lane, nw, nh, out);
 }
 
+// ---------------------------------------------------------------------------
+// The same two-pass convolution on the matrix cores, for 32x32 -> nw x nh with nw, nh in {16, 8}:
+// the classes whose windows are long AND whose outputs are many, i.e. where the dot2 form above
+// spends the most vector instructions.  Integer-exact: v_mfma_i32_16x16x32_i8 multiplies signed bytes,
+// so a pixel enters as p - 128 and an i16 weight as two signed bytes K = 256 K_hi + K_lo:
+//     sum p K = 256 sum (p-128) K_hi + sum (p-128) K_lo + 128 sum K
+// (two products per output block; the last term and the rounding half come in as the C operand).
+//
+//   horizontal  T[y][ox] = clip8(sum_x P[y][x] Kx[ox][x])   D = A B: A = pixel rows (16 per product),
+//               B = weights [x][ox]; the accumulator holds column ox = lane & 15, rows 4g + r (g = lane >> 4)
+//   vertical    O[oy][ox] = clip8(sum_y Ky[oy][y] T[y][ox]) D = A B: A = weights [oy][y], B = T.
+// T never leaves the registers: after the two horizontal products (rows 0..15, 16..31) lane (ox, g)
+// holds T[4g + r][ox] and T[16 + 4g + r][ox], which IS a B operand whose k slots are the rows
+// src(g, j) (pxz_internal.h) -- so the weight operand is stored with its k slots in that order, and the
+// pixel operand of the horizontal product reads its 8 source columns in that order too (one table
+// serves both passes, the axes of a 32x32 tile being alike).
+// ---------------------------------------------------------------------------
+typedef int v4i32 __attribute__((ext_vector_type(4)));
+
+template <int BYTE>
+__device__ __forceinline__ void put_byte_shr(uint32_t &dst, uint32_t value, uint32_t shift)
+{
+	// dst.byte[BYTE] = (value >> shift) & 0xff, other bytes kept: one SDWA shift
+	if constexpr (BYTE == 0)
+		asm("v_lshrrev_b32_sdwa %0, %1, %2 dst_sel:BYTE_0 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD" : "+v"(dst) : "v"(shift), "v"(value));
+	else if constexpr (BYTE == 1)
+		asm("v_lshrrev_b32_sdwa %0, %1, %2 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD" : "+v"(dst) : "v"(shift), "v"(value));
+	else if constexpr (BYTE == 2)
+		asm("v_lshrrev_b32_sdwa %0, %1, %2 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD" : "+v"(dst) : "v"(shift), "v"(value));
+	else
+		asm("v_lshrrev_b32_sdwa %0, %1, %2 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD" : "+v"(dst) : "v"(shift), "v"(value));
+}
+
+__device__ __forceinline__ uint32_t clamp_fixed(int32_t hi, int32_t lo, int32_t top)
+{
+	const int32_t v = (int32_t)(((uint32_t)hi << 8) + (uint32_t)lo);  // 256 * hi + lo (the bias is already in lo)
+	return (uint32_t)(v < 0 ? 0 : (v > top ? top : v));               // clip8, before its shift
+}
+
+__device__ __forceinline__ void resample_mfma32(const uint32_t *s_tab, const AxisTab &tx, const AxisTab &ty, const uint32_t *s_pl,
+                                                uint32_t lane, uint32_t nw, uint32_t nh, uint32_t *out)
+{
+	const uint32_t o = lane & 15u, g = lane >> 4;
+	const uint32_t *mx = s_tab + tx.mf_off, *my = s_tab + ty.mf_off;
+	const long kx_lo = *reinterpret_cast<const long *>(mx + 2u * lane), kx_hi = *reinterpret_cast<const long *>(mx + 128u + 2u * lane);
+	const long ky_lo = *reinterpret_cast<const long *>(my + 2u * lane), ky_hi = *reinterpret_cast<const long *>(my + 128u + 2u * lane);
+	const int32_t bx = (int32_t)mx[256u + o];
+	const v4i32 cx = {bx, bx, bx, bx};
+	const v4i32 cy = *reinterpret_cast<const v4i32 *>(my + 256u + 4u * g);
+	const v4i32 zero = {0, 0, 0, 0};
+	const uint32_t px_ = tx.precision, py = ty.precision;
+	const int32_t top_x = (int32_t)((256u << px_) - 1u), top_y = (int32_t)((256u << py) - 1u);
+	uint32_t pix[4] = {0xff000000u, 0xff000000u, 0xff000000u, 0xff000000u};
+	const uint32_t *rowp = s_pl + o * kRS32 + 2u * g;
+#pragma unroll
+	for (uint32_t c = 0; c < 3; ++c) {
+		uint32_t t[2];
+#pragma unroll
+		for (uint32_t mb = 0; mb < 2; ++mb) {
+			const uint32_t *row = rowp + c * kPD32 + mb * (16u * kRS32);
+			const uint2 d0 = *reinterpret_cast<const uint2 *>(row);       // columns 4g .. 4g+3
+			const uint2 d1 = *reinterpret_cast<const uint2 *>(row + 8u);  // columns 16+4g .. 16+4g+3
+			const uint32_t a0 = __builtin_amdgcn_perm(d0.y, d0.x, 0x06040200u) ^ 0x80808080u;
+			const uint32_t a1 = __builtin_amdgcn_perm(d1.y, d1.x, 0x06040200u) ^ 0x80808080u;
+			const long av = (long)(((unsigned long long)a1 << 32) | (unsigned long long)a0);
+			const v4i32 lo = __builtin_amdgcn_mfma_i32_16x16x32_i8(av, kx_lo, cx, 0, 0, 0);
+			const v4i32 hi = __builtin_amdgcn_mfma_i32_16x16x32_i8(av, kx_hi, zero, 0, 0, 0);
+			uint32_t packed = 0;
+			put_byte_shr<0>(packed, clamp_fixed(hi[0], lo[0], top_x), px_);
+			put_byte_shr<1>(packed, clamp_fixed(hi[1], lo[1], top_x), px_);
+			put_byte_shr<2>(packed, clamp_fixed(hi[2], lo[2], top_x), px_);
+			put_byte_shr<3>(packed, clamp_fixed(hi[3], lo[3], top_x), px_);
+			t[mb] = packed ^ 0x80808080u;
+		}
+		const long tv = (long)(((unsigned long long)t[1] << 32) | (unsigned long long)t[0]);
+		const v4i32 lo = __builtin_amdgcn_mfma_i32_16x16x32_i8(ky_lo, tv, cy, 0, 0, 0);
+		const v4i32 hi = __builtin_amdgcn_mfma_i32_16x16x32_i8(ky_hi, tv, zero, 0, 0, 0);
+#pragma unroll
+		for (int r = 0; r < 4; ++r) {
+			const uint32_t v = clamp_fixed(hi[r], lo[r], top_y);
+			if (c == 0) put_byte_shr<0>(pix[r], v, py);
+			else if (c == 1) put_byte_shr<1>(pix[r], v, py);
+			else put_byte_shr<2>(pix[r], v, py);
+		}
+	}
+	// opaque tile: alpha is the convolution of the constant 255 = the windows' weight sums (fast32_v);
+	// the table says when that is 255 for every output of the axis
+	if (!(mx[288] & my[288])) {
+		const int32_t ah = (int32_t)clip8((1 << (px_ - 1)) + 255 * (int32_t)mx[272u + o], (int)px_);
+#pragma unroll
+		for (int r = 0; r < 4; ++r) {
+			const uint32_t al = clip8((1 << (py - 1)) + ah * (int32_t)my[272u + 4u * g + (uint32_t)r], (int)py);
+			pix[r] = (pix[r] & 0x00ffffffu) | (al << 24);
+			if (al != 255u) pix[r] = unpremultiply(pix[r]);
+		}
+	}
+	if (o < nw) {
+#pragma unroll
+		for (uint32_t r = 0; r < 4; ++r) {
+			const uint32_t oy = 4u * g + r;
+			if (oy < nh) out[oy * nw + o] = pix[r];
+		}
+	}
+}
+
 // Fast-path eligibility of a tile (full 32x32 RGBA, 16-byte aligned rows) and its first byte.
 template <class Args>
 __device__ __forceinline__ bool fast32_tile_src(const Args &a, uint32_t tile_g, const uint8_t *&src)
@@ -1091,7 +1196,9 @@ __global__ void __launch_bounds__(1024) shrink32_kernel(const Fast32Args a)
 	uint32_t *s_pl = lds + a.tab_dw + sub * a.tile_dw;
 	uint32_t *s_tmp = s_pl + 3 * kPD32;  // R, G, B planes only: tiles with transparency go to the worklist
 	auto tile_of_ticket = [&](uint32_t t) -> uint32_t {
-		const unsigned long long g = (unsigned long long)blockIdx.x + (unsigned long long)t * gridDim.x;
+		// runs of 2^chunk_lg adjacent tiles per block: successive tickets walk along an image row
+		const unsigned long long run = (unsigned long long)(t >> a.chunk_lg) * gridDim.x + blockIdx.x;
+		const unsigned long long g = (run << a.chunk_lg) + (t & ((1u << a.chunk_lg) - 1u));
 		return g < (unsigned long long)a.n_tiles ? (uint32_t)g : 0xffffffffu;
 	};
 	auto next_ticket = [&]() -> uint32_t {
@@ -1110,6 +1217,7 @@ __global__ void __launch_bounds__(1024) shrink32_kernel(const Fast32Args a)
 #ifdef PXZ_STAMPS
 	unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 	unsigned long long st_last = stamp_now();
+	const unsigned long long st_begin = wall_clock64();
 #endif
 	uint32_t pend_kind = 0;       // 0 nothing, 1 linear pixels in LDS, 2 clone (re-interleave the planes)
 	uint32_t pend_px = 0;         // pixels parked in LDS (kind 1)
@@ -1261,10 +1369,15 @@ __global__ void __launch_bounds__(1024) shrink32_kernel(const Fast32Args a)
 			} else if (nw != 32u && nh != 32u && a.filter != 0) {
 				const uint32_t lx = m0 < (uint32_t)kMaxLevel ? m0 : (uint32_t)kMaxLevel - 1;
 				const uint32_t ly = m1 < (uint32_t)kMaxLevel ? m1 : (uint32_t)kMaxLevel - 1;
-				// the vertical pass reads only the transposed planes: the R plane is free for the pixels
-				resample_fast32_hv(s_tab, a.tabs[lx], a.tabs[ly], s_pl, s_tmp, tid, nw, nh, s_pl);
+				if (a.tabs[lx].mf_off != 0 && a.tabs[ly].mf_off != 0) {
+					resample_mfma32(s_tab, a.tabs[lx], a.tabs[ly], s_pl, tid, nw, nh, s_tmp);
+					pend_src = s_tmp;
+				} else {
+					// the vertical pass reads only the transposed planes: the R plane is free for the pixels
+					resample_fast32_hv(s_tab, a.tabs[lx], a.tabs[ly], s_pl, s_tmp, tid, nw, nh, s_pl);
+					pend_src = s_pl;
+				}
 				pend_kind = 1;
-				pend_src = s_pl;
 			} else if (a.filter == 0) {
 				// ResizeAlg::Nearest (mod.rs:277): source index = floor((o + 0.5) * 2^m), no alpha handling
 				const uint32_t lgx = 31u - (uint32_t)__builtin_clz(nw);
@@ -1295,7 +1408,13 @@ __global__ void __launch_bounds__(1024) shrink32_kernel(const Fast32Args a)
 		tile_sync<1>();  // the next tile reuses this wave's LDS image
 		PXZ_STAMP(3);  // clone / resample / defer
 	};
+#ifdef PXZ_STAMPS
+	uint32_t st_tiles = 0;
+#endif
 	for (uint32_t tile_g = first; tile_g < a.n_tiles;) {
+#ifdef PXZ_STAMPS
+		++st_tiles;
+#endif
 		const uint32_t tile_next = next_ticket();
 		one_tile(tile_g, tile_next);
 		tile_g = tile_next;
@@ -1305,6 +1424,9 @@ __global__ void __launch_bounds__(1024) shrink32_kernel(const Fast32Args a)
 	if (tid == 0) {
 		unsigned long long *out = reinterpret_cast<unsigned long long *>(a.work + ((a.n_tiles + 2u + 1u) & ~1u));
 		for (int i = 0; i < 8; ++i) atomicAdd(out + i, st_acc[i]);
+		// per-wave run time (100 MHz ticks) | tiles processed << 48; last launch wins
+		out[8 + blockIdx.x * 16u + sub] = ((wall_clock64() - st_begin) & 0xffffffffffffull) | ((unsigned long long)st_tiles << 48);
+		if (sub == 0) out[8 + blockIdx.x * 16u + 15u] = st_begin;
 	}
 #endif
 }
@@ -2088,6 +2210,8 @@ hipError_t launch_shrink(const ShrinkArgs &a, uint32_t channels, uint32_t n_cus,
 		const uint32_t resident = n_cus * (per_cu > 2u ? 2u : per_cu);
 		const uint32_t need = (a.n_tiles + wpb - 1u) / wpb;
 		const uint32_t blocks = need < resident ? need : resident;
+		f.chunk_lg = 3;
+		if (const char *e = getenv("PXZ_CHUNK_LG")) f.chunk_lg = (uint32_t)atoi(e) & 15u;
 		hipError_t e = hipMemsetAsync(a.work, 0, 4, stream);
 		if (e != hipSuccess) return e;
 		if (a.mode == 1) {

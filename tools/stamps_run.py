@@ -32,3 +32,24 @@ tot = sum(d[:4])
 names = ["wait prefetch + stage", "issue prefetch", "detector+decision+meta", "clone/resample"]
 for n, v in zip(names, d): print(f"{n:28s} {v/5/n_tiles:10.1f} cycles/tile  {100*v/tot:5.1f}%")
 print("total per tile (wave cycles):", tot / 5 / n_tiles)
+
+# per-wave run times of the last launch (100 MHz wall clock) and per-block start times (slot 15)
+import numpy as np
+buf = (C.c_uint64 * 4096)()
+off = ((n_tiles + 3) & ~1) * 4 + 64
+assert L.pxz_debug_read_work(h._h, buf, off, 4096 * 8) == 0
+raw = np.array(list(buf), dtype=np.uint64).reshape(256, 16)
+start = raw[:, 15].astype(np.float64) / 100
+dur = (raw[:, :15] & np.uint64(0xffffffffffff)).astype(np.float64) / 100
+cnt = (raw[:, :15] >> np.uint64(48)).astype(np.int64)
+print("tiles per wave: min %d median %d max %d; per block sum min %d max %d" % (cnt.min(), np.median(cnt), cnt.max(), cnt.sum(axis=1).min(), cnt.sum(axis=1).max()))
+print("corr(run time, tiles) = %.3f" % np.corrcoef(dur.ravel(), cnt.ravel())[0, 1])
+print("block start spread (us): %.1f" % (start.max() - start.min()))
+print("per-wave run time percentiles (us):", ["%.1f" % np.percentile(dur, q) for q in (0, 1, 5, 25, 50, 75, 95, 99, 100)])
+end = start[:, None] + dur - start.min()
+print("per-wave finish percentiles (us):", ["%.1f" % np.percentile(end, q) for q in (0, 1, 5, 25, 50, 75, 95, 99, 100)])
+spread = end.max(axis=1) - end.min(axis=1)
+print("within-block finish spread (us): min %.1f median %.1f max %.1f" % (spread.min(), np.median(spread), spread.max()))
+eb = end.max(axis=1)
+print("block finish (us): min %.1f median %.1f max %.1f" % (eb.min(), np.median(eb), eb.max()))
+print("mean block finish per XCD (block % 8):", ["%.1f" % eb[x::8].mean() for x in range(8)])
