@@ -21,6 +21,7 @@ namespace pxz {
 hipError_t launch_shrink(const ShrinkArgs &a, uint32_t channels, uint32_t n_cus, hipStream_t stream);
 hipError_t launch_synth(const SynthArgs &s, hipStream_t stream);
 hipError_t launch_finish(const FinishArgs &f, hipStream_t stream);
+bool fast32_applicable(const ShrinkArgs &a, uint32_t channels);
 hipError_t launch_pack(const PackArgs &a, hipStream_t stream);
 hipError_t launch_oklab32(const ShrinkArgs &a, uint32_t n_cus, hipStream_t stream);
 hipError_t launch_qoi(const QoiArgs &a, hipStream_t stream);
@@ -60,6 +61,8 @@ struct pxz_handle {
 	struct Breaks { uint32_t b[4][pxz::kMaxLevel]; uint32_t asc[4]; };
 	std::map<std::tuple<uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t>, Breaks> breaks;
 	DeviceBuffer in, val, ow, oh, out, sums, chunks, work, qscratch, qmeta;
+	bool work_ready = false;   // both worklist counters are zero / consistent with work_slot
+	uint32_t work_slot = 0;    // the counter the next 32x32 launch uses
 	bool timing = false;
 	std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
 	size_t events_used = 0;
@@ -429,8 +432,13 @@ int timed_launch(pxz_handle *h, pxz::ShrinkArgs &a, uint32_t channels, float *va
 	int rc = ensure(h, h->sums, (size_t)a.n_tiles * 8u);
 	if (rc != PXZ_OK) return rc;
 	a.sums = (uint32_t *)h->sums.ptr;
-	if ((rc = ensure(h, h->work, ((size_t)a.n_tiles + 4u) * 4u + 64u + 4096u * 8u)) != PXZ_OK) return rc;  // + 8 u64 of diagnostic stamps
+	const void *work_before = h->work.ptr;
+	if ((rc = ensure(h, h->work, ((size_t)a.n_tiles + 4u) * 4u + 64u + 4096u * 8u)) != PXZ_OK) return rc;  // + diagnostic stamps
+	if (h->work.ptr != work_before) h->work_ready = false;
 	a.work = (uint32_t *)h->work.ptr;
+	a.value = value;
+	a.lod0 = lod0;
+	a.lod1 = lod1;
 	const pxz::FinishArgs fin{a.sums, value, lod0, lod1, a.n_tiles, a.tiles_per_frame, a.cols, a.rows,
 	                          a.bw, a.bh, a.edge_w, a.edge_h, a.mode, a.factor};
 	hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -452,8 +460,24 @@ int timed_launch(pxz_handle *h, pxz::ShrinkArgs &a, uint32_t channels, float *va
 		a.oklab_given = 1;
 		PXZ_HIP(h, pxz::launch_oklab32(a, h->n_cus, h->stream));
 	}
+	// 32x32 RGBA flow: shrink32_kernel, then the worklist kernel, which also finishes every tile and
+	// zeroes the worklist counter of the next launch (two counters, used alternately)
+	const bool fast = pxz::fast32_applicable(a, channels);
+	if (fast) {
+		if (!h->work_ready) {
+			PXZ_HIP(h, hipMemsetAsync(h->work.ptr, 0, 8, h->stream));
+			h->work_slot = 0;
+		}
+		h->work_ready = false;  // stays false if a launch below fails: the counters are then re-zeroed next time
+		a.work_slot = h->work_slot;
+	}
 	PXZ_HIP(h, pxz::launch_shrink(a, channels, h->n_cus, h->stream));
-	PXZ_HIP(h, pxz::launch_finish(fin, h->stream));
+	if (fast) {
+		h->work_slot ^= 1u;
+		h->work_ready = true;
+	} else {
+		PXZ_HIP(h, pxz::launch_finish(fin, h->stream));
+	}
 	if (h->timing) PXZ_HIP(h, hipEventRecord(e1, h->stream));
 	return PXZ_OK;
 }
@@ -517,7 +541,14 @@ const char *pxz_last_error(const pxz_handle *h) { return h ? h->error.c_str() : 
 int pxz_set_stream(pxz_handle *h, void *hip_stream)
 {
 	if (!h) return PXZ_ERR_INVALID_ARG;
-	h->stream = static_cast<hipStream_t>(hip_stream);
+	hipStream_t next = static_cast<hipStream_t>(hip_stream);
+	if (next != h->stream) {
+		// the handle's scratch buffers (and the worklist counters a launch leaves for the next one) are
+		// ordered by the stream: finish what is queued on the old one before moving on
+		PXZ_HIP(h, hipSetDevice(h->device));
+		PXZ_HIP(h, hipStreamSynchronize(h->stream));
+		h->stream = next;
+	}
 	return PXZ_OK;
 }
 

@@ -58,7 +58,11 @@ struct ShrinkArgs {
 	float factor;
 	// outputs (device); out_px may be null (no resample), out_w/out_h may be null
 	uint32_t oklab_given;    // 1: full 32x32 RGBA tiles already carry their Oklab value in sums[] (oklab32_kernel)
-	uint32_t *work;          // worklist: [0] = count, [1..] = tile ids (null: all tiles)
+	uint32_t *work;          // worklist: [work_slot] = count, [2..] = tile ids (null: all tiles).  The two
+	uint32_t work_slot;      //   counters alternate between launches; a launch zeroes the other one
+	float *value;            // worklist mode only: the kernel finishes its tiles itself (finish_tile) and,
+	float *lod0;             //   after the worklist, the tiles shrink32_kernel completed; each may be null
+	float *lod1;
 	uint32_t *sums;          // 2 per tile: gradient sums (directional) | f32 value bits (Oklab); -> finish_kernel
 	uint32_t *out_w;
 	uint32_t *out_h;
@@ -98,6 +102,7 @@ struct Fast32Args {
 	uint32_t *out_h;
 	uint8_t *out_px;
 	uint32_t *work;
+	uint32_t work_slot;
 	const uint32_t *trows;
 	uint32_t tab_dw, tile_dw;
 	uint32_t chunk_lg;       // tickets deal runs of 2^chunk_lg adjacent tiles

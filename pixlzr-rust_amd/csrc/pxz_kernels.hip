@@ -601,7 +601,9 @@ __device__ __forceinline__ void put_byte_shr(uint32_t &dst, uint32_t value, uint
 __device__ __forceinline__ uint32_t clamp_fixed(int32_t hi, int32_t lo, int32_t top)
 {
 	const int32_t v = (int32_t)(((uint32_t)hi << 8) + (uint32_t)lo);  // 256 * hi + lo (the bias is already in lo)
-	return (uint32_t)(v < 0 ? 0 : (v > top ? top : v));               // clip8, before its shift
+	int32_t r;  // clip8 before its shift: median of (v, 0, top); top is a run-time value, so spell the instruction
+	asm("v_med3_i32 %0, %1, 0, %2" : "=v"(r) : "v"(v), "s"(top));
+	return (uint32_t)r;
 }
 
 __device__ __forceinline__ void resample_mfma32(const uint32_t *s_tab, const AxisTab &tx, const AxisTab &ty, const uint32_t *s_pl,
@@ -694,6 +696,37 @@ __device__ __forceinline__ void fast32_prefetch(const Args &a, uint32_t tile_g, 
 #pragma unroll
 		for (int k = 0; k < 4; ++k) pre[k] = *reinterpret_cast<const uint4 *>(p + (size_t)(8 * k) * a.pitch);
 	}
+}
+
+// Detector result of one tile -> stored block value (and the raw detector outputs for pxz_lod_*):
+// the f64 part of get_block_variance_directionally (operations.rs:253-258), shrink_*'s closures
+// (pixlzr.rs:177-178, :199) and reduce_image_section's value (operations.rs:154).
+constexpr uint32_t kDeferredKey = 0xffffffffu;  // sums[] of a tile shrink32_kernel handed to the worklist
+__device__ __forceinline__ void finish_tile(const uint2 key, uint32_t w, uint32_t h, uint32_t mode, float factor, float *value,
+                                            float *lod0, float *lod1, uint32_t tile_g)
+{
+	float raw0, raw1, v0, v1;
+	if (mode == 1) {
+		const uint64_t fac = (uint64_t)(w - 2) * (uint64_t)(h - 2) * 4096ull;  // operations.rs:253-254
+		if (fac == 0) {
+			// 0/0 on the reference's x86-64 target is the negative default NaN:
+			// parse_value turns it into max(1+NaN, 0) = 0 -> stored value 0
+			raw0 = raw1 = __uint_as_float(0xFFC00000u);
+			v0 = v1 = 0.0f;
+		} else {
+			const double d = (double)fac;
+			raw0 = (float)((double)key.x / d);  // :256
+			raw1 = (float)((double)key.y / d);  // :257
+			v0 = parse_value(raw0 * factor);    // pixlzr.rs:199
+			v1 = parse_value(raw1 * factor);
+		}
+	} else {
+		raw0 = raw1 = __uint_as_float(key.x);
+		v0 = v1 = parse_value(raw0);  // pixlzr.rs:177-178
+	}
+	if (value) value[tile_g] = hypot_f32(v0, v1);  // operations.rs:154
+	if (lod0) lod0[tile_g] = raw0;
+	if (lod1) lod1[tile_g] = raw1;
 }
 
 // ---------------------------------------------------------------------------
@@ -932,6 +965,7 @@ __device__ __forceinline__ void process_tile(const ShrinkArgs &a, const uint32_t
 		reinterpret_cast<uint2 *>(a.sums)[tile_g] = make_uint2(key0, key1);
 		if (a.out_w) a.out_w[tile_g] = nw;
 		if (a.out_h) a.out_h[tile_g] = nh;
+		if (a.work) finish_tile(make_uint2(key0, key1), w, h, (uint32_t)MODE, a.factor, a.value, a.lod0, a.lod1, tile_g);
 	}
 	if (a.out_px == nullptr) return;
 
@@ -1255,7 +1289,10 @@ __global__ void __launch_bounds__(1024) shrink32_kernel(const Fast32Args a)
 	};
 	auto one_tile = [&](const uint32_t tile_g, const uint32_t tile_next) {
 		auto defer = [&]() {
-			if (tid == 0) a.work[1 + atomicAdd(&a.work[0], 1u)] = tile_g;
+			if (tid == 0) {
+				a.work[2 + atomicAdd(&a.work[a.work_slot], 1u)] = tile_g;
+				reinterpret_cast<uint2 *>(a.sums)[tile_g] = make_uint2(kDeferredKey, kDeferredKey);  // not finished here
+			}
 		};
 		if (!pre_valid) {  // ragged edge / unaligned rows: generic kernel
 			flush();
@@ -1422,7 +1459,7 @@ __global__ void __launch_bounds__(1024) shrink32_kernel(const Fast32Args a)
 	flush();  // the last tile's pixels
 #ifdef PXZ_STAMPS
 	if (tid == 0) {
-		unsigned long long *out = reinterpret_cast<unsigned long long *>(a.work + ((a.n_tiles + 2u + 1u) & ~1u));
+		unsigned long long *out = reinterpret_cast<unsigned long long *>(a.work + ((a.n_tiles + 3u + 1u) & ~1u));
 		for (int i = 0; i < 8; ++i) atomicAdd(out + i, st_acc[i]);
 		// per-wave run time (100 MHz ticks) | tiles processed << 48; last launch wins
 		out[8 + blockIdx.x * 16u + sub] = ((wall_clock64() - st_begin) & 0xffffffffffffull) | ((unsigned long long)st_tiles << 48);
@@ -1449,17 +1486,31 @@ __global__ void __launch_bounds__(NW == 1 ? 768 : 64 * NW) shrink_kernel(const S
 		if (threadIdx.x == 0) *s_ticket = wpb;
 		__syncthreads();
 		// with a worklist (left by shrink32_kernel) only the listed tiles are processed
-		const uint32_t count = a.work ? __builtin_amdgcn_readfirstlane(a.work[0]) : a.n_tiles;
+		const uint32_t count = a.work ? __builtin_amdgcn_readfirstlane(a.work[a.work_slot]) : a.n_tiles;
 		uint32_t ticket = sub;
 		for (;;) {
 			const unsigned long long i = (unsigned long long)blockIdx.x + (unsigned long long)ticket * gridDim.x;
 			if (i >= (unsigned long long)count) break;
-			const uint32_t tile_g = a.work ? __builtin_amdgcn_readfirstlane(a.work[1 + (uint32_t)i]) : (uint32_t)i;
+			const uint32_t tile_g = a.work ? __builtin_amdgcn_readfirstlane(a.work[2 + (uint32_t)i]) : (uint32_t)i;
 			process_tile<NW, C, MODE>(a, tile_g, s_pl, nullptr, tid);
 			uint32_t t = 0;
 			if (tid == 0) t = atomicAdd(s_ticket, 1u);
 			ticket = __builtin_amdgcn_readfirstlane(t);
 			tile_sync<1>();  // the next tile reuses this wave's LDS image
+		}
+		if (a.work) {
+			// worklist mode = second and last launch of the 32x32 flow: finish, lane-parallel, the tiles
+			// shrink32_kernel completed (it left kDeferredKey in the others, which process_tile finishes
+			// itself), and zero the worklist counter of the NEXT launch
+			for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < a.n_tiles; t += gridDim.x * blockDim.x) {
+				const uint2 key = reinterpret_cast<const uint2 *>(a.sums)[t];
+				if (key.x == kDeferredKey && key.y == kDeferredKey) continue;
+				const uint32_t tf = t % a.tiles_per_frame;
+				const uint32_t ty = tf / a.cols, tx = tf - ty * a.cols;
+				finish_tile(key, (tx == a.cols - 1) ? a.edge_w : a.bw, (ty == a.rows - 1) ? a.edge_h : a.bh, (uint32_t)MODE, a.factor,
+				            a.value, a.lod0, a.lod1, t);
+			}
+			if (blockIdx.x == 0 && threadIdx.x == 0) a.work[a.work_slot ^ 1u] = 0u;
 		}
 	} else {
 		for (uint32_t tile_g = blockIdx.x; tile_g < a.n_tiles; tile_g += gridDim.x) {
@@ -1673,32 +1724,10 @@ __global__ void __launch_bounds__(256) finish_kernel(const FinishArgs f)
 	const uint32_t tile_g = blockIdx.x * 256u + threadIdx.x;
 	if (tile_g >= f.n_tiles) return;
 	const uint2 key = reinterpret_cast<const uint2 *>(f.sums)[tile_g];
-	float raw0, raw1, v0, v1;
-	if (f.mode == 1) {
-		const uint32_t t = tile_g % f.tiles_per_frame;
-		const uint32_t ty = t / f.cols, tx = t - ty * f.cols;
-		const uint32_t w = (tx == f.cols - 1) ? f.edge_w : f.bw;
-		const uint32_t h = (ty == f.rows - 1) ? f.edge_h : f.bh;
-		const uint64_t fac = (uint64_t)(w - 2) * (uint64_t)(h - 2) * 4096ull;  // operations.rs:253-254
-		if (fac == 0) {
-			// 0/0 on the reference's x86-64 target is the negative default NaN:
-			// parse_value turns it into max(1+NaN, 0) = 0 -> stored value 0
-			raw0 = raw1 = __uint_as_float(0xFFC00000u);
-			v0 = v1 = 0.0f;
-		} else {
-			const double d = (double)fac;
-			raw0 = (float)((double)key.x / d);  // :256
-			raw1 = (float)((double)key.y / d);  // :257
-			v0 = parse_value(raw0 * f.factor);  // pixlzr.rs:199
-			v1 = parse_value(raw1 * f.factor);
-		}
-	} else {
-		raw0 = raw1 = __uint_as_float(key.x);
-		v0 = v1 = parse_value(raw0);  // pixlzr.rs:177-178
-	}
-	if (f.value) f.value[tile_g] = hypot_f32(v0, v1);  // operations.rs:154
-	if (f.lod0) f.lod0[tile_g] = raw0;
-	if (f.lod1) f.lod1[tile_g] = raw1;
+	const uint32_t t = tile_g % f.tiles_per_frame;
+	const uint32_t ty = t / f.cols, tx = t - ty * f.cols;
+	finish_tile(key, (tx == f.cols - 1) ? f.edge_w : f.bw, (ty == f.rows - 1) ? f.edge_h : f.bh, f.mode, f.factor, f.value, f.lod0,
+	            f.lod1, tile_g);
 }
 
 // ---------------------------------------------------------------------------
@@ -2183,6 +2212,7 @@ hipError_t launch_shrink(const ShrinkArgs &a, uint32_t channels, uint32_t n_cus,
 		f.out_h = a.out_h;
 		f.out_px = a.out_px;
 		f.work = a.work;
+		f.work_slot = a.work_slot;
 		f.trows = a.trows;
 		f.tab_dw = a.out_px && a.filter != 0 ? a.tab_dw : 0u;
 		// only the x-axis tables of full tiles are used (the y axis of a 32x32 tile is identical): they
@@ -2212,8 +2242,7 @@ hipError_t launch_shrink(const ShrinkArgs &a, uint32_t channels, uint32_t n_cus,
 		const uint32_t blocks = need < resident ? need : resident;
 		f.chunk_lg = 3;
 		if (const char *e = getenv("PXZ_CHUNK_LG")) f.chunk_lg = (uint32_t)atoi(e) & 15u;
-		hipError_t e = hipMemsetAsync(a.work, 0, 4, stream);
-		if (e != hipSuccess) return e;
+		hipError_t e = hipSuccess;  // the worklist counter of this launch was zeroed by the previous one (or at allocation)
 		if (a.mode == 1) {
 			auto k = shrink32_kernel<1>;
 			if (lds_bytes > 64u * 1024u && (e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)) != hipSuccess) return e;

@@ -12,6 +12,8 @@ dist = int(os.environ.get("DIST", "0"))
 h = P.Handle(0)
 frames = h.synth_frames_device(nf, 4320, 7680, 4, 0, dist)
 mode, factor = (1, 16.0) if variant.startswith("dir") else (0, 1.0)
+if os.environ.get("FACTOR"):
+    factor = float(os.environ["FACTOR"])  # with DIST=3 (noise) the factor picks ONE size class for every tile
 if variant.endswith("lod"):
     for _ in range(n): h.lod_frames_device(frames, 32, 32, mode, factor)
 else:
