@@ -198,7 +198,7 @@ int get_tables(pxz_handle *h, uint32_t bw, uint32_t bh, uint32_t edge_w, uint32_
 				}
 				// 32x32 tiles: operands for the matrix-core form of the two-pass resample (x axis table,
 				// used for both axes of a full tile)
-				if (axis == 0 && cls == 0 && bw == 32 && bh == 32 && (outsz == 16 || outsz == 8)) {
+				if (axis == 0 && cls == 0 && bw == 32 && bh == 32 && (outsz == 16 || outsz == 8 || outsz == 4)) {
 					std::vector<uint32_t> mf(pxz::kMfDwords, 0u);
 					bool fits = true, opaque_stays = true;
 					const int32_t half = 1 << (win.precision - 1);

@@ -7,8 +7,9 @@ from __graft_entry__ import load_product
 P = load_product()
 h = P.Handle(0)
 frames = h.synth_frames_device(8, 4320, 7680, 4, 0, 3)
-def timeit(fn, n=10):
-    fn(); torch.cuda.synchronize()
+def timeit(fn, n=200):
+    for _ in range(100): fn()  # clocks settle after ~80 launches (tools/exp_ramp.py)
+    torch.cuda.synchronize()
     h.enable_timing(True)
     for _ in range(n): fn()
     ms = h.last_kernel_ms(); h.enable_timing(False)
