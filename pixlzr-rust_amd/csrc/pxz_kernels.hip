@@ -1528,11 +1528,22 @@ __global__ void __launch_bounds__(NW == 1 ? 768 : 64 * NW) shrink_kernel(const S
 // end up in the bitstream, so they are replayed in exactly that order.  To keep the chip
 // busy anyway, a block of 16 waves works on 15 tiles at once: waves 0..14 ("producers")
 // each convert one tile to Oklab (f32 + the glibc-cbrtf double-precision steps) and keep
-// the 16 pixels x 3 values of every lane in registers; wave 15 walks 15 x 4 chains
+// the 16 pixels x 3 values of every lane in registers; wave 15 ("chain") walks 15 x 4 chains
 // (channels a, b, l, alpha of every tile) in lock-step, 60 lanes wide, reading the values
-// from double-buffered LDS bands of 8 tile rows that the producers fill one step ahead.
-// Pass 1 sums, pass 2 (after the means are known) sums |x - mean|; the producers re-stage
-// the bands from registers for pass 2.
+// from LDS bands of 8 tile rows.
+//
+// Software pipeline over the batches b_0, b_1, ... of a block, one "period" per batch, four
+// "intervals" (bands) per period, two barriers per interval:
+//   convert phase   producers convert band k of batch p into spare registers and request the
+//                   same band of batch p+1 from HBM; meanwhile the chain adds up the two bands
+//                   written one interval earlier: pass 1 (sum) of batch p and pass 2 (sum of
+//                   |x - mean|) of batch p-1, whose means it published when its pass 1 ended
+//   -- barrier A --
+//   write phase     producers write band k of pass 2 (old registers minus the means), move the
+//                   spare registers in, write band k of pass 1
+//   -- barrier B --
+// so the conversion (the expensive part) and the dependent-add chains run side by side, and
+// one band buffer per pass is enough.
 // ---------------------------------------------------------------------------
 constexpr uint32_t kOkTiles = 15;           // tiles per block and batch (one per producer wave)
 constexpr uint32_t kOkPlane = 256 + 4;      // floats per (tile, channel) band: 8 rows x 32 px + bank skew
@@ -1576,8 +1587,9 @@ __global__ void __launch_bounds__(1024) oklab32_kernel(const ShrinkArgs a)
 	float *s_srgb = reinterpret_cast<float *>(lds);          // 256: sRGB u8 -> linear
 	float *s_alpha = s_srgb + 256;                           // 256: a / 255
 	double *s_scale = reinterpret_cast<double *>(s_alpha + 256);  // 132: 2^(xe/3) * 2^((xe%3)/3), xe = i - 130
-	float *s_mean = reinterpret_cast<float *>(s_scale + 132);     // 64: per (tile, channel) means
-	float *s_band = s_mean + 64;                             // 2 x kOkBand
+	float *s_mean = reinterpret_cast<float *>(s_scale + 132);     // 64: per (tile, channel) means of the batch in pass 2
+	float *s_p1 = s_mean + 64;                               // pass-1 band: values
+	float *s_p2 = s_p1 + kOkBand;                            // pass-2 band: values minus means
 	const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
 	if (threadIdx.x < 256) {
 		s_srgb[threadIdx.x] = __uint_as_float(kSrgbToLinearBits[threadIdx.x]);
@@ -1596,66 +1608,69 @@ __global__ void __launch_bounds__(1024) oklab32_kernel(const ShrinkArgs a)
 	__syncthreads();
 
 	const uint32_t n_batches = (a.n_tiles + kOkTiles - 1) / kOkTiles;
-	const bool producer = wave < kOkTiles;
-	// producers keep the NEXT batch's pixels in flight while they work on the current one
-	uint4 px[4];
-	bool eligible = false;
-	auto fetch = [&](uint32_t batch) {
-		const uint8_t *src = nullptr;
-		eligible = producer && batch < n_batches && fast32_tile_src(a, batch * kOkTiles + wave, src);
-		if (eligible) {
-			const uint8_t *p = src + (size_t)(lane >> 3) * a.pitch + (lane & 7u) * 16u;
-#pragma unroll
-			for (int k = 0; k < 4; ++k) px[k] = *reinterpret_cast<const uint4 *>(p + (size_t)(8 * k) * a.pitch);
+	// batches of this block: blockIdx.x + j * gridDim.x, j < own; periods 0 .. own + 1 drain the pipeline
+	const uint32_t own = n_batches > blockIdx.x ? (n_batches - blockIdx.x + gridDim.x - 1) / gridDim.x : 0u;
+	const uint32_t periods = own + 2u;
+
+	if (wave < kOkTiles) {
+		// ---------------- producers ----------------
+		// raw pixels: the band being converted and the one after it (requested one interval ahead)
+		uint4 px_cur, px_nxt;
+		float lab[4][4][3];     // [band][pixel][a, b, l] of the batch whose pass 2 is being staged
+		uint32_t alpha_px[4];   // its 4 alpha bytes per band
+		const uint32_t row_off = lane >> 3, col_off = (lane & 7u) * 16u;
+		const uint8_t *src_cur = nullptr, *src_next = nullptr;
+		bool elig_next = own > 0 && fast32_tile_src(a, blockIdx.x * kOkTiles + wave, src_next);
+		if (elig_next) {
+			px_cur = *reinterpret_cast<const uint4 *>(src_next + (size_t)row_off * a.pitch + col_off);
+			px_nxt = *reinterpret_cast<const uint4 *>(src_next + (size_t)(row_off + 8u) * a.pitch + col_off);
 		}
-	};
-	fetch(blockIdx.x);
-	for (uint32_t batch = blockIdx.x; batch < n_batches; batch += gridDim.x) {
-		const bool have = eligible;
-		float lab[4][4][3];     // [quad][pixel][a, b, l]
-		uint32_t alpha_px[4];   // the 4 alpha bytes of every quad
-		if (have) {
+		bool have_prev = false;
+		for (uint32_t p = 0; p < periods; ++p) {
+			const bool elig_cur = elig_next;  // batch p (false past the last one)
+			src_cur = src_next;
+			elig_next = p + 1u < own && fast32_tile_src(a, (blockIdx.x + (p + 1u) * gridDim.x) * kOkTiles + wave, src_next);
 #pragma unroll
 			for (int k = 0; k < 4; ++k) {
-				const uint32_t v[4] = {px[k].x, px[k].y, px[k].z, px[k].w};
-				alpha_px[k] = (v[0] >> 24) | ((v[1] >> 24) << 8) | ((v[2] >> 24) << 16) | ((v[3] >> 24) << 24);
+				// ---- convert phase
+				float fresh[4][3];
+				uint32_t fresh_alpha = 0;
+				if (elig_cur) {
+					const uint32_t v[4] = {px_cur.x, px_cur.y, px_cur.z, px_cur.w};
+					fresh_alpha = (v[0] >> 24) | ((v[1] >> 24) << 8) | ((v[2] >> 24) << 16) | ((v[3] >> 24) << 24);
 #pragma unroll
-				for (int j = 0; j < 4; ++j) {
-					// palette 0.7.6: LUT, then Ottosson's matrices with left-to-right f32 sums
-					const float r = s_srgb[v[j] & 255u], g = s_srgb[(v[j] >> 8) & 255u], b = s_srgb[(v[j] >> 16) & 255u];
-					const float l = 0.4122214708f * r + 0.5363325363f * g + 0.0514459929f * b;
-					const float m = 0.2119034982f * r + 0.6806995451f * g + 0.1073969566f * b;
-					const float s3 = 0.0883024619f * r + 0.2817188376f * g + 0.6299787005f * b;
-					const float l_ = cbrt_f32_lut(l, s_scale), m_ = cbrt_f32_lut(m, s_scale), s_ = cbrt_f32_lut(s3, s_scale);
-					lab[k][j][2] = 0.2104542553f * l_ + 0.7936177850f * m_ - 0.0040720468f * s_;  // L
-					lab[k][j][0] = 1.9779984951f * l_ - 2.4285922050f * m_ + 0.4505937099f * s_;  // a
-					lab[k][j][1] = 0.0259040371f * l_ + 0.7827717662f * m_ - 0.8086757660f * s_;  // b
+					for (int j = 0; j < 4; ++j) {
+						// palette 0.7.6: LUT, then Ottosson's matrices with left-to-right f32 sums
+						const float r = s_srgb[v[j] & 255u], g = s_srgb[(v[j] >> 8) & 255u], b = s_srgb[(v[j] >> 16) & 255u];
+						const float l = 0.4122214708f * r + 0.5363325363f * g + 0.0514459929f * b;
+						const float m = 0.2119034982f * r + 0.6806995451f * g + 0.1073969566f * b;
+						const float s3 = 0.0883024619f * r + 0.2817188376f * g + 0.6299787005f * b;
+						const float l_ = cbrt_f32_lut(l, s_scale), m_ = cbrt_f32_lut(m, s_scale), s_ = cbrt_f32_lut(s3, s_scale);
+						fresh[j][2] = 0.2104542553f * l_ + 0.7936177850f * m_ - 0.0040720468f * s_;  // L
+						fresh[j][0] = 1.9779984951f * l_ - 2.4285922050f * m_ + 0.4505937099f * s_;  // a
+						fresh[j][1] = 0.0259040371f * l_ + 0.7827717662f * m_ - 0.8086757660f * s_;  // b
+						// one pixel (three cube-root chains) at a time: the register file also holds a whole tile of results
+						__builtin_amdgcn_sched_barrier(0);
+					}
 				}
-			}
-		}
-		fetch(batch + gridDim.x);  // px[] is consumed: request the next batch now
-		// chain wave state: lane = tile*4 + channel (a, b, l, alpha)
-		const uint32_t ct = lane >> 2, cc = lane & 3u;
-		float acc = 0.0f;
-		float mean4[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-		for (int pass = 0; pass < 2; ++pass) {
-			if (pass == 1) {
-				// the chain wave publishes the means (operations.rs:65-68); producers subtract them in
-				// parallel, so the second chain walk is one add of |d| per element (:80-83)
-				if (wave == kOkTiles) s_mean[lane] = __fdiv_rn(acc, 1024.0f);
-				acc = 0.0f;
-				__syncthreads();
-				if (have) {
-#pragma unroll
-					for (int c = 0; c < 4; ++c) mean4[c] = s_mean[wave * 4u + (uint32_t)c];
+				// px_cur is consumed: move the window on by one band (band k+2, or bands 0/1 of the next batch)
+				px_cur = px_nxt;
+				{
+					const bool same = k < 2;
+					const uint8_t *base = same ? src_cur : src_next;
+					const uint32_t band = same ? (uint32_t)k + 2u : (uint32_t)k - 2u;
+					if (same ? elig_cur : elig_next)
+						px_nxt = *reinterpret_cast<const uint4 *>(base + (size_t)(row_off + 8u * band) * a.pitch + col_off);
 				}
-			}
-#pragma unroll
-			for (int k = 0; k < 4; ++k) {
-				float *buf = s_band + (uint32_t)(k & 1) * kOkBand;
-				if (have) {
-					float *d = buf + (wave * 4u) * kOkPlane + lane * 4u;  // 4 consecutive pixels of this lane
+				__syncthreads();  // A: the chain has consumed the bands of the previous interval
+				// ---- write phase
+				const uint32_t slot = (wave * 4u) * kOkPlane + lane * 4u;  // 4 consecutive pixels of this lane
+				if (have_prev) {
+					// operations.rs:75-84: the chain only has to add |x| of these.  The means were published during
+					// the first convert phase of this period.
+					const float4 mean = *reinterpret_cast<const float4 *>(s_mean + wave * 4u);
+					const float mean4[4] = {mean.x, mean.y, mean.z, mean.w};
+					float *d = s_p2 + slot;
 #pragma unroll
 					for (int c = 0; c < 3; ++c)
 						*reinterpret_cast<float4 *>(d + c * kOkPlane) =
@@ -1664,41 +1679,95 @@ __global__ void __launch_bounds__(1024) oklab32_kernel(const ShrinkArgs a)
 					    make_float4(s_alpha[alpha_px[k] & 255u] - mean4[3], s_alpha[(alpha_px[k] >> 8) & 255u] - mean4[3],
 					                s_alpha[(alpha_px[k] >> 16) & 255u] - mean4[3], s_alpha[alpha_px[k] >> 24] - mean4[3]);
 				}
-				__syncthreads();  // band k is complete; band k-1 has been consumed
-				if (wave == kOkTiles && ct < kOkTiles) {
-					const float *x = buf + (ct * 4u + cc) * kOkPlane;
-					if (pass == 0) {
-#pragma unroll 4
-						for (uint32_t i = 0; i < 256; i += 4) {
-							const float4 v = *reinterpret_cast<const float4 *>(x + i);
-							acc += v.x;  // operations.rs:60-63, row-major pixel order
-							acc += v.y;
-							acc += v.z;
-							acc += v.w;
-						}
+				if (elig_cur) {
+					float *d = s_p1 + slot;
+#pragma unroll
+					for (int c = 0; c < 3; ++c) {
+#pragma unroll
+						for (int j = 0; j < 4; ++j) lab[k][j][c] = fresh[j][c];
+						*reinterpret_cast<float4 *>(d + c * kOkPlane) = make_float4(fresh[0][c], fresh[1][c], fresh[2][c], fresh[3][c]);
+					}
+					alpha_px[k] = fresh_alpha;
+					*reinterpret_cast<float4 *>(d + 3 * kOkPlane) =
+					    make_float4(s_alpha[fresh_alpha & 255u], s_alpha[(fresh_alpha >> 8) & 255u], s_alpha[(fresh_alpha >> 16) & 255u],
+					                s_alpha[fresh_alpha >> 24]);
+				}
+				__syncthreads();  // B: the bands of this interval are complete
+			}
+			have_prev = elig_cur;
+		}
+	} else {
+		// ---------------- chain wave: lane = tile*4 + channel (a, b, l, alpha) ----------------
+		const uint32_t ct = lane >> 2, cc = lane & 3u;
+		const bool live = ct < kOkTiles;
+		float acc1 = 0.0f, acc2 = 0.0f;
+		// one dependent add chain per lane and pass; two register sets take turns so that 16 values are
+		// in flight from LDS while 16 are added
+		auto walk = [&](const float *band, float acc, const bool magnitude) -> float {
+			const float4 *x = reinterpret_cast<const float4 *>(band + (ct * 4u + cc) * kOkPlane);
+			auto add16 = [&](const float4 (&v)[4]) {
+#pragma unroll
+				for (int q = 0; q < 4; ++q) {
+					if (magnitude) {
+						acc += fabsf(v[q].x);  // operations.rs:80-83
+						acc += fabsf(v[q].y);
+						acc += fabsf(v[q].z);
+						acc += fabsf(v[q].w);
 					} else {
-#pragma unroll 4
-						for (uint32_t i = 0; i < 256; i += 4) {
-							const float4 v = *reinterpret_cast<const float4 *>(x + i);
-							acc += fabsf(v.x);
-							acc += fabsf(v.y);
-							acc += fabsf(v.z);
-							acc += fabsf(v.w);
-						}
+						acc += v[q].x;  // operations.rs:60-63, row-major pixel order
+						acc += v[q].y;
+						acc += v[q].z;
+						acc += v[q].w;
 					}
 				}
+			};
+			float4 va[4] = {x[0], x[1], x[2], x[3]}, vb[4];
+#pragma unroll 1
+			for (uint32_t i = 0; i < 64; i += 8) {
+#pragma unroll
+				for (int q = 0; q < 4; ++q) vb[q] = x[i + 4u + (uint32_t)q];
+				__builtin_amdgcn_sched_barrier(0);
+				add16(va);
+				__builtin_amdgcn_sched_barrier(0);
+				const uint32_t n = i + 8u < 64u ? i + 8u : 0u;  // the last round re-reads the first (unused)
+#pragma unroll
+				for (int q = 0; q < 4; ++q) va[q] = x[n + (uint32_t)q];
+				__builtin_amdgcn_sched_barrier(0);
+				add16(vb);
+				__builtin_amdgcn_sched_barrier(0);
 			}
-		}
-		__syncthreads();  // the last band has been consumed before the next batch refills the buffers
-		if (wave == kOkTiles && ct < kOkTiles) {
-			const float d0 = __shfl(acc, (int)(lane & ~3u) + 0, 64), d1 = __shfl(acc, (int)(lane & ~3u) + 1, 64);
-			const float d2 = __shfl(acc, (int)(lane & ~3u) + 2, 64), d3 = __shfl(acc, (int)(lane & ~3u) + 3, 64);
-			const float total = d0 + d1 + d2 + d3;  // :89
-			const float value = __fdiv_rn(total, 1024.0f) * a.factor * 10.0f;  // pixlzr.rs:162
-			const uint32_t tg = batch * kOkTiles + ct;
-			const uint8_t *unused;
-			if (cc == 0 && fast32_tile_src(a, tg, unused))
-				reinterpret_cast<uint2 *>(a.sums)[tg] = make_uint2(__float_as_uint(value), __float_as_uint(value));
+			return acc;
+		};
+		for (uint32_t p = 0; p < periods; ++p) {
+#pragma unroll
+			for (int k = 0; k < 4; ++k) {
+				// the bands written one interval ago: band kk of period pp
+				const uint32_t pp = k > 0 ? p : p - 1u, kk = k > 0 ? (uint32_t)k - 1u : 3u;
+				const bool any = k > 0 || p > 0;
+				const bool p1_valid = any && pp < own;                   // pass 1 of batch pp
+				const bool p2_valid = any && pp >= 1u && pp - 1u < own;  // pass 2 of batch pp - 1
+				if (live && p1_valid) acc1 = walk(s_p1, acc1, false);
+				if (live && p2_valid) acc2 = walk(s_p2, acc2, true);
+				if (kk == 3u) {
+					if (p1_valid) {
+						s_mean[lane] = __fdiv_rn(acc1, 1024.0f);  // operations.rs:65-68; read after barrier A
+						acc1 = 0.0f;
+					}
+					if (p2_valid) {
+						const float d0 = __shfl(acc2, (int)(lane & ~3u) + 0, 64), d1 = __shfl(acc2, (int)(lane & ~3u) + 1, 64);
+						const float d2 = __shfl(acc2, (int)(lane & ~3u) + 2, 64), d3 = __shfl(acc2, (int)(lane & ~3u) + 3, 64);
+						const float total = d0 + d1 + d2 + d3;  // :89
+						const float value = __fdiv_rn(total, 1024.0f) * a.factor * 10.0f;  // pixlzr.rs:162
+						const uint32_t tg = (blockIdx.x + (pp - 1u) * gridDim.x) * kOkTiles + ct;
+						const uint8_t *unused;
+						if (live && cc == 0 && fast32_tile_src(a, tg, unused))
+							reinterpret_cast<uint2 *>(a.sums)[tg] = make_uint2(__float_as_uint(value), __float_as_uint(value));
+						acc2 = 0.0f;
+					}
+				}
+				__syncthreads();  // A
+				__syncthreads();  // B
+			}
 		}
 	}
 }
