@@ -583,6 +583,7 @@ __device__ __forceinline__ void resample_fast32_hv(const uint32_t *trows, const 
 // serves both passes, the axes of a 32x32 tile being alike).
 // ---------------------------------------------------------------------------
 typedef int v4i32 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 template <int BYTE>
 __device__ __forceinline__ void put_byte_shr(uint32_t &dst, uint32_t value, uint32_t shift)
@@ -1639,17 +1640,25 @@ __global__ void __launch_bounds__(1024) oklab32_kernel(const ShrinkArgs a)
 					const uint32_t v[4] = {px_cur.x, px_cur.y, px_cur.z, px_cur.w};
 					fresh_alpha = (v[0] >> 24) | ((v[1] >> 24) << 8) | ((v[2] >> 24) << 16) | ((v[3] >> 24) << 24);
 #pragma unroll
-					for (int j = 0; j < 4; ++j) {
-						// palette 0.7.6: LUT, then Ottosson's matrices with left-to-right f32 sums
-						const float r = s_srgb[v[j] & 255u], g = s_srgb[(v[j] >> 8) & 255u], b = s_srgb[(v[j] >> 16) & 255u];
-						const float l = 0.4122214708f * r + 0.5363325363f * g + 0.0514459929f * b;
-						const float m = 0.2119034982f * r + 0.6806995451f * g + 0.1073969566f * b;
-						const float s3 = 0.0883024619f * r + 0.2817188376f * g + 0.6299787005f * b;
-						const float l_ = cbrt_f32_lut(l, s_scale), m_ = cbrt_f32_lut(m, s_scale), s_ = cbrt_f32_lut(s3, s_scale);
-						fresh[j][2] = 0.2104542553f * l_ + 0.7936177850f * m_ - 0.0040720468f * s_;  // L
-						fresh[j][0] = 1.9779984951f * l_ - 2.4285922050f * m_ + 0.4505937099f * s_;  // a
-						fresh[j][1] = 0.0259040371f * l_ + 0.7827717662f * m_ - 0.8086757660f * s_;  // b
-						// one pixel (three cube-root chains) at a time: the register file also holds a whole tile of results
+					for (int j = 0; j < 4; j += 2) {
+						// palette 0.7.6: LUT, then Ottosson's matrices with left-to-right f32 sums; two pixels per
+						// packed-f32 instruction (same IEEE results per component)
+						const f32x2 r = {s_srgb[v[j] & 255u], s_srgb[v[j + 1] & 255u]};
+						const f32x2 g = {s_srgb[(v[j] >> 8) & 255u], s_srgb[(v[j + 1] >> 8) & 255u]};
+						const f32x2 b = {s_srgb[(v[j] >> 16) & 255u], s_srgb[(v[j + 1] >> 16) & 255u]};
+						const f32x2 l = 0.4122214708f * r + 0.5363325363f * g + 0.0514459929f * b;
+						const f32x2 m = 0.2119034982f * r + 0.6806995451f * g + 0.1073969566f * b;
+						const f32x2 s3 = 0.0883024619f * r + 0.2817188376f * g + 0.6299787005f * b;
+						const f32x2 l_ = {cbrt_f32_lut(l.x, s_scale), cbrt_f32_lut(l.y, s_scale)};
+						const f32x2 m_ = {cbrt_f32_lut(m.x, s_scale), cbrt_f32_lut(m.y, s_scale)};
+						const f32x2 s_ = {cbrt_f32_lut(s3.x, s_scale), cbrt_f32_lut(s3.y, s_scale)};
+						const f32x2 L = 0.2104542553f * l_ + 0.7936177850f * m_ - 0.0040720468f * s_;
+						const f32x2 A = 1.9779984951f * l_ - 2.4285922050f * m_ + 0.4505937099f * s_;
+						const f32x2 B = 0.0259040371f * l_ + 0.7827717662f * m_ - 0.8086757660f * s_;
+						fresh[j][2] = L.x; fresh[j + 1][2] = L.y;
+						fresh[j][0] = A.x; fresh[j + 1][0] = A.y;
+						fresh[j][1] = B.x; fresh[j + 1][1] = B.y;
+						// two pixels (six cube-root chains) at a time: the register file also holds a whole tile of results
 						__builtin_amdgcn_sched_barrier(0);
 					}
 				}
@@ -1701,6 +1710,7 @@ __global__ void __launch_bounds__(1024) oklab32_kernel(const ShrinkArgs a)
 		const uint32_t ct = lane >> 2, cc = lane & 3u;
 		const bool live = ct < kOkTiles;
 		float acc1 = 0.0f, acc2 = 0.0f;
+		__builtin_amdgcn_s_setprio(3);  // the serial part of every interval: first pick of its SIMD's issue slots
 		// one dependent add chain per lane and pass; two register sets take turns so that 16 values are
 		// in flight from LDS while 16 are added
 		auto walk = [&](const float *band, float acc, const bool magnitude) -> float {
