@@ -439,6 +439,13 @@ int timed_launch(pxz_handle *h, pxz::ShrinkArgs &a, uint32_t channels, float *va
 	a.value = value;
 	a.lod0 = lod0;
 	a.lod1 = lod1;
+	// 32x32 fast path: which tiles are full-size, and whether every tile row of the batch is 16-byte aligned
+	a.full_cols = a.full_rows = 0;
+	if (a.bw == 32 && a.bh == 32 && channels == 4 &&
+	    ((reinterpret_cast<uintptr_t>(a.src) | a.pitch | (a.n_tiles > a.tiles_per_frame ? a.frame_stride : 0)) & 15u) == 0) {
+		a.full_cols = a.edge_w == 32 ? a.cols : a.cols - 1;
+		a.full_rows = a.edge_h == 32 ? a.rows : a.rows - 1;
+	}
 	const pxz::FinishArgs fin{a.sums, value, lod0, lod1, a.n_tiles, a.tiles_per_frame, a.cols, a.rows,
 	                          a.bw, a.bh, a.edge_w, a.edge_h, a.mode, a.factor};
 	hipEvent_t e0 = nullptr, e1 = nullptr;

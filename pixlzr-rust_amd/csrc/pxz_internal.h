@@ -58,6 +58,8 @@ struct ShrinkArgs {
 	float factor;
 	// outputs (device); out_px may be null (no resample), out_w/out_h may be null
 	uint32_t oklab_given;    // 1: full 32x32 RGBA tiles already carry their Oklab value in sums[] (oklab32_kernel)
+	uint32_t full_cols, full_rows;  // 32x32 fast path: tile (tx, ty) is eligible iff tx < full_cols && ty < full_rows
+	                                //   (full size, 16-byte aligned rows; 0/0 when the batch is not aligned)
 	uint32_t *work;          // worklist: [work_slot] = count, [2..] = tile ids (null: all tiles).  The two
 	uint32_t work_slot;      //   counters alternate between launches; a launch zeroes the other one
 	float *value;            // worklist mode only: the kernel finishes its tiles itself (finish_tile) and,
@@ -95,7 +97,7 @@ struct Fast32Args {
 	uint64_t frame_stride;
 	uint32_t pitch, cols, rows, tiles_per_frame, n_tiles;
 	FastDiv div_tpf, div_cols;
-	uint32_t edge_w, edge_h, bw, bh;
+	uint32_t full_cols, full_rows;  // as in ShrinkArgs
 	uint32_t filter;
 	uint32_t *sums;
 	uint32_t *out_w;

@@ -681,10 +681,8 @@ __device__ __forceinline__ bool fast32_tile_src(const Args &a, uint32_t tile_g, 
 	const uint32_t frame = fastdiv(tile_g, a.div_tpf);
 	const uint32_t t = tile_g - frame * a.tiles_per_frame;
 	const uint32_t ty = fastdiv(t, a.div_cols), tx = t - ty * a.cols;
-	const uint32_t w = (tx == a.cols - 1) ? a.edge_w : a.bw;
-	const uint32_t h = (ty == a.rows - 1) ? a.edge_h : a.bh;
 	src = a.src + (size_t)frame * a.frame_stride + (size_t)(ty * 32u) * a.pitch + (size_t)(tx * 32u) * 4u;
-	return w == 32 && h == 32 && ((reinterpret_cast<uintptr_t>(src) | a.pitch) & 15u) == 0;
+	return tx < a.full_cols && ty < a.full_rows;  // full size; the alignment of the batch is folded in by the host
 }
 // Issues the four 16-byte loads of a lane's share of a fast tile (rows l/8 + 8k, quad l%8).
 template <class Args>
@@ -2281,10 +2279,8 @@ hipError_t launch_shrink(const ShrinkArgs &a, uint32_t channels, uint32_t n_cus,
 		f.n_tiles = a.n_tiles;
 		f.div_tpf = a.div_tpf;
 		f.div_cols = a.div_cols;
-		f.edge_w = a.edge_w;
-		f.edge_h = a.edge_h;
-		f.bw = 32;
-		f.bh = 32;
+		f.full_cols = a.full_cols;
+		f.full_rows = a.full_rows;
 		f.filter = a.filter;
 		f.sums = a.sums;
 		f.out_w = a.out_w;
