@@ -53,13 +53,22 @@ __device__ __forceinline__ uint32_t fastdiv(uint32_t n, const FastDiv &d)
 	return (t + ((n - t) >> d.sh1)) >> d.sh2;
 }
 
+// n / d for n < 2^20, d >= 1 in five instructions instead of the ~30 of a general 32-bit division:
+// x = (n + 0.5) / d is at least 0.5/d away from every integer, and the float product with the 1-ulp
+// reciprocal is within x * 2^-22 of it, which is below 0.5/d for every n < 2^21.
+__device__ __forceinline__ uint32_t small_div(uint32_t n, uint32_t d)
+{
+	return (uint32_t)(((float)n + 0.5f) * __builtin_amdgcn_rcpf((float)d));
+}
+
 struct RowWalker {
 	uint32_t row, col, drow, dcol, width;
 	__device__ RowWalker(uint32_t first, uint32_t step, uint32_t width_) : width(width_)
 	{
-		row = first / width_;
+		// first and step are lane / thread counts (<= 1024 + a tile's pixel count < 2^20)
+		row = small_div(first, width_);
 		col = first - row * width_;
-		drow = step / width_;
+		drow = small_div(step, width_);
 		dcol = step - drow * width_;
 	}
 	__device__ void next()
@@ -291,7 +300,11 @@ __device__ __forceinline__ uint32_t level_count(uint32_t key, const uint32_t *br
 // Work items are spread over all 64 lanes: when there are fewer than 64 outputs the
 // filter window itself is split over 2..8 lanes and summed with DPP.
 // ---------------------------------------------------------------------------
-constexpr uint32_t kRS32 = 18, kPD32 = 18 * 32, kHS32 = 18, kTD32 = 16 * 18;
+constexpr uint32_t kRS32 = 18, kPD32 = 18 * 32, kHS32 = 18;
+// transposed planes of the dot2 two-pass form: up to 8 output columns (16/8/4-px outputs on both axes go
+// through the matrix cores; the rare 16 x (2|1) tile is handed to the worklist)
+constexpr uint32_t kTD32 = 8 * 18;
+constexpr uint32_t kOut32 = 512;  // dwords of the region after the planes: transposed planes / parked output pixels
 
 template <int LPI>
 __device__ __forceinline__ int32_t group_sum(int32_t v)
@@ -813,11 +826,11 @@ __device__ __forceinline__ void process_tile(const ShrinkArgs &a, const uint32_t
 		if (w > 2 && h > 2) {
 			const uint32_t WR = h - 2;
 			const uint32_t VP = (w >> 1) - 1;  // pixel pairs that start a valid window pair (w even)
-			uint32_t G = ((w & 1u) == 0 && VP >= 1) ? TPT / VP : 0u;
+			uint32_t G = ((w & 1u) == 0 && VP >= 1) ? small_div(TPT, VP) : 0u;
 			if (G > WR) G = WR;
 			if (G >= 1) {
-				const uint32_t RG = (WR + G - 1) / G;  // window rows per lane group
-				const uint32_t g = tid / VP, q = tid - g * VP;
+				const uint32_t RG = small_div(WR + G - 1, G);  // window rows per lane group
+				const uint32_t g = small_div(tid, VP), q = tid - g * VP;
 				const uint32_t y0 = g * RG;
 				if (g < G && y0 < WR) {
 					const uint32_t y1 = (y0 + RG < WR) ? y0 + RG : WR;
@@ -1408,12 +1421,15 @@ __global__ void __launch_bounds__(1024) shrink32_kernel(const Fast32Args a)
 				if (a.tabs[lx].mf_off != 0 && a.tabs[ly].mf_off != 0) {
 					resample_mfma32(s_tab, a.tabs[lx], a.tabs[ly], s_pl, tid, nw, nh, s_tmp);
 					pend_src = s_tmp;
-				} else {
+					pend_kind = 1;
+				} else if (nw <= 8u) {
 					// the vertical pass reads only the transposed planes: the R plane is free for the pixels
 					resample_fast32_hv(s_tab, a.tabs[lx], a.tabs[ly], s_pl, s_tmp, tid, nw, nh, s_pl);
 					pend_src = s_pl;
+					pend_kind = 1;
+				} else {
+					defer();  // 16 x (2|1): its transposed planes would not fit the 16-waves-per-CU LDS image
 				}
-				pend_kind = 1;
 			} else if (a.filter == 0) {
 				// ResizeAlg::Nearest (mod.rs:277): source index = floor((o + 0.5) * 2^m), no alpha handling
 				const uint32_t lgx = 31u - (uint32_t)__builtin_clz(nw);
@@ -2299,9 +2315,10 @@ hipError_t launch_shrink(const ShrinkArgs &a, uint32_t channels, uint32_t n_cus,
 			f.tabs[j] = a.tabs[j];  // x axis, full class; identical to the y axis for 32x32
 		}
 		f.breaks_asc = a.breaks_asc[0];
-		// planes 3 x 576 dwords (R, G, B), transposed planes 3 x 288, slack for zero-weight over-reads
-		// (the transposed-plane region also parks the pixels of nearest / one-pass outputs: always there with out_px)
-		f.tile_dw = f.out_px ? 3u * kPD32 + 3u * kTD32 + 2u * kRS32 : 3u * kPD32 + 4u * kRS32;
+		// planes 3 x 576 dwords (R, G, B), output region (transposed planes 3 x 144 of the dot2 form / parked
+		// pixels of nearest, one-pass and matrix-core outputs: at most 32x16), slack for zero-weight over-reads
+		static_assert(3u * kTD32 <= kOut32, "transposed planes fit the output region");
+		f.tile_dw = f.out_px ? 3u * kPD32 + kOut32 + 2u * kRS32 : 3u * kPD32 + 4u * kRS32;
 		f.tile_dw = (f.tile_dw + 3u) & ~3u;
 		constexpr uint32_t kLds = 160u * 1024u;
 		uint32_t wpb = (kLds - f.tab_dw * 4u - 16u) / (f.tile_dw * 4u);

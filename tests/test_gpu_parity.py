@@ -248,6 +248,32 @@ def test_single_pass_resamples(gpu, oracle, axis):
     assert len(one_pass) >= 3, seen
 
 
+@pytest.mark.parametrize("axis", [0, 1])
+def test_wide_flat_and_tall_thin_classes(gpu, oracle, axis):
+    """Reduced sizes that are large on one axis and tiny on the other (16x2, 16x1, 8x1, 1x16, ...): the fast
+    kernel sends 16 x (2|1) to the worklist and runs n x (2|1), (2|1) x n through the dot2 form; all of them
+    must equal the oracle."""
+    rng = np.random.default_rng(23 + axis)
+    h, w = 256, 512
+    strong = rng.integers(96, 160, size=(h if axis == 0 else w, 3)).astype(np.int32)
+    weak = rng.integers(0, 3, size=(w if axis == 0 else h, 3)).astype(np.int32)
+    img = np.empty((h, w, 4), np.uint8)
+    img[..., 3] = 255
+    if axis == 0:
+        img[..., :3] = np.clip(strong[:, None, :] + weak[None, :, :], 0, 255)
+    else:
+        img[..., :3] = np.clip(strong[None, :, :] + weak[:, None, :], 0, 255)
+    seen = set()
+    for factor in (64.0, 32.0, 16.0, 8.0, 4.0, 2.0, 1.0):
+        for filt in (4, 2):
+            got = gpu.shrink_image(img, 32, 32, 1, filt, factor)
+            exp = oracle.shrink_image(img, 32, 32, 1, filt, factor)
+            assert_same_tiles(got, exp, 4, f"axis{axis} k={factor} f{filt}")
+            seen |= set(histogram(got[1], got[2]))
+    mixed = {k for k in seen if max(k) in (4, 8, 16) and min(k) <= 2}
+    assert len(mixed) >= 3 and any(max(k) == 16 for k in mixed), seen
+
+
 @pytest.mark.parametrize("filt", [0, 1, 2, 3, 4])
 @pytest.mark.parametrize("mode,factors", [(1, (64.0, 16.0, 4.0, 1.0)), (0, (2.0, 0.5))])
 def test_every_filter_on_opaque_fast_path(gpu, oracle, filt, mode, factors):
