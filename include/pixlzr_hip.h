@@ -130,6 +130,30 @@ int pxz_shrink_frames_device(pxz_handle *h, const pxz_frames *frames, const pxz_
 int pxz_lod_frames_device(pxz_handle *h, const pxz_frames *frames, const pxz_params *params,
                           const uint8_t *d_pixels, float *d_lod0, float *d_lod1);
 
+/* ---- decode side ---------------------------------------- */
+
+/* Pixlzr::expand (pixlzr.rs:77-122) + Pixlzr::to_image (pixlzr_image.rs:24-74) on device-resident
+ * tiles: every stored tile (tile_w x tile_h pixels, tightly packed, in a slot of block_w*block_h*channels
+ * bytes -- the layout pxz_shrink_frames_device leaves and decode_block (encoding/mod.rs:202-242) yields)
+ * is resized back to its full size by PixlzrBlock::resize (block.rs:273-334: clone | ResizeAlg::Nearest |
+ * SuperSampling(filter, 2), which is a plain convolution when nothing shrinks; Triangle means Bilinear here,
+ * mod.rs:72-90) and written to its place in the frame.  `frames` describes the OUTPUT; params->block_w,
+ * block_h and filter are used.  Tiles whose stored size is zero or exceeds their place are skipped and
+ * flagged (pxz_expand_status).  Asynchronous on the handle's stream. */
+int pxz_expand_frames_device(pxz_handle *h, const pxz_frames *frames, const pxz_params *params,
+                             const uint32_t *d_tile_w, const uint32_t *d_tile_h, const uint8_t *d_slots,
+                             uint8_t *d_out_pixels);
+
+/* Waits for the handle's stream; *bad_tiles_seen != 0 iff the last pxz_expand_frames_device met a tile
+ * with an invalid stored size. */
+int pxz_expand_status(pxz_handle *h, uint32_t *bad_tiles_seen);
+
+/* The same for one host-resident image (copies in, expands, copies out; PXZ_ERR_INVALID_ARG on an
+ * invalid stored size). */
+int pxz_expand_image(pxz_handle *h, uint32_t width, uint32_t height, uint32_t channels, uint32_t pitch_bytes,
+                     uint32_t block_w, uint32_t block_h, uint32_t filter, const uint32_t *tile_w,
+                     const uint32_t *tile_h, const uint8_t *slots, uint8_t *out_pixels);
+
 /* Block-stream compaction (device): the valid out_w*out_h*channels bytes of every slot, in tile
  * order, into one contiguous stream -- the payload `encode_block` (src/encoding/mod.rs:168-200)
  * consumes tile after tile, and what one rank ships to the writer rank over RCCL.

@@ -231,6 +231,23 @@ def decode_container(data):
                 values=vals, tw=tw, th=th, tc=tc, slots=slots, cols=cols, rows=rows)
 
 
+def expand_image(width, height, bw, bh, channels, filt, tile_w, tile_h, slots):
+    """Pixlzr::expand + to_image: tiles (slots[t] holds tile_w[t]*tile_h[t]*channels tightly packed bytes) ->
+    (height, width, channels) image."""
+    L = lib()
+    L.orc_expand_image.restype = C.c_int
+    L.orc_expand_image.argtypes = [C.c_uint32] * 6 + [C.c_void_p] * 3 + [C.c_size_t, C.c_void_p, C.c_uint32]
+    tile_w = np.ascontiguousarray(tile_w, np.uint32)
+    tile_h = np.ascontiguousarray(tile_h, np.uint32)
+    slots = np.ascontiguousarray(slots, np.uint8)
+    out = np.zeros((height, width, channels), np.uint8)
+    rc = L.orc_expand_image(width, height, bw, bh, channels, filt, _ptr(tile_w), _ptr(tile_h), _ptr(slots),
+                            slots.shape[1], _ptr(out), width * channels)
+    if rc != 0:
+        raise RuntimeError(f"orc_expand_image rc={rc}")
+    return out
+
+
 def synth_frame(width, height, channels=4, frame_index=0, dist=DIST_OPAQUE):
     img = np.empty((height, width, channels), np.uint8)
     lib().orc_synth_frame(_ptr(img), width, height, channels, width * channels, frame_index, dist)

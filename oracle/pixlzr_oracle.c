@@ -351,14 +351,21 @@ static double fir_lanczos3(double x)
 	return 0.0;
 }
 
+static double fir_bilinear(double x)
+{
+	x = fabs(x);
+	return x < 1.0 ? 1.0 - x : 0.0;
+}
+
 typedef double (*fir_filter_fn)(double);
 
-/* src/data_types/mod.rs:65-107, downscale branch: Triangle -> Hamming (!) */
-static int fir_filter_for(uint32_t filter, fir_filter_fn *fn, double *support)
+/* src/data_types/mod.rs:65-107: the downscale branch maps Triangle -> Hamming (!), the upscale branch
+ * (`SuperSampling(filter, 2)`, which is a plain convolution when nothing shrinks) Triangle -> Bilinear */
+static int fir_filter_for(uint32_t filter, int upscale, fir_filter_fn *fn, double *support)
 {
 	switch (filter) {
 	case ORC_TRIANGLE:
-		*fn = fir_hamming;
+		*fn = upscale ? fir_bilinear : fir_hamming;
 		*support = 1.0;
 		return 0;
 	case ORC_CATMULLROM:
@@ -393,11 +400,11 @@ static void fir_axis_free(fir_axis *a)
 }
 
 /* fir `precompute_coefficients` + `Normalizer16::new` (Pillow-SIMD lineage) */
-static int fir_axis_build(fir_axis *a, uint32_t in_size, uint32_t out_size, uint32_t filter)
+static int fir_axis_build(fir_axis *a, uint32_t in_size, uint32_t out_size, uint32_t filter, int upscale)
 {
 	fir_filter_fn fn;
 	double support;
-	if (fir_filter_for(filter, &fn, &support) != 0)
+	if (fir_filter_for(filter, upscale, &fn, &support) != 0)
 		return -1;
 	double scale = (double)in_size / (double)out_size;
 	double filter_scale = scale > 1.0 ? scale : 1.0;
@@ -461,7 +468,7 @@ int orc_fir_coeffs(uint32_t in_size, uint32_t out_size, uint32_t filter,
                    int32_t *starts, int32_t *sizes, int16_t *coeffs, int32_t *window, int32_t *precision)
 {
 	fir_axis a;
-	if (fir_axis_build(&a, in_size, out_size, filter) != 0)
+	if (fir_axis_build(&a, in_size, out_size, filter, out_size > in_size) != 0)
 		return -1;
 	*window = a.window;
 	*precision = a.precision;
@@ -550,12 +557,13 @@ int orc_resize(const uint8_t *src, uint32_t w, uint32_t h, uint32_t c, uint32_t 
 		}
 	}
 	int need_h = nw != w, need_v = nh != h;
+	const int upscale = nw > w || nh > h; /* block.rs:301-304: one flag for both axes */
 	const uint8_t *cur = work;
 	uint32_t cur_w = w;
 	uint8_t *tmp = NULL;
 	if (need_h) {
 		fir_axis ax;
-		fir_axis_build(&ax, w, nw, filter);
+		fir_axis_build(&ax, w, nw, filter, upscale);
 		uint8_t *out = need_v ? (tmp = (uint8_t *)malloc((size_t)nw * h * c)) : dst;
 		int32_t init = 1 << (ax.precision - 1);
 		for (uint32_t y = 0; y < h; y++) {
@@ -578,7 +586,7 @@ int orc_resize(const uint8_t *src, uint32_t w, uint32_t h, uint32_t c, uint32_t 
 	}
 	if (need_v) {
 		fir_axis ay;
-		fir_axis_build(&ay, h, nh, filter);
+		fir_axis_build(&ay, h, nh, filter, upscale);
 		int32_t init = 1 << (ay.precision - 1);
 		for (uint32_t oy = 0; oy < nh; oy++) {
 			const int16_t *k = ay.k + (size_t)oy * ay.window;
@@ -740,4 +748,40 @@ void orc_synth_frame(uint8_t *pixels, uint32_t width, uint32_t height, uint32_t 
 				row[x * 4 + 3] = dist == 1 ? (uint8_t)(128u + fmix32((idx + 3u) ^ seed) % 128u) : 255u;
 		}
 	}
+}
+
+/* ------------------------------------------------------------------------ */
+/* decode side: Pixlzr::expand (pixlzr.rs:77-122) + to_image (pixlzr_image.rs:24-74)              */
+/* every tile is resized back to its full size (edge tiles: the trailing size) with             */
+/* PixlzrBlock::resize (block.rs:273-334: upscale flag -> mod.rs:65-107) and copied to its place */
+/* ------------------------------------------------------------------------ */
+int orc_expand_image(uint32_t width, uint32_t height, uint32_t bw, uint32_t bh, uint32_t channels, uint32_t filter,
+                     const uint32_t *tile_w, const uint32_t *tile_h, const uint8_t *slots, size_t slot_stride,
+                     uint8_t *out_pixels, uint32_t out_pitch)
+{
+	if (!tile_w || !tile_h || !slots || !out_pixels || (channels != 3 && channels != 4) || bw == 0 || bh == 0)
+		return -1;
+	uint32_t cols, rows;
+	orc_grid(width, height, bw, bh, &cols, &rows);
+	uint8_t *full = (uint8_t *)malloc((size_t)bw * bh * channels);
+	if (!full)
+		return -2;
+	for (uint32_t t = 0; t < cols * rows; t++) {
+		uint32_t x0, y0, fw, fh;
+		orc_tile_rect(width, height, bw, bh, t, &x0, &y0, &fw, &fh);
+		if (tile_w[t] == 0 || tile_h[t] == 0 || tile_w[t] > fw || tile_h[t] > fh) {
+			free(full);
+			return -3;
+		}
+		const uint8_t *src = slots + slot_stride * t;
+		if (orc_resize(src, tile_w[t], tile_h[t], channels, tile_w[t] * channels, full, fw, fh, filter) != 0) {
+			free(full);
+			return -4;
+		}
+		for (uint32_t y = 0; y < fh; y++)
+			memcpy(out_pixels + (size_t)(y0 + y) * out_pitch + (size_t)x0 * channels, full + (size_t)y * fw * channels,
+			       (size_t)fw * channels);
+	}
+	free(full);
+	return 0;
 }

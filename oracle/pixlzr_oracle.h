@@ -86,6 +86,12 @@ int orc_shrink_image(const uint8_t *pixels, uint32_t width, uint32_t height, uin
 
 /* ---- bitstream: qoi 0.4.1 + src/encoding/mod.rs:40-89,168-200 ---- */
 /* worst-case bytes for a w*h*c tile including the 14-byte header and 8-byte tail */
+/* Pixlzr::expand + to_image (pixlzr.rs:77-122, pixlzr_image.rs:24-74): tiles (tile_w x tile_h pixels at
+ * slots + t*slot_stride, tightly packed) back to a width x height image; filter as FilterType repr(u8). */
+int orc_expand_image(uint32_t width, uint32_t height, uint32_t bw, uint32_t bh, uint32_t channels, uint32_t filter,
+                     const uint32_t *tile_w, const uint32_t *tile_h, const uint8_t *slots, size_t slot_stride,
+                     uint8_t *out_pixels, uint32_t out_pitch);
+
 size_t orc_qoi_bound(uint32_t w, uint32_t h, uint32_t c);
 /* full QOI stream incl. "qoif" magic; returns length */
 size_t orc_qoi_encode(const uint8_t *data, uint32_t w, uint32_t h, uint32_t c, uint8_t *out);

@@ -19,6 +19,7 @@ EXPORTED_SYMBOLS = [
     "pxz_synchronize", "pxz_grid", "pxz_shrink_image", "pxz_shrink_frames_device", "pxz_lod_frames_device",
     "pxz_pack_tiles_device", "pxz_encode_frames_device", "pxz_encode_container", "pxz_qoi_encode", "pxz_qoi_bound", "pxz_synth_frames_device", "pxz_axis_table",
     "pxz_enable_timing", "pxz_last_kernel_ms",
+    "pxz_expand_frames_device", "pxz_expand_image", "pxz_expand_status",
 ]
 
 STATUS = {0: "PXZ_OK", -1: "PXZ_ERR_INVALID_ARG", -2: "PXZ_ERR_NO_DEVICE", -3: "PXZ_ERR_HIP",
@@ -108,6 +109,12 @@ def load_library():
     L.pxz_qoi_encode.argtypes = [vp, u32, u32, u32, vp, C.c_size_t]
     L.pxz_qoi_bound.restype = C.c_size_t
     L.pxz_qoi_bound.argtypes = [u32] * 3
+    L.pxz_expand_frames_device.restype = C.c_int
+    L.pxz_expand_frames_device.argtypes = [vp, C.POINTER(Frames), C.POINTER(Params)] + [vp] * 4
+    L.pxz_expand_status.restype = C.c_int
+    L.pxz_expand_status.argtypes = [vp, C.POINTER(u32)]
+    L.pxz_expand_image.restype = C.c_int
+    L.pxz_expand_image.argtypes = [vp] + [u32] * 7 + [vp] * 4
     L.pxz_synth_frames_device.restype = C.c_int
     L.pxz_synth_frames_device.argtypes = [vp, C.POINTER(Frames), vp, u32, u32]
     L.pxz_axis_table.restype = C.c_int
@@ -262,6 +269,38 @@ class Handle:
             C.c_void_p(ow.data_ptr()), C.c_void_p(oh.data_ptr()),
             C.c_void_p(slots.data_ptr()) if slots is not None else None))
         return vals, ow, oh, slots
+
+    # ---- decode side: Pixlzr::expand + to_image ----
+    def expand_image(self, width, height, channels, bw, bh, filt, tile_w, tile_h, slots):
+        """Host buffers: stored tiles (slots[t] holds tile_w[t]*tile_h[t]*channels tightly packed bytes in a slot of
+        bw*bh*channels) -> (height, width, channels) image."""
+        tile_w = np.ascontiguousarray(tile_w, np.uint32)
+        tile_h = np.ascontiguousarray(tile_h, np.uint32)
+        slots = np.ascontiguousarray(slots, np.uint8)
+        assert slots.shape[1] == bw * bh * channels
+        out = np.zeros((height, width, channels), np.uint8)
+        self._check(self._L.pxz_expand_image(self._h, width, height, channels, width * channels, bw, bh, filt,
+                                             _p(tile_w), _p(tile_h), _p(slots), _p(out)))
+        return out
+
+    def expand_frames_device(self, shape, bw, bh, filt, ow, oh, slots, out=None):
+        """Device tensors as left by shrink_frames_device (w[N,T], h[N,T], slots[N,T,bw*bh*C]) -> frames [N,H,W,C]."""
+        import torch
+        N, H, W, Cc = shape
+        if out is None:
+            out = torch.empty((N, H, W, Cc), dtype=torch.uint8, device=slots.device)
+        fd, _ = self._frames_desc(out)
+        pd = Params(bw, bh, 0, filt, 0.0, 0)
+        self.use_torch_stream()
+        self._check(self._L.pxz_expand_frames_device(self._h, C.byref(fd), C.byref(pd), C.c_void_p(ow.data_ptr()),
+                                                     C.c_void_p(oh.data_ptr()), C.c_void_p(slots.data_ptr()),
+                                                     C.c_void_p(out.data_ptr())))
+        return out
+
+    def expand_status(self):
+        bad = C.c_uint32(0)
+        self._check(self._L.pxz_expand_status(self._h, C.byref(bad)))
+        return bad.value
 
     def lod_frames_device(self, frames, bw, bh, mode, factor=1.0):
         import torch

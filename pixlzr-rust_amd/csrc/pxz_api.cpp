@@ -22,6 +22,7 @@ hipError_t launch_shrink(const ShrinkArgs &a, uint32_t channels, uint32_t n_cus,
 hipError_t launch_synth(const SynthArgs &s, hipStream_t stream);
 hipError_t launch_finish(const FinishArgs &f, hipStream_t stream);
 bool fast32_applicable(const ShrinkArgs &a, uint32_t channels);
+hipError_t launch_expand(const ExpandArgs &a, uint32_t n_cus, hipStream_t stream);
 hipError_t launch_pack(const PackArgs &a, hipStream_t stream);
 hipError_t launch_oklab32(const ShrinkArgs &a, uint32_t n_cus, hipStream_t stream);
 hipError_t launch_qoi(const QoiArgs &a, hipStream_t stream);
@@ -43,6 +44,14 @@ struct TableSet {
 	uint32_t rows_dw = 0;
 };
 
+// decode side: up-scaling tables of every source size to the full tile size (expand_kernel)
+struct ExpandTables {
+	pxz::ExpandTab *d_dir = nullptr;
+	uint16_t *d_starts = nullptr, *d_sizes = nullptr;
+	int16_t *d_coeffs = nullptr;
+	uint32_t dir_stride = 0;
+};
+
 struct DeviceBuffer {
 	void *ptr = nullptr;
 	size_t cap = 0;
@@ -60,7 +69,8 @@ struct pxz_handle {
 	// level breakpoints per (mode, factor bits, bw, bh, edge_w, edge_h)
 	struct Breaks { uint32_t b[4][pxz::kMaxLevel]; uint32_t asc[4]; };
 	std::map<std::tuple<uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t>, Breaks> breaks;
-	DeviceBuffer in, val, ow, oh, out, sums, chunks, work, qscratch, qmeta;
+	DeviceBuffer in, val, ow, oh, out, sums, chunks, work, qscratch, qmeta, status;
+	std::map<std::tuple<uint32_t, uint32_t, uint32_t, uint32_t, uint32_t>, ExpandTables> expand_tables;
 	bool work_ready = false;   // both worklist counters are zero / consistent with work_slot
 	uint32_t work_slot = 0;    // the counter the next 32x32 launch uses
 	bool timing = false;
@@ -250,6 +260,65 @@ int get_tables(pxz_handle *h, uint32_t bw, uint32_t bh, uint32_t edge_w, uint32_
 	PXZ_HIP(h, hipMemcpy(ts.d_rows, rows.data(), rows.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
 	h->tables[key] = ts;
 	*out = &h->tables[key];
+	return PXZ_OK;
+}
+
+// Tables of the decode side: for each axis and size class (full / ragged edge) one up-scaling table per
+// source size 1 .. full-1 (PixlzrBlock::resize with the upscale flag set, block.rs:301-304).
+int get_expand_tables(pxz_handle *h, uint32_t bw, uint32_t bh, uint32_t edge_w, uint32_t edge_h, uint32_t filter,
+                      const ExpandTables **out)
+{
+	auto key = std::make_tuple(bw, bh, edge_w, edge_h, filter);
+	auto it = h->expand_tables.find(key);
+	if (it != h->expand_tables.end()) {
+		*out = &it->second;
+		return PXZ_OK;
+	}
+	const uint32_t stride = (bw > bh ? bw : bh) + 1u;
+	std::vector<pxz::ExpandTab> dir(4u * stride, pxz::ExpandTab{0, 0, 0, 0});
+	std::vector<uint16_t> starts, sizes;
+	std::vector<int16_t> coeffs;
+	const uint32_t full[2][2] = {{bw, edge_w}, {bh, edge_h}};
+	for (uint32_t axis = 0; axis < 2; ++axis) {
+		for (uint32_t cls = 0; cls < 2; ++cls) {
+			const uint32_t outsz = full[axis][cls];
+			if (cls == 1 && outsz == full[axis][0]) {
+				for (uint32_t in = 0; in < stride; ++in) dir[(axis * 2 + 1) * stride + in] = dir[(axis * 2 + 0) * stride + in];
+				continue;
+			}
+			for (uint32_t in = 1; in < outsz; ++in) {
+				pxz::AxisWindows win;
+				if (!pxz::build_axis(in, outsz, filter, &win, true)) return fail(h, PXZ_ERR_INVALID_ARG, "unknown filter %u", filter);
+				pxz::ExpandTab &t = dir[(axis * 2 + cls) * stride + in];
+				t.start_off = (uint32_t)starts.size();
+				t.coeff_off = (uint32_t)coeffs.size();
+				t.window = (uint16_t)win.window;
+				t.precision = (uint16_t)win.precision;
+				for (uint32_t o = 0; o < outsz; ++o) {
+					starts.push_back((uint16_t)win.starts[o]);
+					sizes.push_back((uint16_t)win.sizes[o]);
+				}
+				coeffs.insert(coeffs.end(), win.coeffs.begin(), win.coeffs.end());
+			}
+		}
+	}
+	if (starts.empty()) {
+		starts.push_back(0);
+		sizes.push_back(0);
+	}
+	if (coeffs.empty()) coeffs.push_back(0);
+	ExpandTables et;
+	et.dir_stride = stride;
+	PXZ_HIP(h, hipMalloc((void **)&et.d_dir, dir.size() * sizeof(pxz::ExpandTab)));
+	PXZ_HIP(h, hipMalloc((void **)&et.d_starts, starts.size() * sizeof(uint16_t)));
+	PXZ_HIP(h, hipMalloc((void **)&et.d_sizes, sizes.size() * sizeof(uint16_t)));
+	PXZ_HIP(h, hipMalloc((void **)&et.d_coeffs, coeffs.size() * sizeof(int16_t)));
+	PXZ_HIP(h, hipMemcpy(et.d_dir, dir.data(), dir.size() * sizeof(pxz::ExpandTab), hipMemcpyHostToDevice));
+	PXZ_HIP(h, hipMemcpy(et.d_starts, starts.data(), starts.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+	PXZ_HIP(h, hipMemcpy(et.d_sizes, sizes.data(), sizes.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+	PXZ_HIP(h, hipMemcpy(et.d_coeffs, coeffs.data(), coeffs.size() * sizeof(int16_t), hipMemcpyHostToDevice));
+	h->expand_tables[key] = et;
+	*out = &h->expand_tables[key];
 	return PXZ_OK;
 }
 
@@ -534,7 +603,13 @@ void pxz_destroy(pxz_handle *h)
 		(void)hipFree(kv.second.d_ksums);
 		(void)hipFree(kv.second.d_rows);
 	}
-	for (DeviceBuffer *b : {&h->in, &h->val, &h->ow, &h->oh, &h->out, &h->sums, &h->chunks, &h->work, &h->qscratch, &h->qmeta})
+	for (auto &kv : h->expand_tables) {
+		(void)hipFree(kv.second.d_dir);
+		(void)hipFree(kv.second.d_starts);
+		(void)hipFree(kv.second.d_sizes);
+		(void)hipFree(kv.second.d_coeffs);
+	}
+	for (DeviceBuffer *b : {&h->in, &h->val, &h->ow, &h->oh, &h->out, &h->sums, &h->chunks, &h->work, &h->qscratch, &h->qmeta, &h->status})
 		if (b->ptr) (void)hipFree(b->ptr);
 	for (auto &ev : h->events) {
 		(void)hipEventDestroy(ev.first);
@@ -603,6 +678,105 @@ int pxz_lod_frames_device(pxz_handle *h, const pxz_frames *frames, const pxz_par
 	if (rc != PXZ_OK) return rc;
 	a.src = d_pixels;
 	return timed_launch(h, a, frames->channels, nullptr, d_lod0, d_lod1);
+}
+
+int pxz_expand_frames_device(pxz_handle *h, const pxz_frames *frames, const pxz_params *params, const uint32_t *d_tile_w,
+                             const uint32_t *d_tile_h, const uint8_t *d_slots, uint8_t *d_out_pixels)
+{
+	if (!h) return PXZ_ERR_INVALID_ARG;
+	if (!frames || !params) return fail(h, PXZ_ERR_INVALID_ARG, "null descriptor");
+	pxz_params p = *params;
+	p.mode = 0;
+	p.factor = 0.0f;  // neither is used on the decode side
+	int rc = check_frames(h, frames, &p);
+	if (rc != PXZ_OK) return rc;
+	if (!d_tile_w || !d_tile_h || !d_slots || !d_out_pixels) return fail(h, PXZ_ERR_INVALID_ARG, "null device pointer");
+	PXZ_HIP(h, hipSetDevice(h->device));
+	const uint32_t bw = p.block_w, bh = p.block_h;
+	uint32_t cols, rows;
+	pxz_grid(frames->width, frames->height, bw, bh, &cols, &rows);
+	if ((uint64_t)cols * rows * frames->n_frames > 0xffffffffull) return fail(h, PXZ_ERR_UNSUPPORTED, "too many tiles");
+	if (bw > 0xffffu || bh > 0xffffu) return fail(h, PXZ_ERR_UNSUPPORTED, "block side above 65535");
+	const uint64_t lds_bytes = 2ull * bw * bh * 4ull + 16ull;  // source pixels + horizontal-pass result of one wave
+	if (lds_bytes > 160u * 1024u)
+		return fail(h, PXZ_ERR_UNSUPPORTED, "a %ux%u tile needs %llu B of LDS (limit 163840)", bw, bh, (unsigned long long)lds_bytes);
+	pxz::ExpandArgs a{};
+	a.tile_w = d_tile_w;
+	a.tile_h = d_tile_h;
+	a.slots = d_slots;
+	a.dst = d_out_pixels;
+	a.frame_stride = frames->n_frames > 1 ? frames->frame_stride_bytes : (uint64_t)frames->pitch_bytes * frames->height;
+	a.pitch = frames->pitch_bytes;
+	a.width = frames->width;
+	a.height = frames->height;
+	a.channels = frames->channels;
+	a.bw = bw;
+	a.bh = bh;
+	a.cols = cols;
+	a.rows = rows;
+	a.tiles_per_frame = cols * rows;
+	a.n_tiles = cols * rows * frames->n_frames;
+	a.edge_w = frames->width - (cols - 1) * bw;
+	a.edge_h = frames->height - (rows - 1) * bh;
+	a.slot_bytes = bw * bh * frames->channels;
+	a.filter = p.filter;
+	const ExpandTables *et = nullptr;
+	if ((rc = get_expand_tables(h, bw, bh, a.edge_w, a.edge_h, p.filter, &et)) != PXZ_OK) return rc;
+	a.tabs = et->d_dir;
+	a.dir_stride = et->dir_stride;
+	a.starts = et->d_starts;
+	a.sizes = et->d_sizes;
+	a.coeffs = et->d_coeffs;
+	a.tile_dw = 2u * bw * bh;
+	if ((rc = ensure(h, h->status, 4)) != PXZ_OK) return rc;
+	a.status = (uint32_t *)h->status.ptr;
+	PXZ_HIP(h, hipMemsetAsync(a.status, 0, 4, h->stream));
+	PXZ_HIP(h, pxz::launch_expand(a, h->n_cus, h->stream));
+	return PXZ_OK;
+}
+
+int pxz_expand_status(pxz_handle *h, uint32_t *bad_tiles_seen)
+{
+	if (!h || !bad_tiles_seen) return PXZ_ERR_INVALID_ARG;
+	*bad_tiles_seen = 0;
+	if (!h->status.ptr) return PXZ_OK;
+	PXZ_HIP(h, hipSetDevice(h->device));
+	PXZ_HIP(h, hipMemcpyAsync(bad_tiles_seen, h->status.ptr, 4, hipMemcpyDeviceToHost, h->stream));
+	PXZ_HIP(h, hipStreamSynchronize(h->stream));
+	return PXZ_OK;
+}
+
+int pxz_expand_image(pxz_handle *h, uint32_t width, uint32_t height, uint32_t channels, uint32_t pitch_bytes, uint32_t block_w,
+                     uint32_t block_h, uint32_t filter, const uint32_t *tile_w, const uint32_t *tile_h, const uint8_t *slots,
+                     uint8_t *out_pixels)
+{
+	if (!h) return PXZ_ERR_INVALID_ARG;
+	if (!tile_w || !tile_h || !slots || !out_pixels) return fail(h, PXZ_ERR_INVALID_ARG, "null pointer");
+	pxz_frames f{width, height, channels, pitch_bytes, 1, 0, 0};
+	pxz_params p{block_w, block_h, 0, filter, 0.0f, 0};
+	int rc = check_frames(h, &f, &p);
+	if (rc != PXZ_OK) return rc;
+	PXZ_HIP(h, hipSetDevice(h->device));
+	uint32_t cols, rows;
+	pxz_grid(width, height, block_w, block_h, &cols, &rows);
+	const size_t tiles = (size_t)cols * rows, slot = (size_t)block_w * block_h * channels;
+	const size_t out_bytes = (size_t)pitch_bytes * (height - 1) + (size_t)width * channels;
+	if ((rc = ensure(h, h->ow, tiles * 4)) != PXZ_OK) return rc;
+	if ((rc = ensure(h, h->oh, tiles * 4)) != PXZ_OK) return rc;
+	if ((rc = ensure(h, h->out, tiles * slot)) != PXZ_OK) return rc;
+	if ((rc = ensure(h, h->in, out_bytes)) != PXZ_OK) return rc;
+	PXZ_HIP(h, hipMemcpyAsync(h->ow.ptr, tile_w, tiles * 4, hipMemcpyHostToDevice, h->stream));
+	PXZ_HIP(h, hipMemcpyAsync(h->oh.ptr, tile_h, tiles * 4, hipMemcpyHostToDevice, h->stream));
+	PXZ_HIP(h, hipMemcpyAsync(h->out.ptr, slots, tiles * slot, hipMemcpyHostToDevice, h->stream));
+	PXZ_HIP(h, hipMemsetAsync(h->in.ptr, 0, out_bytes, h->stream));  // row padding of a pitched image stays zero
+	rc = pxz_expand_frames_device(h, &f, &p, (const uint32_t *)h->ow.ptr, (const uint32_t *)h->oh.ptr, (const uint8_t *)h->out.ptr,
+	                              (uint8_t *)h->in.ptr);
+	if (rc != PXZ_OK) return rc;
+	PXZ_HIP(h, hipMemcpyAsync(out_pixels, h->in.ptr, out_bytes, hipMemcpyDeviceToHost, h->stream));
+	uint32_t bad = 0;
+	if ((rc = pxz_expand_status(h, &bad)) != PXZ_OK) return rc;
+	if (bad) return fail(h, PXZ_ERR_INVALID_ARG, "a tile's stored size is zero or larger than its place in the image");
+	return PXZ_OK;
 }
 
 int pxz_shrink_image(pxz_handle *h, const uint8_t *pixels, uint32_t width, uint32_t height, uint32_t channels,
@@ -740,7 +914,7 @@ int pxz_axis_table(uint32_t in_size, uint32_t out_size, uint32_t filter, int32_t
 {
 	if (in_size == 0 || out_size == 0 || filter > 4) return PXZ_ERR_INVALID_ARG;
 	pxz::AxisWindows w;
-	if (!pxz::build_axis(in_size, out_size, filter, &w)) return PXZ_ERR_INVALID_ARG;
+	if (!pxz::build_axis(in_size, out_size, filter, &w, out_size > in_size)) return PXZ_ERR_INVALID_ARG;
 	if (window) *window = w.window;
 	if (precision) *precision = w.precision;
 	if (starts) std::memcpy(starts, w.starts.data(), sizeof(int32_t) * out_size);

@@ -155,6 +155,32 @@ struct QoiArgs {
 	uint32_t width, height, bw, bh, filter_byte;
 };
 
+// Decode side (expand_kernel): one table per (axis, size class, source size) of an up-scale to the full
+// tile size.  starts/sizes hold one entry per output sample, coeffs out_size * window i16 weights.
+struct ExpandTab {
+	uint32_t start_off;      // into starts[] / sizes[] (nearest: starts[] is the source index)
+	uint32_t coeff_off;      // into coeffs[]
+	uint16_t window;
+	uint16_t precision;
+};
+
+struct ExpandArgs {
+	const uint32_t *tile_w, *tile_h;  // per tile: stored size
+	const uint8_t *slots;             // per tile slot_bytes, tile_w*tile_h*channels valid, tightly packed
+	uint8_t *dst;                     // frames, pitch-linear
+	uint64_t frame_stride;
+	uint32_t pitch, width, height, channels;
+	uint32_t bw, bh, cols, rows, tiles_per_frame, n_tiles, edge_w, edge_h;
+	uint32_t slot_bytes, filter;
+	// tabs[(axis*2 + cls) * dir_stride + in_size], in_size in [1, full]; dir_stride = max(bw, bh) + 1
+	const ExpandTab *tabs;
+	uint32_t dir_stride;
+	const uint16_t *starts, *sizes;
+	const int16_t *coeffs;
+	uint32_t tile_dw;                 // LDS dwords per wave: source pixels + horizontal-pass result
+	uint32_t *status;                 // set to 1 when a tile's stored size is 0 or exceeds its full size
+};
+
 struct SynthArgs {
 	uint8_t *dst;
 	uint64_t frame_stride;

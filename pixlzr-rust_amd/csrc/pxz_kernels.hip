@@ -1824,6 +1824,175 @@ __global__ void __launch_bounds__(256) finish_kernel(const FinishArgs f)
 }
 
 // ---------------------------------------------------------------------------
+// Decode side: Pixlzr::expand (reference pixlzr.rs:77-122) + to_image
+// (pixlzr_image.rs:24-74) in one pass: every stored tile is resized back to its full size with
+// PixlzrBlock::resize (block.rs:273-334: clone, ResizeAlg::Nearest, or the two-pass convolution with
+// u8 intermediate and alpha pre-/un-multiplication for RGBA) and written to its place in the frame.
+// One wave per tile, persistent, tiles dealt by an LDS ticket counter.  LDS per wave: the source tile as
+// one dword per pixel (premultiplied) and the horizontal pass's result [y][ox].  First version: scalar
+// multiply-adds straight from the global tables; correctness and coalesced frame writes first.
+// ---------------------------------------------------------------------------
+template <int C>
+__global__ void __launch_bounds__(256) expand_kernel(const ExpandArgs a)
+{
+	extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+	const uint32_t wpb = blockDim.x / 64u, sub = threadIdx.x / 64u, lane = threadIdx.x % 64u;
+	uint32_t *s_ticket = lds + wpb * a.tile_dw;
+	if (threadIdx.x == 0) *s_ticket = wpb;
+	__syncthreads();
+	uint32_t *s_src = lds + sub * a.tile_dw;
+	uint32_t *s_tmp = s_src + a.bw * a.bh;
+	uint32_t ticket = sub;
+	for (;;) {
+		const unsigned long long tl = (unsigned long long)blockIdx.x + (unsigned long long)ticket * gridDim.x;
+		if (tl >= (unsigned long long)a.n_tiles) break;
+		const uint32_t t = (uint32_t)tl;
+		const uint32_t frame = t / a.tiles_per_frame, tf = t - frame * a.tiles_per_frame;
+		const uint32_t ty = tf / a.cols, tx = tf - ty * a.cols;
+		const uint32_t fw = (tx == a.cols - 1) ? a.edge_w : a.bw, fh = (ty == a.rows - 1) ? a.edge_h : a.bh;
+		const uint32_t tw = a.tile_w[t], th = a.tile_h[t];
+		uint8_t *dst = a.dst + (size_t)frame * a.frame_stride + (size_t)(ty * a.bh) * a.pitch + (size_t)(tx * a.bw) * C;
+		auto put = [&](uint32_t ox, uint32_t oy, uint32_t px) {
+			uint8_t *p = dst + (size_t)oy * a.pitch + ox * (uint32_t)C;
+			if constexpr (C == 4) {
+				*reinterpret_cast<uint32_t *>(p) = px;
+			} else {
+				p[0] = (uint8_t)px;
+				p[1] = (uint8_t)(px >> 8);
+				p[2] = (uint8_t)(px >> 16);
+			}
+		};
+		if (tw == 0 || th == 0 || tw > fw || th > fh) {
+			if (lane == 0) atomicOr(a.status, 1u);
+		} else {
+			// ---- stored pixels -> one dword per pixel
+			const uint8_t *src = a.slots + (size_t)t * a.slot_bytes;
+			const uint32_t n = tw * th;
+			const bool conv = a.filter != 0 && (tw != fw || th != fh);
+			for (uint32_t i = lane; i < n; i += 64u) {
+				uint32_t px;
+				if constexpr (C == 4) {
+					px = reinterpret_cast<const uint32_t *>(src)[i];
+					if (conv) px = premultiply(px);  // fir: U8x4 is alpha-premultiplied before a convolution
+				} else {
+					px = (uint32_t)src[3 * i] | ((uint32_t)src[3 * i + 1] << 8) | ((uint32_t)src[3 * i + 2] << 16) | 0xff000000u;
+				}
+				s_src[i] = px;
+			}
+			tile_sync<1>();
+			const uint32_t cls_x = fw == a.bw ? 0u : 1u, cls_y = fh == a.bh ? 0u : 1u;
+			const ExpandTab tab_x = a.tabs[(0u * 2u + cls_x) * a.dir_stride + tw];
+			const ExpandTab tab_y = a.tabs[(1u * 2u + cls_y) * a.dir_stride + th];
+			if (tw == fw && th == fh) {  // block.rs:279-281: clone
+				RowWalker rw(lane, 64u, fw);
+				for (uint32_t i = lane; i < fw * fh; i += 64u, rw.next()) put(rw.col, rw.row, s_src[i]);
+			} else if (a.filter == 0) {  // ResizeAlg::Nearest
+				const uint16_t *sx = a.starts + tab_x.start_off, *sy = a.starts + tab_y.start_off;
+				RowWalker rw(lane, 64u, fw);
+				for (uint32_t i = lane; i < fw * fh; i += 64u, rw.next()) {
+					const uint32_t x = tw == fw ? rw.col : sx[rw.col], y = th == fh ? rw.row : sy[rw.row];
+					put(rw.col, rw.row, s_src[y * tw + x]);
+				}
+			} else {
+				const bool need_h = tw != fw, need_v = th != fh;
+				const uint32_t *cur = s_src;
+				if (need_h) {
+					// horizontal pass: item = (ox, y) of the th source rows
+					const uint16_t *st = a.starts + tab_x.start_off, *sz = a.sizes + tab_x.start_off;
+					const int16_t *kf = a.coeffs + tab_x.coeff_off;
+					const int prec = tab_x.precision;
+					const int32_t init = 1 << (prec - 1);
+					RowWalker rw(lane, 64u, fw);
+					for (uint32_t i = lane; i < fw * th; i += 64u, rw.next()) {
+						const uint32_t ox = rw.col, y = rw.row;
+						const uint32_t first = st[ox], cnt = sz[ox];
+						const int16_t *k = kf + ox * tab_x.window;
+						const uint32_t *row = s_src + y * tw + first;
+						int32_t acc[4] = {init, init, init, init};
+						for (uint32_t j = 0; j < cnt; ++j) {
+							const uint32_t p = row[j];
+							const int32_t w = k[j];
+							acc[0] += (int32_t)(p & 255u) * w;
+							acc[1] += (int32_t)((p >> 8) & 255u) * w;
+							acc[2] += (int32_t)((p >> 16) & 255u) * w;
+							if constexpr (C == 4) acc[3] += (int32_t)(p >> 24) * w;
+						}
+						uint32_t px = clip8(acc[0], prec) | (clip8(acc[1], prec) << 8) | (clip8(acc[2], prec) << 16);
+						px |= C == 4 ? clip8(acc[3], prec) << 24 : 0xff000000u;
+						if (need_v) {
+							s_tmp[y * fw + ox] = px;
+						} else {
+							if constexpr (C == 4) px = unpremultiply(px);
+							put(ox, y, px);
+						}
+					}
+					cur = s_tmp;
+					tile_sync<1>();
+				}
+				if (need_v) {
+					// vertical pass: item = (ox, oy); the rows of `cur` are fw wide when the horizontal pass ran
+					const uint32_t cw = need_h ? fw : tw;
+					const uint16_t *st = a.starts + tab_y.start_off, *sz = a.sizes + tab_y.start_off;
+					const int16_t *kf = a.coeffs + tab_y.coeff_off;
+					const int prec = tab_y.precision;
+					const int32_t init = 1 << (prec - 1);
+					RowWalker rw(lane, 64u, fw);
+					for (uint32_t i = lane; i < fw * fh; i += 64u, rw.next()) {
+						const uint32_t ox = rw.col, oy = rw.row;
+						const uint32_t first = st[oy], cnt = sz[oy];
+						const int16_t *k = kf + oy * tab_y.window;
+						const uint32_t *col = cur + first * cw + ox;
+						int32_t acc[4] = {init, init, init, init};
+						for (uint32_t j = 0; j < cnt; ++j) {
+							const uint32_t p = col[j * cw];
+							const int32_t w = k[j];
+							acc[0] += (int32_t)(p & 255u) * w;
+							acc[1] += (int32_t)((p >> 8) & 255u) * w;
+							acc[2] += (int32_t)((p >> 16) & 255u) * w;
+							if constexpr (C == 4) acc[3] += (int32_t)(p >> 24) * w;
+						}
+						uint32_t px = clip8(acc[0], prec) | (clip8(acc[1], prec) << 8) | (clip8(acc[2], prec) << 16);
+						px |= C == 4 ? clip8(acc[3], prec) << 24 : 0xff000000u;
+						if constexpr (C == 4) px = unpremultiply(px);
+						put(ox, oy, px);
+					}
+				}
+			}
+		}
+		uint32_t nt = 0;
+		if (lane == 0) nt = atomicAdd(s_ticket, 1u);
+		ticket = __builtin_amdgcn_readfirstlane(nt);
+		tile_sync<1>();  // the next tile reuses this wave's LDS
+	}
+}
+
+hipError_t launch_expand(const ExpandArgs &a, uint32_t n_cus, hipStream_t stream)
+{
+	constexpr uint32_t kLds = 160u * 1024u;
+	const uint32_t tile_bytes = a.tile_dw * 4u;
+	uint32_t wpb = (kLds - 16u) / tile_bytes;
+	if (wpb > 4u) wpb = 4u;
+	if (wpb < 1u) return hipErrorInvalidValue;
+	const uint32_t lds_bytes = wpb * tile_bytes + 16u;
+	uint32_t per_cu = kLds / lds_bytes;
+	if (per_cu > 4u) per_cu = 4u;
+	if (per_cu < 1u) per_cu = 1u;
+	const uint32_t need = (a.n_tiles + wpb - 1u) / wpb, resident = n_cus * per_cu;
+	const uint32_t blocks = need < resident ? need : resident;
+	hipError_t e;
+	if (a.channels == 4) {
+		auto k = expand_kernel<4>;
+		if (lds_bytes > 64u * 1024u && (e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)) != hipSuccess) return e;
+		hipLaunchKernelGGL(k, dim3(blocks), dim3(64u * wpb), lds_bytes, stream, a);
+	} else {
+		auto k = expand_kernel<3>;
+		if (lds_bytes > 64u * 1024u && (e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)) != hipSuccess) return e;
+		hipLaunchKernelGGL(k, dim3(blocks), dim3(64u * wpb), lds_bytes, stream, a);
+	}
+	return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
 // block-stream compaction: the valid bytes of the fixed output slots, tile order,
 // into one contiguous stream (what a writer / the RCCL gather consumes).
 //   offsets[t] = sum_{u<t} w[u]*h[u]*C  (exclusive scan, u64), offsets[n] = total

@@ -62,11 +62,22 @@ double lanczos3(double x)
 	return (x >= -3.0 && x < 3.0) ? sinc(x) * sinc(x / 3.0) : 0.0;
 }
 
-// FilterType -> fir filter for a down-scale (reference src/data_types/mod.rs:297-311)
-bool kernel_for(uint32_t filter, Kernel1D *k)
+double bilinear(double x)
+{
+	x = std::fabs(x);
+	return x < 1.0 ? 1.0 - x : 0.0;
+}
+
+// FilterType -> fir filter (reference src/data_types/mod.rs:65-107): the down-scale branch maps Triangle to
+// Convolution(Hamming), the up-scale branch (SuperSampling(filter, 2): a plain convolution when nothing
+// shrinks) maps it to Bilinear; the other three keep their kernel
+bool kernel_for(uint32_t filter, bool upscale, Kernel1D *k)
 {
 	switch (filter) {
-	case 1: *k = {1.0, hamming}; return true;      // Triangle -> Convolution(Hamming)
+	case 1:
+		if (upscale) *k = {1.0, bilinear};
+		else *k = {1.0, hamming};
+		return true;
 	case 2: *k = {2.0, catmull_rom}; return true;  // CatmullRom
 	case 3: *k = {3.0, gaussian}; return true;     // Gaussian
 	case 4: *k = {3.0, lanczos3}; return true;     // Lanczos3
@@ -76,7 +87,7 @@ bool kernel_for(uint32_t filter, Kernel1D *k)
 
 }  // namespace
 
-bool build_axis(uint32_t in_size, uint32_t out_size, uint32_t filter, AxisWindows *out)
+bool build_axis(uint32_t in_size, uint32_t out_size, uint32_t filter, AxisWindows *out, bool upscale)
 {
 	out->in_size = in_size;
 	out->out_size = out_size;
@@ -96,7 +107,7 @@ bool build_axis(uint32_t in_size, uint32_t out_size, uint32_t filter, AxisWindow
 		return true;
 	}
 	Kernel1D k;
-	if (!kernel_for(filter, &k)) return false;
+	if (!kernel_for(filter, upscale, &k)) return false;
 
 	const double scale = static_cast<double>(in_size) / static_cast<double>(out_size);
 	const double stretch = scale > 1.0 ? scale : 1.0;

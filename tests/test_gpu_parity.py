@@ -331,3 +331,59 @@ def test_device_bitstream_equals_oracle_writer(gpu, oracle, c, mode, factor):
         v, w, h, s = oracle.shrink_image(frames[f], 32, 32, mode, 4, factor)
         ref = oracle.encode_container(672, 416, 32, 32, c, 0, v, None, w, h, s)
         assert data[offs[f]:offs[f + 1]] == ref, f"frame {f}"
+
+
+# ---- decode side: Pixlzr::expand + to_image --------------------------------------------------
+
+def test_expand_reproduces_big_ruscher_pix_png(gpu, oracle, golden_dir):
+    """The reference's own decode fixture: Big-Ruscher.pix expanded with Nearest is Big-Ruscher.pix.png."""
+    d = oracle.decode_container(open(os.path.join(golden_dir, "Big-Ruscher.pix"), "rb").read())
+    ref = np.asarray(Image.open(os.path.join(golden_dir, "Big-Ruscher.pix.png")))[..., :3]
+    slots = np.ascontiguousarray(d["slots"][:, : d["bw"] * d["bh"] * 3])
+    img = gpu.expand_image(d["width"], d["height"], 3, d["bw"], d["bh"], 0, d["tw"], d["th"], slots)
+    assert (img == ref).all()
+
+
+@pytest.mark.parametrize("c", [4, 3])
+@pytest.mark.parametrize("filt", [0, 1, 2, 3, 4])
+def test_expand_matches_oracle(gpu, oracle, c, filt):
+    """Shrink (so that every reduced size from 1x1 to the full tile occurs, ragged edge tiles included), then
+    expand with every FilterType: clone, nearest, one-pass and two-pass convolutions, RGB and RGBA with
+    transparency (premultiplied convolution)."""
+    img = oracle.synth_frame(500, 300, c, 3, 1 if c == 4 else 0)
+    for bw, bh, factor in ((32, 32, 16.0), (32, 32, 2.0), (48, 20, 8.0), (64, 64, 16.0)):
+        vals, ow, oh, slots = oracle.shrink_image(img, bw, bh, 1, 4, factor)
+        exp = oracle.expand_image(500, 300, bw, bh, c, filt, ow, oh, slots)
+        got = gpu.expand_image(500, 300, c, bw, bh, filt, ow, oh, slots)
+        bad = (got != exp).any(axis=2)
+        assert not bad.any(), f"c{c} f{filt} {bw}x{bh} k{factor}: {int(bad.sum())} pixels differ"
+
+
+def test_expand_frames_device_round_trip_properties(gpu, oracle):
+    """Device-resident batch: shrink -> expand.  Tiles kept at full size come back unchanged; the batch equals
+    the per-frame oracle; an invalid stored size is flagged and leaves the tile untouched."""
+    import torch
+    frames = gpu.synth_frames_device(2, 256, 384, 4, first_frame=9, dist=0)
+    vals, ow, oh, slots = gpu.shrink_frames_device(frames, 32, 32, 1, 4, 16.0)
+    out = gpu.expand_frames_device(tuple(frames.shape), 32, 32, 4, ow, oh, slots)
+    torch.cuda.synchronize()
+    assert gpu.expand_status() == 0
+    f, o = frames.cpu().numpy(), out.cpu().numpy()
+    w, h = ow.cpu().numpy(), oh.cpu().numpy()
+    cols = 384 // 32
+    kept = 0
+    for n in range(2):
+        exp = oracle.expand_image(384, 256, 32, 32, 4, 4, w[n], h[n], slots[n].cpu().numpy())
+        assert (o[n] == exp).all()
+        for t in np.nonzero((w[n] == 32) & (h[n] == 32))[0]:
+            ty, tx = divmod(int(t), cols)
+            assert (o[n, ty * 32:ty * 32 + 32, tx * 32:tx * 32 + 32] == f[n, ty * 32:ty * 32 + 32, tx * 32:tx * 32 + 32]).all()
+            kept += 1
+    assert kept > 0
+    bad_w = ow.clone()
+    bad_w[0, 5] = 33
+    out2 = torch.zeros_like(out)
+    gpu.expand_frames_device(tuple(frames.shape), 32, 32, 4, bad_w, oh, slots, out=out2)
+    assert gpu.expand_status() == 1
+    ty, tx = divmod(5, cols)
+    assert int(out2[0, ty * 32:ty * 32 + 32, tx * 32:tx * 32 + 32].max()) == 0

@@ -118,6 +118,9 @@ def test_ruscher_nearest_expand_matches_pix_png(oracle, ruscher, golden_dir):
         tile = d["slots"][t, : tw * th * 3].reshape(th, tw, 3)
         out[y:y + h, x:x + w] = oracle.resize(np.ascontiguousarray(tile), w, h, oracle.NEAREST)
     assert (out == ref).all()
+    # the whole-image form the GPU decode path is checked against
+    whole = oracle.expand_image(1920, 1080, 32, 32, 3, oracle.NEAREST, d["tw"], d["th"], d["slots"])
+    assert (whole == ref).all()
 
 
 # derived KATs for the integer detector (operations.rs:192-259)
