@@ -139,14 +139,25 @@ int pxz_lod_frames_device(pxz_handle *h, const pxz_frames *frames, const pxz_par
  * SuperSampling(filter, 2), which is a plain convolution when nothing shrinks; Triangle means Bilinear here,
  * mod.rs:72-90) and written to its place in the frame.  `frames` describes the OUTPUT; params->block_w,
  * block_h and filter are used.  Tiles whose stored size is zero or exceeds their place are skipped and
- * flagged (pxz_expand_status).  Asynchronous on the handle's stream. */
+ * flagged (pxz_decode_status).  Asynchronous on the handle's stream. */
 int pxz_expand_frames_device(pxz_handle *h, const pxz_frames *frames, const pxz_params *params,
                              const uint32_t *d_tile_w, const uint32_t *d_tile_h, const uint8_t *d_slots,
                              uint8_t *d_out_pixels);
 
-/* Waits for the handle's stream; *bad_tiles_seen != 0 iff the last pxz_expand_frames_device met a tile
- * with an invalid stored size. */
-int pxz_expand_status(pxz_handle *h, uint32_t *bad_tiles_seen);
+/* Pixlzr::decode_from_vec (src/encoding/mod.rs:95-165) + decode_block (:202-242) + the `qoi` decoder it
+ * calls, on the device: n_frames .pixlzr files, back to back in d_files (file f = [off[f], off[f+1])),
+ * become the per-tile values, stored sizes and pixel slots (the layout pxz_expand_frames_device and
+ * pxz_encode_frames_device use).  `frames` gives the geometry every file must carry (width, height,
+ * channels; pitch fields unused), params block_w/block_h.  A malformed file or record is flagged
+ * (pxz_decode_status) and its tiles get size 0x0.  Asynchronous on the handle's stream. */
+int pxz_decode_frames_device(pxz_handle *h, const pxz_frames *frames, const pxz_params *params,
+                             const uint8_t *d_files, const uint64_t *d_file_offsets, float *d_block_value,
+                             uint32_t *d_tile_w, uint32_t *d_tile_h, uint8_t *d_slots);
+
+/* Waits for the handle's stream; flags of the last decode-side call on this handle:
+ * bit 0  pxz_expand_frames_device met a tile whose stored size is zero or exceeds its place,
+ * bit 1  pxz_decode_frames_device met a malformed file or record. */
+int pxz_decode_status(pxz_handle *h, uint32_t *flags);
 
 /* The same for one host-resident image (copies in, expands, copies out; PXZ_ERR_INVALID_ARG on an
  * invalid stored size). */

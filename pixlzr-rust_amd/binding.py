@@ -19,7 +19,7 @@ EXPORTED_SYMBOLS = [
     "pxz_synchronize", "pxz_grid", "pxz_shrink_image", "pxz_shrink_frames_device", "pxz_lod_frames_device",
     "pxz_pack_tiles_device", "pxz_encode_frames_device", "pxz_encode_container", "pxz_qoi_encode", "pxz_qoi_bound", "pxz_synth_frames_device", "pxz_axis_table",
     "pxz_enable_timing", "pxz_last_kernel_ms",
-    "pxz_expand_frames_device", "pxz_expand_image", "pxz_expand_status",
+    "pxz_expand_frames_device", "pxz_expand_image", "pxz_decode_frames_device", "pxz_decode_status",
 ]
 
 STATUS = {0: "PXZ_OK", -1: "PXZ_ERR_INVALID_ARG", -2: "PXZ_ERR_NO_DEVICE", -3: "PXZ_ERR_HIP",
@@ -111,8 +111,10 @@ def load_library():
     L.pxz_qoi_bound.argtypes = [u32] * 3
     L.pxz_expand_frames_device.restype = C.c_int
     L.pxz_expand_frames_device.argtypes = [vp, C.POINTER(Frames), C.POINTER(Params)] + [vp] * 4
-    L.pxz_expand_status.restype = C.c_int
-    L.pxz_expand_status.argtypes = [vp, C.POINTER(u32)]
+    L.pxz_decode_status.restype = C.c_int
+    L.pxz_decode_status.argtypes = [vp, C.POINTER(u32)]
+    L.pxz_decode_frames_device.restype = C.c_int
+    L.pxz_decode_frames_device.argtypes = [vp, C.POINTER(Frames), C.POINTER(Params)] + [vp] * 6
     L.pxz_expand_image.restype = C.c_int
     L.pxz_expand_image.argtypes = [vp] + [u32] * 7 + [vp] * 4
     L.pxz_synth_frames_device.restype = C.c_int
@@ -297,10 +299,32 @@ class Handle:
                                                      C.c_void_p(out.data_ptr())))
         return out
 
-    def expand_status(self):
-        bad = C.c_uint32(0)
-        self._check(self._L.pxz_expand_status(self._h, C.byref(bad)))
-        return bad.value
+    def decode_status(self):
+        """bit 0: invalid stored tile size seen by expand; bit 1: malformed file/record seen by decode."""
+        flags = C.c_uint32(0)
+        self._check(self._L.pxz_decode_status(self._h, C.byref(flags)))
+        return flags.value
+
+    def decode_frames_device(self, files, file_offsets, shape, bw, bh):
+        """files: uint8 CUDA tensor holding N .pixlzr files back to back, file_offsets int64[N+1] (CUDA).
+        Returns (values[N,T], w[N,T], h[N,T], slots[N,T,bw*bh*C]) for frames of `shape` = (N,H,W,C)."""
+        import torch
+        N, H, W, Cc = shape
+        cols, rows = grid(W, H, bw, bh)
+        T = cols * rows
+        dev = files.device
+        vals = torch.zeros((N, T), dtype=torch.float32, device=dev)
+        ow = torch.zeros((N, T), dtype=torch.int32, device=dev)
+        oh = torch.zeros((N, T), dtype=torch.int32, device=dev)
+        slots = torch.zeros((N, T, bw * bh * Cc), dtype=torch.uint8, device=dev)
+        fd = Frames(W, H, Cc, W * Cc, N, 0, W * Cc * H)
+        pd = Params(bw, bh, 0, 0, 0.0, 0)
+        self.use_torch_stream()
+        self._check(self._L.pxz_decode_frames_device(self._h, C.byref(fd), C.byref(pd), C.c_void_p(files.data_ptr()),
+                                                     C.c_void_p(file_offsets.data_ptr()), C.c_void_p(vals.data_ptr()),
+                                                     C.c_void_p(ow.data_ptr()), C.c_void_p(oh.data_ptr()),
+                                                     C.c_void_p(slots.data_ptr())))
+        return vals, ow, oh, slots
 
     def lod_frames_device(self, frames, bw, bh, mode, factor=1.0):
         import torch

@@ -23,6 +23,7 @@ hipError_t launch_synth(const SynthArgs &s, hipStream_t stream);
 hipError_t launch_finish(const FinishArgs &f, hipStream_t stream);
 bool fast32_applicable(const ShrinkArgs &a, uint32_t channels);
 hipError_t launch_expand(const ExpandArgs &a, uint32_t n_cus, hipStream_t stream);
+hipError_t launch_decode(const DecodeArgs &a, hipStream_t stream);
 hipError_t launch_pack(const PackArgs &a, hipStream_t stream);
 hipError_t launch_oklab32(const ShrinkArgs &a, uint32_t n_cus, hipStream_t stream);
 hipError_t launch_qoi(const QoiArgs &a, hipStream_t stream);
@@ -69,7 +70,7 @@ struct pxz_handle {
 	// level breakpoints per (mode, factor bits, bw, bh, edge_w, edge_h)
 	struct Breaks { uint32_t b[4][pxz::kMaxLevel]; uint32_t asc[4]; };
 	std::map<std::tuple<uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t>, Breaks> breaks;
-	DeviceBuffer in, val, ow, oh, out, sums, chunks, work, qscratch, qmeta, status;
+	DeviceBuffer in, val, ow, oh, out, sums, chunks, work, qscratch, qmeta, status, dmeta;
 	std::map<std::tuple<uint32_t, uint32_t, uint32_t, uint32_t, uint32_t>, ExpandTables> expand_tables;
 	bool work_ready = false;   // both worklist counters are zero / consistent with work_slot
 	uint32_t work_slot = 0;    // the counter the next 32x32 launch uses
@@ -609,7 +610,7 @@ void pxz_destroy(pxz_handle *h)
 		(void)hipFree(kv.second.d_sizes);
 		(void)hipFree(kv.second.d_coeffs);
 	}
-	for (DeviceBuffer *b : {&h->in, &h->val, &h->ow, &h->oh, &h->out, &h->sums, &h->chunks, &h->work, &h->qscratch, &h->qmeta, &h->status})
+	for (DeviceBuffer *b : {&h->in, &h->val, &h->ow, &h->oh, &h->out, &h->sums, &h->chunks, &h->work, &h->qscratch, &h->qmeta, &h->status, &h->dmeta})
 		if (b->ptr) (void)hipFree(b->ptr);
 	for (auto &ev : h->events) {
 		(void)hipEventDestroy(ev.first);
@@ -735,13 +736,64 @@ int pxz_expand_frames_device(pxz_handle *h, const pxz_frames *frames, const pxz_
 	return PXZ_OK;
 }
 
-int pxz_expand_status(pxz_handle *h, uint32_t *bad_tiles_seen)
+int pxz_decode_frames_device(pxz_handle *h, const pxz_frames *frames, const pxz_params *params, const uint8_t *d_files,
+                             const uint64_t *d_file_offsets, float *d_block_value, uint32_t *d_tile_w, uint32_t *d_tile_h,
+                             uint8_t *d_slots)
 {
-	if (!h || !bad_tiles_seen) return PXZ_ERR_INVALID_ARG;
-	*bad_tiles_seen = 0;
+	if (!h) return PXZ_ERR_INVALID_ARG;
+	if (!frames || !params) return fail(h, PXZ_ERR_INVALID_ARG, "null descriptor");
+	pxz_params p = *params;
+	p.mode = 0;
+	p.factor = 0.0f;
+	p.filter = 0;
+	pxz_frames f = *frames;
+	f.pitch_bytes = f.width * f.channels;  // only the geometry of the frames matters here
+	f.frame_stride_bytes = (uint64_t)f.pitch_bytes * f.height;
+	int rc = check_frames(h, &f, &p);
+	if (rc != PXZ_OK) return rc;
+	if (!d_files || !d_file_offsets || !d_block_value || !d_tile_w || !d_tile_h || !d_slots)
+		return fail(h, PXZ_ERR_INVALID_ARG, "null device pointer");
+	PXZ_HIP(h, hipSetDevice(h->device));
+	uint32_t cols, rows;
+	pxz_grid(f.width, f.height, p.block_w, p.block_h, &cols, &rows);
+	if ((uint64_t)cols * rows * f.n_frames > 0xffffffffull) return fail(h, PXZ_ERR_UNSUPPORTED, "too many tiles");
+	pxz::DecodeArgs a{};
+	a.files = d_files;
+	a.file_offsets = reinterpret_cast<const unsigned long long *>(d_file_offsets);
+	a.value = d_block_value;
+	a.tile_w = d_tile_w;
+	a.tile_h = d_tile_h;
+	a.slots = d_slots;
+	a.width = f.width;
+	a.height = f.height;
+	a.bw = p.block_w;
+	a.bh = p.block_h;
+	a.cols = cols;
+	a.rows = rows;
+	a.tiles_per_frame = cols * rows;
+	a.n_frames = f.n_frames;
+	a.n_tiles = cols * rows * f.n_frames;
+	a.channels = f.channels;
+	a.slot_bytes = p.block_w * p.block_h * f.channels;
+	a.edge_w = f.width - (cols - 1) * p.block_w;
+	a.edge_h = f.height - (rows - 1) * p.block_h;
+	if ((rc = ensure(h, h->dmeta, (size_t)a.n_tiles * 12u)) != PXZ_OK) return rc;
+	a.rec_off = (unsigned long long *)h->dmeta.ptr;
+	a.rec_len = (uint32_t *)((uint8_t *)h->dmeta.ptr + (size_t)a.n_tiles * 8u);
+	if ((rc = ensure(h, h->status, 4)) != PXZ_OK) return rc;
+	a.status = (uint32_t *)h->status.ptr;
+	PXZ_HIP(h, hipMemsetAsync(a.status, 0, 4, h->stream));
+	PXZ_HIP(h, pxz::launch_decode(a, h->stream));
+	return PXZ_OK;
+}
+
+int pxz_decode_status(pxz_handle *h, uint32_t *flags)
+{
+	if (!h || !flags) return PXZ_ERR_INVALID_ARG;
+	*flags = 0;
 	if (!h->status.ptr) return PXZ_OK;
 	PXZ_HIP(h, hipSetDevice(h->device));
-	PXZ_HIP(h, hipMemcpyAsync(bad_tiles_seen, h->status.ptr, 4, hipMemcpyDeviceToHost, h->stream));
+	PXZ_HIP(h, hipMemcpyAsync(flags, h->status.ptr, 4, hipMemcpyDeviceToHost, h->stream));
 	PXZ_HIP(h, hipStreamSynchronize(h->stream));
 	return PXZ_OK;
 }
@@ -774,7 +826,7 @@ int pxz_expand_image(pxz_handle *h, uint32_t width, uint32_t height, uint32_t ch
 	if (rc != PXZ_OK) return rc;
 	PXZ_HIP(h, hipMemcpyAsync(out_pixels, h->in.ptr, out_bytes, hipMemcpyDeviceToHost, h->stream));
 	uint32_t bad = 0;
-	if ((rc = pxz_expand_status(h, &bad)) != PXZ_OK) return rc;
+	if ((rc = pxz_decode_status(h, &bad)) != PXZ_OK) return rc;
 	if (bad) return fail(h, PXZ_ERR_INVALID_ARG, "a tile's stored size is zero or larger than its place in the image");
 	return PXZ_OK;
 }

@@ -181,6 +181,20 @@ struct ExpandArgs {
 	uint32_t *status;                 // set to 1 when a tile's stored size is 0 or exceeds its full size
 };
 
+// Decode side: .pixlzr files -> tile values, sizes and pixel slots (pixlzr_index_kernel, qoi_decode_kernel)
+struct DecodeArgs {
+	const uint8_t *files;                   // the files back to back
+	const unsigned long long *file_offsets; // n_frames + 1 byte offsets
+	float *value;
+	uint32_t *tile_w, *tile_h;
+	uint8_t *slots;
+	unsigned long long *rec_off;            // scratch, per tile: offset of the record's QOI body in files[]
+	uint32_t *rec_len;                      // scratch, per tile: length of that body (0: unusable)
+	uint32_t *status;                       // bit 1: malformed file / record
+	uint32_t width, height, bw, bh, cols, rows, tiles_per_frame, n_tiles, n_frames, channels, slot_bytes;
+	uint32_t edge_w, edge_h;
+};
+
 struct SynthArgs {
 	uint8_t *dst;
 	uint64_t frame_stride;

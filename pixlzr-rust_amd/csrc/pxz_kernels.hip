@@ -2332,6 +2332,160 @@ hipError_t launch_qoi(const QoiArgs &a, hipStream_t stream)
 }
 
 // ---------------------------------------------------------------------------
+// Decode side: Pixlzr::decode_from_vec (reference src/encoding/mod.rs:95-165) + decode_block (:202-242)
+// + the `qoi` decoder it calls, on the device.
+//   pixlzr_index_kernel  one lane per (file, tile row): header check, the row's start from the line-length
+//                        table, then a walk over the row's records ("block", f32 BE value, u32 BE length,
+//                        QOI minus its magic) -> per tile value, size and body position
+//   qoi_decode_kernel    one lane per tile: the QOI op stream -> pixels in the tile's slot; the 64-entry
+//                        index of every lane lives in LDS as in the encoder
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t be32(const uint8_t *p)
+{
+	return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | (uint32_t)p[3];
+}
+
+__global__ void __launch_bounds__(256) pixlzr_index_kernel(const DecodeArgs a)
+{
+	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+	if (i >= a.n_frames * a.rows) return;
+	const uint32_t f = i / a.rows, r = i - f * a.rows;
+	const unsigned long long f0 = a.file_offsets[f], f1 = a.file_offsets[f + 1];
+	const uint8_t *file = a.files + f0;
+	const unsigned long long flen = f1 - f0;
+	const unsigned long long hdr = 26ull + 4ull * a.rows;
+	auto bad_row = [&]() {
+		atomicOr(a.status, 2u);
+		for (uint32_t c = 0; c < a.cols; ++c) a.rec_len[f * a.tiles_per_frame + r * a.cols + c] = 0u;
+	};
+	const uint8_t magic[9] = {'P', 'I', 'X', 'L', 'Z', 'R', 0, 0, 2};  // constants.rs:10-11: v0.0.2 (filter byte + line table)
+	bool ok = flen >= hdr;
+	if (ok) {
+		for (int k = 0; k < 9; ++k) ok = ok && file[k] == magic[k];
+		ok = ok && be32(file + 10) == a.width && be32(file + 14) == a.height && be32(file + 18) == a.bw && be32(file + 22) == a.bh;
+	}
+	if (!ok) {
+		bad_row();
+		return;
+	}
+	unsigned long long p = hdr, total = hdr;
+	for (uint32_t q = 0; q < a.rows; ++q) {
+		const uint32_t len = be32(file + 26 + 4 * q);
+		if (q < r) p += len;
+		total += len;
+	}
+	if (total != flen) {  // mod.rs:141
+		bad_row();
+		return;
+	}
+	const unsigned long long row_end = p + be32(file + 26 + 4 * r);
+	for (uint32_t c = 0; c < a.cols; ++c) {
+		const uint32_t t = f * a.tiles_per_frame + r * a.cols + c;
+		const uint32_t fw = (c == a.cols - 1) ? a.edge_w : a.bw, fh = (r == a.rows - 1) ? a.edge_h : a.bh;
+		bool good = p + 13ull + 10ull + 8ull <= row_end;
+		if (good) {
+			const uint8_t *rec = file + p;
+			good = rec[0] == 'b' && rec[1] == 'l' && rec[2] == 'o' && rec[3] == 'c' && rec[4] == 'k';
+			const uint32_t qlen = be32(rec + 9);
+			good = good && qlen >= 18u && p + 13ull + qlen <= row_end;
+			if (good) {
+				const uint32_t w = be32(rec + 13), h = be32(rec + 17), ch = rec[21];
+				good = ch == a.channels && w >= 1 && h >= 1 && w <= fw && h <= fh;
+				if (good) {
+					a.value[t] = __uint_as_float(be32(rec + 5));
+					a.tile_w[t] = w;
+					a.tile_h[t] = h;
+					a.rec_off[t] = f0 + p + 13ull + 10ull;  // first op byte
+					a.rec_len[t] = qlen - 10u - 8u;         // ops only: without the header and the end marker
+				}
+				p += 13ull + qlen;
+			}
+		}
+		if (!good) {
+			// the walk cannot continue past a broken record: the rest of the row is unusable
+			atomicOr(a.status, 2u);
+			for (uint32_t cc = c; cc < a.cols; ++cc) a.rec_len[f * a.tiles_per_frame + r * a.cols + cc] = 0u;
+			return;
+		}
+	}
+	if (p != row_end) atomicOr(a.status, 2u);
+}
+
+template <int C>
+__global__ void __launch_bounds__(256) qoi_decode_kernel(const DecodeArgs a)
+{
+	__shared__ uint32_t s_index[4][64][64];  // [wave][slot][lane]
+	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+	const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+	uint32_t(*index)[64] = s_index[wave];
+#pragma unroll 8
+	for (int sidx = 0; sidx < 64; ++sidx) index[sidx][lane] = 0u;  // qoi: index starts as zero pixels
+	if (t >= a.n_tiles) return;
+	const uint32_t len = a.rec_len[t];
+	if (len == 0) {
+		a.tile_w[t] = 0;  // unusable record: the expand step skips and flags it
+		a.tile_h[t] = 0;
+		return;
+	}
+	const uint8_t *p = a.files + a.rec_off[t], *end = p + len;
+	const uint32_t n = a.tile_w[t] * a.tile_h[t];
+	uint8_t *dst = a.slots + (size_t)t * a.slot_bytes;
+	uint32_t px = 0xff000000u, run = 0;
+	for (uint32_t i = 0; i < n; ++i) {
+		if (run > 0) {
+			--run;
+		} else if (p < end) {
+			const uint32_t b1 = *p++;
+			if (b1 == 0xfeu) {  // QOI_OP_RGB
+				px = (px & 0xff000000u) | (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16);
+				p += 3;
+			} else if (b1 == 0xffu) {  // QOI_OP_RGBA
+				px = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
+				p += 4;
+			} else if ((b1 & 0xc0u) == 0x00u) {  // QOI_OP_INDEX
+				px = index[b1][lane];
+			} else if ((b1 & 0xc0u) == 0x40u) {  // QOI_OP_DIFF
+				const uint32_t r = ((px & 255u) + ((b1 >> 4) & 3u) - 2u) & 255u;
+				const uint32_t g = (((px >> 8) & 255u) + ((b1 >> 2) & 3u) - 2u) & 255u;
+				const uint32_t b = (((px >> 16) & 255u) + (b1 & 3u) - 2u) & 255u;
+				px = (px & 0xff000000u) | r | (g << 8) | (b << 16);
+			} else if ((b1 & 0xc0u) == 0x80u) {  // QOI_OP_LUMA
+				const uint32_t b2 = *p++;
+				const uint32_t vg = (b1 & 0x3fu) - 32u;
+				const uint32_t r = ((px & 255u) + vg - 8u + ((b2 >> 4) & 15u)) & 255u;
+				const uint32_t g = (((px >> 8) & 255u) + vg) & 255u;
+				const uint32_t b = (((px >> 16) & 255u) + vg - 8u + (b2 & 15u)) & 255u;
+				px = (px & 0xff000000u) | r | (g << 8) | (b << 16);
+			} else {  // QOI_OP_RUN
+				run = b1 & 0x3fu;
+			}
+			index[((px & 255u) * 3u + ((px >> 8) & 255u) * 5u + ((px >> 16) & 255u) * 7u + (px >> 24) * 11u) & 63u][lane] = px;
+		} else {
+			atomicOr(a.status, 2u);  // the op stream ended before the tile was full
+			a.tile_w[t] = 0;
+			a.tile_h[t] = 0;
+			return;
+		}
+		if constexpr (C == 4) {
+			reinterpret_cast<uint32_t *>(dst)[i] = px;
+		} else {
+			dst[3 * i] = (uint8_t)px;
+			dst[3 * i + 1] = (uint8_t)(px >> 8);
+			dst[3 * i + 2] = (uint8_t)(px >> 16);
+		}
+	}
+}
+
+hipError_t launch_decode(const DecodeArgs &a, hipStream_t stream)
+{
+	hipLaunchKernelGGL(pixlzr_index_kernel, dim3((a.n_frames * a.rows + 255u) / 256u), dim3(256), 0, stream, a);
+	const uint32_t tb = (a.n_tiles + 255u) / 256u;
+	if (a.channels == 4) hipLaunchKernelGGL(qoi_decode_kernel<4>, dim3(tb), dim3(256), 0, stream, a);
+	else hipLaunchKernelGGL(qoi_decode_kernel<3>, dim3(tb), dim3(256), 0, stream, a);
+	return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
 // synthetic frames (DESIGN.md "Synthetic frames"): integer-only, one pixel per thread
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t fmix32(uint32_t h)

@@ -367,7 +367,7 @@ def test_expand_frames_device_round_trip_properties(gpu, oracle):
     vals, ow, oh, slots = gpu.shrink_frames_device(frames, 32, 32, 1, 4, 16.0)
     out = gpu.expand_frames_device(tuple(frames.shape), 32, 32, 4, ow, oh, slots)
     torch.cuda.synchronize()
-    assert gpu.expand_status() == 0
+    assert gpu.decode_status() == 0
     f, o = frames.cpu().numpy(), out.cpu().numpy()
     w, h = ow.cpu().numpy(), oh.cpu().numpy()
     cols = 384 // 32
@@ -384,6 +384,57 @@ def test_expand_frames_device_round_trip_properties(gpu, oracle):
     bad_w[0, 5] = 33
     out2 = torch.zeros_like(out)
     gpu.expand_frames_device(tuple(frames.shape), 32, 32, 4, bad_w, oh, slots, out=out2)
-    assert gpu.expand_status() == 1
+    assert gpu.decode_status() == 1
     ty, tx = divmod(5, cols)
     assert int(out2[0, ty * 32:ty * 32 + 32, tx * 32:tx * 32 + 32].max()) == 0
+
+
+def test_decode_frames_device_reference_files(gpu, oracle, golden_dir):
+    """The reference's own files through the device decoder: every tile's value, size and pixels equal the
+    oracle's decode (which is pinned by re-encoding them byte for byte); then decode + expand(Nearest) of
+    Big-Ruscher.pix is Big-Ruscher.pix.png."""
+    import torch
+    for name, c in (("Big-Ruscher.pix", 3), ("base.pixlzr", 4)):
+        raw = open(os.path.join(golden_dir, name), "rb").read()
+        d = oracle.decode_container(raw)
+        files = torch.frombuffer(bytearray(raw), dtype=torch.uint8).cuda()
+        offs = torch.tensor([0, len(raw)], dtype=torch.int64).cuda()
+        shape = (1, d["height"], d["width"], c)
+        vals, ow, oh, slots = gpu.decode_frames_device(files, offs, shape, d["bw"], d["bh"])
+        torch.cuda.synchronize()
+        assert gpu.decode_status() == 0
+        assert (vals.cpu().numpy()[0].view(np.uint32) == d["values"].view(np.uint32)).all()
+        assert (ow.cpu().numpy()[0] == d["tw"]).all() and (oh.cpu().numpy()[0] == d["th"]).all()
+        got, exp = slots.cpu().numpy()[0], d["slots"]
+        valid = d["tw"].astype(np.int64) * d["th"] * c
+        idx = np.arange(got.shape[1])[None, :] < valid[:, None]
+        assert not ((got != exp[:, : got.shape[1]]) & idx).any()
+        if c == 3:
+            img = gpu.expand_frames_device(shape, d["bw"], d["bh"], 0, ow, oh, slots)
+            ref = np.asarray(Image.open(os.path.join(golden_dir, "Big-Ruscher.pix.png")))[..., :3]
+            assert (img.cpu().numpy()[0] == ref).all()
+
+
+@pytest.mark.parametrize("c", [4, 3])
+def test_encode_decode_round_trip_on_device(gpu, oracle, c):
+    """shrink -> device writer -> device decoder gives back exactly the tiles that went in (values as bits,
+    sizes, valid pixel bytes), for a batch of frames; a corrupted record is flagged and zero-sized."""
+    import torch
+    frames = gpu.synth_frames_device(3, 200, 328, c, first_frame=4, dist=1 if c == 4 else 0)
+    vals, ow, oh, slots = gpu.shrink_frames_device(frames, 32, 32, 1, 4, 16.0)
+    offs, buf = gpu.encode_frames_device(tuple(frames.shape), 32, 32, vals, ow, oh, slots)
+    v2, w2, h2, s2 = gpu.decode_frames_device(buf, offs, tuple(frames.shape), 32, 32)
+    torch.cuda.synchronize()
+    assert gpu.decode_status() == 0
+    assert (v2.view(torch.int32) == vals.view(torch.int32)).all()
+    assert (w2 == ow).all() and (h2 == oh).all()
+    valid = (ow.long() * oh.long() * c)[..., None]
+    idx = torch.arange(slots.shape[-1], device=slots.device)[None, None, :] < valid
+    assert not ((s2 != slots) & idx).any()
+    bad = buf.clone()
+    first_record = 26 + 4 * 7  # 200/32 -> 7 tile rows
+    bad[int(offs[0]) + first_record] = ord("x")  # breaks the "block" magic of tile 0
+    v3, w3, h3, s3 = gpu.decode_frames_device(bad, offs, tuple(frames.shape), 32, 32)
+    assert gpu.decode_status() == 2
+    assert int(w3[0, 0]) == 0 and int(h3[0, 0]) == 0
+    assert (w3[1:] == ow[1:]).all()
