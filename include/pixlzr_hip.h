@@ -165,6 +165,19 @@ int pxz_expand_image(pxz_handle *h, uint32_t width, uint32_t height, uint32_t ch
                      uint32_t block_w, uint32_t block_h, uint32_t filter, const uint32_t *tile_w,
                      const uint32_t *tile_h, const uint8_t *slots, uint8_t *out_pixels);
 
+/* ---- legacy image -> image filter ------------------------ */
+
+/* process_custom (src/process/mod.rs:71-102) with the closures of process() (:107-121: |x - avg| and the
+ * identity): per tile get_block_variance -> reduce_image_section((v, v)) with params->filter (the
+ * down-scaling filter) -> .resize(w0, h0, filter_upscale) -> copy_from into an RGBA8 image
+ * (DynamicImage::new_rgba8, :80-81; RGB input gains alpha 255).  process(image, n) is block_w = block_h = n,
+ * params->filter = PXZ_FILTER_LANCZOS3, filter_upscale = PXZ_FILTER_NEAREST.  params->mode and factor are
+ * ignored.  Two launches' worth of device work (shrink into the handle's scratch, expand into d_out_rgba);
+ * asynchronous on the handle's stream. */
+int pxz_process_frames_device(pxz_handle *h, const pxz_frames *frames, const pxz_params *params,
+                              uint32_t filter_upscale, const uint8_t *d_pixels, uint8_t *d_out_rgba,
+                              uint32_t out_pitch_bytes, uint64_t out_frame_stride_bytes);
+
 /* Block-stream compaction (device): the valid out_w*out_h*channels bytes of every slot, in tile
  * order, into one contiguous stream -- the payload `encode_block` (src/encoding/mod.rs:168-200)
  * consumes tile after tile, and what one rank ships to the writer rank over RCCL.

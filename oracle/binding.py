@@ -248,6 +248,20 @@ def expand_image(width, height, bw, bh, channels, filt, tile_w, tile_h, slots):
     return out
 
 
+def process_image(img, bw, bh, filter_down=4, filter_up=0):
+    """process_custom (process/mod.rs:71-102) with |x - avg| and the identity: (H, W, C) -> (H, W, 4)."""
+    L = lib()
+    L.orc_process_image.restype = C.c_int
+    L.orc_process_image.argtypes = [C.c_void_p] + [C.c_uint32] * 8 + [C.c_void_p, C.c_uint32]
+    img = np.ascontiguousarray(img, np.uint8)
+    H, W, Cc = img.shape
+    out = np.zeros((H, W, 4), np.uint8)
+    rc = L.orc_process_image(_ptr(img), W, H, Cc, W * Cc, bw, bh, filter_down, filter_up, _ptr(out), W * 4)
+    if rc != 0:
+        raise RuntimeError(f"orc_process_image rc={rc}")
+    return out
+
+
 def synth_frame(width, height, channels=4, frame_index=0, dist=DIST_OPAQUE):
     img = np.empty((height, width, channels), np.uint8)
     lib().orc_synth_frame(_ptr(img), width, height, channels, width * channels, frame_index, dist)

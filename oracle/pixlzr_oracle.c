@@ -208,7 +208,19 @@ void orc_oklab_pixel(const uint8_t *px, uint32_t c, float out[4])
 	out[3] = c == 4 ? (float)px[3] / 255.0f : 1.0f;
 }
 
+static float lod_oklab_scaled(const uint8_t *tile, uint32_t w, uint32_t h, uint32_t c, uint32_t pitch, float factor,
+                              float scale2);
+
 float orc_lod_oklab(const uint8_t *tile, uint32_t w, uint32_t h, uint32_t c, uint32_t pitch, float factor)
+{
+	/* after = x * factor * BASE_FACTOR(10.0) (pixlzr.rs:15,162) */
+	return lod_oklab_scaled(tile, w, h, c, pitch, factor, 10.0f);
+}
+
+/* get_block_variance (operations.rs:26-126) with before = |x - avg| and after = (x * factor) * scale2;
+ * factor = scale2 = 1 is the identity closure of process() (process/mod.rs:108-111): x * 1 * 1 == x */
+static float lod_oklab_scaled(const uint8_t *tile, uint32_t w, uint32_t h, uint32_t c, uint32_t pitch, float factor,
+                              float scale2)
 {
 	float count = (float)(w * h); /* :51 */
 	/* sums in the reference's order [a, b, l, alpha] (:60-63 / :98-100) */
@@ -245,8 +257,7 @@ float orc_lod_oklab(const uint8_t *tile, uint32_t w, uint32_t h, uint32_t c, uin
 	float total = c == 4 ? (delta[0] + delta[1] + delta[2] + delta[3]) /* :89 */
 	                     : (delta[0] + delta[1] + delta[2]);            /* :124 */
 	float x = total / count;
-	/* after = x * factor * BASE_FACTOR(10.0) (pixlzr.rs:15,162) */
-	return x * factor * 10.0f;
+	return x * factor * scale2;
 }
 
 /* ------------------------------------------------------------------------ */
@@ -784,4 +795,54 @@ int orc_expand_image(uint32_t width, uint32_t height, uint32_t bw, uint32_t bh, 
 	}
 	free(full);
 	return 0;
+}
+
+/* ------------------------------------------------------------------------ */
+/* legacy image -> image filter: process() (process/mod.rs:107-121) = process_custom (:71-102) with         */
+/* |x - avg|, identity, Lanczos3 down, Nearest up; generalised to any down/up filter (process_custom's own  */
+/* parameters).  Output is RGBA8 (DynamicImage::new_rgba8, :80-81; RGB tiles gain alpha 255 in copy_from).  */
+/* ------------------------------------------------------------------------ */
+int orc_process_image(const uint8_t *pixels, uint32_t width, uint32_t height, uint32_t channels, uint32_t pitch,
+                      uint32_t bw, uint32_t bh, uint32_t filter_down, uint32_t filter_up, uint8_t *out_rgba,
+                      uint32_t out_pitch)
+{
+	if (!pixels || !out_rgba || (channels != 3 && channels != 4) || bw == 0 || bh == 0)
+		return -1;
+	uint32_t cols, rows;
+	orc_grid(width, height, bw, bh, &cols, &rows);
+	uint8_t *small = (uint8_t *)malloc((size_t)bw * bh * channels);
+	uint8_t *full = (uint8_t *)malloc((size_t)bw * bh * channels);
+	if (!small || !full) {
+		free(small);
+		free(full);
+		return -2;
+	}
+	int err = 0;
+	for (uint32_t t = 0; t < cols * rows && !err; t++) {
+		uint32_t x0, y0, w, h;
+		orc_tile_rect(width, height, bw, bh, t, &x0, &y0, &w, &h);
+		const uint8_t *tile = pixels + (size_t)y0 * pitch + (size_t)x0 * channels;
+		float value = lod_oklab_scaled(tile, w, h, channels, pitch, 1.0f, 1.0f);
+		uint32_t nw, nh;
+		float stored;
+		orc_reduce_dims(value, value, w, h, &nw, &nh, &stored);
+		if (orc_resize(tile, w, h, channels, pitch, small, nw, nh, filter_down) != 0 ||
+		    orc_resize(small, nw, nh, channels, nw * channels, full, w, h, filter_up) != 0) {
+			err = -3;
+			break;
+		}
+		for (uint32_t y = 0; y < h; y++) {
+			uint8_t *d = out_rgba + (size_t)(y0 + y) * out_pitch + (size_t)x0 * 4;
+			const uint8_t *sp = full + (size_t)y * w * channels;
+			for (uint32_t x = 0; x < w; x++) {
+				d[4 * x + 0] = sp[channels * x + 0];
+				d[4 * x + 1] = sp[channels * x + 1];
+				d[4 * x + 2] = sp[channels * x + 2];
+				d[4 * x + 3] = channels == 4 ? sp[4 * x + 3] : 255;
+			}
+		}
+	}
+	free(small);
+	free(full);
+	return err;
 }

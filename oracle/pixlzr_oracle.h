@@ -92,6 +92,12 @@ int orc_expand_image(uint32_t width, uint32_t height, uint32_t bw, uint32_t bh, 
                      const uint32_t *tile_w, const uint32_t *tile_h, const uint8_t *slots, size_t slot_stride,
                      uint8_t *out_pixels, uint32_t out_pitch);
 
+/* process() / process_custom (process/mod.rs:71-121): per tile Oklab MAD with the identity closure ->
+ * reduce_image_section((v, v)) with filter_down -> resize back with filter_up -> RGBA8 image. */
+int orc_process_image(const uint8_t *pixels, uint32_t width, uint32_t height, uint32_t channels, uint32_t pitch,
+                      uint32_t bw, uint32_t bh, uint32_t filter_down, uint32_t filter_up, uint8_t *out_rgba,
+                      uint32_t out_pitch);
+
 size_t orc_qoi_bound(uint32_t w, uint32_t h, uint32_t c);
 /* full QOI stream incl. "qoif" magic; returns length */
 size_t orc_qoi_encode(const uint8_t *data, uint32_t w, uint32_t h, uint32_t c, uint8_t *out);

@@ -19,7 +19,7 @@ EXPORTED_SYMBOLS = [
     "pxz_synchronize", "pxz_grid", "pxz_shrink_image", "pxz_shrink_frames_device", "pxz_lod_frames_device",
     "pxz_pack_tiles_device", "pxz_encode_frames_device", "pxz_encode_container", "pxz_qoi_encode", "pxz_qoi_bound", "pxz_synth_frames_device", "pxz_axis_table",
     "pxz_enable_timing", "pxz_last_kernel_ms",
-    "pxz_expand_frames_device", "pxz_expand_image", "pxz_decode_frames_device", "pxz_decode_status",
+    "pxz_expand_frames_device", "pxz_expand_image", "pxz_decode_frames_device", "pxz_decode_status", "pxz_process_frames_device",
 ]
 
 STATUS = {0: "PXZ_OK", -1: "PXZ_ERR_INVALID_ARG", -2: "PXZ_ERR_NO_DEVICE", -3: "PXZ_ERR_HIP",
@@ -111,6 +111,8 @@ def load_library():
     L.pxz_qoi_bound.argtypes = [u32] * 3
     L.pxz_expand_frames_device.restype = C.c_int
     L.pxz_expand_frames_device.argtypes = [vp, C.POINTER(Frames), C.POINTER(Params)] + [vp] * 4
+    L.pxz_process_frames_device.restype = C.c_int
+    L.pxz_process_frames_device.argtypes = [vp, C.POINTER(Frames), C.POINTER(Params), u32, vp, vp, u32, C.c_uint64]
     L.pxz_decode_status.restype = C.c_int
     L.pxz_decode_status.argtypes = [vp, C.POINTER(u32)]
     L.pxz_decode_frames_device.restype = C.c_int
@@ -297,6 +299,18 @@ class Handle:
         self._check(self._L.pxz_expand_frames_device(self._h, C.byref(fd), C.byref(pd), C.c_void_p(ow.data_ptr()),
                                                      C.c_void_p(oh.data_ptr()), C.c_void_p(slots.data_ptr()),
                                                      C.c_void_p(out.data_ptr())))
+        return out
+
+    def process_frames_device(self, frames, bw, bh, filter_down=4, filter_up=0):
+        """process_custom with |x - avg| / identity (process/mod.rs:71-121): frames [N,H,W,C] -> RGBA [N,H,W,4]."""
+        import torch
+        fd, (N, H, W, Cc) = self._frames_desc(frames)
+        out = torch.empty((N, H, W, 4), dtype=torch.uint8, device=frames.device)
+        pd = Params(bw, bh, 0, filter_down, 1.0, 0)
+        self.use_torch_stream()
+        self._check(self._L.pxz_process_frames_device(self._h, C.byref(fd), C.byref(pd), filter_up,
+                                                      C.c_void_p(frames.data_ptr()), C.c_void_p(out.data_ptr()),
+                                                      W * 4, W * 4 * H))
         return out
 
     def decode_status(self):

@@ -473,6 +473,7 @@ int prepare(pxz_handle *h, const pxz_frames *f, const pxz_params *p, bool want_p
 	a->mode = p->mode;
 	a->filter = p->filter;
 	a->factor = p->factor;
+	a->scale2 = 10.0f;  // BASE_FACTOR, pixlzr.rs:15
 	a->slot_bytes = bw * bh * f->channels;
 	build_breaks(h, a);
 	std::memset(a->tabs, 0, sizeof a->tabs);
@@ -681,8 +682,9 @@ int pxz_lod_frames_device(pxz_handle *h, const pxz_frames *frames, const pxz_par
 	return timed_launch(h, a, frames->channels, nullptr, d_lod0, d_lod1);
 }
 
-int pxz_expand_frames_device(pxz_handle *h, const pxz_frames *frames, const pxz_params *params, const uint32_t *d_tile_w,
-                             const uint32_t *d_tile_h, const uint8_t *d_slots, uint8_t *d_out_pixels)
+// frames: the OUTPUT batch (its channels = bytes per output pixel); slot_channels: channels of the stored tiles
+static int expand_launch(pxz_handle *h, const pxz_frames *frames, uint32_t slot_channels, const pxz_params *params,
+                         const uint32_t *d_tile_w, const uint32_t *d_tile_h, const uint8_t *d_slots, uint8_t *d_out_pixels)
 {
 	if (!h) return PXZ_ERR_INVALID_ARG;
 	if (!frames || !params) return fail(h, PXZ_ERR_INVALID_ARG, "null descriptor");
@@ -710,7 +712,7 @@ int pxz_expand_frames_device(pxz_handle *h, const pxz_frames *frames, const pxz_
 	a.pitch = frames->pitch_bytes;
 	a.width = frames->width;
 	a.height = frames->height;
-	a.channels = frames->channels;
+	a.channels = slot_channels;
 	a.bw = bw;
 	a.bh = bh;
 	a.cols = cols;
@@ -719,8 +721,9 @@ int pxz_expand_frames_device(pxz_handle *h, const pxz_frames *frames, const pxz_
 	a.n_tiles = cols * rows * frames->n_frames;
 	a.edge_w = frames->width - (cols - 1) * bw;
 	a.edge_h = frames->height - (rows - 1) * bh;
-	a.slot_bytes = bw * bh * frames->channels;
+	a.slot_bytes = bw * bh * slot_channels;
 	a.filter = p.filter;
+	a.out_channels = frames->channels;
 	const ExpandTables *et = nullptr;
 	if ((rc = get_expand_tables(h, bw, bh, a.edge_w, a.edge_h, p.filter, &et)) != PXZ_OK) return rc;
 	a.tabs = et->d_dir;
@@ -734,6 +737,49 @@ int pxz_expand_frames_device(pxz_handle *h, const pxz_frames *frames, const pxz_
 	PXZ_HIP(h, hipMemsetAsync(a.status, 0, 4, h->stream));
 	PXZ_HIP(h, pxz::launch_expand(a, h->n_cus, h->stream));
 	return PXZ_OK;
+}
+
+int pxz_expand_frames_device(pxz_handle *h, const pxz_frames *frames, const pxz_params *params, const uint32_t *d_tile_w,
+                             const uint32_t *d_tile_h, const uint8_t *d_slots, uint8_t *d_out_pixels)
+{
+	if (!h) return PXZ_ERR_INVALID_ARG;
+	if (!frames) return fail(h, PXZ_ERR_INVALID_ARG, "null descriptor");
+	return expand_launch(h, frames, frames->channels, params, d_tile_w, d_tile_h, d_slots, d_out_pixels);
+}
+
+int pxz_process_frames_device(pxz_handle *h, const pxz_frames *frames, const pxz_params *params, uint32_t filter_upscale,
+                              const uint8_t *d_pixels, uint8_t *d_out_rgba, uint32_t out_pitch_bytes,
+                              uint64_t out_frame_stride_bytes)
+{
+	if (!h) return PXZ_ERR_INVALID_ARG;
+	if (!frames || !params) return fail(h, PXZ_ERR_INVALID_ARG, "null descriptor");
+	if (!d_pixels || !d_out_rgba) return fail(h, PXZ_ERR_INVALID_ARG, "null device pointer");
+	if (filter_upscale > 4) return fail(h, PXZ_ERR_INVALID_ARG, "filter must be 0..4");
+	PXZ_HIP(h, hipSetDevice(h->device));
+	// 1) get_block_variance with |x - avg| and the identity (process/mod.rs:108-111) -> reduce_image_section((v, v))
+	pxz_params p = *params;
+	p.mode = PXZ_MODE_SHRINK_BY;
+	p.factor = 1.0f;
+	pxz::ShrinkArgs a{};
+	int rc = prepare(h, frames, &p, true, &a);
+	if (rc != PXZ_OK) return rc;
+	a.factor = 1.0f;
+	a.scale2 = 1.0f;  // (x * 1) * 1 is x exactly: the identity closure
+	const size_t tiles = a.n_tiles, slot = (size_t)a.bw * a.bh * frames->channels;
+	if ((rc = ensure(h, h->val, tiles * 4)) != PXZ_OK) return rc;
+	if ((rc = ensure(h, h->ow, tiles * 4)) != PXZ_OK) return rc;
+	if ((rc = ensure(h, h->oh, tiles * 4)) != PXZ_OK) return rc;
+	if ((rc = ensure(h, h->out, tiles * slot)) != PXZ_OK) return rc;
+	a.src = d_pixels;
+	a.out_w = (uint32_t *)h->ow.ptr;
+	a.out_h = (uint32_t *)h->oh.ptr;
+	a.out_px = (uint8_t *)h->out.ptr;
+	if ((rc = timed_launch(h, a, frames->channels, (float *)h->val.ptr, nullptr, nullptr)) != PXZ_OK) return rc;
+	// 2) .resize(w0, h0, filter_upscale) + copy_from into the RGBA output (process/mod.rs:58-63)
+	pxz_frames of{frames->width, frames->height, 4, out_pitch_bytes, frames->n_frames, 0, out_frame_stride_bytes};
+	pxz_params up{params->block_w, params->block_h, 0, filter_upscale, 0.0f, 0};
+	return expand_launch(h, &of, frames->channels, &up, (const uint32_t *)h->ow.ptr, (const uint32_t *)h->oh.ptr,
+	                     (const uint8_t *)h->out.ptr, d_out_rgba);
 }
 
 int pxz_decode_frames_device(pxz_handle *h, const pxz_frames *frames, const pxz_params *params, const uint8_t *d_files,

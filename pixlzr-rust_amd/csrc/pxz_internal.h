@@ -58,6 +58,8 @@ struct ShrinkArgs {
 	float factor;
 	// outputs (device); out_px may be null (no resample), out_w/out_h may be null
 	uint32_t oklab_given;    // 1: full 32x32 RGBA tiles already carry their Oklab value in sums[] (oklab32_kernel)
+	float scale2;            // Oklab mode: value = mean deviation * factor * scale2 (10 = BASE_FACTOR of shrink_by,
+	                         //   pixlzr.rs:15,162; 1 with factor 1 = the identity closure of process(), process/mod.rs:107-121)
 	uint32_t full_cols, full_rows;  // 32x32 fast path: tile (tx, ty) is eligible iff tx < full_cols && ty < full_rows
 	                                //   (full size, 16-byte aligned rows; 0/0 when the batch is not aligned)
 	uint32_t *work;          // worklist: [work_slot] = count, [2..] = tile ids (null: all tiles).  The two
@@ -172,6 +174,7 @@ struct ExpandArgs {
 	uint32_t pitch, width, height, channels;
 	uint32_t bw, bh, cols, rows, tiles_per_frame, n_tiles, edge_w, edge_h;
 	uint32_t slot_bytes, filter;
+	uint32_t out_channels;            // bytes per pixel in dst (4 with channels == 3: alpha 255 is added, process())
 	// tabs[(axis*2 + cls) * dir_stride + in_size], in_size in [1, full]; dir_stride = max(bw, bh) + 1
 	const ExpandTab *tabs;
 	uint32_t dir_stride;

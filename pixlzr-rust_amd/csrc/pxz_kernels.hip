@@ -958,7 +958,7 @@ __device__ __forceinline__ void process_tile(const ShrinkArgs &a, const uint32_t
 			total = d0 + d1 + d2;                      // :124
 			if constexpr (C == 4) total = total + __shfl(delta, 3, 64);  // :89
 		}
-		float value = __fdiv_rn(total, count) * a.factor * 10.0f;  // pixlzr.rs:162
+		float value = __fdiv_rn(total, count) * a.factor * a.scale2;  // pixlzr.rs:162
 		if constexpr (NW > 1) {
 			if (threadIdx.x == 0) s_red[0] = __float_as_uint(value);
 			__syncthreads();
@@ -1781,7 +1781,7 @@ __global__ void __launch_bounds__(1024) oklab32_kernel(const ShrinkArgs a)
 						const float d0 = __shfl(acc2, (int)(lane & ~3u) + 0, 64), d1 = __shfl(acc2, (int)(lane & ~3u) + 1, 64);
 						const float d2 = __shfl(acc2, (int)(lane & ~3u) + 2, 64), d3 = __shfl(acc2, (int)(lane & ~3u) + 3, 64);
 						const float total = d0 + d1 + d2 + d3;  // :89
-						const float value = __fdiv_rn(total, 1024.0f) * a.factor * 10.0f;  // pixlzr.rs:162
+						const float value = __fdiv_rn(total, 1024.0f) * a.factor * a.scale2;  // pixlzr.rs:162
 						const uint32_t tg = (blockIdx.x + (pp - 1u) * gridDim.x) * kOkTiles + ct;
 						const uint8_t *unused;
 						if (live && cc == 0 && fast32_tile_src(a, tg, unused))
@@ -1851,11 +1851,13 @@ __global__ void __launch_bounds__(256) expand_kernel(const ExpandArgs a)
 		const uint32_t ty = tf / a.cols, tx = tf - ty * a.cols;
 		const uint32_t fw = (tx == a.cols - 1) ? a.edge_w : a.bw, fh = (ty == a.rows - 1) ? a.edge_h : a.bh;
 		const uint32_t tw = a.tile_w[t], th = a.tile_h[t];
-		uint8_t *dst = a.dst + (size_t)frame * a.frame_stride + (size_t)(ty * a.bh) * a.pitch + (size_t)(tx * a.bw) * C;
+		const bool widen = C == 3 && a.out_channels == 4;  // RGB tiles into an RGBA frame (process())
+		const uint32_t opx = widen ? 4u : (uint32_t)C;
+		uint8_t *dst = a.dst + (size_t)frame * a.frame_stride + (size_t)(ty * a.bh) * a.pitch + (size_t)(tx * a.bw) * opx;
 		auto put = [&](uint32_t ox, uint32_t oy, uint32_t px) {
-			uint8_t *p = dst + (size_t)oy * a.pitch + ox * (uint32_t)C;
-			if constexpr (C == 4) {
-				*reinterpret_cast<uint32_t *>(p) = px;
+			uint8_t *p = dst + (size_t)oy * a.pitch + ox * opx;
+			if (C == 4 || widen) {
+				*reinterpret_cast<uint32_t *>(p) = px;  // C == 3: alpha was set to 255 when the tile was staged
 			} else {
 				p[0] = (uint8_t)px;
 				p[1] = (uint8_t)(px >> 8);

@@ -438,3 +438,22 @@ def test_encode_decode_round_trip_on_device(gpu, oracle, c):
     assert gpu.decode_status() == 2
     assert int(w3[0, 0]) == 0 and int(h3[0, 0]) == 0
     assert (w3[1:] == ow[1:]).all()
+
+
+# ---- legacy image -> image filter: process() / process_custom ----------------------------------
+
+@pytest.mark.parametrize("c,dist", [(4, 0), (4, 1), (3, 0)])
+@pytest.mark.parametrize("block,down,up", [(32, 4, 0), (32, 2, 4), (64, 4, 0), (20, 3, 1)])
+def test_process_matches_oracle(gpu, oracle, c, dist, block, down, up):
+    """process(image, n) = Lanczos3 down / Nearest up (process/mod.rs:107-121) and process_custom with other
+    filter pairs: Oklab MAD with the identity closure, shrink, resize back, RGBA8 output; opaque RGBA through
+    the 32x32 fast kernels, transparent RGBA, RGB (alpha 255 added), ragged grids."""
+    import torch
+    frames = gpu.synth_frames_device(2, 200, 328, c, first_frame=11, dist=dist)
+    out = gpu.process_frames_device(frames, block, block, down, up).cpu().numpy()
+    f = frames.cpu().numpy()
+    for n in range(2):
+        exp = oracle.process_image(f[n], block, block, down, up)
+        bad = (out[n] != exp).any(axis=2)
+        assert not bad.any(), f"frame {n}: {int(bad.sum())} pixels differ"
+    assert gpu.decode_status() == 0
