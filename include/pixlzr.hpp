@@ -5,6 +5,8 @@
 //   Pixlzr::shrink_by             src/data_types/pixlzr.rs:155-185   (runs on the MI355X)
 //   Pixlzr::shrink_directionally  src/data_types/pixlzr.rs:187-205   (runs on the MI355X)
 //   Pixlzr::encode_to_vec / save  src/encoding/mod.rs:40-89, src/io.rs:88-95
+//   Pixlzr::decode_from_vec / open  src/encoding/mod.rs:95-165, src/io.rs:80-87   (runs on the MI355X)
+//   Pixlzr::expand / to_image     src/data_types/pixlzr.rs:77-122, pixlzr_image.rs:24-74 (runs on the MI355X)
 //   PixlzrBlock                   src/data_types/block.rs:56-230
 // Errors: the reference panics inside this path (unwrap / usize underflow); here they are
 // std::runtime_error carrying the pxz_status text.  There is no CPU fallback.
@@ -65,6 +67,18 @@ public:
 
 	std::vector<uint8_t> encode_to_vec() const;   // encoding/mod.rs:40-89
 	void save(const std::string &path) const;     // io.rs:88-95
+
+	// decode side
+	static Pixlzr decode_from_vec(const std::vector<uint8_t> &bytes, int device_id = 0);  // encoding/mod.rs:95-165
+	static Pixlzr open(const std::string &path, int device_id = 0);                       // io.rs:80-87
+	// every tile resized back to its full size (pixlzr.rs:77-122); filter = Some(filter_upscale)
+	Pixlzr expand(FilterType filter_upscale, int device_id = 0) const;
+	// expand + reassembly (pixlzr_image.rs:24-74): interleaved pixels, RGBA if any tile has alpha, else RGB
+	struct Image {
+		uint32_t width = 0, height = 0, channels = 0;
+		std::vector<uint8_t> data;
+	};
+	Image to_image(FilterType filter_upscale, int device_id = 0) const;
 
 private:
 	void shrink_on_device(uint32_t mode, FilterType f, float factor, int device_id);

@@ -154,6 +154,14 @@ int pxz_decode_frames_device(pxz_handle *h, const pxz_frames *frames, const pxz_
                              const uint8_t *d_files, const uint64_t *d_file_offsets, float *d_block_value,
                              uint32_t *d_tile_w, uint32_t *d_tile_h, uint8_t *d_slots);
 
+/* The same for one host-resident file (Pixlzr::decode_from_vec, mod.rs:95-165).  The header fields are
+ * always returned; with all four output pointers NULL the call stops there (size query: the grid is
+ * pxz_grid(width, height, block_w, block_h), slots need block_w*block_h*channels bytes per tile).
+ * PXZ_ERR_INVALID_ARG for a malformed file (the reference panics / returns the qoi error). */
+int pxz_decode_file(pxz_handle *h, const uint8_t *file, size_t len, uint32_t *width, uint32_t *height,
+                    uint32_t *block_w, uint32_t *block_h, uint32_t *channels, uint32_t *filter_byte,
+                    float *block_value, uint32_t *tile_w, uint32_t *tile_h, uint8_t *slots);
+
 /* Waits for the handle's stream; flags of the last decode-side call on this handle:
  * bit 0  pxz_expand_frames_device met a tile whose stored size is zero or exceeds its place,
  * bit 1  pxz_decode_frames_device met a malformed file or record. */

@@ -19,7 +19,7 @@ EXPORTED_SYMBOLS = [
     "pxz_synchronize", "pxz_grid", "pxz_shrink_image", "pxz_shrink_frames_device", "pxz_lod_frames_device",
     "pxz_pack_tiles_device", "pxz_encode_frames_device", "pxz_encode_container", "pxz_qoi_encode", "pxz_qoi_bound", "pxz_synth_frames_device", "pxz_axis_table",
     "pxz_enable_timing", "pxz_last_kernel_ms",
-    "pxz_expand_frames_device", "pxz_expand_image", "pxz_decode_frames_device", "pxz_decode_status", "pxz_process_frames_device",
+    "pxz_expand_frames_device", "pxz_expand_image", "pxz_decode_frames_device", "pxz_decode_file", "pxz_decode_status", "pxz_process_frames_device",
 ]
 
 STATUS = {0: "PXZ_OK", -1: "PXZ_ERR_INVALID_ARG", -2: "PXZ_ERR_NO_DEVICE", -3: "PXZ_ERR_HIP",
@@ -111,6 +111,8 @@ def load_library():
     L.pxz_qoi_bound.argtypes = [u32] * 3
     L.pxz_expand_frames_device.restype = C.c_int
     L.pxz_expand_frames_device.argtypes = [vp, C.POINTER(Frames), C.POINTER(Params)] + [vp] * 4
+    L.pxz_decode_file.restype = C.c_int
+    L.pxz_decode_file.argtypes = [vp, vp, C.c_size_t] + [C.POINTER(u32)] * 6 + [vp] * 4
     L.pxz_process_frames_device.restype = C.c_int
     L.pxz_process_frames_device.argtypes = [vp, C.POINTER(Frames), C.POINTER(Params), u32, vp, vp, u32, C.c_uint64]
     L.pxz_decode_status.restype = C.c_int

@@ -4,6 +4,7 @@
 #include <cmath>
 #include <cstring>
 #include <fstream>
+#include <iterator>
 #include <map>
 #include <stdexcept>
 
@@ -142,6 +143,96 @@ std::vector<uint8_t> Pixlzr::encode_to_vec() const
 	                                       tw.data(), th.data(), slots.data(), out.data(), out.size());
 	if (n < 0) throw std::runtime_error("pxz_encode_container failed: " + std::to_string(n));
 	out.resize((size_t)n);
+	return out;
+}
+
+Pixlzr Pixlzr::decode_from_vec(const std::vector<uint8_t> &bytes, int device_id)
+{
+	pxz_handle *h = g_handles.get(device_id);
+	uint32_t w, hh, bw, bh, c, fb;
+	int rc = pxz_decode_file(h, bytes.data(), bytes.size(), &w, &hh, &bw, &bh, &c, &fb, nullptr, nullptr, nullptr, nullptr);
+	if (rc != PXZ_OK) throw std::runtime_error(std::string("decode_from_vec: ") + pxz_last_error(h));
+	uint32_t cols = 0, rows = 0;
+	pxz_grid(w, hh, bw, bh, &cols, &rows);
+	const size_t tiles = (size_t)cols * rows, slot = (size_t)bw * bh * c;
+	std::vector<float> value(tiles);
+	std::vector<uint32_t> tw(tiles), th(tiles);
+	std::vector<uint8_t> slots(tiles * slot);
+	rc = pxz_decode_file(h, bytes.data(), bytes.size(), &w, &hh, &bw, &bh, &c, &fb, value.data(), tw.data(), th.data(), slots.data());
+	if (rc != PXZ_OK) throw std::runtime_error(std::string("decode_from_vec: ") + pxz_last_error(h));
+	Pixlzr p;
+	p.width = w;
+	p.height = hh;
+	p.block_width = bw;
+	p.block_height = bh;
+	p.filter = (FilterType)(fb <= 4 ? fb : 0);  // From<u8> for FilterType, mod.rs:110-121
+	p.blocks.resize(tiles);
+	for (size_t t = 0; t < tiles; ++t) {
+		PixlzrBlock &b = p.blocks[t];
+		b.width = tw[t];
+		b.height = th[t];
+		b.block_value = value[t];  // decode_block always yields Some(value), mod.rs:210-215
+		b.alpha = c == 4;
+		b.data.assign(slots.begin() + t * slot, slots.begin() + t * slot + (size_t)tw[t] * th[t] * c);
+	}
+	return p;
+}
+
+Pixlzr Pixlzr::open(const std::string &path, int device_id)
+{
+	std::ifstream f(path, std::ios::binary);
+	if (!f) throw std::runtime_error("open: cannot open " + path);
+	std::vector<uint8_t> bytes((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+	return decode_from_vec(bytes, device_id);
+}
+
+Pixlzr::Image Pixlzr::to_image(FilterType f, int device_id) const
+{
+	Image img;
+	if (blocks.empty()) return img;
+	bool any_alpha = false;
+	for (const PixlzrBlock &b : blocks) any_alpha = any_alpha || b.has_alpha();  // pixlzr_image.rs:28-33
+	const uint32_t channels = any_alpha ? 4u : 3u;
+	const size_t tiles = blocks.size(), slot = (size_t)block_width * block_height * channels;
+	if (tiles != (size_t)block_grid_width() * block_grid_height()) throw std::runtime_error("to_image: block list does not match the grid");
+	std::vector<uint32_t> tw(tiles), th(tiles);
+	std::vector<uint8_t> slots(tiles * slot);
+	for (size_t t = 0; t < tiles; ++t) {
+		const PixlzrBlock &b = blocks[t];
+		tw[t] = b.width;
+		th[t] = b.height;
+		const size_t n = (size_t)b.width * b.height;
+		if (n * channels > slot || b.data.size() != n * b.pixel_size()) throw std::runtime_error("to_image: malformed block");
+		uint8_t *d = slots.data() + t * slot;
+		if (b.pixel_size() == channels) {
+			std::memcpy(d, b.data.data(), b.data.size());
+		} else {  // an RGB tile in an RGBA image: alpha 255 (copy_from's pixel conversion)
+			for (size_t i = 0; i < n; ++i) {
+				d[4 * i] = b.data[3 * i];
+				d[4 * i + 1] = b.data[3 * i + 1];
+				d[4 * i + 2] = b.data[3 * i + 2];
+				d[4 * i + 3] = 255;
+			}
+		}
+	}
+	img.width = width;
+	img.height = height;
+	img.channels = channels;
+	img.data.resize((size_t)width * height * channels);
+	pxz_handle *h = g_handles.get(device_id);
+	const int rc = pxz_expand_image(h, width, height, channels, width * channels, block_width, block_height, (uint32_t)f, tw.data(),
+	                                th.data(), slots.data(), img.data.data());
+	if (rc != PXZ_OK) throw std::runtime_error(std::string("pxz_expand_image: ") + pxz_last_error(h));
+	return img;
+}
+
+Pixlzr Pixlzr::expand(FilterType f, int device_id) const
+{
+	// expand = the tiles of to_image before reassembly (pixlzr.rs:77-122): cut them back out of the image
+	const Image img = to_image(f, device_id);
+	ImageView view{img.data.data(), img.width, img.height, img.channels, img.width * img.channels};
+	Pixlzr out = from_image(view, block_width, block_height);
+	out.filter = f;
 	return out;
 }
 

@@ -833,6 +833,57 @@ int pxz_decode_frames_device(pxz_handle *h, const pxz_frames *frames, const pxz_
 	return PXZ_OK;
 }
 
+int pxz_decode_file(pxz_handle *h, const uint8_t *file, size_t len, uint32_t *width, uint32_t *height, uint32_t *block_w,
+                    uint32_t *block_h, uint32_t *channels, uint32_t *filter_byte, float *block_value, uint32_t *tile_w,
+                    uint32_t *tile_h, uint8_t *slots)
+{
+	if (!h) return PXZ_ERR_INVALID_ARG;
+	if (!file || !width || !height || !block_w || !block_h || !channels || !filter_byte) return fail(h, PXZ_ERR_INVALID_ARG, "null pointer");
+	static const uint8_t magic[9] = {'P', 'I', 'X', 'L', 'Z', 'R', 0, 0, 2};
+	if (len < 26 || std::memcmp(file, magic, 9) != 0) return fail(h, PXZ_ERR_INVALID_ARG, "not a .pixlzr v0.0.2 file");
+	auto be = [&](size_t o) { return ((uint32_t)file[o] << 24) | ((uint32_t)file[o + 1] << 16) | ((uint32_t)file[o + 2] << 8) | file[o + 3]; };
+	*filter_byte = file[9];
+	*width = be(10);
+	*height = be(14);
+	*block_w = be(18);
+	*block_h = be(22);
+	if (*width == 0 || *height == 0 || *block_w == 0 || *block_h == 0) return fail(h, PXZ_ERR_INVALID_ARG, "empty image or block in the header");
+	uint32_t cols, rows;
+	pxz_grid(*width, *height, *block_w, *block_h, &cols, &rows);
+	const size_t first = 26 + (size_t)rows * 4;
+	if (len < first + 13 + 10) return fail(h, PXZ_ERR_INVALID_ARG, "file ends inside the first record");
+	*channels = file[first + 21];  // the first record's QOI header (decode_block, mod.rs:202-242)
+	if (*channels != 3 && *channels != 4) return fail(h, PXZ_ERR_INVALID_ARG, "first record has %u channels", *channels);
+	if (!block_value && !tile_w && !tile_h && !slots) return PXZ_OK;  // header query
+	if (!block_value || !tile_w || !tile_h || !slots) return fail(h, PXZ_ERR_INVALID_ARG, "null output pointer");
+	PXZ_HIP(h, hipSetDevice(h->device));
+	const size_t tiles = (size_t)cols * rows, slot = (size_t)*block_w * *block_h * *channels;
+	int rc;
+	if ((rc = ensure(h, h->in, len + 16)) != PXZ_OK) return rc;
+	if ((rc = ensure(h, h->val, tiles * 4)) != PXZ_OK) return rc;
+	if ((rc = ensure(h, h->ow, tiles * 4)) != PXZ_OK) return rc;
+	if ((rc = ensure(h, h->oh, tiles * 4)) != PXZ_OK) return rc;
+	if ((rc = ensure(h, h->out, tiles * slot)) != PXZ_OK) return rc;
+	if ((rc = ensure(h, h->chunks, 16)) != PXZ_OK) return rc;
+	const uint64_t offs[2] = {0, (uint64_t)len};
+	PXZ_HIP(h, hipMemcpyAsync(h->in.ptr, file, len, hipMemcpyHostToDevice, h->stream));
+	PXZ_HIP(h, hipMemcpyAsync(h->chunks.ptr, offs, 16, hipMemcpyHostToDevice, h->stream));
+	PXZ_HIP(h, hipMemsetAsync(h->out.ptr, 0, tiles * slot, h->stream));
+	pxz_frames f{*width, *height, *channels, *width * *channels, 1, 0, 0};
+	pxz_params p{*block_w, *block_h, 0, 0, 0.0f, 0};
+	rc = pxz_decode_frames_device(h, &f, &p, (const uint8_t *)h->in.ptr, (const uint64_t *)h->chunks.ptr, (float *)h->val.ptr,
+	                              (uint32_t *)h->ow.ptr, (uint32_t *)h->oh.ptr, (uint8_t *)h->out.ptr);
+	if (rc != PXZ_OK) return rc;
+	PXZ_HIP(h, hipMemcpyAsync(block_value, h->val.ptr, tiles * 4, hipMemcpyDeviceToHost, h->stream));
+	PXZ_HIP(h, hipMemcpyAsync(tile_w, h->ow.ptr, tiles * 4, hipMemcpyDeviceToHost, h->stream));
+	PXZ_HIP(h, hipMemcpyAsync(tile_h, h->oh.ptr, tiles * 4, hipMemcpyDeviceToHost, h->stream));
+	PXZ_HIP(h, hipMemcpyAsync(slots, h->out.ptr, tiles * slot, hipMemcpyDeviceToHost, h->stream));
+	uint32_t flags = 0;
+	if ((rc = pxz_decode_status(h, &flags)) != PXZ_OK) return rc;
+	if (flags & 2u) return fail(h, PXZ_ERR_INVALID_ARG, "malformed .pixlzr file or record");
+	return PXZ_OK;
+}
+
 int pxz_decode_status(pxz_handle *h, uint32_t *flags)
 {
 	if (!h || !flags) return PXZ_ERR_INVALID_ARG;
