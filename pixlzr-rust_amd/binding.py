@@ -321,7 +321,7 @@ class Handle:
         self._check(self._L.pxz_decode_status(self._h, C.byref(flags)))
         return flags.value
 
-    def decode_frames_device(self, files, file_offsets, shape, bw, bh):
+    def decode_frames_device(self, files, file_offsets, shape, bw, bh, out=None):
         """files: uint8 CUDA tensor holding N .pixlzr files back to back, file_offsets int64[N+1] (CUDA).
         Returns (values[N,T], w[N,T], h[N,T], slots[N,T,bw*bh*C]) for frames of `shape` = (N,H,W,C)."""
         import torch
@@ -329,10 +329,13 @@ class Handle:
         cols, rows = grid(W, H, bw, bh)
         T = cols * rows
         dev = files.device
-        vals = torch.zeros((N, T), dtype=torch.float32, device=dev)
-        ow = torch.zeros((N, T), dtype=torch.int32, device=dev)
-        oh = torch.zeros((N, T), dtype=torch.int32, device=dev)
-        slots = torch.zeros((N, T, bw * bh * Cc), dtype=torch.uint8, device=dev)
+        if out is None:
+            vals = torch.zeros((N, T), dtype=torch.float32, device=dev)
+            ow = torch.zeros((N, T), dtype=torch.int32, device=dev)
+            oh = torch.zeros((N, T), dtype=torch.int32, device=dev)
+            slots = torch.zeros((N, T, bw * bh * Cc), dtype=torch.uint8, device=dev)
+        else:
+            vals, ow, oh, slots = out
         fd = Frames(W, H, Cc, W * Cc, N, 0, W * Cc * H)
         pd = Params(bw, bh, 0, 0, 0.0, 0)
         self.use_torch_stream()

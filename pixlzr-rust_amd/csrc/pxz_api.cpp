@@ -700,7 +700,8 @@ static int expand_launch(pxz_handle *h, const pxz_frames *frames, uint32_t slot_
 	pxz_grid(frames->width, frames->height, bw, bh, &cols, &rows);
 	if ((uint64_t)cols * rows * frames->n_frames > 0xffffffffull) return fail(h, PXZ_ERR_UNSUPPORTED, "too many tiles");
 	if (bw > 0xffffu || bh > 0xffffu) return fail(h, PXZ_ERR_UNSUPPORTED, "block side above 65535");
-	const uint64_t lds_bytes = 2ull * bw * bh * 4ull + 16ull;  // source pixels + horizontal-pass result of one wave
+	// one wave: source pixels + horizontal-pass result + the staged windows (5 dwords per output sample of both axes)
+	const uint64_t lds_bytes = (2ull * bw * bh + 5ull * (bw + bh) + 3ull) / 4ull * 16ull + 16ull;
 	if (lds_bytes > 160u * 1024u)
 		return fail(h, PXZ_ERR_UNSUPPORTED, "a %ux%u tile needs %llu B of LDS (limit 163840)", bw, bh, (unsigned long long)lds_bytes);
 	pxz::ExpandArgs a{};
@@ -731,7 +732,7 @@ static int expand_launch(pxz_handle *h, const pxz_frames *frames, uint32_t slot_
 	a.starts = et->d_starts;
 	a.sizes = et->d_sizes;
 	a.coeffs = et->d_coeffs;
-	a.tile_dw = 2u * bw * bh;
+	a.tile_dw = (2u * bw * bh + 5u * (bw + bh) + 3u) & ~3u;
 	if ((rc = ensure(h, h->status, 4)) != PXZ_OK) return rc;
 	a.status = (uint32_t *)h->status.ptr;
 	PXZ_HIP(h, hipMemsetAsync(a.status, 0, 4, h->stream));
@@ -823,9 +824,11 @@ int pxz_decode_frames_device(pxz_handle *h, const pxz_frames *frames, const pxz_
 	a.slot_bytes = p.block_w * p.block_h * f.channels;
 	a.edge_w = f.width - (cols - 1) * p.block_w;
 	a.edge_h = f.height - (rows - 1) * p.block_h;
-	if ((rc = ensure(h, h->dmeta, (size_t)a.n_tiles * 12u)) != PXZ_OK) return rc;
+	if ((rc = ensure(h, h->dmeta, (size_t)a.n_tiles * 16u + 256u)) != PXZ_OK) return rc;
 	a.rec_off = (unsigned long long *)h->dmeta.ptr;
 	a.rec_len = (uint32_t *)((uint8_t *)h->dmeta.ptr + (size_t)a.n_tiles * 8u);
+	a.perm = a.rec_len + a.n_tiles;
+	a.bins = a.perm + a.n_tiles;
 	if ((rc = ensure(h, h->status, 4)) != PXZ_OK) return rc;
 	a.status = (uint32_t *)h->status.ptr;
 	PXZ_HIP(h, hipMemsetAsync(a.status, 0, 4, h->stream));

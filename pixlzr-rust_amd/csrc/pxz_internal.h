@@ -193,6 +193,7 @@ struct DecodeArgs {
 	uint8_t *slots;
 	unsigned long long *rec_off;            // scratch, per tile: offset of the record's QOI body in files[]
 	uint32_t *rec_len;                      // scratch, per tile: length of that body (0: unusable)
+	uint32_t *perm, *bins;                  // scratch: tiles ordered by pixel count (as in the encoder), 64 counters
 	uint32_t *status;                       // bit 1: malformed file / record
 	uint32_t width, height, bw, bh, cols, rows, tiles_per_frame, n_tiles, n_frames, channels, slot_bytes;
 	uint32_t edge_w, edge_h;

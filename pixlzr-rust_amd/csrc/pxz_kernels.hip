@@ -1885,7 +1885,142 @@ __global__ void __launch_bounds__(256) expand_kernel(const ExpandArgs a)
 			const uint32_t cls_x = fw == a.bw ? 0u : 1u, cls_y = fh == a.bh ? 0u : 1u;
 			const ExpandTab tab_x = a.tabs[(0u * 2u + cls_x) * a.dir_stride + tw];
 			const ExpandTab tab_y = a.tabs[(1u * 2u + cls_y) * a.dir_stride + th];
-			if (tw == fw && th == fh) {  // block.rs:279-281: clone
+			// Vector form (RGBA tiles in RGBA frames whose full width is a multiple of 4): the windows of the tile
+			// are staged into LDS once, a lane then makes 4 rows (horizontal pass) or 4 adjacent columns (vertical
+			// pass, nearest, clone) per item, so weights are fetched once per 16 multiply-adds and the frame is
+			// written 16 bytes per lane.  Same arithmetic as the scalar form below.
+			if (C == 4 && (fw & 3u) == 0 && tab_x.window <= 8 && tab_y.window <= 8) {
+				const uint32_t q4 = fw >> 2;
+				auto put4 = [&](uint32_t q, uint32_t oy, uint4 px) {
+					*reinterpret_cast<uint4 *>(dst + (size_t)oy * a.pitch + q * 16u) = px;
+				};
+				// per output sample 5 dwords: first | count << 16, then 8 weights (i16); x windows, then y windows
+				uint32_t *s_wx = s_tmp + a.bw * a.bh, *s_wy = s_wx + 5u * a.bw;
+				auto stage_windows = [&](uint32_t *w5, const ExpandTab &tab, uint32_t outs) {
+					for (uint32_t o = lane; o < outs; o += 64u) {
+						const uint32_t first = a.starts[tab.start_off + o];
+						const uint32_t cnt = a.filter == 0 ? 1u : a.sizes[tab.start_off + o];
+						uint32_t kk[4] = {0, 0, 0, 0};
+						if (a.filter != 0) {
+							const int16_t *k = a.coeffs + tab.coeff_off + o * tab.window;
+							for (uint32_t j = 0; j < cnt; ++j) kk[j >> 1] |= (uint32_t)(uint16_t)k[j] << (16u * (j & 1u));
+						}
+						uint32_t *d = w5 + 5u * o;
+						d[0] = first | (cnt << 16);
+						d[1] = kk[0]; d[2] = kk[1]; d[3] = kk[2]; d[4] = kk[3];
+					}
+				};
+				if (tw != fw) stage_windows(s_wx, tab_x, fw);
+				if (th != fh) stage_windows(s_wy, tab_y, fh);
+				tile_sync<1>();
+				auto weight = [](const uint32_t (&kk)[4], uint32_t j) -> int32_t {
+					return (int32_t)(int16_t)(kk[j >> 1] >> (16u * (j & 1u)));
+				};
+				if (tw == fw && th == fh) {  // block.rs:279-281: clone
+					for (uint32_t i = lane; i < q4 * fh; i += 64u) {
+						const uint32_t oy = small_div(i, q4), q = i - oy * q4;
+						put4(q, oy, *reinterpret_cast<const uint4 *>(s_src + oy * fw + 4u * q));
+					}
+				} else if (a.filter == 0) {  // ResizeAlg::Nearest
+					for (uint32_t i = lane; i < q4 * fh; i += 64u) {
+						const uint32_t oy = small_div(i, q4), q = i - oy * q4;
+						const uint32_t y = th == fh ? oy : (s_wy[5u * oy] & 0xffffu);
+						const uint32_t *row = s_src + y * tw;
+						uint4 px;
+						if (tw == fw) {
+							px = *reinterpret_cast<const uint4 *>(row + 4u * q);
+						} else {
+							px.x = row[s_wx[5u * (4u * q)] & 0xffffu];
+							px.y = row[s_wx[5u * (4u * q + 1u)] & 0xffffu];
+							px.z = row[s_wx[5u * (4u * q + 2u)] & 0xffffu];
+							px.w = row[s_wx[5u * (4u * q + 3u)] & 0xffffu];
+						}
+						put4(q, oy, px);
+					}
+				} else {
+					const bool need_h = tw != fw, need_v = th != fh;
+					if (need_h) {
+						// horizontal pass: item = (ox, 4 source rows); the rows beyond th repeat the last one (never stored)
+						const int prec = tab_x.precision;
+						const int32_t init = 1 << (prec - 1);
+						const uint32_t groups = (th + 3u) >> 2;
+						for (uint32_t i = lane; i < fw * groups; i += 64u) {
+							const uint32_t yq = small_div(i, fw), ox = i - yq * fw;
+							const uint32_t *wd = s_wx + 5u * ox;
+							const uint32_t hdr = wd[0], first = hdr & 0xffffu, cnt = hdr >> 16;
+							const uint32_t kk[4] = {wd[1], wd[2], wd[3], wd[4]};
+							uint32_t yr[4];
+#pragma unroll
+							for (uint32_t r = 0; r < 4; ++r) yr[r] = 4u * yq + r < th ? 4u * yq + r : th - 1u;
+							int32_t acc[4][4];
+#pragma unroll
+							for (int r = 0; r < 4; ++r)
+#pragma unroll
+								for (int c = 0; c < 4; ++c) acc[r][c] = init;
+							for (uint32_t j = 0; j < cnt; ++j) {
+								const int32_t w = weight(kk, j);
+#pragma unroll
+								for (int r = 0; r < 4; ++r) {
+									const uint32_t p = s_src[yr[r] * tw + first + j];
+									acc[r][0] += (int32_t)(p & 255u) * w;
+									acc[r][1] += (int32_t)((p >> 8) & 255u) * w;
+									acc[r][2] += (int32_t)((p >> 16) & 255u) * w;
+									acc[r][3] += (int32_t)(p >> 24) * w;
+								}
+							}
+#pragma unroll
+							for (uint32_t r = 0; r < 4; ++r) {
+								const uint32_t y = 4u * yq + r;
+								if (y < th) {
+									uint32_t px = clip8(acc[r][0], prec) | (clip8(acc[r][1], prec) << 8) | (clip8(acc[r][2], prec) << 16) |
+									              (clip8(acc[r][3], prec) << 24);
+									if (need_v) {
+										s_tmp[y * fw + ox] = px;
+									} else {
+										put(ox, y, unpremultiply(px));
+									}
+								}
+							}
+						}
+						tile_sync<1>();
+					}
+					if (need_v) {
+						// vertical pass: item = (4 adjacent columns, oy); rows are fw wide (fw == tw when only this pass runs)
+						const uint32_t *cur = need_h ? s_tmp : s_src;
+						const int prec = tab_y.precision;
+						const int32_t init = 1 << (prec - 1);
+						for (uint32_t i = lane; i < q4 * fh; i += 64u) {
+							const uint32_t oy = small_div(i, q4), q = i - oy * q4;
+							const uint32_t *wd = s_wy + 5u * oy;
+							const uint32_t hdr = wd[0], first = hdr & 0xffffu, cnt = hdr >> 16;
+							const uint32_t kk[4] = {wd[1], wd[2], wd[3], wd[4]};
+							int32_t acc[4][4];
+#pragma unroll
+							for (int r = 0; r < 4; ++r)
+#pragma unroll
+								for (int c = 0; c < 4; ++c) acc[r][c] = init;
+							for (uint32_t j = 0; j < cnt; ++j) {
+								const int32_t w = weight(kk, j);
+								const uint4 v = *reinterpret_cast<const uint4 *>(cur + (first + j) * fw + 4u * q);
+								const uint32_t p4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+								for (int r = 0; r < 4; ++r) {
+									acc[r][0] += (int32_t)(p4[r] & 255u) * w;
+									acc[r][1] += (int32_t)((p4[r] >> 8) & 255u) * w;
+									acc[r][2] += (int32_t)((p4[r] >> 16) & 255u) * w;
+									acc[r][3] += (int32_t)(p4[r] >> 24) * w;
+								}
+							}
+							uint32_t o4[4];
+#pragma unroll
+							for (int r = 0; r < 4; ++r)
+								o4[r] = unpremultiply(clip8(acc[r][0], prec) | (clip8(acc[r][1], prec) << 8) | (clip8(acc[r][2], prec) << 16) |
+								                      (clip8(acc[r][3], prec) << 24));
+							put4(q, oy, make_uint4(o4[0], o4[1], o4[2], o4[3]));
+						}
+					}
+				}
+			} else if (tw == fw && th == fh) {  // block.rs:279-281: clone
 				RowWalker rw(lane, 64u, fw);
 				for (uint32_t i = lane; i < fw * fh; i += 64u, rw.next()) put(rw.col, rw.row, s_src[i]);
 			} else if (a.filter == 0) {  // ResizeAlg::Nearest
@@ -2358,7 +2493,12 @@ __global__ void __launch_bounds__(256) pixlzr_index_kernel(const DecodeArgs a)
 	const unsigned long long hdr = 26ull + 4ull * a.rows;
 	auto bad_row = [&]() {
 		atomicOr(a.status, 2u);
-		for (uint32_t c = 0; c < a.cols; ++c) a.rec_len[f * a.tiles_per_frame + r * a.cols + c] = 0u;
+		for (uint32_t c = 0; c < a.cols; ++c) {
+			const uint32_t t = f * a.tiles_per_frame + r * a.cols + c;
+			a.rec_len[t] = 0u;
+			a.tile_w[t] = 0u;
+			a.tile_h[t] = 0u;
+		}
 	};
 	const uint8_t magic[9] = {'P', 'I', 'X', 'L', 'Z', 'R', 0, 0, 2};  // constants.rs:10-11: v0.0.2 (filter byte + line table)
 	bool ok = flen >= hdr;
@@ -2406,7 +2546,12 @@ __global__ void __launch_bounds__(256) pixlzr_index_kernel(const DecodeArgs a)
 		if (!good) {
 			// the walk cannot continue past a broken record: the rest of the row is unusable
 			atomicOr(a.status, 2u);
-			for (uint32_t cc = c; cc < a.cols; ++cc) a.rec_len[f * a.tiles_per_frame + r * a.cols + cc] = 0u;
+			for (uint32_t cc = c; cc < a.cols; ++cc) {
+				const uint32_t tt = f * a.tiles_per_frame + r * a.cols + cc;
+				a.rec_len[tt] = 0u;
+				a.tile_w[tt] = 0u;
+				a.tile_h[tt] = 0u;
+			}
 			return;
 		}
 	}
@@ -2418,32 +2563,54 @@ __global__ void __launch_bounds__(256) qoi_decode_kernel(const DecodeArgs a)
 {
 	__shared__ uint32_t s_index[4][64][64];  // [wave][slot][lane]
 	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-	const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+	const uint32_t i0 = blockIdx.x * 256u + threadIdx.x;
 	uint32_t(*index)[64] = s_index[wave];
 #pragma unroll 8
 	for (int sidx = 0; sidx < 64; ++sidx) index[sidx][lane] = 0u;  // qoi: index starts as zero pixels
-	if (t >= a.n_tiles) return;
+	if (i0 >= a.n_tiles) return;
+	const uint32_t t = a.perm[i0];  // tiles of similar pixel count share a wave (the walk is serial per lane)
 	const uint32_t len = a.rec_len[t];
 	if (len == 0) {
 		a.tile_w[t] = 0;  // unusable record: the expand step skips and flags it
 		a.tile_h[t] = 0;
 		return;
 	}
-	const uint8_t *p = a.files + a.rec_off[t], *end = p + len;
+	// the op bytes, fetched 8 at a time through an aligned 64-bit window (a byte load per op byte would make
+	// every op wait for a memory round trip).  The window may run up to 7 bytes past the last op: those are
+	// bytes of the record's own 8-byte end marker, still inside the file.
+	const unsigned long long first_byte = a.rec_off[t];
+	const unsigned long long *wp = reinterpret_cast<const unsigned long long *>(a.files + (first_byte & ~7ull));
+	unsigned long long acc = *wp++ >> (8u * (uint32_t)(first_byte & 7ull));
+	uint32_t have = 8u - (uint32_t)(first_byte & 7ull);
+	int32_t left = (int32_t)len;
+	auto next_byte = [&]() -> uint32_t {
+		if (have == 0u) {
+			acc = *wp++;
+			have = 8u;
+		}
+		const uint32_t b = (uint32_t)acc & 255u;
+		acc >>= 8;
+		--have;
+		--left;
+		return b;
+	};
 	const uint32_t n = a.tile_w[t] * a.tile_h[t];
 	uint8_t *dst = a.slots + (size_t)t * a.slot_bytes;
 	uint32_t px = 0xff000000u, run = 0;
+	uint4 hold = make_uint4(0, 0, 0, 0);
 	for (uint32_t i = 0; i < n; ++i) {
 		if (run > 0) {
 			--run;
-		} else if (p < end) {
-			const uint32_t b1 = *p++;
+		} else if (left > 0) {
+			// (as in the qoi crate, only the op's first byte is checked against the end of the stream; a truncated
+			// last op reads on into the end marker, which is inside the file)
+			const uint32_t b1 = next_byte();
 			if (b1 == 0xfeu) {  // QOI_OP_RGB
-				px = (px & 0xff000000u) | (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16);
-				p += 3;
+				const uint32_t r = next_byte(), g = next_byte(), b = next_byte();
+				px = (px & 0xff000000u) | r | (g << 8) | (b << 16);
 			} else if (b1 == 0xffu) {  // QOI_OP_RGBA
-				px = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
-				p += 4;
+				const uint32_t r = next_byte(), g = next_byte(), b = next_byte(), al = next_byte();
+				px = r | (g << 8) | (b << 16) | (al << 24);
 			} else if ((b1 & 0xc0u) == 0x00u) {  // QOI_OP_INDEX
 				px = index[b1][lane];
 			} else if ((b1 & 0xc0u) == 0x40u) {  // QOI_OP_DIFF
@@ -2452,7 +2619,7 @@ __global__ void __launch_bounds__(256) qoi_decode_kernel(const DecodeArgs a)
 				const uint32_t b = (((px >> 16) & 255u) + (b1 & 3u) - 2u) & 255u;
 				px = (px & 0xff000000u) | r | (g << 8) | (b << 16);
 			} else if ((b1 & 0xc0u) == 0x80u) {  // QOI_OP_LUMA
-				const uint32_t b2 = *p++;
+				const uint32_t b2 = next_byte();
 				const uint32_t vg = (b1 & 0x3fu) - 32u;
 				const uint32_t r = ((px & 255u) + vg - 8u + ((b2 >> 4) & 15u)) & 255u;
 				const uint32_t g = (((px >> 8) & 255u) + vg) & 255u;
@@ -2469,19 +2636,44 @@ __global__ void __launch_bounds__(256) qoi_decode_kernel(const DecodeArgs a)
 			return;
 		}
 		if constexpr (C == 4) {
-			reinterpret_cast<uint32_t *>(dst)[i] = px;
+			// four pixels per 16-byte store (slots are 16-byte aligned: bw*bh*4 bytes each)
+			const uint32_t k = i & 3u;
+			if (k == 0) hold.x = px;
+			else if (k == 1) hold.y = px;
+			else if (k == 2) hold.z = px;
+			else {
+				hold.w = px;
+				reinterpret_cast<uint4 *>(dst)[i >> 2] = hold;
+			}
 		} else {
 			dst[3 * i] = (uint8_t)px;
 			dst[3 * i + 1] = (uint8_t)(px >> 8);
 			dst[3 * i + 2] = (uint8_t)(px >> 16);
 		}
 	}
+	if constexpr (C == 4) {
+		const uint32_t tail = n & 3u, base = n & ~3u;  // 1x1, 2x1 ... tiles
+		if (tail >= 1) reinterpret_cast<uint32_t *>(dst)[base] = hold.x;
+		if (tail >= 2) reinterpret_cast<uint32_t *>(dst)[base + 1] = hold.y;
+		if (tail >= 3) reinterpret_cast<uint32_t *>(dst)[base + 2] = hold.z;
+	}
 }
 
 hipError_t launch_decode(const DecodeArgs &a, hipStream_t stream)
 {
+	hipError_t e = hipMemsetAsync(a.bins, 0, 64 * sizeof(uint32_t), stream);
+	if (e != hipSuccess) return e;
 	hipLaunchKernelGGL(pixlzr_index_kernel, dim3((a.n_frames * a.rows + 255u) / 256u), dim3(256), 0, stream, a);
 	const uint32_t tb = (a.n_tiles + 255u) / 256u;
+	QoiArgs q{};  // the encoder's binning by pixel count, on the sizes the index kernel has just read
+	q.w = a.tile_w;
+	q.h = a.tile_h;
+	q.n_tiles = a.n_tiles;
+	q.bins = a.bins;
+	q.perm = a.perm;
+	hipLaunchKernelGGL(qoi_bin_count_kernel, dim3(tb), dim3(256), 0, stream, q);
+	hipLaunchKernelGGL(qoi_bin_scan_kernel, dim3(1), dim3(1), 0, stream, q);
+	hipLaunchKernelGGL(qoi_bin_scatter_kernel, dim3(tb), dim3(256), 0, stream, q);
 	if (a.channels == 4) hipLaunchKernelGGL(qoi_decode_kernel<4>, dim3(tb), dim3(256), 0, stream, a);
 	else hipLaunchKernelGGL(qoi_decode_kernel<3>, dim3(tb), dim3(256), 0, stream, a);
 	return hipGetLastError();
