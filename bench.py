@@ -126,19 +126,23 @@ def run_mode(args, handle, frames, mode_name, rank, world, dist_mod, pdist):
 
     final_gather = None
     if gather:
-        exchange()  # untimed warm-up of the exchange (allocations, RCCL channels)
-        torch.cuda.synchronize()
-        dist_mod.barrier()
-        t1 = time.perf_counter()
-        exchange()
-        torch.cuda.synchronize()
-        dist_mod.barrier()
-        gms = (time.perf_counter() - t1) * 1e3
-        t = torch.tensor([gms], dtype=torch.float64, device=frames.device)
-        dist_mod.all_reduce(t, op=dist_mod.ReduceOp.MAX)
-        final_gather = {"ms": float(t[0]), "bytes_at_rank0": gather_state["bytes"],
-                        "what": "device QOI + container of this rank's frames, then gather of the .pixlzr files to rank 0",
-                        "inside_timed_steps": bool(in_step)}
+        # outside the metric: a failure here is reported, it does not take the measured line with it
+        try:
+            exchange()  # untimed warm-up of the exchange (allocations, RCCL channels)
+            torch.cuda.synchronize()
+            dist_mod.barrier()
+            t1 = time.perf_counter()
+            exchange()
+            torch.cuda.synchronize()
+            dist_mod.barrier()
+            gms = (time.perf_counter() - t1) * 1e3
+            t = torch.tensor([gms], dtype=torch.float64, device=frames.device)
+            dist_mod.all_reduce(t, op=dist_mod.ReduceOp.MAX)
+            final_gather = {"ms": float(t[0]), "bytes_at_rank0": gather_state["bytes"],
+                            "what": "device QOI + container of this rank's frames, then gather of the .pixlzr files to rank 0",
+                            "inside_timed_steps": bool(in_step)}
+        except Exception as exc:  # noqa: BLE001
+            final_gather = {"error": f"{type(exc).__name__}: {exc}"[:300]}
 
     tiles = ow.numel()
     out_bytes = int((ow.long() * oh.long()).sum().item()) * C
