@@ -183,7 +183,9 @@ int get_tables(pxz_handle *h, uint32_t bw, uint32_t bh, uint32_t edge_w, uint32_
 				}
 				t.wquads = (uint16_t)wquads;
 				t.rows_off = (uint32_t)rows.size();
-				t.row_stride = (4u + wquads * 2u + 3u) & ~3u;
+				// rows of up to 8 quads are padded with zero weights to header + 16 dwords: the fast path fetches
+				// whole rows with 16-byte loads and needs no per-quad guard
+				t.row_stride = wquads <= 8u ? 20u : (4u + wquads * 2u + 3u) & ~3u;
 				for (uint32_t o = 0; o < outsz; ++o) {
 					const uint32_t first = (uint32_t)win.starts[o], n = (uint32_t)win.sizes[o];
 					const uint32_t lead = first & 3u, nq = (lead + n + 3u) / 4u;

@@ -348,20 +348,21 @@ __device__ __forceinline__ void fast32_h_rows(const uint32_t *trows, const AxisT
 	const uint32_t ox = item & (nw - 1u), y = live ? item >> lgx : 0u;
 	const uint32_t *rowp = trows + tx.rows_off + ox * tx.row_stride;
 	const uint4 hdr = *reinterpret_cast<const uint4 *>(rowp);
-	uint2 kk[QPL];  // quads past the table's window width carry no weight (the row ends there)
+	uint2 kk[QPL];  // table rows are zero-padded to 8 quads (get_tables): quads past the window carry no weight
 #pragma unroll
-	for (int j = 0; j < QPL; ++j)
-		kk[j] = part + (uint32_t)(j * LPI) < tx.wquads ? *reinterpret_cast<const uint2 *>(rowp + 4 + 2 * (part + j * LPI)) : make_uint2(0u, 0u);
+	for (int j = 0; j < QPL; ++j) kk[j] = *reinterpret_cast<const uint2 *>(rowp + 4 + 2 * (part + j * LPI));
 	const uint32_t *row = s_pl + y * kRS32 + hdr.x * 2u + part * 2u;
 	int32_t a0 = 0, a1 = 0, a2 = 0;
 #pragma unroll
 	for (int j = 0; j < QPL; ++j) {
-		const uint2 d0 = *reinterpret_cast<const uint2 *>(row + j * LPI * 2);
-		const uint2 d1 = *reinterpret_cast<const uint2 *>(row + kPD32 + j * LPI * 2);
-		const uint2 d2 = *reinterpret_cast<const uint2 *>(row + 2 * kPD32 + j * LPI * 2);
-		a0 = dot2(d0.y, kk[j].y, dot2(d0.x, kk[j].x, a0));
-		a1 = dot2(d1.y, kk[j].y, dot2(d1.x, kk[j].x, a1));
-		a2 = dot2(d2.y, kk[j].y, dot2(d2.x, kk[j].x, a2));
+		if (LPI > 1 || (uint32_t)j < tx.wquads) {  // LPI == 1: wave-uniform trim of the zero-weight tail
+			const uint2 d0 = *reinterpret_cast<const uint2 *>(row + j * LPI * 2);
+			const uint2 d1 = *reinterpret_cast<const uint2 *>(row + kPD32 + j * LPI * 2);
+			const uint2 d2 = *reinterpret_cast<const uint2 *>(row + 2 * kPD32 + j * LPI * 2);
+			a0 = dot2(d0.y, kk[j].y, dot2(d0.x, kk[j].x, a0));
+			a1 = dot2(d1.y, kk[j].y, dot2(d1.x, kk[j].x, a1));
+			a2 = dot2(d2.y, kk[j].y, dot2(d2.x, kk[j].x, a2));
+		}
 	}
 	a0 = group_sum<LPI>(a0);
 	a1 = group_sum<LPI>(a1);
@@ -390,10 +391,9 @@ __device__ __forceinline__ void fast32_v(const uint32_t *trows, const AxisTab &t
 	const uint32_t *rowp = trows + ty.rows_off + oy * ty.row_stride;
 	const uint4 hdr = *reinterpret_cast<const uint4 *>(rowp);
 	const uint32_t wq = ty.wquads;
-	uint2 kk[QPL];  // quads past the table's window width carry no weight (the row ends there)
+	uint2 kk[QPL];  // zero-padded rows: no guard
 #pragma unroll
-	for (int j = 0; j < QPL; ++j)
-		kk[j] = part + (uint32_t)(j * LPI) < wq ? *reinterpret_cast<const uint2 *>(rowp + 4 + 2 * (part + j * LPI)) : make_uint2(0u, 0u);
+	for (int j = 0; j < QPL; ++j) kk[j] = *reinterpret_cast<const uint2 *>(rowp + 4 + 2 * (part + j * LPI));
 	const int px_ = tx.precision, py = ty.precision;
 	const int32_t ix = 1 << (px_ - 1), iy = 1 << (py - 1);
 	for (uint32_t item = item0; item < ((items + 63u / LPI) & ~(64u / LPI - 1u)); item += 64u / LPI) {
