@@ -22,6 +22,7 @@ hipError_t launch_shrink(const ShrinkArgs &a, uint32_t channels, uint32_t n_cus,
 hipError_t launch_synth(const SynthArgs &s, hipStream_t stream);
 hipError_t launch_finish(const FinishArgs &f, hipStream_t stream);
 bool fast32_applicable(const ShrinkArgs &a, uint32_t channels);
+bool fast64_applicable(const ShrinkArgs &a, uint32_t channels);
 hipError_t launch_expand(const ExpandArgs &a, uint32_t n_cus, hipStream_t stream);
 hipError_t launch_decode(const DecodeArgs &a, hipStream_t stream);
 hipError_t launch_pack(const PackArgs &a, hipStream_t stream);
@@ -43,6 +44,7 @@ struct TableSet {
 	int32_t *d_ksums = nullptr;
 	uint32_t *d_rows = nullptr;
 	uint32_t rows_dw = 0;
+	uint32_t *d_mf64 = nullptr;  // 64x64 fast path: matrix-core operand tables (null: not available)
 };
 
 // decode side: up-scaling tables of every source size to the full tile size (expand_kernel)
@@ -144,6 +146,8 @@ int get_tables(pxz_handle *h, uint32_t bw, uint32_t bh, uint32_t edge_w, uint32_
 	std::vector<uint32_t> coeffs;
 	std::vector<int32_t> ksums;
 	std::vector<uint32_t> rows;
+	std::vector<uint32_t> mf64(4, 0u);  // offset 0 means "no table"
+	bool mf64_complete = bw == 64 && bh == 64 && filter != PXZ_FILTER_NEAREST;
 	const uint32_t sizes[2][2] = {{bw, edge_w}, {bh, edge_h}};
 	for (int axis = 0; axis < 2; ++axis) {
 		for (int cls = 0; cls < 2; ++cls) {
@@ -243,6 +247,42 @@ int get_tables(pxz_handle *h, uint32_t bw, uint32_t bh, uint32_t edge_w, uint32_
 						rows.insert(rows.end(), mf.begin(), mf.end());
 					}
 				}
+				// 64x64 tiles: operands of shrink64_kernel (Fast64Args), every level from 32 px down to 1 px
+				if (axis == 0 && cls == 0 && bw == 64 && bh == 64 && outsz < 64) {
+					const uint32_t nblk = outsz > 16 ? outsz / 16 : 1;
+					std::vector<uint32_t> mf((size_t)nblk * 512 + 72, 0u);
+					bool fits = true, opaque_stays = true;
+					const int32_t half = 1 << (win.precision - 1);
+					for (uint32_t o = 0; o < outsz; ++o) {
+						int32_t k[64] = {0};
+						int32_t total = 0;
+						for (uint32_t i = 0; i < (uint32_t)win.sizes[o]; ++i) {
+							k[(uint32_t)win.starts[o] + i] = win.coeffs[(size_t)o * win.window + i];
+							total += k[(uint32_t)win.starts[o] + i];
+						}
+						const uint32_t blk = o / 16, ol = o % 16;
+						for (uint32_t g = 0; g < 4; ++g) {
+							for (uint32_t j = 0; j < 16; ++j) {
+								const int32_t v = k[16 * g + j];
+								const int32_t lo = ((v + 128) & 255) - 128, hi = (v - lo) / 256;
+								if (hi < -128 || hi > 127) fits = false;
+								const uint32_t lane = g * 16 + ol, dw = blk * 512 + lane * 4 + j / 4, sh = 8 * (j & 3);
+								mf[dw] |= (uint32_t)(uint8_t)lo << sh;
+								mf[256 + dw] |= (uint32_t)(uint8_t)hi << sh;
+							}
+						}
+						mf[nblk * 512 + o] = (uint32_t)(128 * total + half);
+						mf[nblk * 512 + 32 + o] = (uint32_t)total;
+						if (((half + 255 * total) >> win.precision) < 255) opaque_stays = false;
+					}
+					mf[nblk * 512 + 64] = opaque_stays ? 1u : 0u;
+					if (fits && outsz <= 32) {
+						t.mf_off = (uint32_t)mf64.size();
+						mf64.insert(mf64.end(), mf.begin(), mf.end());
+					} else {
+						mf64_complete = false;
+					}
+				}
 			}
 		}
 	}
@@ -258,6 +298,10 @@ int get_tables(pxz_handle *h, uint32_t bw, uint32_t bh, uint32_t edge_w, uint32_
 	PXZ_HIP(h, hipMemcpy(ts.d_bounds, bounds.data(), bounds.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
 	PXZ_HIP(h, hipMemcpy(ts.d_coeffs, coeffs.data(), coeffs.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
 	PXZ_HIP(h, hipMemcpy(ts.d_ksums, ksums.data(), ksums.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+	if (mf64_complete) {
+		PXZ_HIP(h, hipMalloc((void **)&ts.d_mf64, mf64.size() * sizeof(uint32_t)));
+		PXZ_HIP(h, hipMemcpy(ts.d_mf64, mf64.data(), mf64.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+	}
 	ts.rows_dw = (uint32_t)rows.size();
 	PXZ_HIP(h, hipMalloc((void **)&ts.d_rows, rows.size() * sizeof(uint32_t)));
 	PXZ_HIP(h, hipMemcpy(ts.d_rows, rows.data(), rows.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
@@ -495,6 +539,7 @@ int prepare(pxz_handle *h, const pxz_frames *f, const pxz_params *p, bool want_p
 		a->ksums = ts.d_ksums;
 		a->trows = ts.d_rows;
 		a->tab_dw = ts.rows_dw * 4u <= 48u * 1024u ? (ts.rows_dw + 3u) & ~3u : 0u;
+		a->mf64 = ts.d_mf64;
 	}
 	return PXZ_OK;
 }
@@ -514,10 +559,10 @@ int timed_launch(pxz_handle *h, pxz::ShrinkArgs &a, uint32_t channels, float *va
 	a.lod1 = lod1;
 	// 32x32 fast path: which tiles are full-size, and whether every tile row of the batch is 16-byte aligned
 	a.full_cols = a.full_rows = 0;
-	if (a.bw == 32 && a.bh == 32 && channels == 4 &&
+	if (a.bw == a.bh && (a.bw == 32 || a.bw == 64) && channels == 4 &&
 	    ((reinterpret_cast<uintptr_t>(a.src) | a.pitch | (a.n_tiles > a.tiles_per_frame ? a.frame_stride : 0)) & 15u) == 0) {
-		a.full_cols = a.edge_w == 32 ? a.cols : a.cols - 1;
-		a.full_rows = a.edge_h == 32 ? a.rows : a.rows - 1;
+		a.full_cols = a.edge_w == a.bw ? a.cols : a.cols - 1;
+		a.full_rows = a.edge_h == a.bh ? a.rows : a.rows - 1;
 	}
 	const pxz::FinishArgs fin{a.sums, value, lod0, lod1, a.n_tiles, a.tiles_per_frame, a.cols, a.rows,
 	                          a.bw, a.bh, a.edge_w, a.edge_h, a.mode, a.factor};
@@ -542,7 +587,7 @@ int timed_launch(pxz_handle *h, pxz::ShrinkArgs &a, uint32_t channels, float *va
 	}
 	// 32x32 RGBA flow: shrink32_kernel, then the worklist kernel, which also finishes every tile and
 	// zeroes the worklist counter of the next launch (two counters, used alternately)
-	const bool fast = pxz::fast32_applicable(a, channels);
+	const bool fast = pxz::fast32_applicable(a, channels) || pxz::fast64_applicable(a, channels);
 	if (fast) {
 		if (!h->work_ready) {
 			PXZ_HIP(h, hipMemsetAsync(h->work.ptr, 0, 8, h->stream));
@@ -606,6 +651,7 @@ void pxz_destroy(pxz_handle *h)
 		(void)hipFree(kv.second.d_coeffs);
 		(void)hipFree(kv.second.d_ksums);
 		(void)hipFree(kv.second.d_rows);
+		(void)hipFree(kv.second.d_mf64);
 	}
 	for (auto &kv : h->expand_tables) {
 		(void)hipFree(kv.second.d_dir);

@@ -60,6 +60,7 @@ struct ShrinkArgs {
 	uint32_t oklab_given;    // 1: full 32x32 RGBA tiles already carry their Oklab value in sums[] (oklab32_kernel)
 	float scale2;            // Oklab mode: value = mean deviation * factor * scale2 (10 = BASE_FACTOR of shrink_by,
 	                         //   pixlzr.rs:15,162; 1 with factor 1 = the identity closure of process(), process/mod.rs:107-121)
+	const uint32_t *mf64;    // 64x64 fast path: matrix-core operand tables (global memory), see Fast64Args
 	uint32_t full_cols, full_rows;  // 32x32 fast path: tile (tx, ty) is eligible iff tx < full_cols && ty < full_rows
 	                                //   (full size, 16-byte aligned rows; 0/0 when the batch is not aligned)
 	uint32_t *work;          // worklist: [work_slot] = count, [2..] = tile ids (null: all tiles).  The two
@@ -113,6 +114,31 @@ struct Fast32Args {
 	uint32_t breaks[kMaxLevel];
 	uint32_t breaks_asc;
 	AxisTab tabs[kMaxLevel];
+};
+
+// shrink64_kernel: full, aligned, opaque 64x64 RGBA tiles (the reference CLI's default block size), one
+// tile per block of four waves.  Matrix-core operand tables live in global memory (mf64):
+//   per level with out = 32|16|8|4|2|1:  nblk = max(1, out/16) output blocks, each
+//     [lo: 64 lanes x 16 B][hi: 64 lanes x 16 B]   lane (o = l & 15, g = l >> 4): K[16*blk + o][16g .. 16g+15]
+//   then bias[32], ksum[32], flag (as in kMfDwords)
+struct Fast64Args {
+	const uint8_t *src;
+	uint64_t frame_stride;
+	uint32_t pitch, cols, rows, tiles_per_frame, n_tiles;
+	FastDiv div_tpf, div_cols;
+	uint32_t full_cols, full_rows;
+	uint32_t filter;
+	uint32_t *sums;
+	uint32_t *out_w;
+	uint32_t *out_h;
+	uint8_t *out_px;
+	uint32_t *work;
+	uint32_t work_slot;
+	const uint32_t *mf64;
+	uint32_t mf_off[kMaxLevel];      // dword offset of the level's table in mf64 (0: none; the blob starts with a pad)
+	uint32_t precision[kMaxLevel];
+	uint32_t breaks[kMaxLevel];
+	uint32_t breaks_asc;
 };
 
 struct LaunchGeom {

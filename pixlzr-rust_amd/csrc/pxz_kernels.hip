@@ -1484,6 +1484,294 @@ __global__ void __launch_bounds__(1024) shrink32_kernel(const Fast32Args a)
 }
 
 // ---------------------------------------------------------------------------
+// shrink64_kernel: full, 16-byte-aligned, opaque 64x64 RGBA tiles -- the reference CLI's default block size
+// (src/bin/main.rs:19) -- directional detector + clone / two-pass matrix-core resample.  One tile per block
+// of four waves; every phase splits four ways:
+//   stage      wave w loads and stages rows 16w .. 16w+15 (prefetched into registers during the previous tile)
+//   detector   wave w sums the windows whose top row is 16w .. 16w+15 (32 column pairs x 2 groups of 8 rows;
+//              the neighbour pair comes through a wave-wide DPP shift); partial sums meet in LDS
+//   horizontal wave w = one 16-row block of A operands (pixels - 128 as bytes, 64 per row = ONE
+//              v_mfma_i32_16x16x64_i8 per output block and weight byte); results (u8) go to LDS as [ox][y]
+//   vertical   wave w = one (16 output rows, 16 output columns) block: weights x the LDS columns
+// Three block barriers per tile.  Ragged-edge tiles, tiles with transparency and the one-pass classes
+// (64 x n, n x 64) go to the worklist of the generic kernel.
+// ---------------------------------------------------------------------------
+constexpr uint32_t kRS64 = 36, kPD64 = 36 * 64;  // plane row stride (32 + 4 dwords: bank skew, rows stay 16-byte aligned), plane size
+constexpr uint32_t kT64 = 3 * 32 * 16;           // [channel][ox < 32][64 bytes of y] as dwords
+constexpr uint32_t kLds64 = 3 * kPD64 + kT64 + 32;
+
+template <class Args>
+__device__ __forceinline__ bool fast64_tile_src(const Args &a, uint32_t tile_g, const uint8_t *&src)
+{
+	if (tile_g >= a.n_tiles) return false;
+	const uint32_t frame = fastdiv(tile_g, a.div_tpf);
+	const uint32_t t = tile_g - frame * a.tiles_per_frame;
+	const uint32_t ty = fastdiv(t, a.div_cols), tx = t - ty * a.cols;
+	src = a.src + (size_t)frame * a.frame_stride + (size_t)(ty * 64u) * a.pitch + (size_t)(tx * 64u) * 4u;
+	return tx < a.full_cols && ty < a.full_rows;
+}
+
+__global__ void __launch_bounds__(256) shrink64_kernel(const Fast64Args a)
+{
+	extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+	uint32_t *s_pl = lds;                       // 3 planes of u16 pairs
+	uint32_t *s_t = lds + 3 * kPD64;            // horizontal-pass results
+	uint32_t *s_red = s_t + kT64;               // [0..7] partial sums, [8..11] alpha, [12] deferred flag
+	const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+	const uint32_t brk_lane = lane < (uint32_t)kMaxLevel ? a.breaks[lane] : (a.breaks_asc ? 0xffffffffu : 0u);
+	auto level_of = [&](uint32_t key) -> uint32_t {
+		const unsigned long long lt = __builtin_amdgcn_ballot_w64(key < brk_lane);
+		const unsigned long long live = (1ull << kMaxLevel) - 1ull;
+		return (uint32_t)__builtin_popcountll((a.breaks_asc ? ~lt : lt) & live);
+	};
+	// this lane's share of a tile: rows 16w + (lane >> 4) + 4k, 16 bytes at column quad lane & 15
+	uint4 pre[4];
+	bool pre_valid = false;
+	auto prefetch = [&](uint32_t tile_g) {
+		const uint8_t *src;
+		pre_valid = fast64_tile_src(a, tile_g, src);
+		if (pre_valid) {
+			const uint8_t *p = src + (size_t)(16u * wave + (lane >> 4)) * a.pitch + (lane & 15u) * 16u;
+#pragma unroll
+			for (int k = 0; k < 4; ++k) pre[k] = *reinterpret_cast<const uint4 *>(p + (size_t)(4 * k) * a.pitch);
+		}
+	};
+	prefetch(blockIdx.x);
+	for (uint32_t tile_g = blockIdx.x; tile_g < a.n_tiles; tile_g += gridDim.x) {
+		auto defer = [&]() {
+			if (threadIdx.x == 0) {
+				a.work[2 + atomicAdd(&a.work[a.work_slot], 1u)] = tile_g;
+				reinterpret_cast<uint2 *>(a.sums)[tile_g] = make_uint2(kDeferredKey, kDeferredKey);
+			}
+		};
+		if (!pre_valid) {  // ragged edge / unaligned batch (block-uniform)
+			defer();
+			prefetch(tile_g + gridDim.x);
+			continue;
+		}
+		// ---- stage: registers -> planar u16 pairs
+		uint32_t alpha_and = 0xffu;
+#pragma unroll
+		for (int k = 0; k < 4; ++k) alpha_and &= (pre[k].x & pre[k].y & pre[k].z & pre[k].w) >> 24;
+#pragma unroll
+		for (int k = 0; k < 4; ++k) {
+			const uint32_t row = 16u * wave + (lane >> 4) + 4u * (uint32_t)k, col = lane & 15u;
+			const uint4 v = pre[k];
+			uint32_t *d = s_pl + row * kRS64 + col * 2u;
+#pragma unroll
+			for (uint32_t c = 0; c < 3; ++c) {
+				const uint32_t sel = c | 0x0c000c00u | ((4u + c) << 16);
+				uint2 pr;
+				pr.x = __builtin_amdgcn_perm(v.y, v.x, sel);
+				pr.y = __builtin_amdgcn_perm(v.w, v.z, sel);
+				*reinterpret_cast<uint2 *>(d + c * kPD64) = pr;
+			}
+		}
+		const bool wave_transparent = __builtin_amdgcn_ballot_w64(alpha_and != 0xffu) != 0ull;
+		if (lane == 0) s_red[8 + wave] = wave_transparent ? 1u : 0u;
+		prefetch(tile_g + gridDim.x);  // lands while this tile is processed
+		__syncthreads();               // B1: the whole tile is staged
+		if ((s_red[8] | s_red[9] | s_red[10] | s_red[11]) != 0u) {
+			defer();  // transparency: premultiplied convolution and the alpha plane live in the generic kernel
+			__syncthreads();
+			continue;
+		}
+		// ---- detector: window rows 16w + 8gg .. +7, column pair q (windows 2q, 2q+1)
+		uint32_t sum_hz = 0, sum_vr = 0;
+		{
+			const uint32_t q = lane & 31u, gg = lane >> 5;
+			const uint32_t two = 0x00020002u;
+			const uint32_t *pc[3];
+			pc[0] = s_pl + (16u * wave + 8u * gg) * kRS64 + q;
+			pc[1] = pc[0] + kPD64;
+			pc[2] = pc[1] + kPD64;
+			const bool short_group = wave == 3u && gg == 1u;  // window rows 56 .. 61 only
+			uint32_t rA[3], rB[3], tP[3], dP[3];
+#pragma unroll
+			for (int c = 0; c < 3; ++c) {
+				const uint32_t a0 = pc[c][0], a1 = pc[c][1], b0 = pc[c][kRS64], b1 = pc[c][kRS64 + 1];
+				rA[c] = pk_mad_u16(__builtin_amdgcn_alignbit(a1, a0, 16), two, u32(us2(a0) + us2(a1)));
+				rB[c] = pk_mad_u16(__builtin_amdgcn_alignbit(b1, b0, 16), two, u32(us2(b0) + us2(b1)));
+				tP[c] = u32(us2(a0) + us2(b0));
+				dP[c] = b0;
+			}
+#pragma unroll
+			for (int st = 0; st < 4; ++st) {
+				if (st < 3 || !short_group) {
+#pragma unroll
+					for (int c = 0; c < 3; ++c) {
+						const uint32_t *pr = pc[c] + (2 + 2 * st) * (int)kRS64;
+						const uint32_t n0 = pr[0], n1 = pr[1], o0 = pr[kRS64], o1 = pr[kRS64 + 1];
+						const uint32_t rN = pk_mad_u16(__builtin_amdgcn_alignbit(n1, n0, 16), two, u32(us2(n0) + us2(n1)));
+						sum_hz = sad16(rN, rA[c], sum_hz);
+						const uint32_t tN = u32(us2(dP[c]) + us2(n0));
+						const uint32_t c0 = u32(us2(tP[c]) + us2(tN));
+						sum_vr = sad16(dpp_mov<0x130>(c0), c0, sum_vr);  // wave_shl:1 = the pair to the right
+						const uint32_t rO = pk_mad_u16(__builtin_amdgcn_alignbit(o1, o0, 16), two, u32(us2(o0) + us2(o1)));
+						sum_hz = sad16(rO, rB[c], sum_hz);
+						const uint32_t tO = u32(us2(n0) + us2(o0));
+						const uint32_t e0 = u32(us2(tN) + us2(tO));
+						sum_vr = sad16(dpp_mov<0x130>(e0), e0, sum_vr);
+						rA[c] = rN;
+						rB[c] = rO;
+						tP[c] = tO;
+						dP[c] = o0;
+					}
+				}
+			}
+			if (q == 31u) sum_hz = sum_vr = 0;  // pair 31 starts no window (x = 62, 63)
+		}
+		sum_hz = wave_sum_sgpr(sum_hz);
+		sum_vr = wave_sum_sgpr(sum_vr);
+		if (lane == 0) {
+			s_red[2 * wave] = sum_hz;
+			s_red[2 * wave + 1] = sum_vr;
+		}
+		__syncthreads();  // B2: partial sums are in; every wave is done with its neighbours' rows
+		sum_hz = s_red[0] + s_red[2] + s_red[4] + s_red[6];
+		sum_vr = s_red[1] + s_red[3] + s_red[5] + s_red[7];
+		sum_hz = __builtin_amdgcn_readfirstlane(sum_hz);
+		sum_vr = __builtin_amdgcn_readfirstlane(sum_vr);
+		const uint32_t m0 = level_of(sum_hz), m1 = level_of(sum_vr);
+		const uint32_t nw = reduced_size(64u, m0), nh = reduced_size(64u, m1);
+		if (threadIdx.x == 0) {
+			reinterpret_cast<uint2 *>(a.sums)[tile_g] = make_uint2(sum_hz, sum_vr);
+			if (a.out_w) a.out_w[tile_g] = nw;
+			if (a.out_h) a.out_h[tile_g] = nh;
+		}
+		if (a.out_px == nullptr) {
+			__syncthreads();  // s_red is rewritten by the next tile
+			continue;
+		}
+		uint8_t *dst = a.out_px + (size_t)tile_g * (64u * 64u * 4u);
+		if (nw == 64u && nh == 64u) {
+			// clone (block.rs:279-281): re-interleave this wave's 16 rows, 16 bytes per lane and step
+#pragma unroll
+			for (int k = 0; k < 4; ++k) {
+				const uint32_t i = lane + 64u * (uint32_t)k;  // 256 groups of 4 pixels
+				const uint32_t row = 16u * wave + (i >> 4), c4 = i & 15u;
+				const uint32_t *p = s_pl + row * kRS64 + c4 * 2u;
+				const uint2 r = *reinterpret_cast<const uint2 *>(p), g = *reinterpret_cast<const uint2 *>(p + kPD64);
+				const uint2 b = *reinterpret_cast<const uint2 *>(p + 2 * kPD64);
+				const uint32_t opq = 0x00ff00ffu;
+				const uint32_t rg01 = __builtin_amdgcn_perm(g.x, r.x, 0x06020400u), ba01 = __builtin_amdgcn_perm(opq, b.x, 0x06020400u);
+				const uint32_t rg23 = __builtin_amdgcn_perm(g.y, r.y, 0x06020400u), ba23 = __builtin_amdgcn_perm(opq, b.y, 0x06020400u);
+				uint4 o;
+				o.x = __builtin_amdgcn_perm(ba01, rg01, 0x05040100u);
+				o.y = __builtin_amdgcn_perm(ba01, rg01, 0x07060302u);
+				o.z = __builtin_amdgcn_perm(ba23, rg23, 0x05040100u);
+				o.w = __builtin_amdgcn_perm(ba23, rg23, 0x07060302u);
+				reinterpret_cast<uint4 *>(dst)[row * 16u + c4] = o;
+			}
+			__syncthreads();
+			continue;
+		}
+		if (nw == 64u || nh == 64u) {  // one-pass classes: rare, generic kernel
+			defer();
+			__syncthreads();
+			continue;
+		}
+		// ---- two-pass resample on the matrix cores
+		const uint32_t lx = m0 < (uint32_t)kMaxLevel ? m0 : (uint32_t)kMaxLevel - 1;
+		const uint32_t ly = m1 < (uint32_t)kMaxLevel ? m1 : (uint32_t)kMaxLevel - 1;
+		const uint32_t *mx = a.mf64 + a.mf_off[lx], *my = a.mf64 + a.mf_off[ly];
+		const uint32_t nbx = nw > 16u ? 2u : 1u, nby = nh > 16u ? 2u : 1u;
+		const uint32_t *mx_tail = mx + nbx * 512u, *my_tail = my + nby * 512u;  // bias[32], ksum[32], flag
+		const uint32_t px_ = a.precision[lx], py = a.precision[ly];
+		const int32_t top_x = (int32_t)((256u << px_) - 1u), top_y = (int32_t)((256u << py) - 1u);
+		const uint32_t o = lane & 15u, g = lane >> 4;
+		const v4i32 zero = {0, 0, 0, 0};
+		{
+			// horizontal: this wave's 16 rows; A = pixels of row 16w + o, columns 16g .. 16g+15
+			v4i32 wlo[2], whi[2];
+			int32_t bx[2];
+#pragma unroll
+			for (uint32_t nb = 0; nb < 2; ++nb) {
+				if (nb < nbx) {
+					wlo[nb] = *reinterpret_cast<const v4i32 *>(mx + nb * 512u + lane * 4u);
+					whi[nb] = *reinterpret_cast<const v4i32 *>(mx + nb * 512u + 256u + lane * 4u);
+					bx[nb] = (int32_t)mx_tail[16u * nb + o];
+				}
+			}
+			const uint32_t *rowp = s_pl + (16u * wave + o) * kRS64 + 8u * g;
+#pragma unroll
+			for (uint32_t c = 0; c < 3; ++c) {
+				const uint4 d0 = *reinterpret_cast<const uint4 *>(rowp + c * kPD64);
+				const uint4 d1 = *reinterpret_cast<const uint4 *>(rowp + c * kPD64 + 4);
+				v4i32 av;
+				av[0] = (int)(__builtin_amdgcn_perm(d0.y, d0.x, 0x06040200u) ^ 0x80808080u);
+				av[1] = (int)(__builtin_amdgcn_perm(d0.w, d0.z, 0x06040200u) ^ 0x80808080u);
+				av[2] = (int)(__builtin_amdgcn_perm(d1.y, d1.x, 0x06040200u) ^ 0x80808080u);
+				av[3] = (int)(__builtin_amdgcn_perm(d1.w, d1.z, 0x06040200u) ^ 0x80808080u);
+#pragma unroll
+				for (uint32_t nb = 0; nb < 2; ++nb) {
+					if (nb < nbx) {
+						const v4i32 cx = {bx[nb], bx[nb], bx[nb], bx[nb]};
+						const v4i32 lo = __builtin_amdgcn_mfma_i32_16x16x64_i8(av, wlo[nb], cx, 0, 0, 0);
+						const v4i32 hi = __builtin_amdgcn_mfma_i32_16x16x64_i8(av, whi[nb], zero, 0, 0, 0);
+						uint32_t packed = 0;
+						put_byte_shr<0>(packed, clamp_fixed(hi[0], lo[0], top_x), px_);
+						put_byte_shr<1>(packed, clamp_fixed(hi[1], lo[1], top_x), px_);
+						put_byte_shr<2>(packed, clamp_fixed(hi[2], lo[2], top_x), px_);
+						put_byte_shr<3>(packed, clamp_fixed(hi[3], lo[3], top_x), px_);
+						// rows 16w + 4g .. +3 of column ox = 16nb + o
+						s_t[(c * 32u + 16u * nb + o) * 16u + 4u * wave + g] = packed;
+					}
+				}
+			}
+		}
+		__syncthreads();  // B3: all 64 rows of the horizontal pass are in LDS
+		{
+			// vertical: wave = (output row block mb, output column block nb)
+			const uint32_t mb = wave >> 1, nb = wave & 1u;
+			if (mb < nby && nb < nbx) {
+				const v4i32 klo = *reinterpret_cast<const v4i32 *>(my + mb * 512u + lane * 4u);
+				const v4i32 khi = *reinterpret_cast<const v4i32 *>(my + mb * 512u + 256u + lane * 4u);
+				const v4i32 cy = *reinterpret_cast<const v4i32 *>(my_tail + 16u * mb + 4u * g);
+				uint32_t pix[4] = {0xff000000u, 0xff000000u, 0xff000000u, 0xff000000u};
+#pragma unroll
+				for (uint32_t c = 0; c < 3; ++c) {
+					const uint4 tv = *reinterpret_cast<const uint4 *>(s_t + (c * 32u + 16u * nb + o) * 16u + 4u * g);
+					v4i32 bv;
+					bv[0] = (int)(tv.x ^ 0x80808080u);
+					bv[1] = (int)(tv.y ^ 0x80808080u);
+					bv[2] = (int)(tv.z ^ 0x80808080u);
+					bv[3] = (int)(tv.w ^ 0x80808080u);
+					const v4i32 lo = __builtin_amdgcn_mfma_i32_16x16x64_i8(klo, bv, cy, 0, 0, 0);
+					const v4i32 hi = __builtin_amdgcn_mfma_i32_16x16x64_i8(khi, bv, zero, 0, 0, 0);
+#pragma unroll
+					for (int r = 0; r < 4; ++r) {
+						const uint32_t v = clamp_fixed(hi[r], lo[r], top_y);
+						if (c == 0) put_byte_shr<0>(pix[r], v, py);
+						else if (c == 1) put_byte_shr<1>(pix[r], v, py);
+						else put_byte_shr<2>(pix[r], v, py);
+					}
+				}
+				const uint32_t ox = 16u * nb + o;
+				if (!(mx_tail[64] & my_tail[64])) {
+					// opaque tile: alpha is the convolution of the constant 255 = the windows' weight sums
+					const int32_t ah = (int32_t)clip8((1 << (px_ - 1)) + 255 * (int32_t)mx_tail[32u + ox], (int)px_);
+#pragma unroll
+					for (int r = 0; r < 4; ++r) {
+						const uint32_t al = clip8((1 << (py - 1)) + ah * (int32_t)my_tail[32u + 16u * mb + 4u * g + (uint32_t)r], (int)py);
+						pix[r] = (pix[r] & 0x00ffffffu) | (al << 24);
+						if (al != 255u) pix[r] = unpremultiply(pix[r]);
+					}
+				}
+				if (ox < nw) {
+#pragma unroll
+					for (uint32_t r = 0; r < 4; ++r) {
+						const uint32_t oy = 16u * mb + 4u * g + r;
+						if (oy < nh) reinterpret_cast<uint32_t *>(dst)[oy * nw + ox] = pix[r];
+					}
+				}
+			}
+		}
+		// no barrier here: the next tile's B1/B2 separate this vertical pass from the next horizontal one
+	}
+}
+
+// ---------------------------------------------------------------------------
 // generic kernel: persistent over tiles (or over the worklist left by shrink32_kernel).  NW == 1:
 // every wave of the block owns one LDS tile image and walks tiles wave_id, wave_id + total_waves, ...;
 // NW > 1: one tile per block iteration.
@@ -1528,9 +1816,24 @@ __global__ void __launch_bounds__(NW == 1 ? 768 : 64 * NW) shrink_kernel(const S
 			if (blockIdx.x == 0 && threadIdx.x == 0) a.work[a.work_slot ^ 1u] = 0u;
 		}
 	} else {
-		for (uint32_t tile_g = blockIdx.x; tile_g < a.n_tiles; tile_g += gridDim.x) {
+		// with a worklist (left by shrink64_kernel) only the listed tiles are processed
+		const uint32_t count = a.work ? __builtin_amdgcn_readfirstlane(a.work[a.work_slot]) : a.n_tiles;
+		for (uint32_t i = blockIdx.x; i < count; i += gridDim.x) {
+			const uint32_t tile_g = a.work ? __builtin_amdgcn_readfirstlane(a.work[2 + i]) : i;
 			process_tile<NW, C, MODE>(a, tile_g, lds, lds + a.tile_dw, threadIdx.x);
 			__syncthreads();
+		}
+		if (a.work) {
+			// as in the single-wave form: finish the tiles the fast kernel completed, zero the next launch's counter
+			for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < a.n_tiles; t += gridDim.x * blockDim.x) {
+				const uint2 key = reinterpret_cast<const uint2 *>(a.sums)[t];
+				if (key.x == kDeferredKey && key.y == kDeferredKey) continue;
+				const uint32_t tf = t % a.tiles_per_frame;
+				const uint32_t ty = tf / a.cols, tx = tf - ty * a.cols;
+				finish_tile(key, (tx == a.cols - 1) ? a.edge_w : a.bw, (ty == a.rows - 1) ? a.edge_h : a.bh, (uint32_t)MODE, a.factor,
+				            a.value, a.lod0, a.lod1, t);
+			}
+			if (blockIdx.x == 0 && threadIdx.x == 0) a.work[a.work_slot ^ 1u] = 0u;
 		}
 	}
 }
@@ -2791,6 +3094,12 @@ LaunchGeom plan_launch(const ShrinkArgs &a, uint32_t channels, uint32_t n_cus)
 	return g;
 }
 
+bool fast64_applicable(const ShrinkArgs &a, uint32_t channels)
+{
+	return channels == 4 && a.bw == 64 && a.bh == 64 && a.mode == 1 && a.work != nullptr &&
+	       (a.out_px == nullptr || (a.filter != 0 && a.mf64 != nullptr));
+}
+
 bool fast32_applicable(const ShrinkArgs &a, uint32_t channels)
 {
 	return channels == 4 && a.bw == 32 && a.bh == 32 && a.work != nullptr &&
@@ -2800,7 +3109,45 @@ bool fast32_applicable(const ShrinkArgs &a, uint32_t channels)
 hipError_t launch_shrink(const ShrinkArgs &a, uint32_t channels, uint32_t n_cus, hipStream_t stream)
 {
 	ShrinkArgs ga = a;
-	if (fast32_applicable(a, channels)) {
+	if (fast64_applicable(a, channels)) {
+		// 64x64: the four-wave kernel for full opaque tiles; it leaves the rest in the worklist
+		Fast64Args f{};
+		f.src = a.src;
+		f.frame_stride = a.frame_stride;
+		f.pitch = a.pitch;
+		f.cols = a.cols;
+		f.rows = a.rows;
+		f.tiles_per_frame = a.tiles_per_frame;
+		f.n_tiles = a.n_tiles;
+		f.div_tpf = a.div_tpf;
+		f.div_cols = a.div_cols;
+		f.full_cols = a.full_cols;
+		f.full_rows = a.full_rows;
+		f.filter = a.filter;
+		f.sums = a.sums;
+		f.out_w = a.out_w;
+		f.out_h = a.out_h;
+		f.out_px = a.out_px;
+		f.work = a.work;
+		f.work_slot = a.work_slot;
+		f.mf64 = a.mf64;
+		for (int j = 0; j < kMaxLevel; ++j) {
+			f.mf_off[j] = a.tabs[j].mf_off;
+			f.precision[j] = a.tabs[j].precision;
+			f.breaks[j] = a.breaks[0][j];
+		}
+		f.breaks_asc = a.breaks_asc[0];
+		const uint32_t lds_bytes = kLds64 * 4u;
+		constexpr uint32_t kLds = 160u * 1024u;
+		const uint32_t per_cu = kLds / lds_bytes;
+		const uint32_t resident = n_cus * per_cu;
+		const uint32_t blocks = a.n_tiles < resident ? a.n_tiles : resident;
+		hipError_t e;
+		auto k = shrink64_kernel;
+		if (lds_bytes > 64u * 1024u && (e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)) != hipSuccess) return e;
+		hipLaunchKernelGGL(k, dim3(blocks), dim3(256), lds_bytes, stream, f);
+		if ((e = hipGetLastError()) != hipSuccess) return e;
+	} else if (fast32_applicable(a, channels)) {
 		// 1) the lean kernel for full opaque tiles; it leaves the rest in the worklist
 		Fast32Args f{};
 		f.src = a.src;

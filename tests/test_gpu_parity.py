@@ -248,6 +248,49 @@ def test_single_pass_resamples(gpu, oracle, axis):
     assert len(one_pass) >= 3, seen
 
 
+@pytest.mark.parametrize("filt", [1, 2, 3, 4])
+def test_block64_fast_kernel_every_class(gpu, oracle, filt):
+    """The reference CLI's default 64x64 tiles through shrink64_kernel (four waves per tile, matrix-core
+    resample): every reduced size from 64x64 (clone) down to 1x1, the one-pass classes (worklist), a ragged
+    edge, and a batch of frames -- against the oracle."""
+    import torch
+    seen = set()
+    img = oracle.synth_frame(1088, 600, 4, 5, 0)  # 17 x 10 tiles, last row 24 px high
+    for factor in (64.0, 16.0, 4.0, 1.0, 0.25):
+        got = gpu.shrink_image(img, 64, 64, 1, filt, factor)
+        exp = oracle.shrink_image(img, 64, 64, 1, filt, factor, nthreads=8)
+        assert_same_tiles(got, exp, 4, f"64x64 filter {filt} k={factor}")
+        seen |= set(histogram(got[1], got[2]))
+    assert {(64, 64), (32, 32), (16, 16), (8, 8), (4, 4), (2, 2), (1, 1)} <= seen, seen
+    frames = gpu.synth_frames_device(3, 256, 512, 4, first_frame=2, dist=0)
+    vals, ow, oh, slots = gpu.shrink_frames_device(frames, 64, 64, 1, filt, 16.0)
+    f = frames.cpu().numpy()
+    for n in range(3):
+        exp = oracle.shrink_image(f[n], 64, 64, 1, filt, 16.0)
+        assert_same_tiles((vals[n].cpu().numpy(), ow[n].cpu().numpy().astype(np.uint32), oh[n].cpu().numpy().astype(np.uint32),
+                           slots[n].cpu().numpy()), exp, 4, f"batch frame {n}")
+
+
+def test_block64_one_pass_and_transparency_go_through_the_worklist(gpu, oracle):
+    """64 x n / n x 64 outputs and tiles with transparency are handed to the generic kernel by
+    shrink64_kernel; results must not depend on who processed a tile."""
+    rng = np.random.default_rng(5)
+    h, w = 256, 512
+    strong = rng.integers(0, 256, size=(h, 3)).astype(np.int32)
+    weak = rng.integers(0, 12, size=(w, 3)).astype(np.int32)
+    img = np.empty((h, w, 4), np.uint8)
+    img[..., 3] = 255
+    img[..., :3] = np.clip(strong[:, None, :] + weak[None, :, :] - 6, 0, 255)
+    img[100:140, 300:340, 3] = 77  # transparency in a few tiles
+    seen = set()
+    for factor in (256.0, 64.0, 16.0):
+        got = gpu.shrink_image(img, 64, 64, 1, 4, factor)
+        exp = oracle.shrink_image(img, 64, 64, 1, 4, factor)
+        assert_same_tiles(got, exp, 4, f"k={factor}")
+        seen |= set(histogram(got[1], got[2]))
+    assert any((k[0] == 64) != (k[1] == 64) for k in seen), seen
+
+
 @pytest.mark.parametrize("axis", [0, 1])
 def test_wide_flat_and_tall_thin_classes(gpu, oracle, axis):
     """Reduced sizes that are large on one axis and tiny on the other (16x2, 16x1, 8x1, 1x16, ...): the fast
