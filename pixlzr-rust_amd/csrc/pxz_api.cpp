@@ -551,7 +551,7 @@ int timed_launch(pxz_handle *h, pxz::ShrinkArgs &a, uint32_t channels, float *va
 	if (rc != PXZ_OK) return rc;
 	a.sums = (uint32_t *)h->sums.ptr;
 	const void *work_before = h->work.ptr;
-	if ((rc = ensure(h, h->work, ((size_t)a.n_tiles + 4u) * 4u + 64u + 4096u * 8u)) != PXZ_OK) return rc;  // + diagnostic stamps
+	if ((rc = ensure(h, h->work, ((size_t)a.n_tiles + pxz::kWorkList + 4u) * 4u + 64u + 4096u * 8u)) != PXZ_OK) return rc;  // + diagnostic stamps
 	if (h->work.ptr != work_before) h->work_ready = false;
 	a.work = (uint32_t *)h->work.ptr;
 	a.value = value;
@@ -590,7 +590,7 @@ int timed_launch(pxz_handle *h, pxz::ShrinkArgs &a, uint32_t channels, float *va
 	const bool fast = pxz::fast32_applicable(a, channels) || pxz::fast64_applicable(a, channels);
 	if (fast) {
 		if (!h->work_ready) {
-			PXZ_HIP(h, hipMemsetAsync(h->work.ptr, 0, 8, h->stream));
+			PXZ_HIP(h, hipMemsetAsync(h->work.ptr, 0, pxz::kWorkList * 4u, h->stream));
 			h->work_slot = 0;
 		}
 		h->work_ready = false;  // stays false if a launch below fails: the counters are then re-zeroed next time

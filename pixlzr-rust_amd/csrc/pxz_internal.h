@@ -38,6 +38,11 @@ struct AxisTab {
 // accumulator registers hand their rows to the second product.
 constexpr uint32_t kMfDwords = 292;
 
+// Layout of the handle's worklist buffer (dwords): [0], [1] the two worklist counters used alternately,
+// [2 + 64*s, 2 + 64*s + 64) the tile-ticket counters of shrink64_kernel for counter set s, then the list.
+constexpr uint32_t kTicketCounters = 64;
+constexpr uint32_t kWorkList = 2 + 2 * kTicketCounters;
+
 // q = n / d as (t + ((n - t) >> sh1)) >> sh2 with t = mulhi(n, mul)  (Granlund-Montgomery)
 struct FastDiv {
 	uint32_t mul, sh1, sh2;

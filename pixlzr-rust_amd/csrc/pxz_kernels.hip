@@ -1302,7 +1302,7 @@ __global__ void __launch_bounds__(1024) shrink32_kernel(const Fast32Args a)
 	auto one_tile = [&](const uint32_t tile_g, const uint32_t tile_next) {
 		auto defer = [&]() {
 			if (tid == 0) {
-				a.work[2 + atomicAdd(&a.work[a.work_slot], 1u)] = tile_g;
+				a.work[kWorkList + atomicAdd(&a.work[a.work_slot], 1u)] = tile_g;
 				reinterpret_cast<uint2 *>(a.sums)[tile_g] = make_uint2(kDeferredKey, kDeferredKey);  // not finished here
 			}
 		};
@@ -1474,7 +1474,7 @@ __global__ void __launch_bounds__(1024) shrink32_kernel(const Fast32Args a)
 	flush();  // the last tile's pixels
 #ifdef PXZ_STAMPS
 	if (tid == 0) {
-		unsigned long long *out = reinterpret_cast<unsigned long long *>(a.work + ((a.n_tiles + 3u + 1u) & ~1u));
+		unsigned long long *out = reinterpret_cast<unsigned long long *>(a.work + ((a.n_tiles + kWorkList + 1u + 1u) & ~1u));
 		for (int i = 0; i < 8; ++i) atomicAdd(out + i, st_acc[i]);
 		// per-wave run time (100 MHz ticks) | tiles processed << 48; last launch wins
 		out[8 + blockIdx.x * 16u + sub] = ((wall_clock64() - st_begin) & 0xffffffffffffull) | ((unsigned long long)st_tiles << 48);
@@ -1536,17 +1536,49 @@ __global__ void __launch_bounds__(256) shrink64_kernel(const Fast64Args a)
 			for (int k = 0; k < 4; ++k) pre[k] = *reinterpret_cast<const uint4 *>(p + (size_t)(4 * k) * a.pitch);
 		}
 	};
-	prefetch(blockIdx.x);
-	for (uint32_t tile_g = blockIdx.x; tile_g < a.n_tiles; tile_g += gridDim.x) {
+	// Tiles are dealt on demand: tile costs differ several times between size classes, and with ~64 tiles per
+	// block a static stride leaves the unluckiest of a thousand blocks far behind.  kTicketCounters global
+	// counters (one per residue class of the block index, so ~16 blocks share one and an address sees a few
+	// atomics per microsecond); counter c owns tiles c, c + n_ctr, c + 2 n_ctr, ...  A block's first two tiles
+	// are fixed; every iteration draws the ticket of the tile after next at its start and hands it to the
+	// other waves across a barrier the iteration has anyway.
+	const uint32_t n_ctr = gridDim.x < kTicketCounters ? gridDim.x : kTicketCounters;
+	const uint32_t cid = blockIdx.x % n_ctr, nb_c = (gridDim.x - cid + n_ctr - 1u) / n_ctr;
+	uint32_t *ctr = a.work + 2u + kTicketCounters * a.work_slot + cid;
+	auto tile_of = [&](uint32_t k) -> uint32_t {
+		const unsigned long long t = (unsigned long long)k * n_ctr + cid;
+		return t < (unsigned long long)a.n_tiles ? (uint32_t)t : 0xffffffffu;
+	};
+	uint32_t tile_g = tile_of(blockIdx.x / n_ctr), tile_next = tile_of(blockIdx.x / n_ctr + nb_c);
+	prefetch(tile_g);
+	// detector-only launches: equal cost per tile, and an iteration is shorter than an atomic's round trip:
+	// there the "tickets" are simply this block's turn in a fixed rotation
+	const bool dynamic = a.out_px != nullptr;
+	uint32_t turn = blockIdx.x / n_ctr;
+	for (; tile_g < a.n_tiles;) {
+		uint32_t drawn = turn;
+		turn += nb_c;
+		if (dynamic && threadIdx.x == 0) drawn = atomicAdd(ctr, 1u);
+		// (call once per iteration, before a block barrier; the value is read after that barrier)
+		auto publish_ticket = [&]() {
+			if (threadIdx.x == 0) s_red[13] = drawn;
+		};
+		auto advance = [&]() {  // after the barrier that followed publish_ticket()
+			tile_g = tile_next;
+			tile_next = tile_of(2u * nb_c + s_red[13]);
+		};
 		auto defer = [&]() {
 			if (threadIdx.x == 0) {
-				a.work[2 + atomicAdd(&a.work[a.work_slot], 1u)] = tile_g;
+				a.work[kWorkList + atomicAdd(&a.work[a.work_slot], 1u)] = tile_g;
 				reinterpret_cast<uint2 *>(a.sums)[tile_g] = make_uint2(kDeferredKey, kDeferredKey);
 			}
 		};
 		if (!pre_valid) {  // ragged edge / unaligned batch (block-uniform)
 			defer();
-			prefetch(tile_g + gridDim.x);
+			prefetch(tile_next);
+			publish_ticket();
+			__syncthreads();
+			advance();
 			continue;
 		}
 		// ---- stage: registers -> planar u16 pairs
@@ -1569,11 +1601,13 @@ __global__ void __launch_bounds__(256) shrink64_kernel(const Fast64Args a)
 		}
 		const bool wave_transparent = __builtin_amdgcn_ballot_w64(alpha_and != 0xffu) != 0ull;
 		if (lane == 0) s_red[8 + wave] = wave_transparent ? 1u : 0u;
-		prefetch(tile_g + gridDim.x);  // lands while this tile is processed
-		__syncthreads();               // B1: the whole tile is staged
+		prefetch(tile_next);  // lands while this tile is processed
+		__syncthreads();      // B1: the whole tile is staged
 		if ((s_red[8] | s_red[9] | s_red[10] | s_red[11]) != 0u) {
 			defer();  // transparency: premultiplied convolution and the alpha plane live in the generic kernel
+			publish_ticket();
 			__syncthreads();
+			advance();
 			continue;
 		}
 		// ---- detector: window rows 16w + 8gg .. +7, column pair q (windows 2q, 2q+1)
@@ -1627,7 +1661,10 @@ __global__ void __launch_bounds__(256) shrink64_kernel(const Fast64Args a)
 			s_red[2 * wave] = sum_hz;
 			s_red[2 * wave + 1] = sum_vr;
 		}
+		publish_ticket();
 		__syncthreads();  // B2: partial sums are in; every wave is done with its neighbours' rows
+		const uint32_t this_tile = tile_g;
+		advance();
 		sum_hz = s_red[0] + s_red[2] + s_red[4] + s_red[6];
 		sum_vr = s_red[1] + s_red[3] + s_red[5] + s_red[7];
 		sum_hz = __builtin_amdgcn_readfirstlane(sum_hz);
@@ -1635,15 +1672,15 @@ __global__ void __launch_bounds__(256) shrink64_kernel(const Fast64Args a)
 		const uint32_t m0 = level_of(sum_hz), m1 = level_of(sum_vr);
 		const uint32_t nw = reduced_size(64u, m0), nh = reduced_size(64u, m1);
 		if (threadIdx.x == 0) {
-			reinterpret_cast<uint2 *>(a.sums)[tile_g] = make_uint2(sum_hz, sum_vr);
-			if (a.out_w) a.out_w[tile_g] = nw;
-			if (a.out_h) a.out_h[tile_g] = nh;
+			reinterpret_cast<uint2 *>(a.sums)[this_tile] = make_uint2(sum_hz, sum_vr);
+			if (a.out_w) a.out_w[this_tile] = nw;
+			if (a.out_h) a.out_h[this_tile] = nh;
 		}
 		if (a.out_px == nullptr) {
 			__syncthreads();  // s_red is rewritten by the next tile
 			continue;
 		}
-		uint8_t *dst = a.out_px + (size_t)tile_g * (64u * 64u * 4u);
+		uint8_t *dst = a.out_px + (size_t)this_tile * (64u * 64u * 4u);
 		if (nw == 64u && nh == 64u) {
 			// clone (block.rs:279-281): re-interleave this wave's 16 rows, 16 bytes per lane and step
 #pragma unroll
@@ -1666,23 +1703,19 @@ __global__ void __launch_bounds__(256) shrink64_kernel(const Fast64Args a)
 			__syncthreads();
 			continue;
 		}
-		if (nw == 64u || nh == 64u) {  // one-pass classes: rare, generic kernel
-			defer();
-			__syncthreads();
-			continue;
-		}
-		// ---- two-pass resample on the matrix cores
+		// ---- resample on the matrix cores: two passes, or one when an axis keeps its 64 samples
 		const uint32_t lx = m0 < (uint32_t)kMaxLevel ? m0 : (uint32_t)kMaxLevel - 1;
 		const uint32_t ly = m1 < (uint32_t)kMaxLevel ? m1 : (uint32_t)kMaxLevel - 1;
-		const uint32_t *mx = a.mf64 + a.mf_off[lx], *my = a.mf64 + a.mf_off[ly];
-		const uint32_t nbx = nw > 16u ? 2u : 1u, nby = nh > 16u ? 2u : 1u;
+		const bool need_h = nw != 64u, need_v = nh != 64u;
+		const uint32_t *mx = a.mf64 + a.mf_off[need_h ? lx : ly], *my = a.mf64 + a.mf_off[need_v ? ly : lx];
+		const uint32_t nbx = nw > 16u ? 2u : 1u, nby = nh > 16u ? 2u : 1u;  // (of the axes that are resampled)
 		const uint32_t *mx_tail = mx + nbx * 512u, *my_tail = my + nby * 512u;  // bias[32], ksum[32], flag
-		const uint32_t px_ = a.precision[lx], py = a.precision[ly];
+		const uint32_t px_ = a.precision[need_h ? lx : ly], py = a.precision[need_v ? ly : lx];
 		const int32_t top_x = (int32_t)((256u << px_) - 1u), top_y = (int32_t)((256u << py) - 1u);
 		const uint32_t o = lane & 15u, g = lane >> 4;
 		const v4i32 zero = {0, 0, 0, 0};
-		{
-			// horizontal: this wave's 16 rows; A = pixels of row 16w + o, columns 16g .. 16g+15
+		// horizontal pass of this wave's 16 rows into s_t[c][ox][y]; A = pixels of row 16w + o, columns 16g .. 16g+15
+		auto hpass = [&]() {
 			v4i32 wlo[2], whi[2];
 			int32_t bx[2];
 #pragma unroll
@@ -1719,12 +1752,12 @@ __global__ void __launch_bounds__(256) shrink64_kernel(const Fast64Args a)
 					}
 				}
 			}
-		}
-		__syncthreads();  // B3: all 64 rows of the horizontal pass are in LDS
-		{
-			// vertical: wave = (output row block mb, output column block nb)
+		};
+		// vertical pass over the 32 columns held in s_t: wave = (output row block mb, column block nb);
+		// ox0 = first output column of s_t, row_w = output row length, nbc = column blocks present
+		auto vpass = [&](const uint32_t ox0, const uint32_t row_w, const uint32_t nbc, const bool through_h) {
 			const uint32_t mb = wave >> 1, nb = wave & 1u;
-			if (mb < nby && nb < nbx) {
+			if (mb < nby && nb < nbc) {
 				const v4i32 klo = *reinterpret_cast<const v4i32 *>(my + mb * 512u + lane * 4u);
 				const v4i32 khi = *reinterpret_cast<const v4i32 *>(my + mb * 512u + 256u + lane * 4u);
 				const v4i32 cy = *reinterpret_cast<const v4i32 *>(my_tail + 16u * mb + 4u * g);
@@ -1747,10 +1780,10 @@ __global__ void __launch_bounds__(256) shrink64_kernel(const Fast64Args a)
 						else put_byte_shr<2>(pix[r], v, py);
 					}
 				}
-				const uint32_t ox = 16u * nb + o;
-				if (!(mx_tail[64] & my_tail[64])) {
+				const uint32_t oxl = 16u * nb + o;
+				if (!((through_h ? mx_tail[64] : 1u) & my_tail[64])) {
 					// opaque tile: alpha is the convolution of the constant 255 = the windows' weight sums
-					const int32_t ah = (int32_t)clip8((1 << (px_ - 1)) + 255 * (int32_t)mx_tail[32u + ox], (int)px_);
+					const int32_t ah = through_h ? (int32_t)clip8((1 << (px_ - 1)) + 255 * (int32_t)mx_tail[32u + oxl], (int)px_) : 255;
 #pragma unroll
 					for (int r = 0; r < 4; ++r) {
 						const uint32_t al = clip8((1 << (py - 1)) + ah * (int32_t)my_tail[32u + 16u * mb + 4u * g + (uint32_t)r], (int)py);
@@ -1758,16 +1791,58 @@ __global__ void __launch_bounds__(256) shrink64_kernel(const Fast64Args a)
 						if (al != 255u) pix[r] = unpremultiply(pix[r]);
 					}
 				}
-				if (ox < nw) {
+				if (ox0 + oxl < row_w) {
 #pragma unroll
 					for (uint32_t r = 0; r < 4; ++r) {
 						const uint32_t oy = 16u * mb + 4u * g + r;
-						if (oy < nh) reinterpret_cast<uint32_t *>(dst)[oy * nw + ox] = pix[r];
+						if (oy < nh) reinterpret_cast<uint32_t *>(dst)[oy * row_w + ox0 + oxl] = pix[r];
 					}
 				}
 			}
+		};
+		if (need_h && need_v) {
+			hpass();
+			__syncthreads();  // B3: all 64 rows of the horizontal pass are in LDS
+			vpass(0u, nw, nbx, true);
+			// no barrier here: the next tile's B1/B2 separate this vertical pass from the next horizontal one
+		} else if (need_v) {
+			// width kept: the pixels themselves, 32 columns at a time, as bytes [x][y] in s_t
+			for (uint32_t half = 0; half < 2; ++half) {
+				const uint32_t xl = lane & 31u, jj = lane >> 5;
+#pragma unroll
+				for (uint32_t c = 0; c < 3; ++c) {
+					const uint16_t *p16 = reinterpret_cast<const uint16_t *>(s_pl + c * kPD64) + 32u * half + xl;
+#pragma unroll
+					for (uint32_t it = 0; it < 2; ++it) {
+						const uint32_t j = jj + 2u * it, y0 = 16u * wave + 4u * j;
+						const uint32_t b0 = p16[(y0 + 0u) * (2u * kRS64)], b1 = p16[(y0 + 1u) * (2u * kRS64)];
+						const uint32_t b2 = p16[(y0 + 2u) * (2u * kRS64)], b3 = p16[(y0 + 3u) * (2u * kRS64)];
+						s_t[(c * 32u + xl) * 16u + 4u * wave + j] = b0 | (b1 << 8) | (b2 << 16) | (b3 << 24);
+					}
+				}
+				__syncthreads();
+				vpass(32u * half, 64u, 2u, false);
+				__syncthreads();  // s_t is refilled (next half, or the next tile's horizontal pass after only B1/B2)
+			}
+		} else {
+			// height kept: the horizontal pass is the result; gather [c][ox][y] bytes into pixels
+			hpass();
+			__syncthreads();
+			const bool opaque_stays = (mx_tail[64] & 1u) != 0u;
+			for (uint32_t i = threadIdx.x; i < nw * 16u; i += 256u) {
+				const uint32_t ox = i % nw, yq = i / nw;  // nw is a power of two here
+				const uint32_t r4 = s_t[(0u * 32u + ox) * 16u + yq], g4 = s_t[(1u * 32u + ox) * 16u + yq], b4 = s_t[(2u * 32u + ox) * 16u + yq];
+				uint32_t al = 255u;
+				if (!opaque_stays) al = clip8((1 << (px_ - 1)) + 255 * (int32_t)mx_tail[32u + ox], (int)px_);
+#pragma unroll
+				for (uint32_t r = 0; r < 4; ++r) {
+					uint32_t px = ((r4 >> (8u * r)) & 255u) | (((g4 >> (8u * r)) & 255u) << 8) | (((b4 >> (8u * r)) & 255u) << 16) | (al << 24);
+					if (al != 255u) px = unpremultiply(px);
+					reinterpret_cast<uint32_t *>(dst)[(4u * yq + r) * nw + ox] = px;
+				}
+			}
+			__syncthreads();
 		}
-		// no barrier here: the next tile's B1/B2 separate this vertical pass from the next horizontal one
 	}
 }
 
@@ -1794,7 +1869,7 @@ __global__ void __launch_bounds__(NW == 1 ? 768 : 64 * NW) shrink_kernel(const S
 		for (;;) {
 			const unsigned long long i = (unsigned long long)blockIdx.x + (unsigned long long)ticket * gridDim.x;
 			if (i >= (unsigned long long)count) break;
-			const uint32_t tile_g = a.work ? __builtin_amdgcn_readfirstlane(a.work[2 + (uint32_t)i]) : (uint32_t)i;
+			const uint32_t tile_g = a.work ? __builtin_amdgcn_readfirstlane(a.work[kWorkList + (uint32_t)i]) : (uint32_t)i;
 			process_tile<NW, C, MODE>(a, tile_g, s_pl, nullptr, tid);
 			uint32_t t = 0;
 			if (tid == 0) t = atomicAdd(s_ticket, 1u);
@@ -1813,13 +1888,16 @@ __global__ void __launch_bounds__(NW == 1 ? 768 : 64 * NW) shrink_kernel(const S
 				finish_tile(key, (tx == a.cols - 1) ? a.edge_w : a.bw, (ty == a.rows - 1) ? a.edge_h : a.bh, (uint32_t)MODE, a.factor,
 				            a.value, a.lod0, a.lod1, t);
 			}
-			if (blockIdx.x == 0 && threadIdx.x == 0) a.work[a.work_slot ^ 1u] = 0u;
+			if (blockIdx.x == 0) {  // the other set of counters is the next launch's
+				if (threadIdx.x == 0) a.work[a.work_slot ^ 1u] = 0u;
+				if (threadIdx.x < kTicketCounters) a.work[2u + kTicketCounters * (a.work_slot ^ 1u) + threadIdx.x] = 0u;
+			}
 		}
 	} else {
 		// with a worklist (left by shrink64_kernel) only the listed tiles are processed
 		const uint32_t count = a.work ? __builtin_amdgcn_readfirstlane(a.work[a.work_slot]) : a.n_tiles;
 		for (uint32_t i = blockIdx.x; i < count; i += gridDim.x) {
-			const uint32_t tile_g = a.work ? __builtin_amdgcn_readfirstlane(a.work[2 + i]) : i;
+			const uint32_t tile_g = a.work ? __builtin_amdgcn_readfirstlane(a.work[kWorkList + i]) : i;
 			process_tile<NW, C, MODE>(a, tile_g, lds, lds + a.tile_dw, threadIdx.x);
 			__syncthreads();
 		}
@@ -1833,7 +1911,10 @@ __global__ void __launch_bounds__(NW == 1 ? 768 : 64 * NW) shrink_kernel(const S
 				finish_tile(key, (tx == a.cols - 1) ? a.edge_w : a.bw, (ty == a.rows - 1) ? a.edge_h : a.bh, (uint32_t)MODE, a.factor,
 				            a.value, a.lod0, a.lod1, t);
 			}
-			if (blockIdx.x == 0 && threadIdx.x == 0) a.work[a.work_slot ^ 1u] = 0u;
+			if (blockIdx.x == 0) {  // the other set of counters is the next launch's
+				if (threadIdx.x == 0) a.work[a.work_slot ^ 1u] = 0u;
+				if (threadIdx.x < kTicketCounters) a.work[2u + kTicketCounters * (a.work_slot ^ 1u) + threadIdx.x] = 0u;
+			}
 		}
 	}
 }

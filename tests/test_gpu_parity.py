@@ -271,9 +271,9 @@ def test_block64_fast_kernel_every_class(gpu, oracle, filt):
                            slots[n].cpu().numpy()), exp, 4, f"batch frame {n}")
 
 
-def test_block64_one_pass_and_transparency_go_through_the_worklist(gpu, oracle):
-    """64 x n / n x 64 outputs and tiles with transparency are handed to the generic kernel by
-    shrink64_kernel; results must not depend on who processed a tile."""
+def test_block64_one_pass_classes_and_transparency(gpu, oracle):
+    """64 x n / n x 64 outputs (one matrix-core pass inside shrink64_kernel) and tiles with transparency
+    (handed to the generic kernel through the worklist): results must not depend on who processed a tile."""
     rng = np.random.default_rng(5)
     h, w = 256, 512
     strong = rng.integers(0, 256, size=(h, 3)).astype(np.int32)
