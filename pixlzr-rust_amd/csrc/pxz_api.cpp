@@ -26,7 +26,7 @@ bool fast64_applicable(const ShrinkArgs &a, uint32_t channels);
 hipError_t launch_expand(const ExpandArgs &a, uint32_t n_cus, hipStream_t stream);
 hipError_t launch_decode(const DecodeArgs &a, hipStream_t stream);
 hipError_t launch_pack(const PackArgs &a, hipStream_t stream);
-hipError_t launch_oklab32(const ShrinkArgs &a, uint32_t n_cus, hipStream_t stream);
+hipError_t launch_oklab(const ShrinkArgs &a, uint32_t n_cus, hipStream_t stream);
 hipError_t launch_qoi(const QoiArgs &a, hipStream_t stream);
 uint32_t waves_per_tile(uint32_t bw, uint32_t bh);
 }  // namespace pxz
@@ -72,7 +72,7 @@ struct pxz_handle {
 	// level breakpoints per (mode, factor bits, bw, bh, edge_w, edge_h)
 	struct Breaks { uint32_t b[4][pxz::kMaxLevel]; uint32_t asc[4]; };
 	std::map<std::tuple<uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t>, Breaks> breaks;
-	DeviceBuffer in, val, ow, oh, out, sums, chunks, work, qscratch, qmeta, status, dmeta;
+	DeviceBuffer in, val, ow, oh, out, sums, chunks, work, qscratch, qmeta, status, dmeta, okscratch;
 	std::map<std::tuple<uint32_t, uint32_t, uint32_t, uint32_t, uint32_t>, ExpandTables> expand_tables;
 	bool work_ready = false;   // both worklist counters are zero / consistent with work_slot
 	uint32_t work_slot = 0;    // the counter the next 32x32 launch uses
@@ -559,7 +559,7 @@ int timed_launch(pxz_handle *h, pxz::ShrinkArgs &a, uint32_t channels, float *va
 	a.lod1 = lod1;
 	// 32x32 fast path: which tiles are full-size, and whether every tile row of the batch is 16-byte aligned
 	a.full_cols = a.full_rows = 0;
-	if (a.bw == a.bh && (a.bw == 32 || a.bw == 64) && channels == 4 &&
+	if (a.bw == a.bh && (a.bw == 16 || a.bw == 32 || a.bw == 64) && channels == 4 &&
 	    ((reinterpret_cast<uintptr_t>(a.src) | a.pitch | (a.n_tiles > a.tiles_per_frame ? a.frame_stride : 0)) & 15u) == 0) {
 		a.full_cols = a.edge_w == a.bw ? a.cols : a.cols - 1;
 		a.full_rows = a.edge_h == a.bh ? a.rows : a.rows - 1;
@@ -581,9 +581,15 @@ int timed_launch(pxz_handle *h, pxz::ShrinkArgs &a, uint32_t channels, float *va
 	// shrink_by on the headline geometry: the block-cooperative Oklab detector first, then the
 	// fused kernel only stages + resamples (it still runs the generic detector on ragged-edge tiles)
 	a.oklab_given = 0;
-	if (a.mode == PXZ_MODE_SHRINK_BY && channels == 4 && a.bw == 32 && a.bh == 32 && !getenv("PXZ_NO_OKLAB32")) {
+	if (a.mode == PXZ_MODE_SHRINK_BY && channels == 4 && a.bw == a.bh && (a.bw == 16 || a.bw == 32 || a.bw == 64) &&
+	    a.full_cols != 0 && a.full_rows != 0 && !getenv("PXZ_NO_OKLAB32")) {
+		if (a.bw == 64) {
+			// a 64x64 tile does not fit the registers between the detector's two passes: 16 floats per pixel quad in HBM
+			if ((rc = ensure(h, h->okscratch, (size_t)a.n_tiles * 64u * 64u * 16u)) != PXZ_OK) return rc;
+			a.ok_scratch = (float *)h->okscratch.ptr;
+		}
 		a.oklab_given = 1;
-		PXZ_HIP(h, pxz::launch_oklab32(a, h->n_cus, h->stream));
+		PXZ_HIP(h, pxz::launch_oklab(a, h->n_cus, h->stream));
 	}
 	// 32x32 RGBA flow: shrink32_kernel, then the worklist kernel, which also finishes every tile and
 	// zeroes the worklist counter of the next launch (two counters, used alternately)
@@ -659,7 +665,7 @@ void pxz_destroy(pxz_handle *h)
 		(void)hipFree(kv.second.d_sizes);
 		(void)hipFree(kv.second.d_coeffs);
 	}
-	for (DeviceBuffer *b : {&h->in, &h->val, &h->ow, &h->oh, &h->out, &h->sums, &h->chunks, &h->work, &h->qscratch, &h->qmeta, &h->status, &h->dmeta})
+	for (DeviceBuffer *b : {&h->in, &h->val, &h->ow, &h->oh, &h->out, &h->sums, &h->chunks, &h->work, &h->qscratch, &h->qmeta, &h->status, &h->dmeta, &h->okscratch})
 		if (b->ptr) (void)hipFree(b->ptr);
 	for (auto &ev : h->events) {
 		(void)hipEventDestroy(ev.first);

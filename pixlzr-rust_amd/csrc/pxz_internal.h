@@ -65,6 +65,7 @@ struct ShrinkArgs {
 	uint32_t oklab_given;    // 1: full 32x32 RGBA tiles already carry their Oklab value in sums[] (oklab32_kernel)
 	float scale2;            // Oklab mode: value = mean deviation * factor * scale2 (10 = BASE_FACTOR of shrink_by,
 	                         //   pixlzr.rs:15,162; 1 with factor 1 = the identity closure of process(), process/mod.rs:107-121)
+	float *ok_scratch;       // Oklab detector on 64x64 tiles: 16 floats per pixel quad between its passes (HBM)
 	const uint32_t *mf64;    // 64x64 fast path: matrix-core operand tables (global memory), see Fast64Args
 	uint32_t full_cols, full_rows;  // 32x32 fast path: tile (tx, ty) is eligible iff tx < full_cols && ty < full_rows
 	                                //   (full size, 16-byte aligned rows; 0/0 when the batch is not aligned)

@@ -914,6 +914,11 @@ __device__ __forceinline__ void process_tile(const ShrinkArgs &a, const uint32_t
 			m0 = level_count(sum_hz, a.breaks[cls], a.breaks_asc[cls]);
 			m1 = level_count(sum_vr, a.breaks[cls], a.breaks_asc[cls]);
 		}
+	} else if (a.oklab_given && tx < a.full_cols && ty < a.full_rows) {
+		// full tile of a batch the block-cooperative detector (oklab_kernel) has already been over
+		const float value = __uint_as_float(a.sums[2u * tile_g]);
+		key0 = key1 = __float_as_uint(value);
+		m0 = m1 = level_count(__float_as_uint(parse_value(value)), a.breaks[cls], a.breaks_asc[cls]);
 	} else {
 		// get_block_variance, operations.rs:26-126 with shrink_by's closures
 		// (pixlzr.rs:160-162).  Colours are computed once, in parallel, into LDS
@@ -1215,7 +1220,7 @@ __device__ __forceinline__ unsigned long long stamp_now()
 // else (ragged-edge tiles, tiles with transparency, one-pass resamples) is appended to a device
 // worklist that the generic kernel processes afterwards.  Persistent waves, one LDS tile image
 // each, next tile's pixels prefetched into registers, table rows in LDS, lookups in kernarg.
-// MODE 1: directional detector here; MODE 0: value already in sums[] (oklab32_kernel).
+// MODE 1: directional detector here; MODE 0: value already in sums[] (oklab_kernel).
 // ---------------------------------------------------------------------------
 template <int MODE>
 __global__ void __launch_bounds__(1024) shrink32_kernel(const Fast32Args a)
@@ -1511,6 +1516,7 @@ __device__ __forceinline__ bool fast64_tile_src(const Args &a, uint32_t tile_g, 
 	return tx < a.full_cols && ty < a.full_rows;
 }
 
+template <int MODE>
 __global__ void __launch_bounds__(256) shrink64_kernel(const Fast64Args a)
 {
 	extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
@@ -1612,7 +1618,9 @@ __global__ void __launch_bounds__(256) shrink64_kernel(const Fast64Args a)
 		}
 		// ---- detector: window rows 16w + 8gg .. +7, column pair q (windows 2q, 2q+1)
 		uint32_t sum_hz = 0, sum_vr = 0;
-		{
+		uint32_t given_bits = 0;
+		if constexpr (MODE == 0) given_bits = a.sums[2 * tile_g];  // MODE 0: the value is there already (oklab_kernel)
+		if constexpr (MODE == 1) {
 			const uint32_t q = lane & 31u, gg = lane >> 5;
 			const uint32_t two = 0x00020002u;
 			const uint32_t *pc[3];
@@ -1669,7 +1677,15 @@ __global__ void __launch_bounds__(256) shrink64_kernel(const Fast64Args a)
 		sum_vr = s_red[1] + s_red[3] + s_red[5] + s_red[7];
 		sum_hz = __builtin_amdgcn_readfirstlane(sum_hz);
 		sum_vr = __builtin_amdgcn_readfirstlane(sum_vr);
-		const uint32_t m0 = level_of(sum_hz), m1 = level_of(sum_vr);
+		uint32_t m0, m1;
+		if constexpr (MODE == 1) {
+			m0 = level_of(sum_hz);
+			m1 = level_of(sum_vr);
+		} else {
+			const uint32_t vb = __builtin_amdgcn_readfirstlane(given_bits);
+			sum_hz = sum_vr = vb;  // stays what it was
+			m0 = m1 = level_of(__float_as_uint(parse_value(__uint_as_float(vb))));
+		}
 		const uint32_t nw = reduced_size(64u, m0), nh = reduced_size(64u, m1);
 		if (threadIdx.x == 0) {
 			reinterpret_cast<uint2 *>(a.sums)[this_tile] = make_uint2(sum_hz, sum_vr);
@@ -1979,9 +1995,35 @@ __device__ __forceinline__ float cbrt_f32_lut(float x, const double *scale)
 	return x == 0.0f ? 0.0f : y;
 }
 
-template <int MODE_UNUSED>
-__global__ void __launch_bounds__(1024) oklab32_kernel(const ShrinkArgs a)
+// Tile geometry of the block-cooperative Oklab detector, T = 16 | 32 | 64 (square RGBA tiles).  A band is 256
+// pixels of a tile in row-major order = 4 consecutive pixels per lane: 64 / (T/4) rows of T pixels.
+template <int T>
+struct OkGeom {
+	static constexpr uint32_t kBands = T * T / 256;   // 1 | 4 | 16
+	static constexpr uint32_t kLanesPerRow = T / 4;   // 4 | 8 | 16
+	static constexpr uint32_t kRowsPerBand = 256 / T; // 16 | 8 | 4
+	// up to 4 bands the converted tile stays in registers between the passes; a 64x64 tile (192 values per
+	// lane) parks it in a scratch buffer in HBM instead (16 floats per lane and band: 12 values + alpha bytes)
+	static constexpr bool kInRegs = kBands <= 4;
+};
+
+template <int T, class Args>
+__device__ __forceinline__ bool oklab_tile_src(const Args &a, uint32_t tile_g, const uint8_t *&src)
 {
+	if (tile_g >= a.n_tiles) return false;
+	const uint32_t frame = fastdiv(tile_g, a.div_tpf);
+	const uint32_t t = tile_g - frame * a.tiles_per_frame;
+	const uint32_t ty = fastdiv(t, a.div_cols), tx = t - ty * a.cols;
+	src = a.src + (size_t)frame * a.frame_stride + (size_t)(ty * (uint32_t)T) * a.pitch + (size_t)(tx * (uint32_t)T) * 4u;
+	return tx < a.full_cols && ty < a.full_rows;
+}
+
+template <int T>
+__global__ void __launch_bounds__(1024) oklab_kernel(const ShrinkArgs a)
+{
+	using G = OkGeom<T>;
+	constexpr uint32_t NB = G::kBands;
+	constexpr float kCount = (float)(T * T);
 	extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
 	float *s_srgb = reinterpret_cast<float *>(lds);          // 256: sRGB u8 -> linear
 	float *s_alpha = s_srgb + 256;                           // 256: a / 255
@@ -2013,25 +2055,45 @@ __global__ void __launch_bounds__(1024) oklab32_kernel(const ShrinkArgs a)
 
 	if (wave < kOkTiles) {
 		// ---------------- producers ----------------
+		const uint32_t row_off = lane / G::kLanesPerRow, col_off = (lane % G::kLanesPerRow) * 16u;
+		// the pixels of step s = batch * NB + band of this wave's tile sequence (false: nothing to convert there)
+		auto step_src = [&](uint32_t s, const uint8_t *&p) -> bool {
+			const uint32_t j = s / NB, band = s % NB;
+			const uint8_t *src;
+			if (j >= own || !oklab_tile_src<T>(a, (blockIdx.x + j * gridDim.x) * kOkTiles + wave, src)) return false;
+			p = src + (size_t)(row_off + G::kRowsPerBand * band) * a.pitch + col_off;
+			return true;
+		};
 		// raw pixels: the band being converted and the one after it (requested one interval ahead)
-		uint4 px_cur, px_nxt;
-		float lab[4][4][3];     // [band][pixel][a, b, l] of the batch whose pass 2 is being staged
-		uint32_t alpha_px[4];   // its 4 alpha bytes per band
-		const uint32_t row_off = lane >> 3, col_off = (lane & 7u) * 16u;
-		const uint8_t *src_cur = nullptr, *src_next = nullptr;
-		bool elig_next = own > 0 && fast32_tile_src(a, blockIdx.x * kOkTiles + wave, src_next);
-		if (elig_next) {
-			px_cur = *reinterpret_cast<const uint4 *>(src_next + (size_t)row_off * a.pitch + col_off);
-			px_nxt = *reinterpret_cast<const uint4 *>(src_next + (size_t)(row_off + 8u) * a.pitch + col_off);
+		uint4 px_cur = make_uint4(0, 0, 0, 0), px_nxt = make_uint4(0, 0, 0, 0);
+		{
+			const uint8_t *p;
+			if (step_src(0, p)) px_cur = *reinterpret_cast<const uint4 *>(p);
+			if (step_src(1, p)) px_nxt = *reinterpret_cast<const uint4 *>(p);
 		}
-		bool have_prev = false;
+		float lab[G::kInRegs ? NB : 1][4][3];   // [band][pixel][a, b, l] of the batch whose pass 2 is being staged
+		uint32_t alpha_px[G::kInRegs ? NB : 1];  // its 4 alpha bytes per band
+		bool have_prev = false, elig_cur = false;
+		uint32_t tile_prev = 0, tile_cur = 0;
 		for (uint32_t p = 0; p < periods; ++p) {
-			const bool elig_cur = elig_next;  // batch p (false past the last one)
-			src_cur = src_next;
-			elig_next = p + 1u < own && fast32_tile_src(a, (blockIdx.x + (p + 1u) * gridDim.x) * kOkTiles + wave, src_next);
-#pragma unroll
-			for (int k = 0; k < 4; ++k) {
+			{
+				const uint8_t *unused;
+				tile_prev = tile_cur;
+				tile_cur = (blockIdx.x + p * gridDim.x) * kOkTiles + wave;
+				elig_cur = p < own && oklab_tile_src<T>(a, tile_cur, unused);  // batch p (false past the last one)
+			}
+			constexpr int kUnroll = G::kInRegs ? (int)NB : 1;  // register form: lab[k] must be a static index
+#pragma unroll kUnroll
+			for (uint32_t k = 0; k < NB; ++k) {
 				// ---- convert phase
+				float4 old[4];  // scratch form only: band k of the previous batch, back from HBM for pass 2
+				if constexpr (!G::kInRegs) {
+					if (have_prev) {
+						const float4 *sp = reinterpret_cast<const float4 *>(a.ok_scratch) + (((size_t)tile_prev * NB + k) * 64u + lane) * 4u;
+#pragma unroll
+						for (int q = 0; q < 4; ++q) old[q] = sp[q];
+					}
+				}
 				float fresh[4][3];
 				uint32_t fresh_alpha = 0;
 				if (elig_cur) {
@@ -2060,14 +2122,11 @@ __global__ void __launch_bounds__(1024) oklab32_kernel(const ShrinkArgs a)
 						__builtin_amdgcn_sched_barrier(0);
 					}
 				}
-				// px_cur is consumed: move the window on by one band (band k+2, or bands 0/1 of the next batch)
+				// px_cur is consumed: move the window on by one step of the sequence
 				px_cur = px_nxt;
 				{
-					const bool same = k < 2;
-					const uint8_t *base = same ? src_cur : src_next;
-					const uint32_t band = same ? (uint32_t)k + 2u : (uint32_t)k - 2u;
-					if (same ? elig_cur : elig_next)
-						px_nxt = *reinterpret_cast<const uint4 *>(base + (size_t)(row_off + 8u * band) * a.pitch + col_off);
+					const uint8_t *pp;
+					if (step_src(p * NB + k + 2u, pp)) px_nxt = *reinterpret_cast<const uint4 *>(pp);
 				}
 				__syncthreads();  // A: the chain has consumed the bands of the previous interval
 				// ---- write phase
@@ -2077,27 +2136,53 @@ __global__ void __launch_bounds__(1024) oklab32_kernel(const ShrinkArgs a)
 					// the first convert phase of this period.
 					const float4 mean = *reinterpret_cast<const float4 *>(s_mean + wave * 4u);
 					const float mean4[4] = {mean.x, mean.y, mean.z, mean.w};
+					float x[4][3];
+					uint32_t al4;
+					if constexpr (G::kInRegs) {
+#pragma unroll
+						for (int j = 0; j < 4; ++j)
+#pragma unroll
+							for (int c = 0; c < 3; ++c) x[j][c] = lab[k][j][c];
+						al4 = alpha_px[k];
+					} else {
+						const float o12[12] = {old[0].x, old[0].y, old[0].z, old[0].w, old[1].x, old[1].y,
+						                       old[1].z, old[1].w, old[2].x, old[2].y, old[2].z, old[2].w};
+#pragma unroll
+						for (int j = 0; j < 4; ++j)
+#pragma unroll
+							for (int c = 0; c < 3; ++c) x[j][c] = o12[3 * j + c];
+						al4 = __float_as_uint(old[3].x);
+					}
 					float *d = s_p2 + slot;
 #pragma unroll
 					for (int c = 0; c < 3; ++c)
 						*reinterpret_cast<float4 *>(d + c * kOkPlane) =
-						    make_float4(lab[k][0][c] - mean4[c], lab[k][1][c] - mean4[c], lab[k][2][c] - mean4[c], lab[k][3][c] - mean4[c]);
+						    make_float4(x[0][c] - mean4[c], x[1][c] - mean4[c], x[2][c] - mean4[c], x[3][c] - mean4[c]);
 					*reinterpret_cast<float4 *>(d + 3 * kOkPlane) =
-					    make_float4(s_alpha[alpha_px[k] & 255u] - mean4[3], s_alpha[(alpha_px[k] >> 8) & 255u] - mean4[3],
-					                s_alpha[(alpha_px[k] >> 16) & 255u] - mean4[3], s_alpha[alpha_px[k] >> 24] - mean4[3]);
+					    make_float4(s_alpha[al4 & 255u] - mean4[3], s_alpha[(al4 >> 8) & 255u] - mean4[3],
+					                s_alpha[(al4 >> 16) & 255u] - mean4[3], s_alpha[al4 >> 24] - mean4[3]);
 				}
 				if (elig_cur) {
 					float *d = s_p1 + slot;
 #pragma unroll
-					for (int c = 0; c < 3; ++c) {
-#pragma unroll
-						for (int j = 0; j < 4; ++j) lab[k][j][c] = fresh[j][c];
+					for (int c = 0; c < 3; ++c)
 						*reinterpret_cast<float4 *>(d + c * kOkPlane) = make_float4(fresh[0][c], fresh[1][c], fresh[2][c], fresh[3][c]);
-					}
-					alpha_px[k] = fresh_alpha;
 					*reinterpret_cast<float4 *>(d + 3 * kOkPlane) =
 					    make_float4(s_alpha[fresh_alpha & 255u], s_alpha[(fresh_alpha >> 8) & 255u], s_alpha[(fresh_alpha >> 16) & 255u],
 					                s_alpha[fresh_alpha >> 24]);
+					if constexpr (G::kInRegs) {
+#pragma unroll
+						for (int j = 0; j < 4; ++j)
+#pragma unroll
+							for (int c = 0; c < 3; ++c) lab[k][j][c] = fresh[j][c];
+						alpha_px[k] = fresh_alpha;
+					} else {
+						float4 *sp = reinterpret_cast<float4 *>(a.ok_scratch) + (((size_t)tile_cur * NB + k) * 64u + lane) * 4u;
+						sp[0] = make_float4(fresh[0][0], fresh[0][1], fresh[0][2], fresh[1][0]);
+						sp[1] = make_float4(fresh[1][1], fresh[1][2], fresh[2][0], fresh[2][1]);
+						sp[2] = make_float4(fresh[2][2], fresh[3][0], fresh[3][1], fresh[3][2]);
+						sp[3] = make_float4(__uint_as_float(fresh_alpha), 0.f, 0.f, 0.f);
+					}
 				}
 				__syncthreads();  // B: the bands of this interval are complete
 			}
@@ -2147,28 +2232,28 @@ __global__ void __launch_bounds__(1024) oklab32_kernel(const ShrinkArgs a)
 			return acc;
 		};
 		for (uint32_t p = 0; p < periods; ++p) {
-#pragma unroll
-			for (int k = 0; k < 4; ++k) {
+#pragma unroll 1
+			for (uint32_t k = 0; k < NB; ++k) {
 				// the bands written one interval ago: band kk of period pp
-				const uint32_t pp = k > 0 ? p : p - 1u, kk = k > 0 ? (uint32_t)k - 1u : 3u;
+				const uint32_t pp = k > 0 ? p : p - 1u, kk = k > 0 ? k - 1u : NB - 1u;
 				const bool any = k > 0 || p > 0;
 				const bool p1_valid = any && pp < own;                   // pass 1 of batch pp
 				const bool p2_valid = any && pp >= 1u && pp - 1u < own;  // pass 2 of batch pp - 1
 				if (live && p1_valid) acc1 = walk(s_p1, acc1, false);
 				if (live && p2_valid) acc2 = walk(s_p2, acc2, true);
-				if (kk == 3u) {
+				if (kk == NB - 1u) {
 					if (p1_valid) {
-						s_mean[lane] = __fdiv_rn(acc1, 1024.0f);  // operations.rs:65-68; read after barrier A
+						s_mean[lane] = __fdiv_rn(acc1, kCount);  // operations.rs:65-68; read after barrier A
 						acc1 = 0.0f;
 					}
 					if (p2_valid) {
 						const float d0 = __shfl(acc2, (int)(lane & ~3u) + 0, 64), d1 = __shfl(acc2, (int)(lane & ~3u) + 1, 64);
 						const float d2 = __shfl(acc2, (int)(lane & ~3u) + 2, 64), d3 = __shfl(acc2, (int)(lane & ~3u) + 3, 64);
 						const float total = d0 + d1 + d2 + d3;  // :89
-						const float value = __fdiv_rn(total, 1024.0f) * a.factor * a.scale2;  // pixlzr.rs:162
+						const float value = __fdiv_rn(total, kCount) * a.factor * a.scale2;  // pixlzr.rs:162
 						const uint32_t tg = (blockIdx.x + (pp - 1u) * gridDim.x) * kOkTiles + ct;
 						const uint8_t *unused;
-						if (live && cc == 0 && fast32_tile_src(a, tg, unused))
+						if (live && cc == 0 && oklab_tile_src<T>(a, tg, unused))
 							reinterpret_cast<uint2 *>(a.sums)[tg] = make_uint2(__float_as_uint(value), __float_as_uint(value));
 						acc2 = 0.0f;
 					}
@@ -2180,16 +2265,23 @@ __global__ void __launch_bounds__(1024) oklab32_kernel(const ShrinkArgs a)
 	}
 }
 
-hipError_t launch_oklab32(const ShrinkArgs &a, uint32_t n_cus, hipStream_t stream)
+hipError_t launch_oklab(const ShrinkArgs &a, uint32_t n_cus, hipStream_t stream)
 {
 	const uint32_t lds_bytes = (512u + 2u * 132u + 64u) * 4u + 2u * kOkBand * 4u;
-	auto kernel = oklab32_kernel<0>;
-	hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-	if (e != hipSuccess) return e;
 	const uint32_t n_batches = (a.n_tiles + kOkTiles - 1) / kOkTiles;
 	const uint32_t blocks = n_batches < n_cus ? n_batches : n_cus;
-	hipLaunchKernelGGL(kernel, dim3(blocks), dim3(1024), lds_bytes, stream, a);
-	return hipGetLastError();
+	hipError_t e;
+	auto go = [&](auto kernel) -> hipError_t {
+		if ((e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)) != hipSuccess) return e;
+		hipLaunchKernelGGL(kernel, dim3(blocks), dim3(1024), lds_bytes, stream, a);
+		return hipGetLastError();
+	};
+	switch (a.bw) {
+	case 16: return go(oklab_kernel<16>);
+	case 32: return go(oklab_kernel<32>);
+	case 64: return go(oklab_kernel<64>);
+	default: return hipErrorInvalidValue;
+	}
 }
 
 // ---------------------------------------------------------------------------
@@ -3177,7 +3269,7 @@ LaunchGeom plan_launch(const ShrinkArgs &a, uint32_t channels, uint32_t n_cus)
 
 bool fast64_applicable(const ShrinkArgs &a, uint32_t channels)
 {
-	return channels == 4 && a.bw == 64 && a.bh == 64 && a.mode == 1 && a.work != nullptr &&
+	return channels == 4 && a.bw == 64 && a.bh == 64 && (a.mode == 1 || a.oklab_given) && a.work != nullptr &&
 	       (a.out_px == nullptr || (a.filter != 0 && a.mf64 != nullptr));
 }
 
@@ -3224,9 +3316,15 @@ hipError_t launch_shrink(const ShrinkArgs &a, uint32_t channels, uint32_t n_cus,
 		const uint32_t resident = n_cus * per_cu;
 		const uint32_t blocks = a.n_tiles < resident ? a.n_tiles : resident;
 		hipError_t e;
-		auto k = shrink64_kernel;
-		if (lds_bytes > 64u * 1024u && (e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)) != hipSuccess) return e;
-		hipLaunchKernelGGL(k, dim3(blocks), dim3(256), lds_bytes, stream, f);
+		if (a.mode == 1) {
+			auto k = shrink64_kernel<1>;
+			if (lds_bytes > 64u * 1024u && (e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)) != hipSuccess) return e;
+			hipLaunchKernelGGL(k, dim3(blocks), dim3(256), lds_bytes, stream, f);
+		} else {
+			auto k = shrink64_kernel<0>;
+			if (lds_bytes > 64u * 1024u && (e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)) != hipSuccess) return e;
+			hipLaunchKernelGGL(k, dim3(blocks), dim3(256), lds_bytes, stream, f);
+		}
 		if ((e = hipGetLastError()) != hipSuccess) return e;
 	} else if (fast32_applicable(a, channels)) {
 		// 1) the lean kernel for full opaque tiles; it leaves the rest in the worklist
@@ -3294,7 +3392,9 @@ hipError_t launch_shrink(const ShrinkArgs &a, uint32_t channels, uint32_t n_cus,
 	} else {
 		ga.work = nullptr;
 	}
-	ga.oklab_given = 0;  // the generic path computes its own Oklab values
+	// worklist tiles lost their value to the deferred marker: the generic path computes its own; when it
+	// processes every tile (no fast kernel for this size) the block-cooperative detector's values stand
+	if (ga.work != nullptr) ga.oklab_given = 0;
 	const LaunchGeom g = plan_launch(ga, channels, n_cus);
 	switch (waves_per_tile(ga.bw, ga.bh)) {
 	case 1: return launch_nw<1>(ga, channels, g, stream);

@@ -271,6 +271,27 @@ def test_block64_fast_kernel_every_class(gpu, oracle, filt):
                            slots[n].cpu().numpy()), exp, 4, f"batch frame {n}")
 
 
+@pytest.mark.parametrize("block", [16, 64])
+@pytest.mark.parametrize("dist", [0, 1])
+def test_shrink_by_blocks_16_and_64(gpu, oracle, block, dist):
+    """shrink_by (Oklab detector) with the reference CLI's default 64x64 tiles and with 16x16 tiles: the
+    block-cooperative detector (oklab_kernel<16|64>; the 64x64 form parks a tile's colours in HBM between its
+    two passes) + shrink64_kernel<0> / the generic kernel, opaque and transparent RGBA, ragged last row,
+    a batch of frames -- bit-exact block values included."""
+    frames = gpu.synth_frames_device(2, 280, 448, 4, first_frame=6, dist=dist)
+    f = frames.cpu().numpy()
+    seen = set()
+    for factor, filt in ((1.0, 4), (0.25, 2), (4.0, 4)):
+        vals, ow, oh, slots = gpu.shrink_frames_device(frames, block, block, 0, filt, factor)
+        for n in range(2):
+            exp = oracle.shrink_image(f[n], block, block, 0, filt, factor, nthreads=8)
+            got = (vals[n].cpu().numpy(), ow[n].cpu().numpy().astype(np.uint32), oh[n].cpu().numpy().astype(np.uint32),
+                   slots[n].cpu().numpy())
+            assert_same_tiles(got, exp, 4, f"shrink_by {block}x{block} dist {dist} k={factor} frame {n}")
+            seen |= set(histogram(got[1], got[2]))
+    assert len(seen) >= 3, seen
+
+
 def test_block64_one_pass_classes_and_transparency(gpu, oracle):
     """64 x n / n x 64 outputs (one matrix-core pass inside shrink64_kernel) and tiles with transparency
     (handed to the generic kernel through the worklist): results must not depend on who processed a tile."""
