@@ -943,18 +943,52 @@ __device__ __forceinline__ void process_tile(const ShrinkArgs &a, const uint32_t
 		if (threadIdx.x % 64u < NCH && (NW == 1 || threadIdx.x < 64u)) {
 			const uint32_t k = threadIdx.x % 64u;
 			float s = 0.0f;
+			// The adds of a chain depend on each other; the loads (and the alpha divisions) do not: eight
+			// elements are fetched / prepared while the previous eight are added, in the reference's order.
+			auto run8 = [&](auto &&elem, uint32_t len, float acc, const bool magnitude, const float avg) -> float {
+				uint32_t p = 0;
+				if (len >= 8u) {
+					float cur[8], nxt[8];
+#pragma unroll
+					for (int j = 0; j < 8; ++j) cur[j] = elem(p + (uint32_t)j);
+					for (p = 8u; p + 8u <= len; p += 8u) {
+#pragma unroll
+						for (int j = 0; j < 8; ++j) nxt[j] = elem(p + (uint32_t)j);
+						__builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+						for (int j = 0; j < 8; ++j) acc += magnitude ? fabsf(cur[j] - avg) : cur[j];
+						__builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+						for (int j = 0; j < 8; ++j) cur[j] = nxt[j];
+					}
+#pragma unroll
+					for (int j = 0; j < 8; ++j) acc += magnitude ? fabsf(cur[j] - avg) : cur[j];
+				}
+				for (; p < len; ++p) {
+					const float v = elem(p);
+					acc += magnitude ? fabsf(v - avg) : v;
+				}
+				return acc;
+			};
 			if (k < 3) {
 				const float *plane = s_lab + k * n;
-				for (uint32_t p = 0; p < n; ++p) s += plane[p];  // :60-62
-				const float avg = __fdiv_rn(s, count);           // :65-67
-				for (uint32_t p = 0; p < n; ++p) delta += fabsf(plane[p] - avg);  // :80-82
+				auto at = [&](uint32_t p) { return plane[p]; };
+				s = run8(at, n, 0.0f, false, 0.0f);                 // :60-62
+				const float avg = __fdiv_rn(s, count);               // :65-67
+				delta = run8(at, n, 0.0f, true, avg);                // :80-82
 			} else {
 				const uint16_t *al = pl16 + 6u * PD;
-				for (uint32_t y = 0; y < h; ++y)
-					for (uint32_t x = 0; x < w; ++x) s += __fdiv_rn((float)al[y * rs * 2u + x], 255.0f);  // :63
+				for (uint32_t y = 0; y < h; ++y) {
+					const uint16_t *row = al + y * rs * 2u;
+					auto at = [&](uint32_t x) { return __fdiv_rn((float)row[x], 255.0f); };
+					s = run8(at, w, s, false, 0.0f);  // :63
+				}
 				const float avg = __fdiv_rn(s, count);
-				for (uint32_t y = 0; y < h; ++y)
-					for (uint32_t x = 0; x < w; ++x) delta += fabsf(__fdiv_rn((float)al[y * rs * 2u + x], 255.0f) - avg);
+				for (uint32_t y = 0; y < h; ++y) {
+					const uint16_t *row = al + y * rs * 2u;
+					auto at = [&](uint32_t x) { return __fdiv_rn((float)row[x], 255.0f); };
+					delta = run8(at, w, delta, true, avg);
+				}
 			}
 		}
 		float total;
