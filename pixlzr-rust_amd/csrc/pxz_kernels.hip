@@ -2090,32 +2090,33 @@ __global__ void __launch_bounds__(1024) oklab_kernel(const ShrinkArgs a)
 	if (wave < kOkTiles) {
 		// ---------------- producers ----------------
 		const uint32_t row_off = lane / G::kLanesPerRow, col_off = (lane % G::kLanesPerRow) * 16u;
-		// the pixels of step s = batch * NB + band of this wave's tile sequence (false: nothing to convert there)
-		auto step_src = [&](uint32_t s, const uint8_t *&p) -> bool {
-			const uint32_t j = s / NB, band = s % NB;
+		// source pointers (lane's first group of band 0) of this wave's tiles in batches p, p+1, p+2; null: nothing there
+		auto batch_src = [&](uint32_t j) -> const uint8_t * {
 			const uint8_t *src;
-			if (j >= own || !oklab_tile_src<T>(a, (blockIdx.x + j * gridDim.x) * kOkTiles + wave, src)) return false;
-			p = src + (size_t)(row_off + G::kRowsPerBand * band) * a.pitch + col_off;
-			return true;
+			if (j >= own || !oklab_tile_src<T>(a, (blockIdx.x + j * gridDim.x) * kOkTiles + wave, src)) return nullptr;
+			return src + (size_t)row_off * a.pitch + col_off;
 		};
+		const uint8_t *src0 = nullptr, *src1 = batch_src(0), *src2 = batch_src(1);
+		const size_t band_step = (size_t)G::kRowsPerBand * a.pitch;
 		// raw pixels: the band being converted and the one after it (requested one interval ahead)
 		uint4 px_cur = make_uint4(0, 0, 0, 0), px_nxt = make_uint4(0, 0, 0, 0);
-		{
-			const uint8_t *p;
-			if (step_src(0, p)) px_cur = *reinterpret_cast<const uint4 *>(p);
-			if (step_src(1, p)) px_nxt = *reinterpret_cast<const uint4 *>(p);
+		if (src1) px_cur = *reinterpret_cast<const uint4 *>(src1);
+		if (NB > 1) {
+			if (src1) px_nxt = *reinterpret_cast<const uint4 *>(src1 + band_step);
+		} else if (src2) {
+			px_nxt = *reinterpret_cast<const uint4 *>(src2);
 		}
 		float lab[G::kInRegs ? NB : 1][4][3];   // [band][pixel][a, b, l] of the batch whose pass 2 is being staged
 		uint32_t alpha_px[G::kInRegs ? NB : 1];  // its 4 alpha bytes per band
 		bool have_prev = false, elig_cur = false;
 		uint32_t tile_prev = 0, tile_cur = 0;
 		for (uint32_t p = 0; p < periods; ++p) {
-			{
-				const uint8_t *unused;
-				tile_prev = tile_cur;
-				tile_cur = (blockIdx.x + p * gridDim.x) * kOkTiles + wave;
-				elig_cur = p < own && oklab_tile_src<T>(a, tile_cur, unused);  // batch p (false past the last one)
-			}
+			tile_prev = tile_cur;
+			tile_cur = (blockIdx.x + p * gridDim.x) * kOkTiles + wave;
+			src0 = src1;  // batch p
+			src1 = src2;  // batch p + 1
+			src2 = batch_src(p + 2u);
+			elig_cur = src0 != nullptr;  // (false past the last batch and for tiles the detector does not take)
 			constexpr int kUnroll = G::kInRegs ? (int)NB : 1;  // register form: lab[k] must be a static index
 #pragma unroll kUnroll
 			for (uint32_t k = 0; k < NB; ++k) {
@@ -2159,8 +2160,10 @@ __global__ void __launch_bounds__(1024) oklab_kernel(const ShrinkArgs a)
 				// px_cur is consumed: move the window on by one step of the sequence
 				px_cur = px_nxt;
 				{
-					const uint8_t *pp;
-					if (step_src(p * NB + k + 2u, pp)) px_nxt = *reinterpret_cast<const uint4 *>(pp);
+					// two steps ahead: band k+2 of this batch, or an early band of the next one / the one after
+					const uint32_t ahead = k + 2u, bo = ahead / NB, band = ahead % NB;
+					const uint8_t *base = bo == 0 ? src0 : (bo == 1 ? src1 : src2);
+					if (base) px_nxt = *reinterpret_cast<const uint4 *>(base + band * band_step);
 				}
 				__syncthreads();  // A: the chain has consumed the bands of the previous interval
 				// ---- write phase
