@@ -558,11 +558,13 @@ int timed_launch(pxz_handle *h, pxz::ShrinkArgs &a, uint32_t channels, float *va
 	a.lod0 = lod0;
 	a.lod1 = lod1;
 	// 32x32 fast path: which tiles are full-size, and whether every tile row of the batch is 16-byte aligned
-	a.full_cols = a.full_rows = 0;
+	a.full_cols = a.full_rows = a.ok_rows = 0;
 	if (a.bw == a.bh && (a.bw == 16 || a.bw == 32 || a.bw == 64) && channels == 4 &&
 	    ((reinterpret_cast<uintptr_t>(a.src) | a.pitch | (a.n_tiles > a.tiles_per_frame ? a.frame_stride : 0)) & 15u) == 0) {
 		a.full_cols = a.edge_w == a.bw ? a.cols : a.cols - 1;
 		a.full_rows = a.edge_h == a.bh ? a.rows : a.rows - 1;
+		// the Oklab detector also takes a ragged last row of whole bands (256 pixels = 256/bw rows)
+		a.ok_rows = a.edge_h % (256u / a.bw) == 0 ? a.rows : a.full_rows;
 	}
 	const pxz::FinishArgs fin{a.sums, value, lod0, lod1, a.n_tiles, a.tiles_per_frame, a.cols, a.rows,
 	                          a.bw, a.bh, a.edge_w, a.edge_h, a.mode, a.factor};

@@ -67,6 +67,8 @@ struct ShrinkArgs {
 	                         //   pixlzr.rs:15,162; 1 with factor 1 = the identity closure of process(), process/mod.rs:107-121)
 	float *ok_scratch;       // Oklab detector on 64x64 tiles: 16 floats per pixel quad between its passes (HBM)
 	const uint32_t *mf64;    // 64x64 fast path: matrix-core operand tables (global memory), see Fast64Args
+	uint32_t ok_rows;        // tile rows the block-cooperative Oklab detector takes: full_rows, plus the ragged last row
+	                         //   when its height is a whole number of that detector's bands
 	uint32_t full_cols, full_rows;  // 32x32 fast path: tile (tx, ty) is eligible iff tx < full_cols && ty < full_rows
 	                                //   (full size, 16-byte aligned rows; 0/0 when the batch is not aligned)
 	uint32_t *work;          // worklist: [work_slot] = count, [2..] = tile ids (null: all tiles).  The two
@@ -106,7 +108,7 @@ struct Fast32Args {
 	uint64_t frame_stride;
 	uint32_t pitch, cols, rows, tiles_per_frame, n_tiles;
 	FastDiv div_tpf, div_cols;
-	uint32_t full_cols, full_rows;  // as in ShrinkArgs
+	uint32_t full_cols, full_rows, ok_rows;  // as in ShrinkArgs
 	uint32_t filter;
 	uint32_t *sums;
 	uint32_t *out_w;
@@ -132,7 +134,7 @@ struct Fast64Args {
 	uint64_t frame_stride;
 	uint32_t pitch, cols, rows, tiles_per_frame, n_tiles;
 	FastDiv div_tpf, div_cols;
-	uint32_t full_cols, full_rows;
+	uint32_t full_cols, full_rows, ok_rows;
 	uint32_t filter;
 	uint32_t *sums;
 	uint32_t *out_w;

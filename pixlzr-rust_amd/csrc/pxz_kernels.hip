@@ -914,7 +914,7 @@ __device__ __forceinline__ void process_tile(const ShrinkArgs &a, const uint32_t
 			m0 = level_count(sum_hz, a.breaks[cls], a.breaks_asc[cls]);
 			m1 = level_count(sum_vr, a.breaks[cls], a.breaks_asc[cls]);
 		}
-	} else if (a.oklab_given && tx < a.full_cols && ty < a.full_rows) {
+	} else if (a.oklab_given && tx < a.full_cols && ty < a.ok_rows) {
 		// full tile of a batch the block-cooperative detector (oklab_kernel) has already been over
 		const float value = __uint_as_float(a.sums[2u * tile_g]);
 		key0 = key1 = __float_as_uint(value);
@@ -1342,7 +1342,13 @@ __global__ void __launch_bounds__(1024) shrink32_kernel(const Fast32Args a)
 		auto defer = [&]() {
 			if (tid == 0) {
 				a.work[kWorkList + atomicAdd(&a.work[a.work_slot], 1u)] = tile_g;
-				reinterpret_cast<uint2 *>(a.sums)[tile_g] = make_uint2(kDeferredKey, kDeferredKey);  // not finished here
+				bool keep = false;  // MODE 0: a value the block-cooperative detector left is final and stays
+				if constexpr (MODE == 0) {
+					const uint32_t t = tile_g - fastdiv(tile_g, a.div_tpf) * a.tiles_per_frame;
+					const uint32_t ty = fastdiv(t, a.div_cols), tx = t - ty * a.cols;
+					keep = tx < a.full_cols && ty < a.ok_rows;
+				}
+				if (!keep) reinterpret_cast<uint2 *>(a.sums)[tile_g] = make_uint2(kDeferredKey, kDeferredKey);  // not finished here
 			}
 		};
 		if (!pre_valid) {  // ragged edge / unaligned rows: generic kernel
@@ -1610,7 +1616,13 @@ __global__ void __launch_bounds__(256) shrink64_kernel(const Fast64Args a)
 		auto defer = [&]() {
 			if (threadIdx.x == 0) {
 				a.work[kWorkList + atomicAdd(&a.work[a.work_slot], 1u)] = tile_g;
-				reinterpret_cast<uint2 *>(a.sums)[tile_g] = make_uint2(kDeferredKey, kDeferredKey);
+				bool keep = false;  // MODE 0: a value the block-cooperative detector left is final and stays
+				if constexpr (MODE == 0) {
+					const uint32_t t = tile_g - fastdiv(tile_g, a.div_tpf) * a.tiles_per_frame;
+					const uint32_t ty = fastdiv(t, a.div_cols), tx = t - ty * a.cols;
+					keep = tx < a.full_cols && ty < a.ok_rows;
+				}
+				if (!keep) reinterpret_cast<uint2 *>(a.sums)[tile_g] = make_uint2(kDeferredKey, kDeferredKey);
 			}
 		};
 		if (!pre_valid) {  // ragged edge / unaligned batch (block-uniform)
@@ -2041,15 +2053,18 @@ struct OkGeom {
 	static constexpr bool kInRegs = kBands <= 4;
 };
 
+// Tiles the block-cooperative detector takes: full width, and a height of whole bands (every full tile; the
+// ragged last row of the grid when its height happens to be one).  tile_h = 0 when it does not.
 template <int T, class Args>
-__device__ __forceinline__ bool oklab_tile_src(const Args &a, uint32_t tile_g, const uint8_t *&src)
+__device__ __forceinline__ uint32_t oklab_tile_src(const Args &a, uint32_t tile_g, const uint8_t *&src)
 {
-	if (tile_g >= a.n_tiles) return false;
+	if (tile_g >= a.n_tiles) return 0u;
 	const uint32_t frame = fastdiv(tile_g, a.div_tpf);
 	const uint32_t t = tile_g - frame * a.tiles_per_frame;
 	const uint32_t ty = fastdiv(t, a.div_cols), tx = t - ty * a.cols;
 	src = a.src + (size_t)frame * a.frame_stride + (size_t)(ty * (uint32_t)T) * a.pitch + (size_t)(tx * (uint32_t)T) * 4u;
-	return tx < a.full_cols && ty < a.full_rows;
+	if (tx >= a.full_cols || ty >= a.ok_rows) return 0u;
+	return ty == a.rows - 1u ? a.edge_h : (uint32_t)T;
 }
 
 template <int T>
@@ -2057,7 +2072,6 @@ __global__ void __launch_bounds__(1024) oklab_kernel(const ShrinkArgs a)
 {
 	using G = OkGeom<T>;
 	constexpr uint32_t NB = G::kBands;
-	constexpr float kCount = (float)(T * T);
 	extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
 	float *s_srgb = reinterpret_cast<float *>(lds);          // 256: sRGB u8 -> linear
 	float *s_alpha = s_srgb + 256;                           // 256: a / 255
@@ -2091,18 +2105,23 @@ __global__ void __launch_bounds__(1024) oklab_kernel(const ShrinkArgs a)
 		// ---------------- producers ----------------
 		const uint32_t row_off = lane / G::kLanesPerRow, col_off = (lane % G::kLanesPerRow) * 16u;
 		// source pointers (lane's first group of band 0) of this wave's tiles in batches p, p+1, p+2; null: nothing there
-		auto batch_src = [&](uint32_t j) -> const uint8_t * {
+		auto batch_src = [&](uint32_t j, uint32_t &bands) -> const uint8_t * {
 			const uint8_t *src;
-			if (j >= own || !oklab_tile_src<T>(a, (blockIdx.x + j * gridDim.x) * kOkTiles + wave, src)) return nullptr;
+			bands = 0;
+			if (j >= own) return nullptr;
+			const uint32_t th = oklab_tile_src<T>(a, (blockIdx.x + j * gridDim.x) * kOkTiles + wave, src);
+			if (th == 0) return nullptr;
+			bands = th / G::kRowsPerBand;  // (a ragged tile is only taken with a whole number of bands)
 			return src + (size_t)row_off * a.pitch + col_off;
 		};
-		const uint8_t *src0 = nullptr, *src1 = batch_src(0), *src2 = batch_src(1);
+		uint32_t nb0 = 0, nb1 = 0, nb2 = 0, nb_prev = 0;  // bands of this wave's tile in batches p, p+1, p+2, p-1
+		const uint8_t *src0 = nullptr, *src1 = batch_src(0, nb1), *src2 = batch_src(1, nb2);
 		const size_t band_step = (size_t)G::kRowsPerBand * a.pitch;
 		// raw pixels: the band being converted and the one after it (requested one interval ahead)
 		uint4 px_cur = make_uint4(0, 0, 0, 0), px_nxt = make_uint4(0, 0, 0, 0);
 		if (src1) px_cur = *reinterpret_cast<const uint4 *>(src1);
 		if (NB > 1) {
-			if (src1) px_nxt = *reinterpret_cast<const uint4 *>(src1 + band_step);
+			if (src1 && nb1 > 1u) px_nxt = *reinterpret_cast<const uint4 *>(src1 + band_step);
 		} else if (src2) {
 			px_nxt = *reinterpret_cast<const uint4 *>(src2);
 		}
@@ -2115,7 +2134,10 @@ __global__ void __launch_bounds__(1024) oklab_kernel(const ShrinkArgs a)
 			tile_cur = (blockIdx.x + p * gridDim.x) * kOkTiles + wave;
 			src0 = src1;  // batch p
 			src1 = src2;  // batch p + 1
-			src2 = batch_src(p + 2u);
+			nb_prev = nb0;
+			nb0 = nb1;
+			nb1 = nb2;
+			src2 = batch_src(p + 2u, nb2);
 			elig_cur = src0 != nullptr;  // (false past the last batch and for tiles the detector does not take)
 			constexpr int kUnroll = G::kInRegs ? (int)NB : 1;  // register form: lab[k] must be a static index
 #pragma unroll kUnroll
@@ -2123,7 +2145,7 @@ __global__ void __launch_bounds__(1024) oklab_kernel(const ShrinkArgs a)
 				// ---- convert phase
 				float4 old[4];  // scratch form only: band k of the previous batch, back from HBM for pass 2
 				if constexpr (!G::kInRegs) {
-					if (have_prev) {
+					if (have_prev && k < nb_prev) {
 						const float4 *sp = reinterpret_cast<const float4 *>(a.ok_scratch) + (((size_t)tile_prev * NB + k) * 64u + lane) * 4u;
 #pragma unroll
 						for (int q = 0; q < 4; ++q) old[q] = sp[q];
@@ -2131,7 +2153,7 @@ __global__ void __launch_bounds__(1024) oklab_kernel(const ShrinkArgs a)
 				}
 				float fresh[4][3];
 				uint32_t fresh_alpha = 0;
-				if (elig_cur) {
+				if (elig_cur && k < nb0) {
 					const uint32_t v[4] = {px_cur.x, px_cur.y, px_cur.z, px_cur.w};
 					fresh_alpha = (v[0] >> 24) | ((v[1] >> 24) << 8) | ((v[2] >> 24) << 16) | ((v[3] >> 24) << 24);
 #pragma unroll
@@ -2163,12 +2185,13 @@ __global__ void __launch_bounds__(1024) oklab_kernel(const ShrinkArgs a)
 					// two steps ahead: band k+2 of this batch, or an early band of the next one / the one after
 					const uint32_t ahead = k + 2u, bo = ahead / NB, band = ahead % NB;
 					const uint8_t *base = bo == 0 ? src0 : (bo == 1 ? src1 : src2);
-					if (base) px_nxt = *reinterpret_cast<const uint4 *>(base + band * band_step);
+					const uint32_t nbb = bo == 0 ? nb0 : (bo == 1 ? nb1 : nb2);
+					if (base && band < nbb) px_nxt = *reinterpret_cast<const uint4 *>(base + band * band_step);
 				}
 				__syncthreads();  // A: the chain has consumed the bands of the previous interval
 				// ---- write phase
 				const uint32_t slot = (wave * 4u) * kOkPlane + lane * 4u;  // 4 consecutive pixels of this lane
-				if (have_prev) {
+				if (have_prev && k < nb_prev) {
 					// operations.rs:75-84: the chain only has to add |x| of these.  The means were published during
 					// the first convert phase of this period.
 					const float4 mean = *reinterpret_cast<const float4 *>(s_mean + wave * 4u);
@@ -2199,7 +2222,7 @@ __global__ void __launch_bounds__(1024) oklab_kernel(const ShrinkArgs a)
 					    make_float4(s_alpha[al4 & 255u] - mean4[3], s_alpha[(al4 >> 8) & 255u] - mean4[3],
 					                s_alpha[(al4 >> 16) & 255u] - mean4[3], s_alpha[al4 >> 24] - mean4[3]);
 				}
-				if (elig_cur) {
+				if (elig_cur && k < nb0) {
 					float *d = s_p1 + slot;
 #pragma unroll
 					for (int c = 0; c < 3; ++c)
@@ -2268,7 +2291,14 @@ __global__ void __launch_bounds__(1024) oklab_kernel(const ShrinkArgs a)
 			}
 			return acc;
 		};
+		uint32_t h0 = 0, hm1 = 0, hm2 = 0;  // height of this lane's tile in batches p, p-1, p-2 (0: not taken)
 		for (uint32_t p = 0; p < periods; ++p) {
+			{
+				const uint8_t *unused;
+				hm2 = hm1;
+				hm1 = h0;
+				h0 = (live && p < own) ? oklab_tile_src<T>(a, (blockIdx.x + p * gridDim.x) * kOkTiles + ct, unused) : 0u;
+			}
 #pragma unroll 1
 			for (uint32_t k = 0; k < NB; ++k) {
 				// the bands written one interval ago: band kk of period pp
@@ -2276,21 +2306,21 @@ __global__ void __launch_bounds__(1024) oklab_kernel(const ShrinkArgs a)
 				const bool any = k > 0 || p > 0;
 				const bool p1_valid = any && pp < own;                   // pass 1 of batch pp
 				const bool p2_valid = any && pp >= 1u && pp - 1u < own;  // pass 2 of batch pp - 1
-				if (live && p1_valid) acc1 = walk(s_p1, acc1, false);
-				if (live && p2_valid) acc2 = walk(s_p2, acc2, true);
+				const uint32_t h1 = k > 0 ? h0 : hm1, h2 = k > 0 ? hm1 : hm2;  // tile heights of those two batches
+				if (p1_valid && kk * G::kRowsPerBand < h1) acc1 = walk(s_p1, acc1, false);
+				if (p2_valid && kk * G::kRowsPerBand < h2) acc2 = walk(s_p2, acc2, true);
 				if (kk == NB - 1u) {
 					if (p1_valid) {
-						s_mean[lane] = __fdiv_rn(acc1, kCount);  // operations.rs:65-68; read after barrier A
+						s_mean[lane] = __fdiv_rn(acc1, (float)((uint32_t)T * h1));  // operations.rs:65-68; read after barrier A
 						acc1 = 0.0f;
 					}
 					if (p2_valid) {
 						const float d0 = __shfl(acc2, (int)(lane & ~3u) + 0, 64), d1 = __shfl(acc2, (int)(lane & ~3u) + 1, 64);
 						const float d2 = __shfl(acc2, (int)(lane & ~3u) + 2, 64), d3 = __shfl(acc2, (int)(lane & ~3u) + 3, 64);
 						const float total = d0 + d1 + d2 + d3;  // :89
-						const float value = __fdiv_rn(total, kCount) * a.factor * a.scale2;  // pixlzr.rs:162
+						const float value = __fdiv_rn(total, (float)((uint32_t)T * h2)) * a.factor * a.scale2;  // pixlzr.rs:162
 						const uint32_t tg = (blockIdx.x + (pp - 1u) * gridDim.x) * kOkTiles + ct;
-						const uint8_t *unused;
-						if (live && cc == 0 && oklab_tile_src<T>(a, tg, unused))
+						if (live && cc == 0 && h2 != 0u)
 							reinterpret_cast<uint2 *>(a.sums)[tg] = make_uint2(__float_as_uint(value), __float_as_uint(value));
 						acc2 = 0.0f;
 					}
@@ -3333,6 +3363,7 @@ hipError_t launch_shrink(const ShrinkArgs &a, uint32_t channels, uint32_t n_cus,
 		f.div_cols = a.div_cols;
 		f.full_cols = a.full_cols;
 		f.full_rows = a.full_rows;
+		f.ok_rows = a.ok_rows;
 		f.filter = a.filter;
 		f.sums = a.sums;
 		f.out_w = a.out_w;
@@ -3377,6 +3408,7 @@ hipError_t launch_shrink(const ShrinkArgs &a, uint32_t channels, uint32_t n_cus,
 		f.div_cols = a.div_cols;
 		f.full_cols = a.full_cols;
 		f.full_rows = a.full_rows;
+		f.ok_rows = a.ok_rows;
 		f.filter = a.filter;
 		f.sums = a.sums;
 		f.out_w = a.out_w;
@@ -3429,9 +3461,8 @@ hipError_t launch_shrink(const ShrinkArgs &a, uint32_t channels, uint32_t n_cus,
 	} else {
 		ga.work = nullptr;
 	}
-	// worklist tiles lost their value to the deferred marker: the generic path computes its own; when it
-	// processes every tile (no fast kernel for this size) the block-cooperative detector's values stand
-	if (ga.work != nullptr) ga.oklab_given = 0;
+	// (the block-cooperative detector's values stand for every tile it took, deferred or not: the fast
+	// kernels leave those tiles' sums alone)
 	const LaunchGeom g = plan_launch(ga, channels, n_cus);
 	switch (waves_per_tile(ga.bw, ga.bh)) {
 	case 1: return launch_nw<1>(ga, channels, g, stream);
