@@ -25,6 +25,8 @@ bool fast32_applicable(const ShrinkArgs &a, uint32_t channels);
 bool fast64_applicable(const ShrinkArgs &a, uint32_t channels);
 hipError_t launch_expand(const ExpandArgs &a, uint32_t n_cus, hipStream_t stream);
 hipError_t launch_decode(const DecodeArgs &a, hipStream_t stream);
+hipError_t launch_widen(const WidenArgs &a, hipStream_t stream);
+hipError_t launch_narrow(const NarrowArgs &a, hipStream_t stream);
 hipError_t launch_pack(const PackArgs &a, hipStream_t stream);
 hipError_t launch_oklab(const ShrinkArgs &a, uint32_t n_cus, hipStream_t stream);
 hipError_t launch_qoi(const QoiArgs &a, hipStream_t stream);
@@ -45,6 +47,7 @@ struct TableSet {
 	uint32_t *d_rows = nullptr;
 	uint32_t rows_dw = 0;
 	uint32_t *d_mf64 = nullptr;  // 64x64 fast path: matrix-core operand tables (null: not available)
+	bool opaque_stays = true;    // a constant-255 alpha comes back as 255 from every window of every table
 };
 
 // decode side: up-scaling tables of every source size to the full tile size (expand_kernel)
@@ -72,7 +75,7 @@ struct pxz_handle {
 	// level breakpoints per (mode, factor bits, bw, bh, edge_w, edge_h)
 	struct Breaks { uint32_t b[4][pxz::kMaxLevel]; uint32_t asc[4]; };
 	std::map<std::tuple<uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t>, Breaks> breaks;
-	DeviceBuffer in, val, ow, oh, out, sums, chunks, work, qscratch, qmeta, status, dmeta, okscratch;
+	DeviceBuffer in, val, ow, oh, out, sums, chunks, work, qscratch, qmeta, status, dmeta, okscratch, rgba, slots4;
 	std::map<std::tuple<uint32_t, uint32_t, uint32_t, uint32_t, uint32_t>, ExpandTables> expand_tables;
 	bool work_ready = false;   // both worklist counters are zero / consistent with work_slot
 	uint32_t work_slot = 0;    // the counter the next 32x32 launch uses
@@ -146,6 +149,7 @@ int get_tables(pxz_handle *h, uint32_t bw, uint32_t bh, uint32_t edge_w, uint32_
 	std::vector<uint32_t> coeffs;
 	std::vector<int32_t> ksums;
 	std::vector<uint32_t> rows;
+	bool all_opaque_stays = true;
 	std::vector<uint32_t> mf64(4, 0u);  // offset 0 means "no table"
 	bool mf64_complete = bw == 64 && bh == 64 && filter != PXZ_FILTER_NEAREST;
 	const uint32_t sizes[2][2] = {{bw, edge_w}, {bh, edge_h}};
@@ -212,6 +216,7 @@ int get_tables(pxz_handle *h, uint32_t bw, uint32_t bh, uint32_t edge_w, uint32_
 						rows[row0 + 4 + d] = pr;
 					}
 					ksums.push_back(total);
+					if ((((1 << (win.precision - 1)) + 255 * total) >> win.precision) < 255) all_opaque_stays = false;
 				}
 				// 32x32 tiles: operands for the matrix-core form of the two-pass resample (x axis table,
 				// used for both axes of a full tile)
@@ -292,6 +297,7 @@ int get_tables(pxz_handle *h, uint32_t bw, uint32_t bh, uint32_t edge_w, uint32_
 	rows.resize(rows.size() + 32, 0u);  // the fast path always fetches 4+16 dwords per row
 	TableSet ts;
 	ts.tabs = tabs;
+	ts.opaque_stays = all_opaque_stays;
 	PXZ_HIP(h, hipMalloc((void **)&ts.d_bounds, bounds.size() * sizeof(uint16_t)));
 	PXZ_HIP(h, hipMalloc((void **)&ts.d_coeffs, coeffs.size() * sizeof(uint32_t)));
 	PXZ_HIP(h, hipMalloc((void **)&ts.d_ksums, ksums.size() * sizeof(int32_t)));
@@ -667,7 +673,7 @@ void pxz_destroy(pxz_handle *h)
 		(void)hipFree(kv.second.d_sizes);
 		(void)hipFree(kv.second.d_coeffs);
 	}
-	for (DeviceBuffer *b : {&h->in, &h->val, &h->ow, &h->oh, &h->out, &h->sums, &h->chunks, &h->work, &h->qscratch, &h->qmeta, &h->status, &h->dmeta, &h->okscratch})
+	for (DeviceBuffer *b : {&h->in, &h->val, &h->ow, &h->oh, &h->out, &h->sums, &h->chunks, &h->work, &h->qscratch, &h->qmeta, &h->status, &h->dmeta, &h->okscratch, &h->rgba, &h->slots4})
 		if (b->ptr) (void)hipFree(b->ptr);
 	for (auto &ev : h->events) {
 		(void)hipEventDestroy(ev.first);
@@ -708,21 +714,67 @@ int pxz_grid(uint32_t width, uint32_t height, uint32_t block_w, uint32_t block_h
 	return PXZ_OK;
 }
 
+// One shrink / detector pass over a batch.  identity: the closures of process() instead of shrink_by's.
+// RGB batches whose tile size has an RGBA fast path are widened to RGBA (alpha 255) in scratch memory, run
+// there, and their tile slots narrowed back (see rgb_to_rgba_kernel for why the results are the same).
+static int run_shrink(pxz_handle *h, const pxz_frames *frames, const pxz_params *params, const uint8_t *d_pixels,
+                      float *d_block_value, uint32_t *d_out_w, uint32_t *d_out_h, uint8_t *d_out_pixels, float *d_lod0,
+                      float *d_lod1, bool identity)
+{
+	PXZ_HIP(h, hipSetDevice(h->device));
+	pxz::ShrinkArgs a{};
+	int rc = prepare(h, frames, params, d_out_pixels != nullptr, &a);
+	if (rc != PXZ_OK) return rc;
+	bool widen = frames->channels == 3 && a.bw == a.bh && (a.bw == 32 || a.bw == 64) && !getenv("PXZ_NO_WIDEN");
+	if (widen && d_out_pixels && params->filter != PXZ_FILTER_NEAREST) {
+		const TableSet *tsp = nullptr;
+		if ((rc = get_tables(h, a.bw, a.bh, a.edge_w, a.edge_h, params->filter, &tsp)) != PXZ_OK) return rc;
+		widen = tsp->opaque_stays;
+	}
+	pxz_frames f4 = *frames;
+	const uint8_t *src = d_pixels;
+	uint8_t *out_px = d_out_pixels;
+	if (widen) {
+		f4.channels = 4;
+		f4.pitch_bytes = (frames->width * 4u + 15u) & ~15u;
+		f4.frame_stride_bytes = (uint64_t)f4.pitch_bytes * frames->height;
+		if ((rc = ensure(h, h->rgba, (size_t)f4.frame_stride_bytes * frames->n_frames)) != PXZ_OK) return rc;
+		const pxz::WidenArgs w{d_pixels, (uint8_t *)h->rgba.ptr,
+		                       frames->n_frames > 1 ? frames->frame_stride_bytes : (uint64_t)frames->pitch_bytes * frames->height,
+		                       f4.frame_stride_bytes, frames->pitch_bytes, f4.pitch_bytes, frames->width, frames->height,
+		                       frames->n_frames};
+		PXZ_HIP(h, pxz::launch_widen(w, h->stream));
+		if ((rc = prepare(h, &f4, params, d_out_pixels != nullptr, &a)) != PXZ_OK) return rc;
+		src = (const uint8_t *)h->rgba.ptr;
+		if (d_out_pixels) {
+			if ((rc = ensure(h, h->slots4, (size_t)a.n_tiles * a.bw * a.bh * 4u)) != PXZ_OK) return rc;
+			out_px = (uint8_t *)h->slots4.ptr;
+		}
+	}
+	if (identity) {
+		a.factor = 1.0f;
+		a.scale2 = 1.0f;  // (x * 1) * 1 is x exactly: the identity closure
+	}
+	a.src = src;
+	a.out_w = d_out_w;
+	a.out_h = d_out_h;
+	a.out_px = out_px;
+	if ((rc = timed_launch(h, a, widen ? 4u : frames->channels, d_block_value, d_lod0, d_lod1)) != PXZ_OK) return rc;
+	if (widen && d_out_pixels) {
+		const pxz::NarrowArgs n{(const uint8_t *)h->slots4.ptr, d_out_pixels, d_out_w, d_out_h, a.n_tiles, a.bw * a.bh * 4u,
+		                        a.bw * a.bh * 3u};
+		PXZ_HIP(h, pxz::launch_narrow(n, h->stream));
+	}
+	return PXZ_OK;
+}
+
 int pxz_shrink_frames_device(pxz_handle *h, const pxz_frames *frames, const pxz_params *params,
                              const uint8_t *d_pixels, float *d_block_value, uint32_t *d_out_w, uint32_t *d_out_h,
                              uint8_t *d_out_pixels)
 {
 	if (!h) return PXZ_ERR_INVALID_ARG;
 	if (!d_pixels || !d_block_value || !d_out_w || !d_out_h) return fail(h, PXZ_ERR_INVALID_ARG, "null device pointer");
-	PXZ_HIP(h, hipSetDevice(h->device));
-	pxz::ShrinkArgs a{};
-	int rc = prepare(h, frames, params, d_out_pixels != nullptr, &a);
-	if (rc != PXZ_OK) return rc;
-	a.src = d_pixels;
-	a.out_w = d_out_w;
-	a.out_h = d_out_h;
-	a.out_px = d_out_pixels;
-	return timed_launch(h, a, frames->channels, d_block_value, nullptr, nullptr);
+	return run_shrink(h, frames, params, d_pixels, d_block_value, d_out_w, d_out_h, d_out_pixels, nullptr, nullptr, false);
 }
 
 int pxz_lod_frames_device(pxz_handle *h, const pxz_frames *frames, const pxz_params *params,
@@ -730,12 +782,7 @@ int pxz_lod_frames_device(pxz_handle *h, const pxz_frames *frames, const pxz_par
 {
 	if (!h) return PXZ_ERR_INVALID_ARG;
 	if (!d_pixels || !d_lod0 || !d_lod1) return fail(h, PXZ_ERR_INVALID_ARG, "null device pointer");
-	PXZ_HIP(h, hipSetDevice(h->device));
-	pxz::ShrinkArgs a{};
-	int rc = prepare(h, frames, params, false, &a);
-	if (rc != PXZ_OK) return rc;
-	a.src = d_pixels;
-	return timed_launch(h, a, frames->channels, nullptr, d_lod0, d_lod1);
+	return run_shrink(h, frames, params, d_pixels, nullptr, nullptr, nullptr, nullptr, d_lod0, d_lod1, false);
 }
 
 // frames: the OUTPUT batch (its channels = bytes per output pixel); slot_channels: channels of the stored tiles
@@ -817,21 +864,18 @@ int pxz_process_frames_device(pxz_handle *h, const pxz_frames *frames, const pxz
 	pxz_params p = *params;
 	p.mode = PXZ_MODE_SHRINK_BY;
 	p.factor = 1.0f;
-	pxz::ShrinkArgs a{};
-	int rc = prepare(h, frames, &p, true, &a);
+	int rc = check_frames(h, frames, &p);
 	if (rc != PXZ_OK) return rc;
-	a.factor = 1.0f;
-	a.scale2 = 1.0f;  // (x * 1) * 1 is x exactly: the identity closure
-	const size_t tiles = a.n_tiles, slot = (size_t)a.bw * a.bh * frames->channels;
+	uint32_t cols, rows;
+	pxz_grid(frames->width, frames->height, p.block_w, p.block_h, &cols, &rows);
+	const size_t tiles = (size_t)cols * rows * frames->n_frames, slot = (size_t)p.block_w * p.block_h * frames->channels;
 	if ((rc = ensure(h, h->val, tiles * 4)) != PXZ_OK) return rc;
 	if ((rc = ensure(h, h->ow, tiles * 4)) != PXZ_OK) return rc;
 	if ((rc = ensure(h, h->oh, tiles * 4)) != PXZ_OK) return rc;
 	if ((rc = ensure(h, h->out, tiles * slot)) != PXZ_OK) return rc;
-	a.src = d_pixels;
-	a.out_w = (uint32_t *)h->ow.ptr;
-	a.out_h = (uint32_t *)h->oh.ptr;
-	a.out_px = (uint8_t *)h->out.ptr;
-	if ((rc = timed_launch(h, a, frames->channels, (float *)h->val.ptr, nullptr, nullptr)) != PXZ_OK) return rc;
+	if ((rc = run_shrink(h, frames, &p, d_pixels, (float *)h->val.ptr, (uint32_t *)h->ow.ptr, (uint32_t *)h->oh.ptr,
+	                     (uint8_t *)h->out.ptr, nullptr, nullptr, true)) != PXZ_OK)
+		return rc;
 	// 2) .resize(w0, h0, filter_upscale) + copy_from into the RGBA output (process/mod.rs:58-63)
 	pxz_frames of{frames->width, frames->height, 4, out_pitch_bytes, frames->n_frames, 0, out_frame_stride_bytes};
 	pxz_params up{params->block_w, params->block_h, 0, filter_upscale, 0.0f, 0};

@@ -233,6 +233,20 @@ struct DecodeArgs {
 	uint32_t edge_w, edge_h;
 };
 
+// RGB frames ride the RGBA fast paths: widen to RGBA (alpha 255) on the way in, narrow the tile slots on the way out
+struct WidenArgs {
+	const uint8_t *src;
+	uint8_t *dst;
+	uint64_t src_frame_stride, dst_frame_stride;
+	uint32_t src_pitch, dst_pitch, width, height, n_frames;
+};
+struct NarrowArgs {
+	const uint8_t *slots4;
+	uint8_t *slots3;
+	const uint32_t *w, *h;
+	uint32_t n_tiles, slot4_bytes, slot3_bytes;
+};
+
 struct SynthArgs {
 	uint8_t *dst;
 	uint64_t frame_stride;

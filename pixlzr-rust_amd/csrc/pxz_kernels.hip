@@ -3223,6 +3223,48 @@ hipError_t launch_decode(const DecodeArgs &a, hipStream_t stream)
 }
 
 // ---------------------------------------------------------------------------
+// RGB input on the RGBA fast paths.  An RGB tile and the same tile with alpha 255 give the same detector values
+// (the alpha chain of the Oklab detector sums exact ones: mean 1, deviation 0, and x + 0 = x) and the same
+// resampled colours (premultiplying by 255 is the identity; the host checks that the constant-255 alpha comes
+// back as 255 from every table in use, so nothing is un-premultiplied).  So RGB frames are widened once on the
+// way in and the tile slots narrowed on the way out, instead of running the generic kernel on 3-byte pixels.
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) rgb_to_rgba_kernel(const WidenArgs a)
+{
+	const uint32_t x = blockIdx.x * 256u + threadIdx.x, y = blockIdx.y, f = blockIdx.z;
+	if (x >= a.width) return;
+	const uint8_t *p = a.src + (size_t)f * a.src_frame_stride + (size_t)y * a.src_pitch + (size_t)x * 3u;
+	const uint32_t px = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | 0xff000000u;
+	*reinterpret_cast<uint32_t *>(a.dst + (size_t)f * a.dst_frame_stride + (size_t)y * a.dst_pitch + (size_t)x * 4u) = px;
+}
+
+__global__ void __launch_bounds__(256) slots_rgba_to_rgb_kernel(const NarrowArgs a)
+{
+	const uint32_t t = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+	if (t >= a.n_tiles) return;
+	const uint32_t n = a.w[t] * a.h[t];
+	const uint32_t *s = reinterpret_cast<const uint32_t *>(a.slots4 + (size_t)t * a.slot4_bytes);
+	uint8_t *d = a.slots3 + (size_t)t * a.slot3_bytes;
+	for (uint32_t i = lane; i < n; i += 64u) {
+		const uint32_t px = s[i];
+		d[3u * i] = (uint8_t)px;
+		d[3u * i + 1u] = (uint8_t)(px >> 8);
+		d[3u * i + 2u] = (uint8_t)(px >> 16);
+	}
+}
+
+hipError_t launch_widen(const WidenArgs &a, hipStream_t stream)
+{
+	hipLaunchKernelGGL(rgb_to_rgba_kernel, dim3((a.width + 255u) / 256u, a.height, a.n_frames), dim3(256), 0, stream, a);
+	return hipGetLastError();
+}
+hipError_t launch_narrow(const NarrowArgs &a, hipStream_t stream)
+{
+	hipLaunchKernelGGL(slots_rgba_to_rgb_kernel, dim3((a.n_tiles + 3u) / 4u), dim3(256), 0, stream, a);
+	return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
 // synthetic frames (DESIGN.md "Synthetic frames"): integer-only, one pixel per thread
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t fmix32(uint32_t h)
