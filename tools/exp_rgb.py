@@ -7,7 +7,7 @@ from __graft_entry__ import load_product
 P = load_product()
 h = P.Handle(0)
 c = int(os.environ.get("C", "3"))
-frames = h.synth_frames_device(8, 4320, 7680, c, 0, 0)
+frames = h.synth_frames_device(8, 4320, 7680, c, 0, int(os.environ.get("DIST", "0")))
 for mode, factor, name in ((1, 16.0, "directional"), (0, 1.0, "shrink_by")):
     for bs in (32, 64):
         out = h.shrink_frames_device(frames, bs, bs, mode, 4, factor)
