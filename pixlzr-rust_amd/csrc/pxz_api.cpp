@@ -23,6 +23,7 @@ hipError_t launch_synth(const SynthArgs &s, hipStream_t stream);
 hipError_t launch_finish(const FinishArgs &f, hipStream_t stream);
 bool fast32_applicable(const ShrinkArgs &a, uint32_t channels);
 bool fast64_applicable(const ShrinkArgs &a, uint32_t channels);
+bool fast16_applicable(const ShrinkArgs &a, uint32_t channels);
 hipError_t launch_expand(const ExpandArgs &a, uint32_t n_cus, hipStream_t stream);
 hipError_t launch_decode(const DecodeArgs &a, hipStream_t stream);
 hipError_t launch_widen(const WidenArgs &a, hipStream_t stream);
@@ -601,7 +602,14 @@ int timed_launch(pxz_handle *h, pxz::ShrinkArgs &a, uint32_t channels, float *va
 	}
 	// 32x32 RGBA flow: shrink32_kernel, then the worklist kernel, which also finishes every tile and
 	// zeroes the worklist counter of the next launch (two counters, used alternately)
-	const bool fast = pxz::fast32_applicable(a, channels) || pxz::fast64_applicable(a, channels);
+	{
+		// shrink16_kernel walks 2x2 groups of tiles
+		const uint32_t gcols = (a.cols + 1u) / 2u, grows = (a.rows + 1u) / 2u;
+		a.div_gpf = make_fastdiv(gcols * grows);
+		a.div_gcols = make_fastdiv(gcols);
+		a.n_frames_x_groups = gcols * grows * (a.n_tiles / a.tiles_per_frame);
+	}
+	const bool fast = pxz::fast32_applicable(a, channels) || pxz::fast64_applicable(a, channels) || pxz::fast16_applicable(a, channels);
 	if (fast) {
 		if (!h->work_ready) {
 			PXZ_HIP(h, hipMemsetAsync(h->work.ptr, 0, pxz::kWorkList * 4u, h->stream));

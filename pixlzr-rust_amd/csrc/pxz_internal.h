@@ -65,6 +65,8 @@ struct ShrinkArgs {
 	uint32_t oklab_given;    // 1: full 32x32 RGBA tiles already carry their Oklab value in sums[] (oklab32_kernel)
 	float scale2;            // Oklab mode: value = mean deviation * factor * scale2 (10 = BASE_FACTOR of shrink_by,
 	                         //   pixlzr.rs:15,162; 1 with factor 1 = the identity closure of process(), process/mod.rs:107-121)
+	FastDiv div_gpf, div_gcols;  // shrink16_kernel: divisors for its 2x2 tile groups (groups per frame, group columns)
+	uint32_t n_frames_x_groups;  //   and the number of groups in the batch
 	float *ok_scratch;       // Oklab detector on 64x64 tiles: 16 floats per pixel quad between its passes (HBM)
 	const uint32_t *mf64;    // 64x64 fast path: matrix-core operand tables (global memory), see Fast64Args
 	uint32_t ok_rows;        // tile rows the block-cooperative Oklab detector takes: full_rows, plus the ragged last row
@@ -108,6 +110,8 @@ struct Fast32Args {
 	uint64_t frame_stride;
 	uint32_t pitch, cols, rows, tiles_per_frame, n_tiles;
 	FastDiv div_tpf, div_cols;
+	uint32_t n_groups;       // shrink16_kernel: 2x2 groups of tiles, ceil(cols/2) * ceil(rows/2) per frame
+	FastDiv div_gpf, div_gcols;
 	uint32_t full_cols, full_rows, ok_rows;  // as in ShrinkArgs
 	uint32_t filter;
 	uint32_t *sums;

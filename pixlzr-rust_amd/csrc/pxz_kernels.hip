@@ -340,11 +340,11 @@ __device__ __forceinline__ void load_row(const uint32_t *rowp, RowRegs &r)
 // (each lane takes quads part, part+LPI, ...; weights beyond the window are zero in the table)
 template <int LPI>
 __device__ __forceinline__ void fast32_h_rows(const uint32_t *trows, const AxisTab &tx, const uint32_t *s_pl, uint32_t *s_tmp,
-                                              uint32_t lane, uint32_t nw, uint32_t lgx)
+                                              uint32_t lane, uint32_t nw, uint32_t lgx, uint32_t in_rows = 32u)
 {
 	constexpr int QPL = 8 / LPI;  // quads per lane
 	const uint32_t item = lane / LPI, part = lane % LPI;
-	const bool live = item < nw * 32u;
+	const bool live = item < nw * in_rows;
 	const uint32_t ox = item & (nw - 1u), y = live ? item >> lgx : 0u;
 	const uint32_t *rowp = trows + tx.rows_off + ox * tx.row_stride;
 	const uint4 hdr = *reinterpret_cast<const uint4 *>(rowp);
@@ -515,14 +515,14 @@ __device__ __forceinline__ void fast32_h_only(const uint32_t *trows, const AxisT
 // every time; WQ = quads per window (weights past a lane's own window are zero in the table)
 template <int WQ>
 __device__ __forceinline__ void fast32_h_pairs(const uint32_t *trows, const AxisTab &tx, const uint32_t *s_pl, uint32_t *s_tmp,
-                                               uint32_t lane, uint32_t nw, uint32_t lgx)
+                                               uint32_t lane, uint32_t nw, uint32_t lgx, uint32_t row_pairs = 16u)
 {
 	const uint32_t ox = lane & (nw - 1u);
 	RowRegs r;
 	load_row(trows + tx.rows_off + ox * tx.row_stride, r);
 	const int prec = tx.precision;
 	const int32_t init = 1 << (prec - 1);
-	for (uint32_t i = lane; i < nw * 16u; i += 64u) {
+	for (uint32_t i = lane; i < nw * row_pairs; i += 64u) {
 		const uint32_t yp = i >> lgx;
 		const uint32_t *row = s_pl + yp * (2 * kRS32) + r.fq * 2u;
 		int32_t a0 = init, a1 = init, a2 = init, b0 = init, b1 = init, b2 = init;
@@ -576,6 +576,33 @@ __device__ __forceinline__ void resample_fast32_hv(const uint32_t *trows, const 
 	else if (items >= 32u) fast32_v<2>(trows, tx, ty, s_tmp, lane, nw, nh, out);
 	else if (items >= 16u) fast32_v<4>(trows, tx, ty, s_tmp, lane, nw, nh, out);
 	else fast32_v<8>(trows, tx, ty, s_tmp, lane, nw, nh, out);
+}
+
+// The same for a 16x16 tile that sits somewhere inside the 32x32 LDS image (s_pl points at its first pixel
+// pair): windows of at most 4 quads, 16 source rows, nw and nh in {8, 4, 2, 1}.
+__device__ __forceinline__ void resample_fast16_hv(const uint32_t *trows, const AxisTab &tx, const AxisTab &ty, const uint32_t *s_pl,
+                                                   uint32_t *s_tmp, uint32_t lane, uint32_t nw, uint32_t nh, uint32_t *out)
+{
+	const uint32_t lgx = 31u - (uint32_t)__builtin_clz(nw);
+	if (nw >= 4) {
+		switch (tx.wquads) {
+		case 1: fast32_h_pairs<1>(trows, tx, s_pl, s_tmp, lane, nw, lgx, 8u); break;
+		case 2: fast32_h_pairs<2>(trows, tx, s_pl, s_tmp, lane, nw, lgx, 8u); break;
+		case 3: fast32_h_pairs<3>(trows, tx, s_pl, s_tmp, lane, nw, lgx, 8u); break;
+		default: fast32_h_pairs<4>(trows, tx, s_pl, s_tmp, lane, nw, lgx, 8u); break;
+		}
+	} else if (nw == 2) {
+		fast32_h_rows<2>(trows, tx, s_pl, s_tmp, lane, nw, lgx, 16u);
+	} else {
+		fast32_h_rows<4>(trows, tx, s_pl, s_tmp, lane, nw, lgx, 16u);
+	}
+	tile_sync<1>();
+	const uint32_t items = nw * nh;
+	if (items >= 64u) fast32_v<1>(trows, tx, ty, s_tmp, lane, nw, nh, out);
+	else if (items >= 32u) fast32_v<2>(trows, tx, ty, s_tmp, lane, nw, nh, out);
+	else if (items >= 16u) fast32_v<4>(trows, tx, ty, s_tmp, lane, nw, nh, out);
+	else fast32_v<8>(trows, tx, ty, s_tmp, lane, nw, nh, out);
+	tile_sync<1>();  // the next tile of the group reuses the transposed planes
 }
 
 // ---------------------------------------------------------------------------
@@ -1526,6 +1553,260 @@ __global__ void __launch_bounds__(1024) shrink32_kernel(const Fast32Args a)
 		if (sub == 0) out[8 + blockIdx.x * 16u + 15u] = st_begin;
 	}
 #endif
+}
+
+// ---------------------------------------------------------------------------
+// shrink16_kernel: 16x16 RGBA tiles, four at a time -- a 2x2 group of tiles is one 32x32 region, loaded,
+// staged and scanned by the detector exactly like a tile of shrink32_kernel; only the windows that would
+// straddle two tiles are left out, the sums are kept per tile (segmented reduction), and each of the four
+// tiles then gets its own level decision and its own small resample out of the shared LDS image.
+// Groups are dealt to the waves of a block through the LDS ticket counter.  Groups with a ragged or missing
+// tile, tiles with transparency and the one-pass classes (16 x n, n x 16) go to the worklist.
+// MODE 1: directional detector here; MODE 0: values already in sums[] (oklab_kernel<16>).
+// ---------------------------------------------------------------------------
+template <int MODE>
+__global__ void __launch_bounds__(1024) shrink16_kernel(const Fast32Args a)
+{
+	extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+	const uint32_t wpb = blockDim.x / 64u, sub = threadIdx.x / 64u, tid = threadIdx.x % 64u;
+	for (uint32_t i = threadIdx.x; i < a.tab_dw / 4u; i += blockDim.x)
+		reinterpret_cast<uint4 *>(lds)[i] = reinterpret_cast<const uint4 *>(a.trows)[i];
+	uint32_t *s_ticket = lds + a.tab_dw + wpb * a.tile_dw;
+	if (threadIdx.x == 0) *s_ticket = wpb;
+	__syncthreads();
+	const uint32_t *s_tab = lds;
+	const uint32_t brk_lane = tid < (uint32_t)kMaxLevel ? a.breaks[tid] : (a.breaks_asc ? 0xffffffffu : 0u);
+	auto level_of = [&](uint32_t key) -> uint32_t {
+		const unsigned long long lt = __builtin_amdgcn_ballot_w64(key < brk_lane);
+		const unsigned long long live = (1ull << kMaxLevel) - 1ull;
+		return (uint32_t)__builtin_popcountll((a.breaks_asc ? ~lt : lt) & live);
+	};
+	uint32_t *s_pl = lds + a.tab_dw + sub * a.tile_dw;
+	uint32_t *s_tmp = s_pl + 3 * kPD32;
+	// groups of 2x2 tiles: gcols x grows per frame
+	const uint32_t gcols = (a.cols + 1u) >> 1, grows = (a.rows + 1u) >> 1, gpf = gcols * grows;
+	auto group_of_ticket = [&](uint32_t t) -> uint32_t {
+		const unsigned long long run = (unsigned long long)(t >> a.chunk_lg) * gridDim.x + blockIdx.x;
+		const unsigned long long g = (run << a.chunk_lg) + (t & ((1u << a.chunk_lg) - 1u));
+		return g < (unsigned long long)a.n_groups ? (uint32_t)g : 0xffffffffu;
+	};
+	auto next_ticket = [&]() -> uint32_t {
+		uint32_t t = 0;
+		if (tid == 0) t = atomicAdd(s_ticket, 1u);
+		return group_of_ticket(__builtin_amdgcn_readfirstlane(t));
+	};
+	// a group's place: frame, (gx, gy); full: all four tiles exist, are full-size and the batch is aligned
+	struct Place {
+		uint32_t frame, gx, gy;
+		bool full;
+		const uint8_t *src;
+	};
+	auto place_of = [&](uint32_t grp) -> Place {
+		Place p{0, 0, 0, false, nullptr};
+		if (grp >= a.n_groups) return p;
+		p.frame = fastdiv(grp, a.div_gpf);
+		const uint32_t r = grp - p.frame * gpf;
+		p.gy = fastdiv(r, a.div_gcols);
+		p.gx = r - p.gy * gcols;
+		p.src = a.src + (size_t)p.frame * a.frame_stride + (size_t)(p.gy * 32u) * a.pitch + (size_t)(p.gx * 32u) * 4u;
+		p.full = 2u * p.gx + 1u < a.full_cols && 2u * p.gy + 1u < a.full_rows;
+		return p;
+	};
+	uint4 pre[4];
+	bool pre_valid = false;
+	auto prefetch = [&](uint32_t grp) {
+		const Place p = place_of(grp);
+		pre_valid = p.full;
+		if (pre_valid) {
+			const uint8_t *q = p.src + (size_t)(tid >> 3) * a.pitch + (tid & 7u) * 16u;
+#pragma unroll
+			for (int k = 0; k < 4; ++k) pre[k] = *reinterpret_cast<const uint4 *>(q + (size_t)(8 * k) * a.pitch);
+		}
+	};
+	const uint32_t first = group_of_ticket(__builtin_amdgcn_readfirstlane(sub));
+	prefetch(first);
+	for (uint32_t grp = first; grp < a.n_groups;) {
+		const uint32_t grp_next = next_ticket();
+		const Place pl = place_of(grp);
+		// tile ids of the group: t(dx, dy) = frame * tiles_per_frame + (2 gy + dy) * cols + 2 gx + dx
+		const uint32_t t00 = pl.frame * a.tiles_per_frame + (2u * pl.gy) * a.cols + 2u * pl.gx;
+		auto tile_id = [&](uint32_t k) -> uint32_t { return t00 + (k & 1u) + (k >> 1) * a.cols; };
+		auto defer_tile = [&](uint32_t t) {
+			if (tid == 0) {
+				a.work[kWorkList + atomicAdd(&a.work[a.work_slot], 1u)] = t;
+				bool keep = false;  // MODE 0: a value the block-cooperative detector left is final and stays
+				if constexpr (MODE == 0) {
+					const uint32_t tt = t - pl.frame * a.tiles_per_frame;
+					const uint32_t ty = fastdiv(tt, a.div_cols), tx = tt - ty * a.cols;
+					keep = tx < a.full_cols && ty < a.ok_rows;
+				}
+				if (!keep) reinterpret_cast<uint2 *>(a.sums)[t] = make_uint2(kDeferredKey, kDeferredKey);
+			}
+		};
+		if (!pre_valid) {
+			// a ragged or incomplete group (or an unaligned batch): its tiles one by one to the generic kernel
+#pragma unroll
+			for (uint32_t k = 0; k < 4; ++k)
+				if (2u * pl.gx + (k & 1u) < a.cols && 2u * pl.gy + (k >> 1) < a.rows) defer_tile(tile_id(k));
+			prefetch(grp_next);
+			grp = grp_next;
+			continue;
+		}
+		uint32_t given[4] = {0, 0, 0, 0};
+		if constexpr (MODE == 0) {
+#pragma unroll
+			for (uint32_t k = 0; k < 4; ++k) given[k] = a.sums[2 * tile_id(k)];
+		}
+		// ---- stage: registers -> planar u16 pairs (as shrink32_kernel)
+		uint32_t alpha_and = 0xffu;
+#pragma unroll
+		for (int k = 0; k < 4; ++k) alpha_and &= (pre[k].x & pre[k].y & pre[k].z & pre[k].w) >> 24;
+		const bool transparent = __builtin_amdgcn_ballot_w64(alpha_and != 0xffu) != 0ull;
+#pragma unroll
+		for (int k = 0; k < 4; ++k) {
+			const uint32_t row = (tid >> 3) + 8u * (uint32_t)k, col = tid & 7u;
+			const uint4 v = pre[k];
+			uint32_t *d = s_pl + row * kRS32 + col * 2u;
+#pragma unroll
+			for (uint32_t c = 0; c < 3; ++c) {
+				const uint32_t sel = c | 0x0c000c00u | ((4u + c) << 16);
+				uint2 pr;
+				pr.x = __builtin_amdgcn_perm(v.y, v.x, sel);
+				pr.y = __builtin_amdgcn_perm(v.w, v.z, sel);
+				*reinterpret_cast<uint2 *>(d + c * kPD32) = pr;
+			}
+		}
+		prefetch(grp_next);
+		if (transparent) {
+			// (one transparent tile sends the whole group: the generic kernel has the alpha plane)
+#pragma unroll
+			for (uint32_t k = 0; k < 4; ++k) defer_tile(tile_id(k));
+			grp = grp_next;
+			continue;
+		}
+		tile_sync<1>();
+		// ---- detector: as shrink32_kernel, minus the windows that would straddle two tiles
+		uint32_t m0[4], m1[4], key0[4], key1[4];
+		if constexpr (MODE == 1) {
+			uint32_t sum_hz = 0, sum_vr = 0;
+			const uint32_t q = tid & 15u, g = tid >> 4;
+			const uint32_t two = 0x00020002u;
+			const uint32_t *pc[3];
+			pc[0] = s_pl + g * (8u * kRS32) + q;
+			pc[1] = pc[0] + kPD32;
+			pc[2] = pc[1] + kPD32;
+			uint32_t rA[3], rB[3], tP[3], dP[3];
+#pragma unroll
+			for (int c = 0; c < 3; ++c) {
+				const uint32_t a0 = pc[c][0], a1 = pc[c][1], b0 = pc[c][kRS32], b1 = pc[c][kRS32 + 1];
+				rA[c] = pk_mad_u16(__builtin_amdgcn_alignbit(a1, a0, 16), two, u32(us2(a0) + us2(a1)));
+				rB[c] = pk_mad_u16(__builtin_amdgcn_alignbit(b1, b0, 16), two, u32(us2(b0) + us2(b1)));
+				tP[c] = u32(us2(a0) + us2(b0));
+				dP[c] = b0;
+			}
+#pragma unroll
+			for (int st = 0; st < 4; ++st) {
+				if (st < 3 || (g & 1u) == 0u) {  // groups 1 and 3 hold window rows 8 .. 13 of their tiles: 3 steps
+#pragma unroll
+					for (int c = 0; c < 3; ++c) {
+						const uint32_t *pr = pc[c] + (2 + 2 * st) * (int)kRS32;
+						const uint32_t n0 = pr[0], n1 = pr[1], o0 = pr[kRS32], o1 = pr[kRS32 + 1];
+						const uint32_t rN = pk_mad_u16(__builtin_amdgcn_alignbit(n1, n0, 16), two, u32(us2(n0) + us2(n1)));
+						sum_hz = sad16(rN, rA[c], sum_hz);
+						const uint32_t tN = u32(us2(dP[c]) + us2(n0));
+						const uint32_t c0 = u32(us2(tP[c]) + us2(tN));
+						sum_vr = sad16(dpp_mov<0x101>(c0), c0, sum_vr);
+						const uint32_t rO = pk_mad_u16(__builtin_amdgcn_alignbit(o1, o0, 16), two, u32(us2(o0) + us2(o1)));
+						sum_hz = sad16(rO, rB[c], sum_hz);
+						const uint32_t tO = u32(us2(n0) + us2(o0));
+						const uint32_t e0 = u32(us2(tN) + us2(tO));
+						sum_vr = sad16(dpp_mov<0x101>(e0), e0, sum_vr);
+						rA[c] = rN;
+						rB[c] = rO;
+						tP[c] = tO;
+						dP[c] = o0;
+					}
+				}
+			}
+			if ((q & 7u) == 7u) sum_hz = sum_vr = 0;  // pairs 7 and 15 start no window inside their tile
+			// per tile: 8 lanes (q >> 3) of two 16-lane rows (g >> 1): sum inside the 8-lane groups, then pick
+			sum_hz = (uint32_t)group_sum<8>((int32_t)sum_hz);
+			sum_vr = (uint32_t)group_sum<8>((int32_t)sum_vr);
+#pragma unroll
+			for (uint32_t k = 0; k < 4; ++k) {
+				const uint32_t l0 = 32u * (k >> 1) + 8u * (k & 1u);  // first lane of tile k's first row; its second row is 16 on
+				key0[k] = (uint32_t)__builtin_amdgcn_readlane((int)sum_hz, l0) + (uint32_t)__builtin_amdgcn_readlane((int)sum_hz, l0 + 16u);
+				key1[k] = (uint32_t)__builtin_amdgcn_readlane((int)sum_vr, l0) + (uint32_t)__builtin_amdgcn_readlane((int)sum_vr, l0 + 16u);
+				m0[k] = level_of(key0[k]);
+				m1[k] = level_of(key1[k]);
+			}
+		} else {
+#pragma unroll
+			for (uint32_t k = 0; k < 4; ++k) {
+				const uint32_t vb = __builtin_amdgcn_readfirstlane(given[k]);
+				key0[k] = key1[k] = vb;
+				m0[k] = m1[k] = level_of(__float_as_uint(parse_value(__uint_as_float(vb))));
+			}
+		}
+		uint32_t nw[4], nh[4];
+#pragma unroll
+		for (uint32_t k = 0; k < 4; ++k) {
+			nw[k] = reduced_size(16u, m0[k]);
+			nh[k] = reduced_size(16u, m1[k]);
+		}
+		// ---- per tile: metadata, then clone / nearest / two-pass resample straight into its slot
+#pragma unroll
+		for (uint32_t k = 0; k < 4; ++k) {
+			const uint32_t t = tile_id(k);
+			const bool one_pass = a.out_px != nullptr && (nw[k] == 16u) != (nh[k] == 16u) && a.filter != 0;
+			if (one_pass) {  // 16 x n, n x 16: generic kernel (it writes the tile's metadata itself)
+				defer_tile(t);
+				continue;
+			}
+			if (tid == 0) {
+				reinterpret_cast<uint2 *>(a.sums)[t] = make_uint2(key0[k], key1[k]);
+				if (a.out_w) a.out_w[t] = nw[k];
+				if (a.out_h) a.out_h[t] = nh[k];
+			}
+			if (a.out_px == nullptr) continue;
+			uint32_t *dst = reinterpret_cast<uint32_t *>(a.out_px + (size_t)t * 1024u);
+			const uint32_t *tile_pl = s_pl + (16u * (k >> 1)) * kRS32 + 8u * (k & 1u);  // first pixel pair of the tile
+			if (nw[k] == 16u && nh[k] == 16u) {
+				// clone (block.rs:279-281): 64 groups of 4 pixels, one per lane
+				const uint32_t row = tid >> 2, c4 = tid & 3u;
+				const uint32_t *p = tile_pl + row * kRS32 + c4 * 2u;
+				const uint2 r = *reinterpret_cast<const uint2 *>(p), gch = *reinterpret_cast<const uint2 *>(p + kPD32);
+				const uint2 b = *reinterpret_cast<const uint2 *>(p + 2 * kPD32);
+				const uint32_t opq = 0x00ff00ffu;
+				const uint32_t rg01 = __builtin_amdgcn_perm(gch.x, r.x, 0x06020400u), ba01 = __builtin_amdgcn_perm(opq, b.x, 0x06020400u);
+				const uint32_t rg23 = __builtin_amdgcn_perm(gch.y, r.y, 0x06020400u), ba23 = __builtin_amdgcn_perm(opq, b.y, 0x06020400u);
+				uint4 o;
+				o.x = __builtin_amdgcn_perm(ba01, rg01, 0x05040100u);
+				o.y = __builtin_amdgcn_perm(ba01, rg01, 0x07060302u);
+				o.z = __builtin_amdgcn_perm(ba23, rg23, 0x05040100u);
+				o.w = __builtin_amdgcn_perm(ba23, rg23, 0x07060302u);
+				reinterpret_cast<uint4 *>(dst)[tid] = o;
+			} else if (a.filter == 0) {
+				// ResizeAlg::Nearest: source index = floor((o + 0.5) * 2^m); any (nw, nh)
+				const uint32_t mx = m0[k], my = m1[k];
+				const uint32_t lgx = 31u - (uint32_t)__builtin_clz(nw[k]);
+				const uint16_t *pl16 = reinterpret_cast<const uint16_t *>(tile_pl);
+				for (uint32_t i = tid; i < nw[k] * nh[k]; i += 64u) {
+					const uint32_t ox = i & (nw[k] - 1u), oy = i >> lgx;
+					const uint32_t x = mx == 0 ? ox : (mx < 5u ? (2u * ox + 1u) << (mx - 1u) : 8u);
+					const uint32_t y = my == 0 ? oy : (my < 5u ? (2u * oy + 1u) << (my - 1u) : 8u);
+					const uint32_t idx = y * (2u * kRS32) + x;
+					dst[i] = (uint32_t)pl16[idx] | ((uint32_t)pl16[idx + 2u * kPD32] << 8) | ((uint32_t)pl16[idx + 4u * kPD32] << 16) | 0xff000000u;
+				}
+			} else {
+				const uint32_t lx = m0[k] < (uint32_t)kMaxLevel ? m0[k] : (uint32_t)kMaxLevel - 1;
+				const uint32_t ly = m1[k] < (uint32_t)kMaxLevel ? m1[k] : (uint32_t)kMaxLevel - 1;
+				resample_fast16_hv(s_tab, a.tabs[lx], a.tabs[ly], tile_pl, s_tmp, tid, nw[k], nh[k], dst);
+			}
+		}
+		tile_sync<1>();  // the next group reuses this wave's LDS image
+		grp = grp_next;
+	}
 }
 
 // ---------------------------------------------------------------------------
@@ -3404,6 +3685,12 @@ bool fast64_applicable(const ShrinkArgs &a, uint32_t channels)
 	       (a.out_px == nullptr || (a.filter != 0 && a.mf64 != nullptr));
 }
 
+bool fast16_applicable(const ShrinkArgs &a, uint32_t channels)
+{
+	return channels == 4 && a.bw == 16 && a.bh == 16 && a.work != nullptr &&
+	       (a.out_px == nullptr || a.filter == 0 || a.tab_dw != 0) && !(a.mode == 0 && !a.oklab_given);
+}
+
 bool fast32_applicable(const ShrinkArgs &a, uint32_t channels)
 {
 	return channels == 4 && a.bw == 32 && a.bh == 32 && a.work != nullptr &&
@@ -3458,9 +3745,14 @@ hipError_t launch_shrink(const ShrinkArgs &a, uint32_t channels, uint32_t n_cus,
 			hipLaunchKernelGGL(k, dim3(blocks), dim3(256), lds_bytes, stream, f);
 		}
 		if ((e = hipGetLastError()) != hipSuccess) return e;
-	} else if (fast32_applicable(a, channels)) {
-		// 1) the lean kernel for full opaque tiles; it leaves the rest in the worklist
+	} else if (fast32_applicable(a, channels) || fast16_applicable(a, channels)) {
+		// 1) the lean kernel for full opaque tiles (32x32), or for 2x2 groups of them (16x16); it leaves the rest
+		// in the worklist
+		const bool groups16 = a.bw == 16;
 		Fast32Args f{};
+		f.n_groups = a.n_frames_x_groups;
+		f.div_gpf = a.div_gpf;
+		f.div_gcols = a.div_gcols;
 		f.src = a.src;
 		f.frame_stride = a.frame_stride;
 		f.pitch = a.pitch;
@@ -3506,12 +3798,23 @@ hipError_t launch_shrink(const ShrinkArgs &a, uint32_t channels, uint32_t n_cus,
 		const uint32_t lds_bytes = f.tab_dw * 4u + wpb * f.tile_dw * 4u + 16u;  // + the ticket counter
 		const uint32_t per_cu = kLds / lds_bytes > 0 ? kLds / lds_bytes : 1u;
 		const uint32_t resident = n_cus * (per_cu > 2u ? 2u : per_cu);
-		const uint32_t need = (a.n_tiles + wpb - 1u) / wpb;
+		const uint32_t units = groups16 ? f.n_groups : a.n_tiles;
+		const uint32_t need = (units + wpb - 1u) / wpb;
 		const uint32_t blocks = need < resident ? need : resident;
 		f.chunk_lg = 3;
 		if (const char *e = getenv("PXZ_CHUNK_LG")) f.chunk_lg = (uint32_t)atoi(e) & 15u;
 		hipError_t e = hipSuccess;  // the worklist counter of this launch was zeroed by the previous one (or at allocation)
-		if (a.mode == 1) {
+		if (groups16) {
+			if (a.mode == 1) {
+				auto k = shrink16_kernel<1>;
+				if (lds_bytes > 64u * 1024u && (e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)) != hipSuccess) return e;
+				hipLaunchKernelGGL(k, dim3(blocks), dim3(64u * wpb), lds_bytes, stream, f);
+			} else {
+				auto k = shrink16_kernel<0>;
+				if (lds_bytes > 64u * 1024u && (e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)) != hipSuccess) return e;
+				hipLaunchKernelGGL(k, dim3(blocks), dim3(64u * wpb), lds_bytes, stream, f);
+			}
+		} else if (a.mode == 1) {
 			auto k = shrink32_kernel<1>;
 			if (lds_bytes > 64u * 1024u && (e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)) != hipSuccess) return e;
 			hipLaunchKernelGGL(k, dim3(blocks), dim3(64u * wpb), lds_bytes, stream, f);

@@ -271,6 +271,28 @@ def test_block64_fast_kernel_every_class(gpu, oracle, filt):
                            slots[n].cpu().numpy()), exp, 4, f"batch frame {n}")
 
 
+@pytest.mark.parametrize("filt", [0, 1, 2, 3, 4])
+def test_block16_group_kernel_every_class(gpu, oracle, filt):
+    """16x16 tiles through shrink16_kernel (2x2 groups of tiles per 32x32 LDS image, per-tile sums by a
+    segmented reduction): every reduced size from 16x16 (clone) to 1x1, mixed classes inside a group, the
+    one-pass classes and ragged / odd group counts (worklist), transparency, a batch of frames."""
+    seen = set()
+    img = oracle.synth_frame(1000, 328, 4, 9, 0)  # 63 x 21 tiles: odd counts, last column 8 px wide, last row 8 px high
+    for factor in (64.0, 16.0, 4.0, 1.0, 0.25):
+        got = gpu.shrink_image(img, 16, 16, 1, filt, factor)
+        exp = oracle.shrink_image(img, 16, 16, 1, filt, factor, nthreads=8)
+        assert_same_tiles(got, exp, 4, f"16x16 filter {filt} k={factor}")
+        seen |= set(histogram(got[1], got[2]))
+    assert {(16, 16), (8, 8), (4, 4), (2, 2), (1, 1)} <= seen, seen
+    frames = gpu.synth_frames_device(3, 160, 256, 4, first_frame=1, dist=1)  # transparency: whole groups are deferred
+    vals, ow, oh, slots = gpu.shrink_frames_device(frames, 16, 16, 1, filt, 16.0)
+    f = frames.cpu().numpy()
+    for n in range(3):
+        exp = oracle.shrink_image(f[n], 16, 16, 1, filt, 16.0)
+        assert_same_tiles((vals[n].cpu().numpy(), ow[n].cpu().numpy().astype(np.uint32), oh[n].cpu().numpy().astype(np.uint32),
+                           slots[n].cpu().numpy()), exp, 4, f"batch frame {n}")
+
+
 @pytest.mark.parametrize("block", [16, 64])
 @pytest.mark.parametrize("dist", [0, 1])
 def test_shrink_by_blocks_16_and_64(gpu, oracle, block, dist):

@@ -19,6 +19,6 @@ for bs in (16, 32, 64):
     wbytes = int((ow.long() * oh.long()).sum().item()) * 4 + 12 * ow.numel()
     algo = frames.numel() + wbytes
     res[bs] = dict(kernel_ms=round(ms, 3), mp_per_s=round(frames.numel() / 4 / 1e6 / ms * 1e3), achieved_gbps=round(algo / ms / 1e6), tiles=ow.numel(),
-                   kernel={16: "shrink_kernel (generic)", 32: "shrink32_kernel", 64: "shrink64_kernel"}[bs])
+                   kernel={16: "shrink16_kernel", 32: "shrink32_kernel", 64: "shrink64_kernel"}[bs])
     del out
 print(json.dumps(res))
