@@ -733,7 +733,7 @@ static int run_shrink(pxz_handle *h, const pxz_frames *frames, const pxz_params 
 	pxz::ShrinkArgs a{};
 	int rc = prepare(h, frames, params, d_out_pixels != nullptr, &a);
 	if (rc != PXZ_OK) return rc;
-	bool widen = frames->channels == 3 && a.bw == a.bh && (a.bw == 32 || a.bw == 64) && !getenv("PXZ_NO_WIDEN");
+	bool widen = frames->channels == 3 && a.bw == a.bh && (a.bw == 16 || a.bw == 32 || a.bw == 64) && !getenv("PXZ_NO_WIDEN");
 	if (widen && d_out_pixels && params->filter != PXZ_FILTER_NEAREST) {
 		const TableSet *tsp = nullptr;
 		if ((rc = get_tables(h, a.bw, a.bh, a.edge_w, a.edge_h, params->filter, &tsp)) != PXZ_OK) return rc;
