@@ -1823,7 +1823,8 @@ __global__ void __launch_bounds__(1024) shrink16_kernel(const Fast32Args a)
 // (64 x n, n x 64) go to the worklist of the generic kernel.
 // ---------------------------------------------------------------------------
 constexpr uint32_t kRS64 = 36, kPD64 = 36 * 64;  // plane row stride (32 + 4 dwords: bank skew, rows stay 16-byte aligned), plane size
-constexpr uint32_t kT64 = 3 * 32 * 16;           // [channel][ox < 32][64 bytes of y] as dwords
+constexpr uint32_t kTS64 = 20;                   // dwords per column of the horizontal pass: 16 (64 bytes of y) + 4 of bank skew
+constexpr uint32_t kT64 = 3 * 32 * kTS64;        // [channel][ox < 32][kTS64]
 constexpr uint32_t kLds64 = 3 * kPD64 + kT64 + 32;
 
 template <class Args>
@@ -2091,7 +2092,7 @@ __global__ void __launch_bounds__(256) shrink64_kernel(const Fast64Args a)
 						put_byte_shr<2>(packed, clamp_fixed(hi[2], lo[2], top_x), px_);
 						put_byte_shr<3>(packed, clamp_fixed(hi[3], lo[3], top_x), px_);
 						// rows 16w + 4g .. +3 of column ox = 16nb + o
-						s_t[(c * 32u + 16u * nb + o) * 16u + 4u * wave + g] = packed;
+						s_t[(c * 32u + 16u * nb + o) * kTS64 + 4u * wave + g] = packed;
 					}
 				}
 			}
@@ -2107,7 +2108,7 @@ __global__ void __launch_bounds__(256) shrink64_kernel(const Fast64Args a)
 				uint32_t pix[4] = {0xff000000u, 0xff000000u, 0xff000000u, 0xff000000u};
 #pragma unroll
 				for (uint32_t c = 0; c < 3; ++c) {
-					const uint4 tv = *reinterpret_cast<const uint4 *>(s_t + (c * 32u + 16u * nb + o) * 16u + 4u * g);
+					const uint4 tv = *reinterpret_cast<const uint4 *>(s_t + (c * 32u + 16u * nb + o) * kTS64 + 4u * g);
 					v4i32 bv;
 					bv[0] = (int)(tv.x ^ 0x80808080u);
 					bv[1] = (int)(tv.y ^ 0x80808080u);
@@ -2160,7 +2161,7 @@ __global__ void __launch_bounds__(256) shrink64_kernel(const Fast64Args a)
 						const uint32_t j = jj + 2u * it, y0 = 16u * wave + 4u * j;
 						const uint32_t b0 = p16[(y0 + 0u) * (2u * kRS64)], b1 = p16[(y0 + 1u) * (2u * kRS64)];
 						const uint32_t b2 = p16[(y0 + 2u) * (2u * kRS64)], b3 = p16[(y0 + 3u) * (2u * kRS64)];
-						s_t[(c * 32u + xl) * 16u + 4u * wave + j] = b0 | (b1 << 8) | (b2 << 16) | (b3 << 24);
+						s_t[(c * 32u + xl) * kTS64 + 4u * wave + j] = b0 | (b1 << 8) | (b2 << 16) | (b3 << 24);
 					}
 				}
 				__syncthreads();
@@ -2174,7 +2175,7 @@ __global__ void __launch_bounds__(256) shrink64_kernel(const Fast64Args a)
 			const bool opaque_stays = (mx_tail[64] & 1u) != 0u;
 			for (uint32_t i = threadIdx.x; i < nw * 16u; i += 256u) {
 				const uint32_t ox = i % nw, yq = i / nw;  // nw is a power of two here
-				const uint32_t r4 = s_t[(0u * 32u + ox) * 16u + yq], g4 = s_t[(1u * 32u + ox) * 16u + yq], b4 = s_t[(2u * 32u + ox) * 16u + yq];
+				const uint32_t r4 = s_t[(0u * 32u + ox) * kTS64 + yq], g4 = s_t[(1u * 32u + ox) * kTS64 + yq], b4 = s_t[(2u * 32u + ox) * kTS64 + yq];
 				uint32_t al = 255u;
 				if (!opaque_stays) al = clip8((1 << (px_ - 1)) + 255 * (int32_t)mx_tail[32u + ox], (int)px_);
 #pragma unroll
