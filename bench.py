@@ -47,6 +47,7 @@ def parse():
     ap.add_argument("--filter", type=int, default=4)
     ap.add_argument("--dist", type=int, default=0, help="0 opaque, 1 alpha, 2 flat, 3 noise")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-sizes", action="store_true", help="skip the 64x64 / 16x16 side measurements")
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip the final block-stream gather to rank 0")
     ap.add_argument("--gather-every-step", action="store_true",
                     help="N>1: encode + gather the files inside every timed step instead of once after the timed region")
@@ -234,6 +235,22 @@ def main():
     for name in names:
         results[name] = run_mode(args, handle, frames, name, rank, world, dist, product.dist)
 
+    # not the metric: the same frames at the reference CLI's default 64x64 tiles and at 16x16 (kernel time only)
+    others = {}
+    if world == 1 and not args.no_other_sizes:
+        for bs in (64, 16):
+            for name, (pxz_mode, factor) in MODES.items():
+                out = handle.shrink_frames_device(frames, bs, bs, pxz_mode, args.filter, factor)
+                for _ in range(20):
+                    handle.shrink_frames_device(frames, bs, bs, pxz_mode, args.filter, factor, out=out)
+                torch.cuda.synchronize()
+                handle.enable_timing(True)
+                for _ in range(40):
+                    handle.shrink_frames_device(frames, bs, bs, pxz_mode, args.filter, factor, out=out)
+                ms = handle.last_kernel_ms()
+                handle.enable_timing(False)
+                others[f"{bs}x{bs} {name}"] = {"kernel_ms": ms, "mp_per_s": nf * args.width * args.height / 1e6 / (ms * 1e-3)}
+                del out
     if rank == 0:
         r = results[primary]
         total_mp = world * nf * args.width * args.height / 1e6
@@ -263,6 +280,8 @@ def main():
             "modes": {k: {kk: v[kk] for kk in ("ms_per_step", "mp_per_s_per_gpu", "kernel_ms", "achieved_gbps",
                                                 "algo_bytes_per_launch", "histogram")} for k, v in results.items()},
         }
+        if others:
+            line["other_tile_sizes"] = others
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args, primary)
         print(json.dumps(line), flush=True)
