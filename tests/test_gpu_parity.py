@@ -543,3 +543,27 @@ def test_process_matches_oracle(gpu, oracle, c, dist, block, down, up):
         bad = (out[n] != exp).any(axis=2)
         assert not bad.any(), f"frame {n}: {int(bad.sum())} pixels differ"
     assert gpu.decode_status() == 0
+
+
+@pytest.mark.parametrize("c", [4, 3])
+@pytest.mark.parametrize("block", [16, 32, 64])
+def test_strided_batches_on_the_fast_paths(gpu, oracle, block, c):
+    """Frames that are views into a larger allocation (row pitch and frame stride larger than the image,
+    still 16-byte aligned) and their misaligned twins (odd column offset: every fast path must stand down),
+    both detectors, RGBA and RGB (widened)."""
+    import torch
+    H, W = 192, 320
+    big = torch.zeros((3, H + 7, W + 16, c), dtype=torch.uint8, device="cuda")
+    src = gpu.synth_frames_device(3, H, W, c, first_frame=21, dist=0)
+    for x0 in (0, 4 if c == 4 else 16, 1):  # 16-byte aligned at 0 and 16 bytes in; misaligned at 1 pixel
+        big.zero_()
+        view = big[:, 3:3 + H, x0:x0 + W]
+        view.copy_(src)
+        for mode, factor in ((1, 16.0), (0, 1.0)):
+            vals, ow, oh, slots = gpu.shrink_frames_device(view, block, block, mode, 4, factor)
+            f = src.cpu().numpy()
+            for n in range(3):
+                exp = oracle.shrink_image(f[n], block, block, mode, 4, factor, nthreads=8)
+                got = (vals[n].cpu().numpy(), ow[n].cpu().numpy().astype(np.uint32), oh[n].cpu().numpy().astype(np.uint32),
+                       slots[n].cpu().numpy())
+                assert_same_tiles(got, exp, c, f"{block}x{block} c{c} x0={x0} mode {mode} frame {n}")
