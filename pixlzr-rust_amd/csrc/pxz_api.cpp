@@ -593,8 +593,8 @@ int timed_launch(pxz_handle *h, pxz::ShrinkArgs &a, uint32_t channels, float *va
 	if (a.mode == PXZ_MODE_SHRINK_BY && channels == 4 && a.bw == a.bh && (a.bw == 16 || a.bw == 32 || a.bw == 64) &&
 	    a.full_cols != 0 && a.full_rows != 0 && !getenv("PXZ_NO_OKLAB32")) {
 		if (a.bw == 64) {
-			// a 64x64 tile does not fit the registers between the detector's two passes: 16 floats per pixel quad in HBM
-			if ((rc = ensure(h, h->okscratch, (size_t)a.n_tiles * 64u * 64u * 16u)) != PXZ_OK) return rc;
+			// a 64x64 tile does not fit the registers between the detector's two passes: 13 dwords per pixel quad in HBM
+			if ((rc = ensure(h, h->okscratch, (size_t)a.n_tiles * 16u * 3328u)) != PXZ_OK) return rc;
 			a.ok_scratch = (float *)h->okscratch.ptr;
 		}
 		a.oklab_given = 1;

@@ -2331,7 +2331,7 @@ struct OkGeom {
 	static constexpr uint32_t kLanesPerRow = T / 4;   // 4 | 8 | 16
 	static constexpr uint32_t kRowsPerBand = 256 / T; // 16 | 8 | 4
 	// up to 4 bands the converted tile stays in registers between the passes; a 64x64 tile (192 values per
-	// lane) parks it in a scratch buffer in HBM instead (16 floats per lane and band: 12 values + alpha bytes)
+	// lane) parks it in a scratch buffer in HBM instead (13 dwords per lane and band: 12 values + the alpha bytes)
 	static constexpr bool kInRegs = kBands <= 4;
 };
 
@@ -2428,9 +2428,12 @@ __global__ void __launch_bounds__(1024) oklab_kernel(const ShrinkArgs a)
 				float4 old[4];  // scratch form only: band k of the previous batch, back from HBM for pass 2
 				if constexpr (!G::kInRegs) {
 					if (have_prev && k < nb_prev) {
-						const float4 *sp = reinterpret_cast<const float4 *>(a.ok_scratch) + (((size_t)tile_prev * NB + k) * 64u + lane) * 4u;
+						// per (tile, band): three arrays of 64 float4 (the 12 values of a lane) + 64 alpha words = 3328 bytes
+						const float *sb = a.ok_scratch + ((size_t)tile_prev * NB + k) * 832u;
+						const float4 *sp = reinterpret_cast<const float4 *>(sb) + lane;
 #pragma unroll
-						for (int q = 0; q < 4; ++q) old[q] = sp[q];
+						for (int q = 0; q < 3; ++q) old[q] = sp[64 * q];
+						old[3].x = sb[768u + lane];
 					}
 				}
 				float fresh[4][3];
@@ -2519,11 +2522,12 @@ __global__ void __launch_bounds__(1024) oklab_kernel(const ShrinkArgs a)
 							for (int c = 0; c < 3; ++c) lab[k][j][c] = fresh[j][c];
 						alpha_px[k] = fresh_alpha;
 					} else {
-						float4 *sp = reinterpret_cast<float4 *>(a.ok_scratch) + (((size_t)tile_cur * NB + k) * 64u + lane) * 4u;
+						float *sb = a.ok_scratch + ((size_t)tile_cur * NB + k) * 832u;
+						float4 *sp = reinterpret_cast<float4 *>(sb) + lane;
 						sp[0] = make_float4(fresh[0][0], fresh[0][1], fresh[0][2], fresh[1][0]);
-						sp[1] = make_float4(fresh[1][1], fresh[1][2], fresh[2][0], fresh[2][1]);
-						sp[2] = make_float4(fresh[2][2], fresh[3][0], fresh[3][1], fresh[3][2]);
-						sp[3] = make_float4(__uint_as_float(fresh_alpha), 0.f, 0.f, 0.f);
+						sp[64] = make_float4(fresh[1][1], fresh[1][2], fresh[2][0], fresh[2][1]);
+						sp[128] = make_float4(fresh[2][2], fresh[3][0], fresh[3][1], fresh[3][2]);
+						sb[768u + lane] = __uint_as_float(fresh_alpha);
 					}
 				}
 				__syncthreads();  // B: the bands of this interval are complete
