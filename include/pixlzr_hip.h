@@ -94,8 +94,14 @@ typedef struct pxz_params {
 	uint32_t mode;              /* pxz_mode */
 	uint32_t filter;            /* pxz_filter (filter_downscale) */
 	float factor;               /* shrinking factor, src/bin/main.rs:26-29 */
-	uint32_t reserved;          /* 0 */
+	uint32_t reserved;          /* 0, or PXZ_HINT_* bits */
 } pxz_params;
+
+/* Performance hints (pxz_params.reserved); results never depend on them.
+ * PXZ_HINT_TRANSPARENCY: many tiles of these RGBA frames carry alpha < 255.  32x32 tiles with transparency are
+ * then resampled by a dedicated kernel (four LDS planes, premultiplied matrix-core convolution) instead of the
+ * generic one, at the price of one more launch per call.  pxz_shrink_image samples the image and sets it itself. */
+#define PXZ_HINT_TRANSPARENCY 1u
 
 /* ---- the hot path ----------------------------------------------------- */
 

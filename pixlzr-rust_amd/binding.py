@@ -254,8 +254,9 @@ class Handle:
         assert frames.stride(3) == 1 and frames.stride(2) == Cc
         return Frames(W, H, Cc, frames.stride(1), N, 0, frames.stride(0)), (N, H, W, Cc)
 
-    def shrink_frames_device(self, frames, bw, bh, mode, filt, factor, want_pixels=True, out=None):
-        """frames: uint8 CUDA tensor [N,H,W,C].  Returns (values[N,T], w[N,T], h[N,T], slots[N,T,bw*bh*C]|None)."""
+    def shrink_frames_device(self, frames, bw, bh, mode, filt, factor, want_pixels=True, out=None, transparency_hint=False):
+        """frames: uint8 CUDA tensor [N,H,W,C].  Returns (values[N,T], w[N,T], h[N,T], slots[N,T,bw*bh*C]|None).
+        transparency_hint: PXZ_HINT_TRANSPARENCY (many tiles with alpha < 255; a pure performance hint)."""
         import torch
         fd, (N, H, W, Cc) = self._frames_desc(frames)
         cols, rows = grid(W, H, bw, bh)
@@ -268,7 +269,7 @@ class Handle:
             slots = torch.empty((N, T, bw * bh * Cc), dtype=torch.uint8, device=dev) if want_pixels else None
         else:
             vals, ow, oh, slots = out
-        pd = Params(bw, bh, mode, filt, factor, 0)
+        pd = Params(bw, bh, mode, filt, factor, 1 if transparency_hint else 0)
         self.use_torch_stream()
         self._check(self._L.pxz_shrink_frames_device(
             self._h, C.byref(fd), C.byref(pd), C.c_void_p(frames.data_ptr()), C.c_void_p(vals.data_ptr()),

@@ -221,7 +221,7 @@ int get_tables(pxz_handle *h, uint32_t bw, uint32_t bh, uint32_t edge_w, uint32_
 				}
 				// 32x32 tiles: operands for the matrix-core form of the two-pass resample (x axis table,
 				// used for both axes of a full tile)
-				if (axis == 0 && cls == 0 && bw == 32 && bh == 32 && (outsz == 16 || outsz == 8 || outsz == 4)) {
+				if (axis == 0 && cls == 0 && bw == 32 && bh == 32 && outsz <= 16) {
 					std::vector<uint32_t> mf(pxz::kMfDwords, 0u);
 					bool fits = true, opaque_stays = true;
 					const int32_t half = 1 << (win.precision - 1);
@@ -527,6 +527,7 @@ int prepare(pxz_handle *h, const pxz_frames *f, const pxz_params *p, bool want_p
 	a->filter = p->filter;
 	a->factor = p->factor;
 	a->scale2 = 10.0f;  // BASE_FACTOR, pixlzr.rs:15
+	a->alpha_kernel = (p->reserved & PXZ_HINT_TRANSPARENCY) != 0 && !getenv("PXZ_NO_ALPHA_KERNEL");
 	a->slot_bytes = bw * bh * f->channels;
 	build_breaks(h, a);
 	std::memset(a->tabs, 0, sizeof a->tabs);
@@ -558,7 +559,7 @@ int timed_launch(pxz_handle *h, pxz::ShrinkArgs &a, uint32_t channels, float *va
 	if (rc != PXZ_OK) return rc;
 	a.sums = (uint32_t *)h->sums.ptr;
 	const void *work_before = h->work.ptr;
-	if ((rc = ensure(h, h->work, ((size_t)a.n_tiles + pxz::kWorkList + 4u) * 4u + 64u + 4096u * 8u)) != PXZ_OK) return rc;  // + diagnostic stamps
+	if ((rc = ensure(h, h->work, (2u * (size_t)a.n_tiles + pxz::kWorkList + 4u) * 4u + 64u + 4096u * 8u)) != PXZ_OK) return rc;  // + diagnostic stamps
 	if (h->work.ptr != work_before) h->work_ready = false;
 	a.work = (uint32_t *)h->work.ptr;
 	a.value = value;
@@ -1049,6 +1050,15 @@ int pxz_shrink_image(pxz_handle *h, const uint8_t *pixels, uint32_t width, uint3
 	pxz_params p{block_w, block_h, mode, filter, factor, 0};
 	int rc = check_frames(h, &f, &p);
 	if (rc != PXZ_OK) return rc;
+	if (channels == 4) {
+		// the pixels are here on the host: a sparse look at the alpha channel (one pixel in 61 per sampled row, every
+		// 7th row) decides whether the kernel for transparent tiles is worth its launch
+		uint32_t seen = 0, looked = 0;
+		for (uint32_t y = 0; y < height; y += 7)
+			for (uint32_t x = (y * 13u) % 61u; x < width; x += 61, ++looked)
+				seen += pixels[(size_t)y * pitch_bytes + (size_t)x * 4u + 3u] != 255u;
+		if (looked && seen * 50u > looked) p.reserved |= PXZ_HINT_TRANSPARENCY;  // > 2 % of the samples
+	}
 	PXZ_HIP(h, hipSetDevice(h->device));
 	uint32_t cols, rows;
 	pxz_grid(width, height, block_w, block_h, &cols, &rows);

@@ -38,10 +38,12 @@ struct AxisTab {
 // accumulator registers hand their rows to the second product.
 constexpr uint32_t kMfDwords = 292;
 
-// Layout of the handle's worklist buffer (dwords): [0], [1] the two worklist counters used alternately,
-// [2 + 64*s, 2 + 64*s + 64) the tile-ticket counters of shrink64_kernel for counter set s, then the list.
+// Layout of the handle's worklist buffer (dwords): [0], [1] the two worklist counters (list B: tiles for the
+// generic kernel) used alternately, [2 + 64*s, 2 + 64*s + 64) the tile-ticket counters of shrink64_kernel for
+// counter set s, [kWorkA + s] the counters of list A, then list B and list A (n_tiles entries each).
 constexpr uint32_t kTicketCounters = 64;
-constexpr uint32_t kWorkList = 2 + 2 * kTicketCounters;
+constexpr uint32_t kWorkA = 2 + 2 * kTicketCounters;  // two counters of list A (transparent tiles for shrink32a_kernel)
+constexpr uint32_t kWorkList = kWorkA + 2;             // list B starts here (n_tiles entries), list A follows it
 
 // q = n / d as (t + ((n - t) >> sh1)) >> sh2 with t = mulhi(n, mul)  (Granlund-Montgomery)
 struct FastDiv {
@@ -73,6 +75,7 @@ struct ShrinkArgs {
 	                         //   when its height is a whole number of that detector's bands
 	uint32_t full_cols, full_rows;  // 32x32 fast path: tile (tx, ty) is eligible iff tx < full_cols && ty < full_rows
 	                                //   (full size, 16-byte aligned rows; 0/0 when the batch is not aligned)
+	uint32_t alpha_kernel;   // the caller announced frames with transparency (pxz_params.reserved bit 0)
 	uint32_t *work;          // worklist: [work_slot] = count, [2..] = tile ids (null: all tiles).  The two
 	uint32_t work_slot;      //   counters alternate between launches; a launch zeroes the other one
 	float *value;            // worklist mode only: the kernel finishes its tiles itself (finish_tile) and,
@@ -120,6 +123,7 @@ struct Fast32Args {
 	uint8_t *out_px;
 	uint32_t *work;
 	uint32_t work_slot;
+	uint32_t alpha_list;     // 1: full tiles with transparency go to list A (shrink32a_kernel), else to list B (generic kernel)
 	const uint32_t *trows;
 	uint32_t tab_dw, tile_dw;
 	uint32_t chunk_lg;       // tickets deal runs of 2^chunk_lg adjacent tiles

@@ -647,6 +647,9 @@ __device__ __forceinline__ uint32_t clamp_fixed(int32_t hi, int32_t lo, int32_t 
 	return (uint32_t)r;
 }
 
+// NCH = 3: opaque tile, alpha from the weight sums.  NCH = 4: the planes hold premultiplied colours and the
+// alpha plane; all four are convolved and every output pixel is un-premultiplied (fir's U8x4 path).
+template <int NCH>
 __device__ __forceinline__ void resample_mfma32(const uint32_t *s_tab, const AxisTab &tx, const AxisTab &ty, const uint32_t *s_pl,
                                                 uint32_t lane, uint32_t nw, uint32_t nh, uint32_t *out)
 {
@@ -663,7 +666,7 @@ __device__ __forceinline__ void resample_mfma32(const uint32_t *s_tab, const Axi
 	uint32_t pix[4] = {0xff000000u, 0xff000000u, 0xff000000u, 0xff000000u};
 	const uint32_t *rowp = s_pl + o * kRS32 + 2u * g;
 #pragma unroll
-	for (uint32_t c = 0; c < 3; ++c) {
+	for (uint32_t c = 0; c < (uint32_t)NCH; ++c) {
 		uint32_t t[2];
 #pragma unroll
 		for (uint32_t mb = 0; mb < 2; ++mb) {
@@ -690,12 +693,16 @@ __device__ __forceinline__ void resample_mfma32(const uint32_t *s_tab, const Axi
 			const uint32_t v = clamp_fixed(hi[r], lo[r], top_y);
 			if (c == 0) put_byte_shr<0>(pix[r], v, py);
 			else if (c == 1) put_byte_shr<1>(pix[r], v, py);
-			else put_byte_shr<2>(pix[r], v, py);
+			else if (c == 2) put_byte_shr<2>(pix[r], v, py);
+			else put_byte_shr<3>(pix[r], v, py);
 		}
 	}
-	// opaque tile: alpha is the convolution of the constant 255 = the windows' weight sums (fast32_v);
-	// the table says when that is 255 for every output of the axis
-	if (!(mx[288] & my[288])) {
+	if constexpr (NCH == 4) {
+#pragma unroll
+		for (int r = 0; r < 4; ++r) pix[r] = unpremultiply(pix[r]);
+	} else if (!(mx[288] & my[288])) {
+		// opaque tile: alpha is the convolution of the constant 255 = the windows' weight sums (fast32_v);
+		// the table says when that is 255 for every output of the axis
 		const int32_t ah = (int32_t)clip8((1 << (px_ - 1)) + 255 * (int32_t)mx[272u + o], (int)px_);
 #pragma unroll
 		for (int r = 0; r < 4; ++r) {
@@ -1411,9 +1418,18 @@ __global__ void __launch_bounds__(1024) shrink32_kernel(const Fast32Args a)
 		}
 		PXZ_STAMP(0);  // wait for the prefetched pixels + staging
 		fast32_prefetch(a, tile_next, tid, pre, pre_valid);  // lands while this tile is processed
-		if (transparent) {
-			// transparency: premultiplied convolution and the alpha plane live in the generic kernel
-			defer();
+		if (transparent && a.out_px != nullptr) {
+			// transparency: the premultiplied convolution needs the alpha plane -- shrink32a_kernel (list A) when the
+			// caller announced transparent frames, else the generic kernel (list B).  (Detector-only launches do not
+			// care: the detector never looks at alpha.)
+			if (a.alpha_list) {
+				if (tid == 0) {
+					a.work[kWorkList + a.n_tiles + atomicAdd(&a.work[kWorkA + a.work_slot], 1u)] = tile_g;
+					if constexpr (MODE == 1) reinterpret_cast<uint2 *>(a.sums)[tile_g] = make_uint2(kDeferredKey, kDeferredKey);
+				}
+			} else {
+				defer();
+			}
 			return;
 		}
 		tile_sync<1>();
@@ -1490,8 +1506,9 @@ __global__ void __launch_bounds__(1024) shrink32_kernel(const Fast32Args a)
 			} else if (nw != 32u && nh != 32u && a.filter != 0) {
 				const uint32_t lx = m0 < (uint32_t)kMaxLevel ? m0 : (uint32_t)kMaxLevel - 1;
 				const uint32_t ly = m1 < (uint32_t)kMaxLevel ? m1 : (uint32_t)kMaxLevel - 1;
-				if (a.tabs[lx].mf_off != 0 && a.tabs[ly].mf_off != 0) {
-					resample_mfma32(s_tab, a.tabs[lx], a.tabs[ly], s_pl, tid, nw, nh, s_tmp);
+				if (a.tabs[lx].mf_off != 0 && a.tabs[ly].mf_off != 0 && nw >= 4u && nh >= 4u) {
+					// (2- and 1-px outputs have tables too -- shrink32a_kernel uses them -- but the dot2 form is cheaper there)
+					resample_mfma32<3>(s_tab, a.tabs[lx], a.tabs[ly], s_pl, tid, nw, nh, s_tmp);
 					pend_src = s_tmp;
 					pend_kind = 1;
 				} else if (nw <= 8u) {
@@ -1546,13 +1563,203 @@ __global__ void __launch_bounds__(1024) shrink32_kernel(const Fast32Args a)
 	flush();  // the last tile's pixels
 #ifdef PXZ_STAMPS
 	if (tid == 0) {
-		unsigned long long *out = reinterpret_cast<unsigned long long *>(a.work + ((a.n_tiles + kWorkList + 1u + 1u) & ~1u));
+		unsigned long long *out = reinterpret_cast<unsigned long long *>(a.work + ((2u * a.n_tiles + kWorkList + 1u + 1u) & ~1u));
 		for (int i = 0; i < 8; ++i) atomicAdd(out + i, st_acc[i]);
 		// per-wave run time (100 MHz ticks) | tiles processed << 48; last launch wins
 		out[8 + blockIdx.x * 16u + sub] = ((wall_clock64() - st_begin) & 0xffffffffffffull) | ((unsigned long long)st_tiles << 48);
 		if (sub == 0) out[8 + blockIdx.x * 16u + 15u] = st_begin;
 	}
 #endif
+}
+
+// ---------------------------------------------------------------------------
+// shrink32a_kernel: the full 32x32 RGBA tiles WITH transparency that shrink32_kernel set aside (list A of the
+// worklist buffer).  Same staging / detector / level decision, but a fourth LDS plane keeps the alpha channel
+// and the resample is fir's U8x4 path: colours premultiplied in place (packed u16 arithmetic), all four planes
+// through the matrix-core resample (every output size <= 16), every output pixel un-premultiplied.  Clone and
+// nearest pick from the four planes as they are; the one-pass classes (32 x n, n x 32) go on to the generic
+// kernel (list B).  13 waves per CU (four planes); outputs are stored directly.
+// ---------------------------------------------------------------------------
+template <int MODE>
+__global__ void __launch_bounds__(1024) shrink32a_kernel(const Fast32Args a)
+{
+	extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+	const uint32_t wpb = blockDim.x / 64u, sub = threadIdx.x / 64u, tid = threadIdx.x % 64u;
+	for (uint32_t i = threadIdx.x; i < a.tab_dw / 4u; i += blockDim.x)
+		reinterpret_cast<uint4 *>(lds)[i] = reinterpret_cast<const uint4 *>(a.trows)[i];
+	uint32_t *s_ticket = lds + a.tab_dw + wpb * a.tile_dw;
+	if (threadIdx.x == 0) *s_ticket = wpb;
+	__syncthreads();
+	const uint32_t *s_tab = lds;
+	const uint32_t brk_lane = tid < (uint32_t)kMaxLevel ? a.breaks[tid] : (a.breaks_asc ? 0xffffffffu : 0u);
+	auto level_of = [&](uint32_t key) -> uint32_t {
+		const unsigned long long lt = __builtin_amdgcn_ballot_w64(key < brk_lane);
+		const unsigned long long live = (1ull << kMaxLevel) - 1ull;
+		return (uint32_t)__builtin_popcountll((a.breaks_asc ? ~lt : lt) & live);
+	};
+	uint32_t *s_pl = lds + a.tab_dw + sub * a.tile_dw;  // four planes: R, G, B, A
+	const uint32_t count = __builtin_amdgcn_readfirstlane(a.work[kWorkA + a.work_slot]);
+	const uint32_t *list = a.work + kWorkList + a.n_tiles;
+	auto tile_of_ticket = [&](uint32_t t) -> uint32_t {
+		const unsigned long long i = (unsigned long long)blockIdx.x + (unsigned long long)t * gridDim.x;
+		return i < (unsigned long long)count ? list[(uint32_t)i] : 0xffffffffu;
+	};
+	auto next_ticket = [&]() -> uint32_t {
+		uint32_t t = 0;
+		if (tid == 0) t = atomicAdd(s_ticket, 1u);
+		return __builtin_amdgcn_readfirstlane(tile_of_ticket(__builtin_amdgcn_readfirstlane(t)));
+	};
+	uint4 pre[4];
+	bool pre_valid = false;
+	const uint32_t first = __builtin_amdgcn_readfirstlane(tile_of_ticket(__builtin_amdgcn_readfirstlane(sub)));
+	fast32_prefetch(a, first, tid, pre, pre_valid);
+	for (uint32_t tile_g = first; tile_g < a.n_tiles;) {
+		const uint32_t tile_next = next_ticket();
+		auto defer = [&]() {  // on to the generic kernel (list B); the marker in sums[] is there already (MODE 1) / not wanted (MODE 0)
+			if (tid == 0) a.work[kWorkList + atomicAdd(&a.work[a.work_slot], 1u)] = tile_g;
+		};
+		uint32_t given_bits = 0;
+		if constexpr (MODE == 0) given_bits = a.sums[2 * tile_g];
+		// ---- stage: registers -> four planes of u16 pairs (only full, aligned tiles are ever listed)
+#pragma unroll
+		for (int k = 0; k < 4; ++k) {
+			const uint32_t row = (tid >> 3) + 8u * (uint32_t)k, col = tid & 7u;
+			const uint4 v = pre[k];
+			uint32_t *d = s_pl + row * kRS32 + col * 2u;
+#pragma unroll
+			for (uint32_t c = 0; c < 4; ++c) {
+				const uint32_t sel = c | 0x0c000c00u | ((4u + c) << 16);
+				uint2 pr;
+				pr.x = __builtin_amdgcn_perm(v.y, v.x, sel);
+				pr.y = __builtin_amdgcn_perm(v.w, v.z, sel);
+				*reinterpret_cast<uint2 *>(d + c * kPD32) = pr;
+			}
+		}
+		fast32_prefetch(a, tile_next, tid, pre, pre_valid);
+		tile_sync<1>();
+		// ---- detector + level decision (as shrink32_kernel: the colour planes are still as loaded)
+		uint32_t m0, m1;
+		if constexpr (MODE == 1) {
+			uint32_t sum_hz = 0, sum_vr = 0;
+			const uint32_t q = tid & 15u, g = tid >> 4;
+			const uint32_t two = 0x00020002u;
+			const uint32_t *pc[3];
+			pc[0] = s_pl + g * (8u * kRS32) + q;
+			pc[1] = pc[0] + kPD32;
+			pc[2] = pc[1] + kPD32;
+			uint32_t rA[3], rB[3], tP[3], dP[3];
+#pragma unroll
+			for (int c = 0; c < 3; ++c) {
+				const uint32_t a0 = pc[c][0], a1 = pc[c][1], b0 = pc[c][kRS32], b1 = pc[c][kRS32 + 1];
+				rA[c] = pk_mad_u16(__builtin_amdgcn_alignbit(a1, a0, 16), two, u32(us2(a0) + us2(a1)));
+				rB[c] = pk_mad_u16(__builtin_amdgcn_alignbit(b1, b0, 16), two, u32(us2(b0) + us2(b1)));
+				tP[c] = u32(us2(a0) + us2(b0));
+				dP[c] = b0;
+			}
+#pragma unroll
+			for (int st = 0; st < 4; ++st) {
+				if (st < 3 || g != 3u) {
+#pragma unroll
+					for (int c = 0; c < 3; ++c) {
+						const uint32_t *pr = pc[c] + (2 + 2 * st) * (int)kRS32;
+						const uint32_t n0 = pr[0], n1 = pr[1], o0 = pr[kRS32], o1 = pr[kRS32 + 1];
+						const uint32_t rN = pk_mad_u16(__builtin_amdgcn_alignbit(n1, n0, 16), two, u32(us2(n0) + us2(n1)));
+						sum_hz = sad16(rN, rA[c], sum_hz);
+						const uint32_t tN = u32(us2(dP[c]) + us2(n0));
+						const uint32_t c0 = u32(us2(tP[c]) + us2(tN));
+						sum_vr = sad16(dpp_mov<0x101>(c0), c0, sum_vr);
+						const uint32_t rO = pk_mad_u16(__builtin_amdgcn_alignbit(o1, o0, 16), two, u32(us2(o0) + us2(o1)));
+						sum_hz = sad16(rO, rB[c], sum_hz);
+						const uint32_t tO = u32(us2(n0) + us2(o0));
+						const uint32_t e0 = u32(us2(tN) + us2(tO));
+						sum_vr = sad16(dpp_mov<0x101>(e0), e0, sum_vr);
+						rA[c] = rN;
+						rB[c] = rO;
+						tP[c] = tO;
+						dP[c] = o0;
+					}
+				}
+			}
+			if (q == 15u) sum_hz = sum_vr = 0;
+			sum_hz = wave_sum_sgpr(sum_hz);
+			sum_vr = wave_sum_sgpr(sum_vr);
+			m0 = level_of(sum_hz);
+			m1 = level_of(sum_vr);
+			if (tid == 0) reinterpret_cast<uint2 *>(a.sums)[tile_g] = make_uint2(sum_hz, sum_vr);
+		} else {
+			const uint32_t vb = __builtin_amdgcn_readfirstlane(given_bits);
+			m0 = m1 = level_of(__float_as_uint(parse_value(__uint_as_float(vb))));
+		}
+		const uint32_t nw = reduced_size(32u, m0), nh = reduced_size(32u, m1);
+		const bool one_pass = (nw == 32u) != (nh == 32u) && a.filter != 0;
+		if (one_pass) {
+			// 32 x n / n x 32 with transparency: generic kernel.  MODE 1: it must not be finished from these sums
+			if constexpr (MODE == 1) {
+				if (tid == 0) reinterpret_cast<uint2 *>(a.sums)[tile_g] = make_uint2(kDeferredKey, kDeferredKey);
+			}
+			defer();
+			tile_sync<1>();
+			tile_g = tile_next;
+			continue;
+		}
+		if (tid == 0) {
+			if (a.out_w) a.out_w[tile_g] = nw;
+			if (a.out_h) a.out_h[tile_g] = nh;
+		}
+		uint32_t *dst = reinterpret_cast<uint32_t *>(a.out_px + (size_t)tile_g * 4096u);
+		if (nw == 32u && nh == 32u) {
+			// clone (block.rs:279-281): re-interleave the four planes
+#pragma unroll
+			for (int k = 0; k < 4; ++k) {
+				const uint32_t i = tid + 64u * (uint32_t)k;
+				const uint32_t *p = s_pl + (i >> 3) * kRS32 + (i & 7u) * 2u;
+				const uint2 r = *reinterpret_cast<const uint2 *>(p), g = *reinterpret_cast<const uint2 *>(p + kPD32);
+				const uint2 b = *reinterpret_cast<const uint2 *>(p + 2 * kPD32), al = *reinterpret_cast<const uint2 *>(p + 3 * kPD32);
+				const uint32_t rg01 = __builtin_amdgcn_perm(g.x, r.x, 0x06020400u), ba01 = __builtin_amdgcn_perm(al.x, b.x, 0x06020400u);
+				const uint32_t rg23 = __builtin_amdgcn_perm(g.y, r.y, 0x06020400u), ba23 = __builtin_amdgcn_perm(al.y, b.y, 0x06020400u);
+				uint4 o;
+				o.x = __builtin_amdgcn_perm(ba01, rg01, 0x05040100u);
+				o.y = __builtin_amdgcn_perm(ba01, rg01, 0x07060302u);
+				o.z = __builtin_amdgcn_perm(ba23, rg23, 0x05040100u);
+				o.w = __builtin_amdgcn_perm(ba23, rg23, 0x07060302u);
+				reinterpret_cast<uint4 *>(dst)[i] = o;
+			}
+		} else if (a.filter == 0) {
+			// ResizeAlg::Nearest (mod.rs:277): pick, no alpha handling
+			const uint32_t lgx = 31u - (uint32_t)__builtin_clz(nw);
+			const uint32_t hx = m0 ? (1u << (m0 < 6u ? m0 - 1u : 4u)) : 0u, hy = m1 ? (1u << (m1 < 6u ? m1 - 1u : 4u)) : 0u;
+			const uint16_t *pl16 = reinterpret_cast<const uint16_t *>(s_pl);
+			for (uint32_t i = tid; i < nw * nh; i += 64u) {
+				const uint32_t ox = i & (nw - 1u), oy = i >> lgx;
+				const uint32_t x = m0 == 0 ? ox : (m0 < 6u ? (2u * ox + 1u) * hx : 16u);
+				const uint32_t y = m1 == 0 ? oy : (m1 < 6u ? (2u * oy + 1u) * hy : 16u);
+				const uint32_t idx = y * (2u * kRS32) + x;
+				dst[i] = (uint32_t)pl16[idx] | ((uint32_t)pl16[idx + 2u * kPD32] << 8) | ((uint32_t)pl16[idx + 4u * kPD32] << 16) |
+				         ((uint32_t)pl16[idx + 6u * kPD32] << 24);
+			}
+		} else {
+			// fir, U8x4: premultiply the colour planes in place -- mul_div_255 on both pixels of a dword at once:
+			// t = v*a + 128 <= 65153, t + (t >> 8) <= 65407: nothing leaves its 16-bit half
+#pragma unroll
+			for (uint32_t it = 0; it < 8; ++it) {
+				const uint32_t i = tid + 64u * it;
+				uint32_t *p = s_pl + (i >> 4) * kRS32 + (i & 15u);
+				const ushort2v al = us2(p[3 * kPD32]);
+#pragma unroll
+				for (uint32_t c = 0; c < 3; ++c) {
+					ushort2v t = us2(p[c * kPD32]) * al + (ushort2v)(128);
+					t = t + (t >> (ushort2v)(8));
+					p[c * kPD32] = u32(t >> (ushort2v)(8));
+				}
+			}
+			tile_sync<1>();
+			const uint32_t lx = m0 < (uint32_t)kMaxLevel ? m0 : (uint32_t)kMaxLevel - 1;
+			const uint32_t ly = m1 < (uint32_t)kMaxLevel ? m1 : (uint32_t)kMaxLevel - 1;
+			resample_mfma32<4>(s_tab, a.tabs[lx], a.tabs[ly], s_pl, tid, nw, nh, dst);
+		}
+		tile_sync<1>();  // the next tile reuses this wave's LDS image
+		tile_g = tile_next;
+	}
 }
 
 // ---------------------------------------------------------------------------
@@ -2233,7 +2440,10 @@ __global__ void __launch_bounds__(NW == 1 ? 768 : 64 * NW) shrink_kernel(const S
 				            a.value, a.lod0, a.lod1, t);
 			}
 			if (blockIdx.x == 0) {  // the other set of counters is the next launch's
-				if (threadIdx.x == 0) a.work[a.work_slot ^ 1u] = 0u;
+				if (threadIdx.x == 0) {
+					a.work[a.work_slot ^ 1u] = 0u;
+					a.work[kWorkA + (a.work_slot ^ 1u)] = 0u;
+				}
 				if (threadIdx.x < kTicketCounters) a.work[2u + kTicketCounters * (a.work_slot ^ 1u) + threadIdx.x] = 0u;
 			}
 		}
@@ -2256,7 +2466,10 @@ __global__ void __launch_bounds__(NW == 1 ? 768 : 64 * NW) shrink_kernel(const S
 				            a.value, a.lod0, a.lod1, t);
 			}
 			if (blockIdx.x == 0) {  // the other set of counters is the next launch's
-				if (threadIdx.x == 0) a.work[a.work_slot ^ 1u] = 0u;
+				if (threadIdx.x == 0) {
+					a.work[a.work_slot ^ 1u] = 0u;
+					a.work[kWorkA + (a.work_slot ^ 1u)] = 0u;
+				}
 				if (threadIdx.x < kTicketCounters) a.work[2u + kTicketCounters * (a.work_slot ^ 1u) + threadIdx.x] = 0u;
 			}
 		}
@@ -3777,6 +3990,7 @@ hipError_t launch_shrink(const ShrinkArgs &a, uint32_t channels, uint32_t n_cus,
 		f.out_px = a.out_px;
 		f.work = a.work;
 		f.work_slot = a.work_slot;
+		f.alpha_list = (!groups16 && a.alpha_kernel && a.out_px != nullptr && (a.filter == 0 || a.tab_dw != 0)) ? 1u : 0u;
 		f.trows = a.trows;
 		f.tab_dw = a.out_px && a.filter != 0 ? a.tab_dw : 0u;
 		// only the x-axis tables of full tiles are used (the y axis of a 32x32 tile is identical): they
@@ -3829,6 +4043,24 @@ hipError_t launch_shrink(const ShrinkArgs &a, uint32_t channels, uint32_t n_cus,
 			hipLaunchKernelGGL(k, dim3(blocks), dim3(64u * wpb), lds_bytes, stream, f);
 		}
 		if ((e = hipGetLastError()) != hipSuccess) return e;
+		if (!groups16 && a.alpha_kernel && a.out_px != nullptr) {
+			// 1b) the full tiles with transparency that shrink32_kernel listed: four planes, no output region
+			Fast32Args fa = f;
+			fa.tile_dw = (4u * kPD32 + 2u * kRS32 + 3u) & ~3u;
+			uint32_t wa = (kLds - fa.tab_dw * 4u - 16u) / (fa.tile_dw * 4u);
+			if (wa > 16u) wa = 16u;
+			const uint32_t lds_a = fa.tab_dw * 4u + wa * fa.tile_dw * 4u + 16u;
+			if (a.mode == 1) {
+				auto k = shrink32a_kernel<1>;
+				if (lds_a > 64u * 1024u && (e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a)) != hipSuccess) return e;
+				hipLaunchKernelGGL(k, dim3(n_cus), dim3(64u * wa), lds_a, stream, fa);
+			} else {
+				auto k = shrink32a_kernel<0>;
+				if (lds_a > 64u * 1024u && (e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a)) != hipSuccess) return e;
+				hipLaunchKernelGGL(k, dim3(n_cus), dim3(64u * wa), lds_a, stream, fa);
+			}
+			if ((e = hipGetLastError()) != hipSuccess) return e;
+		}
 		// 2) the generic kernel walks the worklist (usually empty or a few percent of the tiles)
 	} else {
 		ga.work = nullptr;

@@ -567,3 +567,23 @@ def test_strided_batches_on_the_fast_paths(gpu, oracle, block, c):
                 got = (vals[n].cpu().numpy(), ow[n].cpu().numpy().astype(np.uint32), oh[n].cpu().numpy().astype(np.uint32),
                        slots[n].cpu().numpy())
                 assert_same_tiles(got, exp, c, f"{block}x{block} c{c} x0={x0} mode {mode} frame {n}")
+
+
+@pytest.mark.parametrize("mode,factor", [(1, 16.0), (1, 2.0), (0, 1.0)])
+@pytest.mark.parametrize("filt", [0, 2, 4])
+def test_transparent_tiles_through_the_alpha_kernel(gpu, oracle, mode, factor, filt):
+    """Frames whose every tile carries alpha < 255, with PXZ_HINT_TRANSPARENCY: shrink32a_kernel (four LDS planes,
+    premultiplied matrix-core convolution, un-premultiply) for the full tiles, the generic kernel for the ragged
+    edge and the one-pass classes; and without the hint (generic kernel for all of them): same bits either way."""
+    frames = gpu.synth_frames_device(2, 200, 328, 4, first_frame=14, dist=1)
+    f = frames.cpu().numpy()
+    seen = set()
+    for hint in (True, False):
+        vals, ow, oh, slots = gpu.shrink_frames_device(frames, 32, 32, mode, filt, factor, transparency_hint=hint)
+        for n in range(2):
+            exp = oracle.shrink_image(f[n], 32, 32, mode, filt, factor, nthreads=8)
+            got = (vals[n].cpu().numpy(), ow[n].cpu().numpy().astype(np.uint32), oh[n].cpu().numpy().astype(np.uint32),
+                   slots[n].cpu().numpy())
+            assert_same_tiles(got, exp, 4, f"hint {hint} mode {mode} k={factor} f{filt} frame {n}")
+            seen |= set(histogram(got[1], got[2]))
+    assert len(seen) >= 3, seen

@@ -20,7 +20,7 @@ L.pxz_debug_read_work.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t
 n_tiles = out[1].numel() if not LOD else out[0].numel()
 def read():
     buf = (C.c_uint64 * 8)()
-    off = ((n_tiles + 130 + 2) & ~1) * 4
+    off = ((2 * n_tiles + 132 + 2) & ~1) * 4
     assert L.pxz_debug_read_work(h._h, buf, off, 64) == 0
     return list(buf)
 before = read()
@@ -36,7 +36,7 @@ print("total per tile (wave cycles):", tot / 5 / n_tiles)
 # per-wave run times of the last launch (100 MHz wall clock) and per-block start times (slot 15)
 import numpy as np
 buf = (C.c_uint64 * 4096)()
-off = ((n_tiles + 130 + 2) & ~1) * 4 + 64
+off = ((2 * n_tiles + 132 + 2) & ~1) * 4 + 64
 assert L.pxz_debug_read_work(h._h, buf, off, 4096 * 8) == 0
 raw = np.array(list(buf), dtype=np.uint64).reshape(256, 16)
 start = raw[:, 15].astype(np.float64) / 100
