@@ -78,6 +78,8 @@ struct pxz_handle {
 	std::map<std::tuple<uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t>, Breaks> breaks;
 	DeviceBuffer in, val, ow, oh, out, sums, chunks, work, qscratch, qmeta, status, dmeta, okscratch, rgba, slots4;
 	std::map<std::tuple<uint32_t, uint32_t, uint32_t, uint32_t, uint32_t>, ExpandTables> expand_tables;
+	uint32_t *host_stats = nullptr;  // pinned, device-visible: [0] = tiles with transparency the last finished 32x32 launch saw
+	uint32_t *dev_stats = nullptr;   //   (its device-side address); read without synchronisation, steers only the kernel choice
 	bool work_ready = false;   // both worklist counters are zero / consistent with work_slot
 	uint32_t work_slot = 0;    // the counter the next 32x32 launch uses
 	bool timing = false;
@@ -528,6 +530,8 @@ int prepare(pxz_handle *h, const pxz_frames *f, const pxz_params *p, bool want_p
 	a->factor = p->factor;
 	a->scale2 = 10.0f;  // BASE_FACTOR, pixlzr.rs:15
 	a->alpha_kernel = (p->reserved & PXZ_HINT_TRANSPARENCY) != 0 && !getenv("PXZ_NO_ALPHA_KERNEL");
+	a->list_a_too = 0;
+	a->stats = nullptr;
 	a->slot_bytes = bw * bh * f->channels;
 	build_breaks(h, a);
 	std::memset(a->tabs, 0, sizeof a->tabs);
@@ -565,6 +569,12 @@ int timed_launch(pxz_handle *h, pxz::ShrinkArgs &a, uint32_t channels, float *va
 	a.value = value;
 	a.lod0 = lod0;
 	a.lod1 = lod1;
+	// Transparency without the caller's hint: the last finished launch reported how many full tiles had any
+	// (one dword in pinned memory, written by the worklist kernel).  Past ~2000 tiles shrink32a_kernel pays for
+	// its launch.  Either way the results are the same; only the kernel that produces them differs.
+	a.stats = h->dev_stats;
+	if (!a.alpha_kernel && h->host_stats && *const_cast<volatile uint32_t *>(h->host_stats) >= 2048u && !getenv("PXZ_NO_ALPHA_KERNEL"))
+		a.alpha_kernel = 1;
 	// 32x32 fast path: which tiles are full-size, and whether every tile row of the batch is 16-byte aligned
 	a.full_cols = a.full_rows = a.ok_rows = 0;
 	if (a.bw == a.bh && (a.bw == 16 || a.bw == 32 || a.bw == 64) && channels == 4 &&
@@ -661,6 +671,17 @@ int pxz_create(int device_id, pxz_handle **out)
 		delete h;
 		return PXZ_ERR_UNSUPPORTED;  // platform log2f is not a clean step around 2^(k+1/2)
 	}
+	void *hs = nullptr, *ds = nullptr;
+	if (hipHostMalloc(&hs, 64, hipHostMallocMapped) == hipSuccess) {
+		std::memset(hs, 0, 64);
+		if (hipHostGetDevicePointer(&ds, hs, 0) == hipSuccess) {
+			h->host_stats = static_cast<uint32_t *>(hs);
+			h->dev_stats = static_cast<uint32_t *>(ds);
+		} else {
+			(void)hipHostFree(hs);
+		}
+	}
+	(void)hipGetLastError();  // no pinned dword: no adaptive kernel choice, nothing else changes
 	*out = h;
 	return PXZ_OK;
 }
@@ -687,6 +708,10 @@ void pxz_destroy(pxz_handle *h)
 	for (auto &ev : h->events) {
 		(void)hipEventDestroy(ev.first);
 		(void)hipEventDestroy(ev.second);
+	}
+	if (h->host_stats) {
+		(void)hipDeviceSynchronize();  // a queued launch may still write it
+		(void)hipHostFree(h->host_stats);
 	}
 	delete h;
 }

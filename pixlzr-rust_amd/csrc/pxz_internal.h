@@ -75,7 +75,9 @@ struct ShrinkArgs {
 	                         //   when its height is a whole number of that detector's bands
 	uint32_t full_cols, full_rows;  // 32x32 fast path: tile (tx, ty) is eligible iff tx < full_cols && ty < full_rows
 	                                //   (full size, 16-byte aligned rows; 0/0 when the batch is not aligned)
-	uint32_t alpha_kernel;   // the caller announced frames with transparency (pxz_params.reserved bit 0)
+	uint32_t alpha_kernel;   // frames with transparency announced (pxz_params.reserved bit 0) or seen by the last launch
+	uint32_t list_a_too;     // worklist kernel: list A (full tiles with transparency) was not taken by shrink32a_kernel
+	uint32_t *stats;         // pinned host dword (device address) <- number of list-A tiles of this launch; may be null
 	uint32_t *work;          // worklist: [work_slot] = count, [2..] = tile ids (null: all tiles).  The two
 	uint32_t work_slot;      //   counters alternate between launches; a launch zeroes the other one
 	float *value;            // worklist mode only: the kernel finishes its tiles itself (finish_tile) and,

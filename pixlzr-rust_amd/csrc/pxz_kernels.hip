@@ -1282,6 +1282,30 @@ __device__ __forceinline__ unsigned long long stamp_now()
 	} while (0)
 #endif
 
+// Worklist appends, batched: a global atomic on ONE address completes every ~12 ns chip-wide, so a frame whose
+// every tile is listed (transparent frames: 259 200 tiles) would spend 3 ms on the counter alone.  Each wave
+// (or block) parks up to kListBatch tile numbers in LDS and reserves their list slots with one atomic.
+constexpr uint32_t kListBatch = 16;
+__device__ __forceinline__ void list_flush(uint32_t *buf, uint32_t &cnt, uint32_t *list, uint32_t *counter, uint32_t lane)
+{
+	if (cnt == 0u) return;
+	uint32_t base = 0;
+	if (lane == 0u) base = atomicAdd(counter, cnt);
+	base = __builtin_amdgcn_readfirstlane(base);
+	asm volatile("" ::: "memory");
+	if (lane < cnt) list[base + lane] = buf[lane];
+	asm volatile("" ::: "memory");
+	cnt = 0u;
+}
+// cnt is uniform over the lanes that call this (a wave, or thread 0 of a block with lane == 0 semantics)
+__device__ __forceinline__ void list_push(uint32_t *buf, uint32_t &cnt, uint32_t tile, uint32_t *list, uint32_t *counter,
+										   uint32_t lane)
+{
+	if (lane == 0u) buf[cnt] = tile;
+	++cnt;
+	if (cnt == kListBatch) list_flush(buf, cnt, list, counter, lane);
+}
+
 // ---------------------------------------------------------------------------
 // shrink32_kernel: the common case on its own — full, 16-byte-aligned 32x32 RGBA tiles whose
 // resample is a clone, a nearest pick, or a two-pass convolution of an opaque tile.  Everything
@@ -1314,6 +1338,8 @@ __global__ void __launch_bounds__(1024) shrink32_kernel(const Fast32Args a)
 	};
 	uint32_t *s_pl = lds + a.tab_dw + sub * a.tile_dw;
 	uint32_t *s_tmp = s_pl + 3 * kPD32;  // R, G, B planes only: tiles with transparency go to the worklist
+	uint32_t *s_batch = s_ticket + 4u + sub * (2u * kListBatch);  // this wave's pending list-B / list-A entries
+	uint32_t n_listb = 0, n_lista = 0;
 	auto tile_of_ticket = [&](uint32_t t) -> uint32_t {
 		// runs of 2^chunk_lg adjacent tiles per block: successive tickets walk along an image row
 		const unsigned long long run = (unsigned long long)(t >> a.chunk_lg) * gridDim.x + blockIdx.x;
@@ -1374,8 +1400,8 @@ __global__ void __launch_bounds__(1024) shrink32_kernel(const Fast32Args a)
 	};
 	auto one_tile = [&](const uint32_t tile_g, const uint32_t tile_next) {
 		auto defer = [&]() {
+			list_push(s_batch, n_listb, tile_g, a.work + kWorkList, a.work + a.work_slot, tid);
 			if (tid == 0) {
-				a.work[kWorkList + atomicAdd(&a.work[a.work_slot], 1u)] = tile_g;
 				bool keep = false;  // MODE 0: a value the block-cooperative detector left is final and stays
 				if constexpr (MODE == 0) {
 					const uint32_t t = tile_g - fastdiv(tile_g, a.div_tpf) * a.tiles_per_frame;
@@ -1423,10 +1449,9 @@ __global__ void __launch_bounds__(1024) shrink32_kernel(const Fast32Args a)
 			// caller announced transparent frames, else the generic kernel (list B).  (Detector-only launches do not
 			// care: the detector never looks at alpha.)
 			if (a.alpha_list) {
-				if (tid == 0) {
-					a.work[kWorkList + a.n_tiles + atomicAdd(&a.work[kWorkA + a.work_slot], 1u)] = tile_g;
-					if constexpr (MODE == 1) reinterpret_cast<uint2 *>(a.sums)[tile_g] = make_uint2(kDeferredKey, kDeferredKey);
-				}
+				list_push(s_batch + kListBatch, n_lista, tile_g, a.work + kWorkList + a.n_tiles, a.work + kWorkA + a.work_slot, tid);
+				if constexpr (MODE == 1)
+					if (tid == 0) reinterpret_cast<uint2 *>(a.sums)[tile_g] = make_uint2(kDeferredKey, kDeferredKey);
 			} else {
 				defer();
 			}
@@ -1561,6 +1586,8 @@ __global__ void __launch_bounds__(1024) shrink32_kernel(const Fast32Args a)
 		tile_g = tile_next;
 	}
 	flush();  // the last tile's pixels
+	list_flush(s_batch, n_listb, a.work + kWorkList, a.work + a.work_slot, tid);
+	list_flush(s_batch + kListBatch, n_lista, a.work + kWorkList + a.n_tiles, a.work + kWorkA + a.work_slot, tid);
 #ifdef PXZ_STAMPS
 	if (tid == 0) {
 		unsigned long long *out = reinterpret_cast<unsigned long long *>(a.work + ((2u * a.n_tiles + kWorkList + 1u + 1u) & ~1u));
@@ -1598,6 +1625,8 @@ __global__ void __launch_bounds__(1024) shrink32a_kernel(const Fast32Args a)
 		return (uint32_t)__builtin_popcountll((a.breaks_asc ? ~lt : lt) & live);
 	};
 	uint32_t *s_pl = lds + a.tab_dw + sub * a.tile_dw;  // four planes: R, G, B, A
+	uint32_t *s_batch = s_ticket + 4u + sub * kListBatch;  // this wave's pending list-B entries
+	uint32_t n_listb = 0;
 	const uint32_t count = __builtin_amdgcn_readfirstlane(a.work[kWorkA + a.work_slot]);
 	const uint32_t *list = a.work + kWorkList + a.n_tiles;
 	auto tile_of_ticket = [&](uint32_t t) -> uint32_t {
@@ -1616,7 +1645,7 @@ __global__ void __launch_bounds__(1024) shrink32a_kernel(const Fast32Args a)
 	for (uint32_t tile_g = first; tile_g < a.n_tiles;) {
 		const uint32_t tile_next = next_ticket();
 		auto defer = [&]() {  // on to the generic kernel (list B); the marker in sums[] is there already (MODE 1) / not wanted (MODE 0)
-			if (tid == 0) a.work[kWorkList + atomicAdd(&a.work[a.work_slot], 1u)] = tile_g;
+			list_push(s_batch, n_listb, tile_g, a.work + kWorkList, a.work + a.work_slot, tid);
 		};
 		uint32_t given_bits = 0;
 		if constexpr (MODE == 0) given_bits = a.sums[2 * tile_g];
@@ -1760,6 +1789,7 @@ __global__ void __launch_bounds__(1024) shrink32a_kernel(const Fast32Args a)
 		tile_sync<1>();  // the next tile reuses this wave's LDS image
 		tile_g = tile_next;
 	}
+	list_flush(s_batch, n_listb, a.work + kWorkList, a.work + a.work_slot, tid);
 }
 
 // ---------------------------------------------------------------------------
@@ -1790,6 +1820,8 @@ __global__ void __launch_bounds__(1024) shrink16_kernel(const Fast32Args a)
 	};
 	uint32_t *s_pl = lds + a.tab_dw + sub * a.tile_dw;
 	uint32_t *s_tmp = s_pl + 3 * kPD32;
+	uint32_t *s_batch = s_ticket + 4u + sub * kListBatch;  // this wave's pending list-B entries
+	uint32_t n_listb = 0;
 	// groups of 2x2 tiles: gcols x grows per frame
 	const uint32_t gcols = (a.cols + 1u) >> 1, grows = (a.rows + 1u) >> 1, gpf = gcols * grows;
 	auto group_of_ticket = [&](uint32_t t) -> uint32_t {
@@ -1839,8 +1871,8 @@ __global__ void __launch_bounds__(1024) shrink16_kernel(const Fast32Args a)
 		const uint32_t t00 = pl.frame * a.tiles_per_frame + (2u * pl.gy) * a.cols + 2u * pl.gx;
 		auto tile_id = [&](uint32_t k) -> uint32_t { return t00 + (k & 1u) + (k >> 1) * a.cols; };
 		auto defer_tile = [&](uint32_t t) {
+			list_push(s_batch, n_listb, t, a.work + kWorkList, a.work + a.work_slot, tid);
 			if (tid == 0) {
-				a.work[kWorkList + atomicAdd(&a.work[a.work_slot], 1u)] = t;
 				bool keep = false;  // MODE 0: a value the block-cooperative detector left is final and stays
 				if constexpr (MODE == 0) {
 					const uint32_t tt = t - pl.frame * a.tiles_per_frame;
@@ -2014,6 +2046,7 @@ __global__ void __launch_bounds__(1024) shrink16_kernel(const Fast32Args a)
 		tile_sync<1>();  // the next group reuses this wave's LDS image
 		grp = grp_next;
 	}
+	list_flush(s_batch, n_listb, a.work + kWorkList, a.work + a.work_slot, tid);
 }
 
 // ---------------------------------------------------------------------------
@@ -2051,7 +2084,7 @@ __global__ void __launch_bounds__(256) shrink64_kernel(const Fast64Args a)
 	extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
 	uint32_t *s_pl = lds;                       // 3 planes of u16 pairs
 	uint32_t *s_t = lds + 3 * kPD64;            // horizontal-pass results
-	uint32_t *s_red = s_t + kT64;               // [0..7] partial sums, [8..11] alpha, [12] deferred flag
+	uint32_t *s_red = s_t + kT64;               // [0..7] partial sums, [8..11] alpha, [12] deferred flag, [13] ticket, [16..31] list batch
 	const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
 	const uint32_t brk_lane = lane < (uint32_t)kMaxLevel ? a.breaks[lane] : (a.breaks_asc ? 0xffffffffu : 0u);
 	auto level_of = [&](uint32_t key) -> uint32_t {
@@ -2090,6 +2123,7 @@ __global__ void __launch_bounds__(256) shrink64_kernel(const Fast64Args a)
 	// there the "tickets" are simply this block's turn in a fixed rotation
 	const bool dynamic = a.out_px != nullptr;
 	uint32_t turn = blockIdx.x / n_ctr;
+	uint32_t n_listb = 0;  // pending list-B entries in s_red[16..31]
 	for (; tile_g < a.n_tiles;) {
 		uint32_t drawn = turn;
 		turn += nb_c;
@@ -2103,8 +2137,9 @@ __global__ void __launch_bounds__(256) shrink64_kernel(const Fast64Args a)
 			tile_next = tile_of(2u * nb_c + s_red[13]);
 		};
 		auto defer = [&]() {
+			// (block-uniform; only wave 0's lanes 0..15 ever touch the batch)
+			list_push(s_red + 16, n_listb, tile_g, a.work + kWorkList, a.work + a.work_slot, threadIdx.x);
 			if (threadIdx.x == 0) {
-				a.work[kWorkList + atomicAdd(&a.work[a.work_slot], 1u)] = tile_g;
 				bool keep = false;  // MODE 0: a value the block-cooperative detector left is final and stays
 				if constexpr (MODE == 0) {
 					const uint32_t t = tile_g - fastdiv(tile_g, a.div_tpf) * a.tiles_per_frame;
@@ -2395,6 +2430,7 @@ __global__ void __launch_bounds__(256) shrink64_kernel(const Fast64Args a)
 			__syncthreads();
 		}
 	}
+	list_flush(s_red + 16, n_listb, a.work + kWorkList, a.work + a.work_slot, threadIdx.x);
 }
 
 // ---------------------------------------------------------------------------
@@ -2415,12 +2451,18 @@ __global__ void __launch_bounds__(NW == 1 ? 768 : 64 * NW) shrink_kernel(const S
 		if (threadIdx.x == 0) *s_ticket = wpb;
 		__syncthreads();
 		// with a worklist (left by shrink32_kernel) only the listed tiles are processed
-		const uint32_t count = a.work ? __builtin_amdgcn_readfirstlane(a.work[a.work_slot]) : a.n_tiles;
+		const uint32_t count_b = a.work ? __builtin_amdgcn_readfirstlane(a.work[a.work_slot]) : a.n_tiles;
+		const uint32_t count_a = a.work ? __builtin_amdgcn_readfirstlane(a.work[kWorkA + a.work_slot]) : 0u;
+		const uint32_t count = count_b + (a.list_a_too ? count_a : 0u);  // (each list holds a tile at most once: <= n_tiles)
 		uint32_t ticket = sub;
 		for (;;) {
 			const unsigned long long i = (unsigned long long)blockIdx.x + (unsigned long long)ticket * gridDim.x;
 			if (i >= (unsigned long long)count) break;
-			const uint32_t tile_g = a.work ? __builtin_amdgcn_readfirstlane(a.work[kWorkList + (uint32_t)i]) : (uint32_t)i;
+			uint32_t tile_g = (uint32_t)i;
+			if (a.work) {
+				const uint32_t at = (uint32_t)i < count_b ? (uint32_t)i : a.n_tiles + ((uint32_t)i - count_b);  // list B, then list A
+				tile_g = __builtin_amdgcn_readfirstlane(a.work[kWorkList + at]);
+			}
 			process_tile<NW, C, MODE>(a, tile_g, s_pl, nullptr, tid);
 			uint32_t t = 0;
 			if (tid == 0) t = atomicAdd(s_ticket, 1u);
@@ -2443,6 +2485,7 @@ __global__ void __launch_bounds__(NW == 1 ? 768 : 64 * NW) shrink_kernel(const S
 				if (threadIdx.x == 0) {
 					a.work[a.work_slot ^ 1u] = 0u;
 					a.work[kWorkA + (a.work_slot ^ 1u)] = 0u;
+					if (a.stats) *a.stats = count_a;  // steers the next launches' kernel choice (pxz_api.cpp)
 				}
 				if (threadIdx.x < kTicketCounters) a.work[2u + kTicketCounters * (a.work_slot ^ 1u) + threadIdx.x] = 0u;
 			}
@@ -3990,7 +4033,11 @@ hipError_t launch_shrink(const ShrinkArgs &a, uint32_t channels, uint32_t n_cus,
 		f.out_px = a.out_px;
 		f.work = a.work;
 		f.work_slot = a.work_slot;
-		f.alpha_list = (!groups16 && a.alpha_kernel && a.out_px != nullptr && (a.filter == 0 || a.tab_dw != 0)) ? 1u : 0u;
+		// full tiles with transparency always go to list A; shrink32a_kernel takes it when transparency was announced
+		// or seen before, else the worklist kernel walks it after list B
+		f.alpha_list = (!groups16 && a.out_px != nullptr && (a.filter == 0 || a.tab_dw != 0)) ? 1u : 0u;
+		const bool run_alpha = f.alpha_list != 0 && a.alpha_kernel != 0;
+		ga.list_a_too = f.alpha_list != 0 && !run_alpha ? 1u : 0u;
 		f.trows = a.trows;
 		f.tab_dw = a.out_px && a.filter != 0 ? a.tab_dw : 0u;
 		// only the x-axis tables of full tiles are used (the y axis of a 32x32 tile is identical): they
@@ -4008,13 +4055,14 @@ hipError_t launch_shrink(const ShrinkArgs &a, uint32_t channels, uint32_t n_cus,
 		f.tile_dw = f.out_px ? 3u * kPD32 + kOut32 + 2u * kRS32 : 3u * kPD32 + 4u * kRS32;
 		f.tile_dw = (f.tile_dw + 3u) & ~3u;
 		constexpr uint32_t kLds = 160u * 1024u;
-		uint32_t wpb = (kLds - f.tab_dw * 4u - 16u) / (f.tile_dw * 4u);
+		constexpr uint32_t kTail = 16u + 16u * 2u * kListBatch * 4u;  // the ticket counter + every wave's list batches
+		uint32_t wpb = (kLds - f.tab_dw * 4u - kTail) / (f.tile_dw * 4u);
 		if (wpb > 16u) wpb = 16u;
 		if (const char *e = getenv("PXZ_WPB")) {
 			const uint32_t v = (uint32_t)atoi(e);
 			if (v >= 1 && v < wpb) wpb = v;
 		}
-		const uint32_t lds_bytes = f.tab_dw * 4u + wpb * f.tile_dw * 4u + 16u;  // + the ticket counter
+		const uint32_t lds_bytes = f.tab_dw * 4u + wpb * f.tile_dw * 4u + kTail;
 		const uint32_t per_cu = kLds / lds_bytes > 0 ? kLds / lds_bytes : 1u;
 		const uint32_t resident = n_cus * (per_cu > 2u ? 2u : per_cu);
 		const uint32_t units = groups16 ? f.n_groups : a.n_tiles;
@@ -4043,13 +4091,13 @@ hipError_t launch_shrink(const ShrinkArgs &a, uint32_t channels, uint32_t n_cus,
 			hipLaunchKernelGGL(k, dim3(blocks), dim3(64u * wpb), lds_bytes, stream, f);
 		}
 		if ((e = hipGetLastError()) != hipSuccess) return e;
-		if (!groups16 && a.alpha_kernel && a.out_px != nullptr) {
+		if (run_alpha) {
 			// 1b) the full tiles with transparency that shrink32_kernel listed: four planes, no output region
 			Fast32Args fa = f;
 			fa.tile_dw = (4u * kPD32 + 2u * kRS32 + 3u) & ~3u;
-			uint32_t wa = (kLds - fa.tab_dw * 4u - 16u) / (fa.tile_dw * 4u);
+			uint32_t wa = (kLds - fa.tab_dw * 4u - kTail) / (fa.tile_dw * 4u);
 			if (wa > 16u) wa = 16u;
-			const uint32_t lds_a = fa.tab_dw * 4u + wa * fa.tile_dw * 4u + 16u;
+			const uint32_t lds_a = fa.tab_dw * 4u + wa * fa.tile_dw * 4u + kTail;
 			if (a.mode == 1) {
 				auto k = shrink32a_kernel<1>;
 				if (lds_a > 64u * 1024u && (e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a)) != hipSuccess) return e;
