@@ -587,3 +587,62 @@ def test_transparent_tiles_through_the_alpha_kernel(gpu, oracle, mode, factor, f
             assert_same_tiles(got, exp, 4, f"hint {hint} mode {mode} k={factor} f{filt} frame {n}")
             seen |= set(histogram(got[1], got[2]))
     assert len(seen) >= 3, seen
+
+
+def _sweep_cases(n, seed):
+    rng = np.random.default_rng(seed)
+    sizes = [2, 3, 4, 6, 8, 12, 16, 20, 24, 32, 40, 48, 64, 80, 96]
+    out = []
+    for i in range(n):
+        bw, bh = int(rng.choice(sizes)), int(rng.choice(sizes))
+        if rng.random() < 0.5:
+            bh = bw  # square tiles take the fast kernels for 16 / 32 / 64
+        if rng.random() < 0.4:
+            bw = bh = int(rng.choice([16, 32, 64]))
+        w = int(rng.integers(bw, 6 * bw + 40))
+        h = int(rng.integers(bh, 5 * bh + 40))
+        out.append((i, w, h, bw, bh, int(rng.choice([3, 4])), int(rng.integers(0, 2)), int(rng.integers(0, 5))))
+    return out
+
+
+@pytest.mark.parametrize("i,w,h,bw,bh,c,mode,filt", _sweep_cases(48, 20260214))
+def test_seeded_sweep_of_geometries(gpu, oracle, i, w, h, bw, bh, c, mode, filt):
+    """Seeded sweep: frame and tile sizes, channels, detector, filter, factor and alpha layout drawn at random;
+    frames mix flat, smooth and noisy regions (every level class shows up) with opaque, partly and fully
+    transparent patches.  1-px edge tiles under the directional detector must fail as the reference does."""
+    rng = np.random.default_rng(1000 + i)
+    img = oracle.synth_frame(w, h, c, i, 1 if (c == 4 and i % 3 == 0) else 0).copy()
+    for _ in range(4):  # noisy / flat patches
+        x0, y0 = int(rng.integers(0, w)), int(rng.integers(0, h))
+        x1, y1 = int(rng.integers(x0, w)) + 1, int(rng.integers(y0, h)) + 1
+        if rng.random() < 0.5:
+            amp = int(rng.choice([2, 8, 40, 120]))
+            patch = img[y0:y1, x0:x1, :3].astype(np.int32) + rng.integers(-amp, amp + 1, size=(y1 - y0, x1 - x0, 3))
+            img[y0:y1, x0:x1, :3] = patch.clip(0, 255).astype(np.uint8)
+        else:
+            img[y0:y1, x0:x1, :3] = rng.integers(0, 256, size=3, dtype=np.uint8)
+    if c == 4:
+        for _ in range(3):
+            x0, y0 = int(rng.integers(0, w)), int(rng.integers(0, h))
+            x1, y1 = int(rng.integers(x0, w)) + 1, int(rng.integers(y0, h)) + 1
+            kind = rng.random()
+            if kind < 0.3:
+                img[y0:y1, x0:x1, 3] = 0
+            elif kind < 0.6:
+                img[y0:y1, x0:x1, 3] = rng.integers(0, 256, size=(y1 - y0, x1 - x0), dtype=np.uint8)
+            else:
+                img[y0:y1, x0:x1, 3] = 255
+    factor = float(rng.choice([0.5, 2.0, 8.0, 16.0, 64.0])) if mode == 1 else float(rng.choice([0.05, 0.2, 0.5, 1.0, 3.0]))
+    edge_w, edge_h = w % bw or bw, h % bh or bh
+    if mode == 1 and (min(edge_w, edge_h, bw, bh) == 1):
+        with pytest.raises(Exception) as e:
+            gpu.shrink_image(img, bw, bh, mode, filt, factor)
+        assert getattr(e.value, "code", None) == -4
+        with pytest.raises(RuntimeError):
+            oracle.shrink_image(img, bw, bh, mode, filt, factor)
+        return
+    if mode == 0 and bw * bh > 7168:
+        pytest.skip("Oklab detector keeps 3 f32 planes of a tile in LDS")
+    got = gpu.shrink_image(img, bw, bh, mode, filt, factor)
+    exp = oracle.shrink_image(img, bw, bh, mode, filt, factor)
+    assert_same_tiles(got, exp, c, f"case {i}: {w}x{h} b{bw}x{bh} c{c} mode{mode} f{filt} k={factor}")
