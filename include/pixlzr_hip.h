@@ -100,7 +100,9 @@ typedef struct pxz_params {
 /* Performance hints (pxz_params.reserved); results never depend on them.
  * PXZ_HINT_TRANSPARENCY: many tiles of these RGBA frames carry alpha < 255.  32x32 tiles with transparency are
  * then resampled by a dedicated kernel (four LDS planes, premultiplied matrix-core convolution) instead of the
- * generic one, at the price of one more launch per call.  pxz_shrink_image samples the image and sets it itself. */
+ * generic one, at the price of one more launch per call.  pxz_shrink_image samples the image and sets it itself;
+ * without the hint a handle switches to that kernel by itself once a finished launch has reported >= 2048 such
+ * tiles (and back when a launch reports fewer). */
 #define PXZ_HINT_TRANSPARENCY 1u
 
 /* ---- the hot path ----------------------------------------------------- */
