@@ -2064,8 +2064,8 @@ __global__ void __launch_bounds__(1024) shrink16_kernel(const Fast32Args a)
 // ---------------------------------------------------------------------------
 constexpr uint32_t kRS64 = 36, kPD64 = 36 * 64;  // plane row stride (32 + 4 dwords: bank skew, rows stay 16-byte aligned), plane size
 constexpr uint32_t kTS64 = 20;                   // dwords per column of the horizontal pass: 16 (64 bytes of y) + 4 of bank skew
-constexpr uint32_t kT64 = 3 * 32 * kTS64;        // [channel][ox < 32][kTS64]
-constexpr uint32_t kLds64 = 3 * kPD64 + kT64 + 32;
+constexpr uint32_t kRed64 = 48;                  // partial sums, flags, ticket, two worklist batches
+constexpr uint32_t lds64_dwords(uint32_t nch) { return nch * kPD64 + nch * 32u * kTS64 + kRed64; }  // planes + [channel][ox < 32][kTS64] + s_red
 
 template <class Args>
 __device__ __forceinline__ bool fast64_tile_src(const Args &a, uint32_t tile_g, const uint8_t *&src)
@@ -2078,13 +2078,17 @@ __device__ __forceinline__ bool fast64_tile_src(const Args &a, uint32_t tile_g, 
 	return tx < a.full_cols && ty < a.full_rows;
 }
 
-template <int MODE>
+// ALPHA: the full tiles WITH transparency the opaque kernel put on list A -- a fourth plane keeps the alpha
+// channel, the colours are premultiplied in place once the detector is done with them (fir's U8x4 path), all
+// four planes go through the passes and every output pixel is un-premultiplied.
+template <int MODE, bool ALPHA>
 __global__ void __launch_bounds__(256) shrink64_kernel(const Fast64Args a)
 {
+	constexpr uint32_t NCH = ALPHA ? 4u : 3u;
 	extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-	uint32_t *s_pl = lds;                       // 3 planes of u16 pairs
-	uint32_t *s_t = lds + 3 * kPD64;            // horizontal-pass results
-	uint32_t *s_red = s_t + kT64;               // [0..7] partial sums, [8..11] alpha, [12] deferred flag, [13] ticket, [16..31] list batch
+	uint32_t *s_pl = lds;                       // NCH planes of u16 pairs
+	uint32_t *s_t = lds + NCH * kPD64;          // horizontal-pass results
+	uint32_t *s_red = s_t + NCH * 32u * kTS64;  // [0..7] partial sums, [8..11] alpha, [13] ticket, [16..31] list-B batch, [32..47] list-A batch
 	const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
 	const uint32_t brk_lane = lane < (uint32_t)kMaxLevel ? a.breaks[lane] : (a.breaks_asc ? 0xffffffffu : 0u);
 	auto level_of = [&](uint32_t key) -> uint32_t {
@@ -2110,20 +2114,24 @@ __global__ void __launch_bounds__(256) shrink64_kernel(const Fast64Args a)
 	// atomics per microsecond); counter c owns tiles c, c + n_ctr, c + 2 n_ctr, ...  A block's first two tiles
 	// are fixed; every iteration draws the ticket of the tile after next at its start and hands it to the
 	// other waves across a barrier the iteration has anyway.
-	const uint32_t n_ctr = gridDim.x < kTicketCounters ? gridDim.x : kTicketCounters;
+	// (ALPHA: the items are the entries of list A, in a fixed rotation over the blocks)
+	const uint32_t n_ctr = ALPHA ? gridDim.x : (gridDim.x < kTicketCounters ? gridDim.x : kTicketCounters);
 	const uint32_t cid = blockIdx.x % n_ctr, nb_c = (gridDim.x - cid + n_ctr - 1u) / n_ctr;
 	uint32_t *ctr = a.work + 2u + kTicketCounters * a.work_slot + cid;
+	const uint32_t n_items = ALPHA ? a.work[kWorkA + a.work_slot] : a.n_tiles;
 	auto tile_of = [&](uint32_t k) -> uint32_t {
 		const unsigned long long t = (unsigned long long)k * n_ctr + cid;
-		return t < (unsigned long long)a.n_tiles ? (uint32_t)t : 0xffffffffu;
+		if (t >= (unsigned long long)n_items) return 0xffffffffu;
+		if constexpr (ALPHA) return a.work[kWorkList + a.n_tiles + (uint32_t)t];
+		return (uint32_t)t;
 	};
 	uint32_t tile_g = tile_of(blockIdx.x / n_ctr), tile_next = tile_of(blockIdx.x / n_ctr + nb_c);
 	prefetch(tile_g);
 	// detector-only launches: equal cost per tile, and an iteration is shorter than an atomic's round trip:
 	// there the "tickets" are simply this block's turn in a fixed rotation
-	const bool dynamic = a.out_px != nullptr;
+	const bool dynamic = !ALPHA && a.out_px != nullptr;
 	uint32_t turn = blockIdx.x / n_ctr;
-	uint32_t n_listb = 0;  // pending list-B entries in s_red[16..31]
+	uint32_t n_listb = 0, n_lista = 0;  // pending list-B entries in s_red[16..31], list-A entries in s_red[32..47]
 	for (; tile_g < a.n_tiles;) {
 		uint32_t drawn = turn;
 		turn += nb_c;
@@ -2167,7 +2175,7 @@ __global__ void __launch_bounds__(256) shrink64_kernel(const Fast64Args a)
 			const uint4 v = pre[k];
 			uint32_t *d = s_pl + row * kRS64 + col * 2u;
 #pragma unroll
-			for (uint32_t c = 0; c < 3; ++c) {
+			for (uint32_t c = 0; c < NCH; ++c) {
 				const uint32_t sel = c | 0x0c000c00u | ((4u + c) << 16);
 				uint2 pr;
 				pr.x = __builtin_amdgcn_perm(v.y, v.x, sel);
@@ -2179,8 +2187,12 @@ __global__ void __launch_bounds__(256) shrink64_kernel(const Fast64Args a)
 		if (lane == 0) s_red[8 + wave] = wave_transparent ? 1u : 0u;
 		prefetch(tile_next);  // lands while this tile is processed
 		__syncthreads();      // B1: the whole tile is staged
-		if ((s_red[8] | s_red[9] | s_red[10] | s_red[11]) != 0u) {
-			defer();  // transparency: premultiplied convolution and the alpha plane live in the generic kernel
+		if (!ALPHA && a.out_px != nullptr && (s_red[8] | s_red[9] | s_red[10] | s_red[11]) != 0u) {
+			// transparency: the premultiplied convolution needs the alpha plane -- list A (the ALPHA instance of this
+			// kernel, or the generic kernel when that one is not launched).  Detector-only launches do not care.
+			list_push(s_red + 32, n_lista, tile_g, a.work + kWorkList + a.n_tiles, a.work + kWorkA + a.work_slot, threadIdx.x);
+			if constexpr (MODE == 1)
+				if (threadIdx.x == 0) reinterpret_cast<uint2 *>(a.sums)[tile_g] = make_uint2(kDeferredKey, kDeferredKey);
 			publish_ticket();
 			__syncthreads();
 			advance();
@@ -2276,9 +2288,10 @@ __global__ void __launch_bounds__(256) shrink64_kernel(const Fast64Args a)
 				const uint32_t *p = s_pl + row * kRS64 + c4 * 2u;
 				const uint2 r = *reinterpret_cast<const uint2 *>(p), g = *reinterpret_cast<const uint2 *>(p + kPD64);
 				const uint2 b = *reinterpret_cast<const uint2 *>(p + 2 * kPD64);
-				const uint32_t opq = 0x00ff00ffu;
-				const uint32_t rg01 = __builtin_amdgcn_perm(g.x, r.x, 0x06020400u), ba01 = __builtin_amdgcn_perm(opq, b.x, 0x06020400u);
-				const uint32_t rg23 = __builtin_amdgcn_perm(g.y, r.y, 0x06020400u), ba23 = __builtin_amdgcn_perm(opq, b.y, 0x06020400u);
+				uint2 al = make_uint2(0x00ff00ffu, 0x00ff00ffu);
+				if constexpr (ALPHA) al = *reinterpret_cast<const uint2 *>(p + 3 * kPD64);
+				const uint32_t rg01 = __builtin_amdgcn_perm(g.x, r.x, 0x06020400u), ba01 = __builtin_amdgcn_perm(al.x, b.x, 0x06020400u);
+				const uint32_t rg23 = __builtin_amdgcn_perm(g.y, r.y, 0x06020400u), ba23 = __builtin_amdgcn_perm(al.y, b.y, 0x06020400u);
 				uint4 o;
 				o.x = __builtin_amdgcn_perm(ba01, rg01, 0x05040100u);
 				o.y = __builtin_amdgcn_perm(ba01, rg01, 0x07060302u);
@@ -2288,6 +2301,24 @@ __global__ void __launch_bounds__(256) shrink64_kernel(const Fast64Args a)
 			}
 			__syncthreads();
 			continue;
+		}
+		if constexpr (ALPHA) {
+			// fir, U8x4: premultiply this wave's 16 rows in place (every wave is past B2: nobody reads them for the
+			// detector any more, and both passes' first reads are of the wave's own rows).  mul_div_255 on both
+			// pixels of a dword: t = v*a + 128 <= 65153, t + (t >> 8) <= 65407 -- nothing leaves its 16-bit half
+#pragma unroll
+			for (uint32_t it = 0; it < 8; ++it) {
+				const uint32_t i = lane + 64u * it;
+				uint32_t *p = s_pl + (16u * wave + (i >> 5)) * kRS64 + (i & 31u);
+				const ushort2v al = us2(p[3 * kPD64]);
+#pragma unroll
+				for (uint32_t c = 0; c < 3; ++c) {
+					ushort2v t = us2(p[c * kPD64]) * al + (ushort2v)(128);
+					t = t + (t >> (ushort2v)(8));
+					p[c * kPD64] = u32(t >> (ushort2v)(8));
+				}
+			}
+			tile_sync<1>();
 		}
 		// ---- resample on the matrix cores: two passes, or one when an axis keeps its 64 samples
 		const uint32_t lx = m0 < (uint32_t)kMaxLevel ? m0 : (uint32_t)kMaxLevel - 1;
@@ -2314,7 +2345,7 @@ __global__ void __launch_bounds__(256) shrink64_kernel(const Fast64Args a)
 			}
 			const uint32_t *rowp = s_pl + (16u * wave + o) * kRS64 + 8u * g;
 #pragma unroll
-			for (uint32_t c = 0; c < 3; ++c) {
+			for (uint32_t c = 0; c < NCH; ++c) {
 				const uint4 d0 = *reinterpret_cast<const uint4 *>(rowp + c * kPD64);
 				const uint4 d1 = *reinterpret_cast<const uint4 *>(rowp + c * kPD64 + 4);
 				v4i32 av;
@@ -2348,8 +2379,9 @@ __global__ void __launch_bounds__(256) shrink64_kernel(const Fast64Args a)
 				const v4i32 khi = *reinterpret_cast<const v4i32 *>(my + mb * 512u + 256u + lane * 4u);
 				const v4i32 cy = *reinterpret_cast<const v4i32 *>(my_tail + 16u * mb + 4u * g);
 				uint32_t pix[4] = {0xff000000u, 0xff000000u, 0xff000000u, 0xff000000u};
+				if constexpr (ALPHA) pix[0] = pix[1] = pix[2] = pix[3] = 0u;
 #pragma unroll
-				for (uint32_t c = 0; c < 3; ++c) {
+				for (uint32_t c = 0; c < NCH; ++c) {
 					const uint4 tv = *reinterpret_cast<const uint4 *>(s_t + (c * 32u + 16u * nb + o) * kTS64 + 4u * g);
 					v4i32 bv;
 					bv[0] = (int)(tv.x ^ 0x80808080u);
@@ -2363,11 +2395,15 @@ __global__ void __launch_bounds__(256) shrink64_kernel(const Fast64Args a)
 						const uint32_t v = clamp_fixed(hi[r], lo[r], top_y);
 						if (c == 0) put_byte_shr<0>(pix[r], v, py);
 						else if (c == 1) put_byte_shr<1>(pix[r], v, py);
-						else put_byte_shr<2>(pix[r], v, py);
+						else if (c == 2) put_byte_shr<2>(pix[r], v, py);
+						else put_byte_shr<3>(pix[r], v, py);
 					}
 				}
 				const uint32_t oxl = 16u * nb + o;
-				if (!((through_h ? mx_tail[64] : 1u) & my_tail[64])) {
+				if constexpr (ALPHA) {
+#pragma unroll
+					for (int r = 0; r < 4; ++r) pix[r] = unpremultiply(pix[r]);
+				} else if (!((through_h ? mx_tail[64] : 1u) & my_tail[64])) {
 					// opaque tile: alpha is the convolution of the constant 255 = the windows' weight sums
 					const int32_t ah = through_h ? (int32_t)clip8((1 << (px_ - 1)) + 255 * (int32_t)mx_tail[32u + oxl], (int)px_) : 255;
 #pragma unroll
@@ -2396,7 +2432,7 @@ __global__ void __launch_bounds__(256) shrink64_kernel(const Fast64Args a)
 			for (uint32_t half = 0; half < 2; ++half) {
 				const uint32_t xl = lane & 31u, jj = lane >> 5;
 #pragma unroll
-				for (uint32_t c = 0; c < 3; ++c) {
+				for (uint32_t c = 0; c < NCH; ++c) {
 					const uint16_t *p16 = reinterpret_cast<const uint16_t *>(s_pl + c * kPD64) + 32u * half + xl;
 #pragma unroll
 					for (uint32_t it = 0; it < 2; ++it) {
@@ -2418,10 +2454,12 @@ __global__ void __launch_bounds__(256) shrink64_kernel(const Fast64Args a)
 			for (uint32_t i = threadIdx.x; i < nw * 16u; i += 256u) {
 				const uint32_t ox = i % nw, yq = i / nw;  // nw is a power of two here
 				const uint32_t r4 = s_t[(0u * 32u + ox) * kTS64 + yq], g4 = s_t[(1u * 32u + ox) * kTS64 + yq], b4 = s_t[(2u * 32u + ox) * kTS64 + yq];
-				uint32_t al = 255u;
-				if (!opaque_stays) al = clip8((1 << (px_ - 1)) + 255 * (int32_t)mx_tail[32u + ox], (int)px_);
+				uint32_t al = 255u, a4 = 0u;
+				if constexpr (ALPHA) a4 = s_t[(3u * 32u + ox) * kTS64 + yq];
+				else if (!opaque_stays) al = clip8((1 << (px_ - 1)) + 255 * (int32_t)mx_tail[32u + ox], (int)px_);
 #pragma unroll
 				for (uint32_t r = 0; r < 4; ++r) {
+					if constexpr (ALPHA) al = (a4 >> (8u * r)) & 255u;
 					uint32_t px = ((r4 >> (8u * r)) & 255u) | (((g4 >> (8u * r)) & 255u) << 8) | (((b4 >> (8u * r)) & 255u) << 16) | (al << 24);
 					if (al != 255u) px = unpremultiply(px);
 					reinterpret_cast<uint32_t *>(dst)[(4u * yq + r) * nw + ox] = px;
@@ -2431,6 +2469,7 @@ __global__ void __launch_bounds__(256) shrink64_kernel(const Fast64Args a)
 		}
 	}
 	list_flush(s_red + 16, n_listb, a.work + kWorkList, a.work + a.work_slot, threadIdx.x);
+	list_flush(s_red + 32, n_lista, a.work + kWorkList + a.n_tiles, a.work + kWorkA + a.work_slot, threadIdx.x);
 }
 
 // ---------------------------------------------------------------------------
@@ -2492,9 +2531,12 @@ __global__ void __launch_bounds__(NW == 1 ? 768 : 64 * NW) shrink_kernel(const S
 		}
 	} else {
 		// with a worklist (left by shrink64_kernel) only the listed tiles are processed
-		const uint32_t count = a.work ? __builtin_amdgcn_readfirstlane(a.work[a.work_slot]) : a.n_tiles;
+		const uint32_t count_b = a.work ? __builtin_amdgcn_readfirstlane(a.work[a.work_slot]) : a.n_tiles;
+		const uint32_t count_a = a.work ? __builtin_amdgcn_readfirstlane(a.work[kWorkA + a.work_slot]) : 0u;
+		const uint32_t count = count_b + (a.list_a_too ? count_a : 0u);
 		for (uint32_t i = blockIdx.x; i < count; i += gridDim.x) {
-			const uint32_t tile_g = a.work ? __builtin_amdgcn_readfirstlane(a.work[kWorkList + i]) : i;
+			uint32_t tile_g = i;
+			if (a.work) tile_g = __builtin_amdgcn_readfirstlane(a.work[kWorkList + (i < count_b ? i : a.n_tiles + (i - count_b))]);  // list B, then list A
 			process_tile<NW, C, MODE>(a, tile_g, lds, lds + a.tile_dw, threadIdx.x);
 			__syncthreads();
 		}
@@ -2512,6 +2554,7 @@ __global__ void __launch_bounds__(NW == 1 ? 768 : 64 * NW) shrink_kernel(const S
 				if (threadIdx.x == 0) {
 					a.work[a.work_slot ^ 1u] = 0u;
 					a.work[kWorkA + (a.work_slot ^ 1u)] = 0u;
+					if (a.stats) *a.stats = count_a;
 				}
 				if (threadIdx.x < kTicketCounters) a.work[2u + kTicketCounters * (a.work_slot ^ 1u) + threadIdx.x] = 0u;
 			}
@@ -3990,22 +4033,40 @@ hipError_t launch_shrink(const ShrinkArgs &a, uint32_t channels, uint32_t n_cus,
 			f.breaks[j] = a.breaks[0][j];
 		}
 		f.breaks_asc = a.breaks_asc[0];
-		const uint32_t lds_bytes = kLds64 * 4u;
+		const uint32_t lds_bytes = lds64_dwords(3) * 4u;
 		constexpr uint32_t kLds = 160u * 1024u;
 		const uint32_t per_cu = kLds / lds_bytes;
 		const uint32_t resident = n_cus * per_cu;
 		const uint32_t blocks = a.n_tiles < resident ? a.n_tiles : resident;
 		hipError_t e;
 		if (a.mode == 1) {
-			auto k = shrink64_kernel<1>;
+			auto k = shrink64_kernel<1, false>;
 			if (lds_bytes > 64u * 1024u && (e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)) != hipSuccess) return e;
 			hipLaunchKernelGGL(k, dim3(blocks), dim3(256), lds_bytes, stream, f);
 		} else {
-			auto k = shrink64_kernel<0>;
+			auto k = shrink64_kernel<0, false>;
 			if (lds_bytes > 64u * 1024u && (e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)) != hipSuccess) return e;
 			hipLaunchKernelGGL(k, dim3(blocks), dim3(256), lds_bytes, stream, f);
 		}
 		if ((e = hipGetLastError()) != hipSuccess) return e;
+		// full tiles with transparency are on list A: the four-plane instance takes it when transparency was
+		// announced or seen before, else the generic kernel walks it after list B
+		const bool run_alpha = a.out_px != nullptr && a.alpha_kernel != 0;
+		ga.list_a_too = a.out_px != nullptr && !run_alpha ? 1u : 0u;
+		if (run_alpha) {
+			const uint32_t lds_a = lds64_dwords(4) * 4u;
+			const uint32_t blocks_a = n_cus * (kLds / lds_a);
+			if (a.mode == 1) {
+				auto k = shrink64_kernel<1, true>;
+				if (lds_a > 64u * 1024u && (e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a)) != hipSuccess) return e;
+				hipLaunchKernelGGL(k, dim3(blocks_a), dim3(256), lds_a, stream, f);
+			} else {
+				auto k = shrink64_kernel<0, true>;
+				if (lds_a > 64u * 1024u && (e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a)) != hipSuccess) return e;
+				hipLaunchKernelGGL(k, dim3(blocks_a), dim3(256), lds_a, stream, f);
+			}
+			if ((e = hipGetLastError()) != hipSuccess) return e;
+		}
 	} else if (fast32_applicable(a, channels) || fast16_applicable(a, channels)) {
 		// 1) the lean kernel for full opaque tiles (32x32), or for 2x2 groups of them (16x16); it leaves the rest
 		// in the worklist

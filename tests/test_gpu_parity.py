@@ -589,6 +589,29 @@ def test_transparent_tiles_through_the_alpha_kernel(gpu, oracle, mode, factor, f
     assert len(seen) >= 3, seen
 
 
+@pytest.mark.parametrize("mode,factors", [(1, (64.0, 16.0, 4.0, 1.0)), (0, (3.0, 1.0, 0.3))])
+@pytest.mark.parametrize("filt", [1, 4])
+def test_transparent_64x64_tiles_through_the_alpha_instance(gpu, oracle, mode, factors, filt):
+    """64x64 tiles with alpha < 255 and PXZ_HINT_TRANSPARENCY: shrink64_kernel<MODE, true> (four planes, premultiply
+    after the detector, four channels through both matrix-core passes, un-premultiply), including its one-pass
+    classes and clones; un-hinted the generic kernel takes the same tiles from list A: same bits."""
+    frames = gpu.synth_frames_device(2, 280, 448, 4, first_frame=5, dist=1)
+    frames[1, :130, :130, 3] = 255     # some opaque tiles in between
+    frames[0, 64:128, 64:256, 3] = 0   # and fully transparent ones
+    f = frames.cpu().numpy()
+    seen = set()
+    for factor in factors:
+        for hint in (True, False):
+            vals, ow, oh, slots = gpu.shrink_frames_device(frames, 64, 64, mode, filt, factor, transparency_hint=hint)
+            for n in range(2):
+                exp = oracle.shrink_image(f[n], 64, 64, mode, filt, factor, nthreads=8)
+                got = (vals[n].cpu().numpy(), ow[n].cpu().numpy().astype(np.uint32), oh[n].cpu().numpy().astype(np.uint32),
+                       slots[n].cpu().numpy())
+                assert_same_tiles(got, exp, 4, f"hint {hint} mode {mode} k={factor} f{filt} frame {n}")
+                seen |= set(histogram(got[1], got[2]))
+    assert len(seen) >= 4, seen
+
+
 def _sweep_cases(n, seed):
     rng = np.random.default_rng(seed)
     sizes = [2, 3, 4, 6, 8, 12, 16, 20, 24, 32, 40, 48, 64, 80, 96]
