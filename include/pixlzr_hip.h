@@ -123,6 +123,18 @@ int pxz_shrink_image(pxz_handle *h, const uint8_t *pixels, uint32_t width, uint3
                      uint32_t mode, uint32_t filter, float factor,
                      float *block_value, uint32_t *out_w, uint32_t *out_h, uint8_t *out_pixels);
 
+/* The same call with the pixels as ONE tightly packed stream (tile order, each tile out_w*out_h*channels
+ * bytes) instead of fixed slots: what the reference keeps per block (PixlzrBlock's pixel Vec, block.rs) and
+ * a fraction of the slot array over PCIe.  Two steps so that the caller allocates exactly what comes back:
+ * pxz_shrink_image_packed runs the path, returns values and dimensions and *packed_len; the stream stays in
+ * the handle until pxz_fetch_packed copies it out (capacity >= packed_len) or the next call on the handle.
+ * Tile t starts at the sum of out_w*out_h*channels over the tiles before it. */
+int pxz_shrink_image_packed(pxz_handle *h, const uint8_t *pixels, uint32_t width, uint32_t height,
+                            uint32_t channels, uint32_t pitch_bytes, uint32_t block_w, uint32_t block_h,
+                            uint32_t mode, uint32_t filter, float factor,
+                            float *block_value, uint32_t *out_w, uint32_t *out_h, uint64_t *packed_len);
+int pxz_fetch_packed(pxz_handle *h, uint8_t *dst, uint64_t capacity);
+
 /* Same over a batch of device-resident frames: the measured path (frames come
  * from a GPU decoder / stay in HBM).  All pointers are device pointers; outputs
  * are frame-major: index = frame*tiles + tile; out_pixels slot stride as above.

@@ -16,7 +16,7 @@ DIST_OPAQUE, DIST_ALPHA, DIST_FLAT, DIST_NOISE = range(4)
 # every symbol include/pixlzr_hip.h declares
 EXPORTED_SYMBOLS = [
     "pxz_version", "pxz_device_count", "pxz_create", "pxz_destroy", "pxz_last_error", "pxz_set_stream",
-    "pxz_synchronize", "pxz_grid", "pxz_shrink_image", "pxz_shrink_frames_device", "pxz_lod_frames_device",
+    "pxz_synchronize", "pxz_grid", "pxz_shrink_image", "pxz_shrink_image_packed", "pxz_fetch_packed", "pxz_shrink_frames_device", "pxz_lod_frames_device",
     "pxz_pack_tiles_device", "pxz_encode_frames_device", "pxz_encode_container", "pxz_qoi_encode", "pxz_qoi_bound", "pxz_synth_frames_device", "pxz_axis_table",
     "pxz_enable_timing", "pxz_last_kernel_ms",
     "pxz_expand_frames_device", "pxz_expand_image", "pxz_decode_frames_device", "pxz_decode_file", "pxz_decode_status", "pxz_process_frames_device",
@@ -95,6 +95,10 @@ def load_library():
     L.pxz_grid.argtypes = [u32] * 4 + [C.POINTER(u32)] * 2
     L.pxz_shrink_image.restype = C.c_int
     L.pxz_shrink_image.argtypes = [vp, vp] + [u32] * 8 + [f32] + [vp] * 4
+    L.pxz_shrink_image_packed.restype = C.c_int
+    L.pxz_shrink_image_packed.argtypes = [vp, vp] + [u32] * 8 + [f32] + [vp] * 4
+    L.pxz_fetch_packed.restype = C.c_int
+    L.pxz_fetch_packed.argtypes = [vp, vp, C.c_uint64]
     L.pxz_shrink_frames_device.restype = C.c_int
     L.pxz_shrink_frames_device.argtypes = [vp, C.POINTER(Frames), C.POINTER(Params)] + [vp] * 5
     L.pxz_lod_frames_device.restype = C.c_int
@@ -245,6 +249,22 @@ class Handle:
         self._check(self._L.pxz_shrink_image(self._h, C.c_void_p(img.ctypes.data), W, H, Cc, img.strides[0], bw, bh,
                                              mode, filt, C.c_float(factor), _p(vals), _p(ow), _p(oh), _p(slots)))
         return vals, ow, oh, slots
+
+    def shrink_image_packed(self, img, bw, bh, mode, filt, factor):
+        """pxz_shrink_image_packed + pxz_fetch_packed: (values, w, h, stream) with the tiles' pixels back to back."""
+        H, W, Cc = img.shape
+        assert img.dtype == np.uint8 and img.strides[2] == 1 and img.strides[1] == Cc
+        cols, rows = grid(W, H, bw, bh)
+        n = cols * rows
+        vals = np.zeros(n, np.float32)
+        ow = np.zeros(n, np.uint32)
+        oh = np.zeros(n, np.uint32)
+        total = C.c_uint64(0)
+        self._check(self._L.pxz_shrink_image_packed(self._h, C.c_void_p(img.ctypes.data), W, H, Cc, img.strides[0], bw, bh,
+                                                    mode, filt, C.c_float(factor), _p(vals), _p(ow), _p(oh), C.byref(total)))
+        stream = np.empty(total.value, np.uint8)
+        self._check(self._L.pxz_fetch_packed(self._h, _p(stream), total.value))
+        return vals, ow, oh, stream
 
     # ---- device entry points ----
     @staticmethod

@@ -92,21 +92,28 @@ void Pixlzr::shrink_on_device(uint32_t mode, FilterType f, float factor, int dev
 				std::memcpy(image.data() + ((size_t)(ty * block_height + r) * width + (size_t)tx * block_width) * channels,
 				            b.data.data() + (size_t)r * b.width * channels, (size_t)b.width * channels);
 		}
-	const size_t slot = (size_t)block_width * block_height * channels;
 	std::vector<float> value(tiles);
 	std::vector<uint32_t> ow(tiles), oh(tiles);
-	std::vector<uint8_t> px(tiles * slot);
 	pxz_handle *h = g_handles.get(device_id);
-	const int rc = pxz_shrink_image(h, image.data(), width, height, channels, width * channels, block_width, block_height,
-	                                mode, (uint32_t)f, factor, value.data(), ow.data(), oh.data(), px.data());
-	if (rc != PXZ_OK) throw std::runtime_error(std::string("pxz_shrink_image: ") + pxz_last_error(h));
+	// the tiles' pixels come back as one tightly packed stream: only what the blocks keep crosses PCIe
+	uint64_t packed_len = 0;
+	int rc = pxz_shrink_image_packed(h, image.data(), width, height, channels, width * channels, block_width, block_height,
+	                                 mode, (uint32_t)f, factor, value.data(), ow.data(), oh.data(), &packed_len);
+	if (rc != PXZ_OK) throw std::runtime_error(std::string("pxz_shrink_image_packed: ") + pxz_last_error(h));
+	std::vector<uint8_t> px(packed_len);
+	rc = pxz_fetch_packed(h, px.data(), packed_len);
+	if (rc != PXZ_OK) throw std::runtime_error(std::string("pxz_fetch_packed: ") + pxz_last_error(h));
+	size_t at = 0;
 	for (size_t t = 0; t < tiles; ++t) {
+		const size_t n = (size_t)ow[t] * oh[t] * channels;
 		PixlzrBlock &b = blocks[t];
-		if (mode == PXZ_MODE_SHRINK_BY && b.block_value) continue;  // pixlzr.rs:168-170
-		b.width = ow[t];
-		b.height = oh[t];
-		b.block_value = value[t];  // operations.rs:154
-		b.data.assign(px.begin() + t * slot, px.begin() + t * slot + (size_t)ow[t] * oh[t] * channels);
+		if (!(mode == PXZ_MODE_SHRINK_BY && b.block_value)) {  // pixlzr.rs:168-170: a block with a value is kept
+			b.width = ow[t];
+			b.height = oh[t];
+			b.block_value = value[t];  // operations.rs:154
+			b.data.assign(px.begin() + at, px.begin() + at + n);
+		}
+		at += n;
 	}
 }
 

@@ -76,7 +76,8 @@ struct pxz_handle {
 	// level breakpoints per (mode, factor bits, bw, bh, edge_w, edge_h)
 	struct Breaks { uint32_t b[4][pxz::kMaxLevel]; uint32_t asc[4]; };
 	std::map<std::tuple<uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t>, Breaks> breaks;
-	DeviceBuffer in, val, ow, oh, out, sums, chunks, work, qscratch, qmeta, status, dmeta, okscratch, rgba, slots4;
+	DeviceBuffer in, val, ow, oh, out, sums, chunks, work, qscratch, qmeta, status, dmeta, okscratch, rgba, slots4, pk, pkoff;
+	uint64_t packed_len = 0;   // bytes of the stream pxz_shrink_image_packed left in `pk` (0: none)
 	std::map<std::tuple<uint32_t, uint32_t, uint32_t, uint32_t, uint32_t>, ExpandTables> expand_tables;
 	uint32_t *host_stats = nullptr;  // pinned, device-visible: [0] = tiles with transparency the last finished 32x32 launch saw
 	uint32_t *dev_stats = nullptr;   //   (its device-side address); read without synchronisation, steers only the kernel choice
@@ -642,6 +643,19 @@ int timed_launch(pxz_handle *h, pxz::ShrinkArgs &a, uint32_t channels, float *va
 
 }  // namespace
 
+namespace {
+// The pixels are here on the host: a sparse look at the alpha channel (one pixel in 61 per sampled row, every 7th
+// row) decides whether the kernels for transparent tiles are worth their launch (> 2 % of the samples).
+bool host_image_has_transparency(const uint8_t *pixels, uint32_t width, uint32_t height, uint32_t pitch_bytes)
+{
+	uint32_t seen = 0, looked = 0;
+	for (uint32_t y = 0; y < height; y += 7)
+		for (uint32_t x = (y * 13u) % 61u; x < width; x += 61, ++looked)
+			seen += pixels[(size_t)y * pitch_bytes + (size_t)x * 4u + 3u] != 255u;
+	return looked && seen * 50u > looked;
+}
+}  // namespace
+
 extern "C" {
 
 const char *pxz_version(void) { return "pixlzr-hip 0.1.0 (gfx950)"; }
@@ -1075,15 +1089,7 @@ int pxz_shrink_image(pxz_handle *h, const uint8_t *pixels, uint32_t width, uint3
 	pxz_params p{block_w, block_h, mode, filter, factor, 0};
 	int rc = check_frames(h, &f, &p);
 	if (rc != PXZ_OK) return rc;
-	if (channels == 4) {
-		// the pixels are here on the host: a sparse look at the alpha channel (one pixel in 61 per sampled row, every
-		// 7th row) decides whether the kernel for transparent tiles is worth its launch
-		uint32_t seen = 0, looked = 0;
-		for (uint32_t y = 0; y < height; y += 7)
-			for (uint32_t x = (y * 13u) % 61u; x < width; x += 61, ++looked)
-				seen += pixels[(size_t)y * pitch_bytes + (size_t)x * 4u + 3u] != 255u;
-		if (looked && seen * 50u > looked) p.reserved |= PXZ_HINT_TRANSPARENCY;  // > 2 % of the samples
-	}
+	if (channels == 4 && host_image_has_transparency(pixels, width, height, pitch_bytes)) p.reserved |= PXZ_HINT_TRANSPARENCY;
 	PXZ_HIP(h, hipSetDevice(h->device));
 	uint32_t cols, rows;
 	pxz_grid(width, height, block_w, block_h, &cols, &rows);
@@ -1103,6 +1109,65 @@ int pxz_shrink_image(pxz_handle *h, const uint8_t *pixels, uint32_t width, uint3
 	PXZ_HIP(h, hipMemcpyAsync(out_w, h->ow.ptr, tiles * 4, hipMemcpyDeviceToHost, h->stream));
 	PXZ_HIP(h, hipMemcpyAsync(out_h, h->oh.ptr, tiles * 4, hipMemcpyDeviceToHost, h->stream));
 	if (out_pixels) PXZ_HIP(h, hipMemcpyAsync(out_pixels, h->out.ptr, tiles * slot, hipMemcpyDeviceToHost, h->stream));
+	PXZ_HIP(h, hipStreamSynchronize(h->stream));
+	return PXZ_OK;
+}
+
+int pxz_shrink_image_packed(pxz_handle *h, const uint8_t *pixels, uint32_t width, uint32_t height, uint32_t channels,
+                            uint32_t pitch_bytes, uint32_t block_w, uint32_t block_h, uint32_t mode, uint32_t filter,
+                            float factor, float *block_value, uint32_t *out_w, uint32_t *out_h, uint64_t *packed_len)
+{
+	if (!h) return PXZ_ERR_INVALID_ARG;
+	h->packed_len = 0;
+	if (!pixels || !block_value || !out_w || !out_h || !packed_len) return fail(h, PXZ_ERR_INVALID_ARG, "null pointer");
+	*packed_len = 0;
+	pxz_frames f{width, height, channels, pitch_bytes, 1, 0, 0};
+	pxz_params p{block_w, block_h, mode, filter, factor, 0};
+	int rc = check_frames(h, &f, &p);
+	if (rc != PXZ_OK) return rc;
+	if (channels == 4 && host_image_has_transparency(pixels, width, height, pitch_bytes)) p.reserved |= PXZ_HINT_TRANSPARENCY;
+	PXZ_HIP(h, hipSetDevice(h->device));
+	uint32_t cols, rows;
+	pxz_grid(width, height, block_w, block_h, &cols, &rows);
+	const size_t tiles = (size_t)cols * rows;
+	const size_t in_bytes = (size_t)pitch_bytes * (height - 1) + (size_t)width * channels;
+	const size_t slot = (size_t)block_w * block_h * channels;
+	const size_t most = (size_t)width * height * channels;  // no tile grows
+	if ((rc = ensure(h, h->in, in_bytes)) != PXZ_OK) return rc;
+	if ((rc = ensure(h, h->val, tiles * 4)) != PXZ_OK) return rc;
+	if ((rc = ensure(h, h->ow, tiles * 4)) != PXZ_OK) return rc;
+	if ((rc = ensure(h, h->oh, tiles * 4)) != PXZ_OK) return rc;
+	if ((rc = ensure(h, h->out, tiles * slot)) != PXZ_OK) return rc;
+	if ((rc = ensure(h, h->pk, most)) != PXZ_OK) return rc;
+	if ((rc = ensure(h, h->pkoff, (tiles + 1) * 8)) != PXZ_OK) return rc;
+	PXZ_HIP(h, hipMemcpyAsync(h->in.ptr, pixels, in_bytes, hipMemcpyHostToDevice, h->stream));
+	rc = pxz_shrink_frames_device(h, &f, &p, (const uint8_t *)h->in.ptr, (float *)h->val.ptr, (uint32_t *)h->ow.ptr,
+	                              (uint32_t *)h->oh.ptr, (uint8_t *)h->out.ptr);
+	if (rc != PXZ_OK) return rc;
+	rc = pxz_pack_tiles_device(h, (uint32_t)tiles, channels, (uint32_t)slot, (const uint32_t *)h->ow.ptr, (const uint32_t *)h->oh.ptr,
+	                           (const uint8_t *)h->out.ptr, (uint64_t *)h->pkoff.ptr, (uint8_t *)h->pk.ptr, most);
+	if (rc != PXZ_OK) return rc;
+	uint64_t total = 0;
+	PXZ_HIP(h, hipMemcpyAsync(block_value, h->val.ptr, tiles * 4, hipMemcpyDeviceToHost, h->stream));
+	PXZ_HIP(h, hipMemcpyAsync(out_w, h->ow.ptr, tiles * 4, hipMemcpyDeviceToHost, h->stream));
+	PXZ_HIP(h, hipMemcpyAsync(out_h, h->oh.ptr, tiles * 4, hipMemcpyDeviceToHost, h->stream));
+	PXZ_HIP(h, hipMemcpyAsync(&total, (const uint64_t *)h->pkoff.ptr + tiles, 8, hipMemcpyDeviceToHost, h->stream));
+	PXZ_HIP(h, hipStreamSynchronize(h->stream));
+	if (total > most) return fail(h, PXZ_ERR_HIP, "packed stream longer than the image (%llu > %zu)", (unsigned long long)total, most);
+	h->packed_len = total;
+	*packed_len = total;
+	return PXZ_OK;
+}
+
+int pxz_fetch_packed(pxz_handle *h, uint8_t *dst, uint64_t capacity)
+{
+	if (!h) return PXZ_ERR_INVALID_ARG;
+	if (!dst && h->packed_len != 0) return fail(h, PXZ_ERR_INVALID_ARG, "null pointer");
+	if (capacity < h->packed_len) return fail(h, PXZ_ERR_INVALID_ARG, "capacity %llu < packed length %llu",
+	                                          (unsigned long long)capacity, (unsigned long long)h->packed_len);
+	if (h->packed_len == 0) return PXZ_OK;
+	PXZ_HIP(h, hipSetDevice(h->device));
+	PXZ_HIP(h, hipMemcpyAsync(dst, h->pk.ptr, h->packed_len, hipMemcpyDeviceToHost, h->stream));
 	PXZ_HIP(h, hipStreamSynchronize(h->stream));
 	return PXZ_OK;
 }

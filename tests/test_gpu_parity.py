@@ -612,6 +612,25 @@ def test_transparent_64x64_tiles_through_the_alpha_instance(gpu, oracle, mode, f
     assert len(seen) >= 4, seen
 
 
+@pytest.mark.parametrize("w,h,bs,c,mode,factor", [(640, 360, 32, 4, 1, 8.0), (333, 217, 64, 3, 0, 0.5), (100, 75, 16, 4, 1, 2.0)])
+def test_packed_host_boundary_equals_the_slots(gpu, oracle, w, h, bs, c, mode, factor):
+    """pxz_shrink_image_packed + pxz_fetch_packed: same values and dimensions as pxz_shrink_image, and the stream is
+    the tiles' valid bytes back to back in tile order (= the oracle's payloads)."""
+    img = oracle.synth_frame(w, h, c, 9, 1 if c == 4 else 0)
+    vals, ow, oh, slots = gpu.shrink_image(img, bs, bs, mode, 4, factor)
+    pv, pw, ph, stream = gpu.shrink_image_packed(img, bs, bs, mode, 4, factor)
+    assert (pv.view(np.uint32) == vals.view(np.uint32)).all() and (pw == ow).all() and (ph == oh).all()
+    exp = oracle.shrink_image(img, bs, bs, mode, 4, factor)
+    sizes = ow.astype(np.int64) * oh * c
+    assert stream.size == int(sizes.sum())
+    expect = np.concatenate([exp[3][t, :n] for t, n in enumerate(sizes.tolist())])
+    assert (stream == expect).all()
+    # capacity check of the second step
+    with pytest.raises(Exception) as e:
+        gpu._check(gpu._L.pxz_fetch_packed(gpu._h, stream.ctypes.data, stream.size - 1))
+    assert getattr(e.value, "code", None) == -1
+
+
 def _sweep_cases(n, seed):
     rng = np.random.default_rng(seed)
     sizes = [2, 3, 4, 6, 8, 12, 16, 20, 24, 32, 40, 48, 64, 80, 96]
