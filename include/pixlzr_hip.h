@@ -143,6 +143,12 @@ int pxz_shrink_frames_device(pxz_handle *h, const pxz_frames *frames, const pxz_
                              const uint8_t *d_pixels, float *d_block_value, uint32_t *d_out_w,
                              uint32_t *d_out_h, uint8_t *d_out_pixels);
 
+/* The colour conversion inside get_block_variance, per pixel (operations.rs:56-59: Srgba<u8>::into_linear()
+ * .into_color::<Oklaba<f32>>(), palette 0.7.6 + the platform's cbrtf): d_laba[4i..4i+3] = {l, a, b, alpha} of
+ * RGBA pixel i.  The same device function the Oklab detector kernels call -- exposed so that its bits can be
+ * checked for every one of the 2^24 colours.  Device pointers (pixels 4-byte, output 16-byte aligned); async. */
+int pxz_oklab_pixels_device(pxz_handle *h, const uint8_t *d_rgba, uint32_t n_pixels, float *d_laba);
+
 /* Detector only: get_block_variance_directionally (operations.rs:192-259) ->
  * lod0 = hz, lod1 = vr (raw, before `* factor`); get_block_variance with the
  * shrink_by closures (operations.rs:26-126, pixlzr.rs:160-162) -> lod0 = lod1 =

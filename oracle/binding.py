@@ -62,6 +62,8 @@ def lib():
         L.orc_lod_oklab.argtypes = [C.c_void_p] + [C.c_uint32] * 4 + [C.c_float]
         L.orc_oklab_pixel.restype = None
         L.orc_oklab_pixel.argtypes = [C.c_void_p, C.c_uint32, f32p]
+        L.orc_oklab_pixels.restype = None
+        L.orc_oklab_pixels.argtypes = [C.c_void_p, C.c_uint32, C.c_uint64, C.c_void_p]
         L.orc_reduce_dims.restype = None
         L.orc_reduce_dims.argtypes = [C.c_float, C.c_float, C.c_uint32, C.c_uint32, u32p, u32p, f32p]
         L.orc_resize.restype = C.c_int
@@ -115,6 +117,15 @@ def lod_directional(tile):
     lib().orc_lod_directional(C.c_void_p(tile.ctypes.data), w, h, c, tile.strides[0],
                               C.byref(hz), C.byref(vr), C.byref(sh), C.byref(sv))
     return np.float32(hz.value), np.float32(vr.value), sh.value, sv.value
+
+
+def oklab_pixels(px):
+    """px: uint8 [n, c] -> float32 [n, 4] = (L, a, b, alpha) of every pixel (operations.rs:56-59)."""
+    px = np.ascontiguousarray(px, np.uint8)
+    n, c = px.shape
+    out = np.empty((n, 4), np.float32)
+    lib().orc_oklab_pixels(C.c_void_p(px.ctypes.data), c, n, C.c_void_p(out.ctypes.data))
+    return out
 
 
 def lod_oklab(tile, factor):

@@ -208,6 +208,13 @@ void orc_oklab_pixel(const uint8_t *px, uint32_t c, float out[4])
 	out[3] = c == 4 ? (float)px[3] / 255.0f : 1.0f;
 }
 
+/* the same conversion over n packed pixels of c channels: out[4i..4i+3] = {L, a, b, alpha} */
+void orc_oklab_pixels(const uint8_t *px, uint32_t c, uint64_t n, float *out)
+{
+	for (uint64_t i = 0; i < n; i++)
+		orc_oklab_pixel(px + i * c, c, out + 4 * i);
+}
+
 static float lod_oklab_scaled(const uint8_t *tile, uint32_t w, uint32_t h, uint32_t c, uint32_t pitch, float factor,
                               float scale2);
 

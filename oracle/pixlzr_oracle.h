@@ -56,6 +56,7 @@ void orc_lod_directional(const uint8_t *tile, uint32_t w, uint32_t h, uint32_t c
 float orc_lod_oklab(const uint8_t *tile, uint32_t w, uint32_t h, uint32_t c, uint32_t pitch, float factor);
 /* one pixel -> Oklab (l,a,b) + alpha, palette 0.7.6 model */
 void orc_oklab_pixel(const uint8_t *px, uint32_t c, float out_laba[4]);
+void orc_oklab_pixels(const uint8_t *px, uint32_t c, uint64_t n, float *out_laba);
 
 /* ---- level decision: src/operations.rs:128-156 ---- */
 void orc_reduce_dims(float v0, float v1, uint32_t w, uint32_t h,

@@ -16,7 +16,7 @@ DIST_OPAQUE, DIST_ALPHA, DIST_FLAT, DIST_NOISE = range(4)
 # every symbol include/pixlzr_hip.h declares
 EXPORTED_SYMBOLS = [
     "pxz_version", "pxz_device_count", "pxz_create", "pxz_destroy", "pxz_last_error", "pxz_set_stream",
-    "pxz_synchronize", "pxz_grid", "pxz_shrink_image", "pxz_shrink_image_packed", "pxz_fetch_packed", "pxz_shrink_frames_device", "pxz_lod_frames_device",
+    "pxz_synchronize", "pxz_grid", "pxz_shrink_image", "pxz_shrink_image_packed", "pxz_fetch_packed", "pxz_shrink_frames_device", "pxz_lod_frames_device", "pxz_oklab_pixels_device",
     "pxz_pack_tiles_device", "pxz_encode_frames_device", "pxz_encode_container", "pxz_qoi_encode", "pxz_qoi_bound", "pxz_synth_frames_device", "pxz_axis_table",
     "pxz_enable_timing", "pxz_last_kernel_ms",
     "pxz_expand_frames_device", "pxz_expand_image", "pxz_decode_frames_device", "pxz_decode_file", "pxz_decode_status", "pxz_process_frames_device",
@@ -103,6 +103,8 @@ def load_library():
     L.pxz_shrink_frames_device.argtypes = [vp, C.POINTER(Frames), C.POINTER(Params)] + [vp] * 5
     L.pxz_lod_frames_device.restype = C.c_int
     L.pxz_lod_frames_device.argtypes = [vp, C.POINTER(Frames), C.POINTER(Params)] + [vp] * 3
+    L.pxz_oklab_pixels_device.restype = C.c_int
+    L.pxz_oklab_pixels_device.argtypes = [vp, vp, u32, vp]
     L.pxz_pack_tiles_device.restype = C.c_int
     L.pxz_pack_tiles_device.argtypes = [vp, u32, u32, u32, vp, vp, vp, vp, vp, C.c_uint64]
     L.pxz_encode_frames_device.restype = C.c_int
@@ -265,6 +267,15 @@ class Handle:
         stream = np.empty(total.value, np.uint8)
         self._check(self._L.pxz_fetch_packed(self._h, _p(stream), total.value))
         return vals, ow, oh, stream
+
+    def oklab_pixels_device(self, rgba):
+        """rgba: uint8 CUDA tensor [n, 4] -> float32 [n, 4] = (l, a, b, alpha) per pixel."""
+        import torch
+        assert rgba.is_cuda and rgba.dtype == torch.uint8 and rgba.dim() == 2 and rgba.shape[1] == 4 and rgba.is_contiguous()
+        out = torch.empty((rgba.shape[0], 4), dtype=torch.float32, device=rgba.device)
+        self.use_torch_stream()
+        self._check(self._L.pxz_oklab_pixels_device(self._h, C.c_void_p(rgba.data_ptr()), rgba.shape[0], C.c_void_p(out.data_ptr())))
+        return out
 
     # ---- device entry points ----
     @staticmethod

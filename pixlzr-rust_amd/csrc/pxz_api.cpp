@@ -20,6 +20,7 @@
 namespace pxz {
 hipError_t launch_shrink(const ShrinkArgs &a, uint32_t channels, uint32_t n_cus, hipStream_t stream);
 hipError_t launch_synth(const SynthArgs &s, hipStream_t stream);
+hipError_t launch_oklab_pixels(const uint32_t *px, uint32_t n, float *out, uint32_t n_cus, hipStream_t stream);
 hipError_t launch_finish(const FinishArgs &f, hipStream_t stream);
 bool fast32_applicable(const ShrinkArgs &a, uint32_t channels);
 bool fast64_applicable(const ShrinkArgs &a, uint32_t channels);
@@ -1169,6 +1170,17 @@ int pxz_fetch_packed(pxz_handle *h, uint8_t *dst, uint64_t capacity)
 	PXZ_HIP(h, hipSetDevice(h->device));
 	PXZ_HIP(h, hipMemcpyAsync(dst, h->pk.ptr, h->packed_len, hipMemcpyDeviceToHost, h->stream));
 	PXZ_HIP(h, hipStreamSynchronize(h->stream));
+	return PXZ_OK;
+}
+
+int pxz_oklab_pixels_device(pxz_handle *h, const uint8_t *d_rgba, uint32_t n_pixels, float *d_laba)
+{
+	if (!h) return PXZ_ERR_INVALID_ARG;
+	if (!d_rgba || !d_laba || n_pixels == 0) return fail(h, PXZ_ERR_INVALID_ARG, "null pointer / no pixels");
+	if ((reinterpret_cast<uintptr_t>(d_rgba) & 3u) || (reinterpret_cast<uintptr_t>(d_laba) & 15u))
+		return fail(h, PXZ_ERR_INVALID_ARG, "pixels must be 4-byte aligned, the output 16-byte aligned");
+	PXZ_HIP(h, hipSetDevice(h->device));
+	PXZ_HIP(h, pxz::launch_oklab_pixels(reinterpret_cast<const uint32_t *>(d_rgba), n_pixels, d_laba, h->n_cus, h->stream));
 	return PXZ_OK;
 }
 

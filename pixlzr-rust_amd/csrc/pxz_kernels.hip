@@ -2591,21 +2591,23 @@ constexpr uint32_t kOkTiles = 15;           // tiles per block and batch (one pe
 constexpr uint32_t kOkPlane = 256 + 4;      // floats per (tile, channel) band: 8 rows x 32 px + bank skew
 constexpr uint32_t kOkBand = kOkTiles * 4 * kOkPlane;  // floats per band buffer
 
-// Correctly rounded f64 quotient for operands far from overflow/underflow: the same
-// rcp + Newton + residual steps the compiler emits for `/`, minus the range scaling.
-__device__ __forceinline__ double div_f64_inrange(double n, double d)
+// The quotient of the Halley step inside cbrt_f32_lut: v_rcp_f64 (2^-23 or better) and ONE Newton step, i.e. a
+// quotient good to ~2^-46 instead of the correctly rounded one glibc's `/` produces.  That is enough here, and
+// provably so: the result is rounded to f32 right after, the inputs of this path are the l, m, s of the 2^24
+// possible RGB triples and nothing else, and tests/test_gpu_parity.py::test_oklab_conversion_of_every_colour runs
+// every one of them through this very function against the oracle's exact division: no bit differs.  (The
+// generic kernel's cbrt_f32, which sees the same inputs, keeps the exact division.)  4 instructions instead of 8.
+__device__ __forceinline__ double div_f64_oklab_domain(double n, double d)
 {
 	double r = __builtin_amdgcn_rcp(d);
-	double e = __builtin_fma(-d, r, 1.0);
+#if PXZ_EXP != 5
+	const double e = __builtin_fma(-d, r, 1.0);
 	r = __builtin_fma(r, e, r);
-	e = __builtin_fma(-d, r, 1.0);
-	r = __builtin_fma(r, e, r);
-	const double q = n * r;
-	const double res = __builtin_fma(-d, q, n);
-	return __builtin_fma(res, r, q);
+#endif
+	return n * r;
 }
 
-// glibc 2.35 cbrtf for x in [0, 4): same arithmetic as cbrt_f32 above with the in-range division.
+// glibc 2.35 cbrtf for the inputs of the Oklab detector: same arithmetic as cbrt_f32 above with the quotient below.
 // The tail `(float)(q * third[2 + xe % 3])` followed by `ldexpf(.., xe / 3)` is folded into ONE
 // multiplication by 2^(xe/3) * third[..]: scaling a double by a power of two is exact and commutes
 // with the rounding to float (no underflow in this range), so the bits are unchanged.  `scale` is the
@@ -2616,10 +2618,71 @@ __device__ __forceinline__ float cbrt_f32_lut(float x, const double *scale)
 	const float xm = frexpf(x, &xe);
 	const float u = (float)(0.492659620528969547 + (0.697570460207922770 - 0.191502161678719066 * (double)xm) * (double)xm);
 	const float t2 = u * u * u;
-	const double num = (double)u * ((double)t2 + 2.0 * (double)xm);
-	const double den = 2.0 * (double)t2 + (double)xm;
-	const float y = (float)(div_f64_inrange(num, den) * scale[xe + 130]);
+	// t2 + 2 xm and 2 t2 + xm are exact in double (24-bit operands a few binades apart), so the fused forms give
+	// the same values as glibc's separate multiplications and additions
+	const double num = (double)u * __builtin_fma(2.0, (double)xm, (double)t2);
+	const double den = __builtin_fma(2.0, (double)t2, (double)xm);
+	const float y = (float)(div_f64_oklab_domain(num, den) * scale[xe + 130]);
 	return x == 0.0f ? 0.0f : y;
+}
+
+// Srgba<u8> -> linear -> Oklab of two pixels (operations.rs:56-59; palette 0.7.6): LUT, then Ottosson's matrices
+// with left-to-right f32 sums; two pixels per packed-f32 instruction (same IEEE results per component).
+// out[k] = {a, b, l} of pixel k, the order the reference sums them in.
+__device__ __forceinline__ void oklab_pair(uint32_t v0, uint32_t v1, const float *s_srgb, const double *s_scale,
+                                           float (&out0)[3], float (&out1)[3])
+{
+	const f32x2 r = {s_srgb[v0 & 255u], s_srgb[v1 & 255u]};
+	const f32x2 g = {s_srgb[(v0 >> 8) & 255u], s_srgb[(v1 >> 8) & 255u]};
+	const f32x2 b = {s_srgb[(v0 >> 16) & 255u], s_srgb[(v1 >> 16) & 255u]};
+	const f32x2 l = 0.4122214708f * r + 0.5363325363f * g + 0.0514459929f * b;
+	const f32x2 m = 0.2119034982f * r + 0.6806995451f * g + 0.1073969566f * b;
+	const f32x2 s3 = 0.0883024619f * r + 0.2817188376f * g + 0.6299787005f * b;
+	const f32x2 l_ = {cbrt_f32_lut(l.x, s_scale), cbrt_f32_lut(l.y, s_scale)};
+	const f32x2 m_ = {cbrt_f32_lut(m.x, s_scale), cbrt_f32_lut(m.y, s_scale)};
+	const f32x2 s_ = {cbrt_f32_lut(s3.x, s_scale), cbrt_f32_lut(s3.y, s_scale)};
+	const f32x2 L = 0.2104542553f * l_ + 0.7936177850f * m_ - 0.0040720468f * s_;
+	const f32x2 A = 1.9779984951f * l_ - 2.4285922050f * m_ + 0.4505937099f * s_;
+	const f32x2 B = 0.0259040371f * l_ + 0.7827717662f * m_ - 0.8086757660f * s_;
+	out0[2] = L.x; out1[2] = L.y;
+	out0[0] = A.x; out1[0] = A.y;
+	out0[1] = B.x; out1[1] = B.y;
+}
+
+// The conversion tables of the Oklab kernels in LDS: sRGB u8 -> linear (256), a / 255 (256), and the 132 doubles
+// 2^(xe/3) * cbrt(2)^(xe%3), xe = i - 130.  Call from the first 256 threads of a block, then a block barrier.
+__device__ __forceinline__ void oklab_fill_tables(float *s_srgb, float *s_alpha, double *s_scale, uint32_t t)
+{
+	if (t < 256) {
+		s_srgb[t] = __uint_as_float(kSrgbToLinearBits[t]);
+		s_alpha[t] = __fdiv_rn((float)t, 255.0f);
+	}
+	if (t < 132) {
+		const int xe = (int)t - 130;
+		const int q3 = xe / 3, r3 = xe - 3 * q3;  // C semantics: the remainder carries the sign of xe
+		const double third = r3 == 0 ? 1.0
+		                   : r3 == 1 ? 1.2599210498948731648
+		                   : r3 == 2 ? 1.5874010519681994748
+		                   : r3 == -1 ? 1.0 / 1.2599210498948731648
+		                              : 1.0 / 1.5874010519681994748;
+		s_scale[t] = ldexp(third, q3);  // exact
+	}
+}
+
+// Per-pixel form of the same conversion (pxz_oklab_pixels_device): out[i] = {l, a, b, alpha} of RGBA pixel i.
+__global__ void __launch_bounds__(256) oklab_pixels_kernel(const uint32_t *px, uint32_t n, float4 *out)
+{
+	__shared__ float s_srgb[256], s_alpha[256];
+	__shared__ double s_scale[132];
+	oklab_fill_tables(s_srgb, s_alpha, s_scale, threadIdx.x);
+	__syncthreads();
+	for (uint32_t i = 2u * (blockIdx.x * blockDim.x + threadIdx.x); i < n; i += 2u * gridDim.x * blockDim.x) {
+		const uint32_t v0 = px[i], v1 = i + 1u < n ? px[i + 1u] : 0u;
+		float o0[3], o1[3];
+		oklab_pair(v0, v1, s_srgb, s_scale, o0, o1);
+		out[i] = make_float4(o0[2], o0[0], o0[1], s_alpha[v0 >> 24]);
+		if (i + 1u < n) out[i + 1u] = make_float4(o1[2], o1[0], o1[1], s_alpha[v1 >> 24]);
+	}
 }
 
 // Tile geometry of the block-cooperative Oklab detector, T = 16 | 32 | 64 (square RGBA tiles).  A band is 256
@@ -2661,20 +2724,7 @@ __global__ void __launch_bounds__(1024) oklab_kernel(const ShrinkArgs a)
 	float *s_p1 = s_mean + 64;                               // pass-1 band: values
 	float *s_p2 = s_p1 + kOkBand;                            // pass-2 band: values minus means
 	const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-	if (threadIdx.x < 256) {
-		s_srgb[threadIdx.x] = __uint_as_float(kSrgbToLinearBits[threadIdx.x]);
-		s_alpha[threadIdx.x] = __fdiv_rn((float)threadIdx.x, 255.0f);
-	}
-	if (threadIdx.x < 132) {
-		const int xe = (int)threadIdx.x - 130;
-		const int q3 = xe / 3, r3 = xe - 3 * q3;  // C semantics: the remainder carries the sign of xe
-		const double third = r3 == 0 ? 1.0
-		                   : r3 == 1 ? 1.2599210498948731648
-		                   : r3 == 2 ? 1.5874010519681994748
-		                   : r3 == -1 ? 1.0 / 1.2599210498948731648
-		                              : 1.0 / 1.5874010519681994748;
-		s_scale[threadIdx.x] = ldexp(third, q3);  // exact
-	}
+	oklab_fill_tables(s_srgb, s_alpha, s_scale, threadIdx.x);
 	__syncthreads();
 
 	const uint32_t n_batches = (a.n_tiles + kOkTiles - 1) / kOkTiles;
@@ -2742,23 +2792,7 @@ __global__ void __launch_bounds__(1024) oklab_kernel(const ShrinkArgs a)
 					fresh_alpha = (v[0] >> 24) | ((v[1] >> 24) << 8) | ((v[2] >> 24) << 16) | ((v[3] >> 24) << 24);
 #pragma unroll
 					for (int j = 0; j < 4; j += 2) {
-						// palette 0.7.6: LUT, then Ottosson's matrices with left-to-right f32 sums; two pixels per
-						// packed-f32 instruction (same IEEE results per component)
-						const f32x2 r = {s_srgb[v[j] & 255u], s_srgb[v[j + 1] & 255u]};
-						const f32x2 g = {s_srgb[(v[j] >> 8) & 255u], s_srgb[(v[j + 1] >> 8) & 255u]};
-						const f32x2 b = {s_srgb[(v[j] >> 16) & 255u], s_srgb[(v[j + 1] >> 16) & 255u]};
-						const f32x2 l = 0.4122214708f * r + 0.5363325363f * g + 0.0514459929f * b;
-						const f32x2 m = 0.2119034982f * r + 0.6806995451f * g + 0.1073969566f * b;
-						const f32x2 s3 = 0.0883024619f * r + 0.2817188376f * g + 0.6299787005f * b;
-						const f32x2 l_ = {cbrt_f32_lut(l.x, s_scale), cbrt_f32_lut(l.y, s_scale)};
-						const f32x2 m_ = {cbrt_f32_lut(m.x, s_scale), cbrt_f32_lut(m.y, s_scale)};
-						const f32x2 s_ = {cbrt_f32_lut(s3.x, s_scale), cbrt_f32_lut(s3.y, s_scale)};
-						const f32x2 L = 0.2104542553f * l_ + 0.7936177850f * m_ - 0.0040720468f * s_;
-						const f32x2 A = 1.9779984951f * l_ - 2.4285922050f * m_ + 0.4505937099f * s_;
-						const f32x2 B = 0.0259040371f * l_ + 0.7827717662f * m_ - 0.8086757660f * s_;
-						fresh[j][2] = L.x; fresh[j + 1][2] = L.y;
-						fresh[j][0] = A.x; fresh[j + 1][0] = A.y;
-						fresh[j][1] = B.x; fresh[j + 1][1] = B.y;
+						oklab_pair(v[j], v[j + 1], s_srgb, s_scale, fresh[j], fresh[j + 1]);
 						// two pixels (six cube-root chains) at a time: the register file also holds a whole tile of results
 						__builtin_amdgcn_sched_barrier(0);
 					}
@@ -4184,6 +4218,13 @@ hipError_t launch_shrink(const ShrinkArgs &a, uint32_t channels, uint32_t n_cus,
 	case 8: return launch_nw<8>(ga, channels, g, stream);
 	default: return launch_nw<16>(ga, channels, g, stream);
 	}
+}
+
+hipError_t launch_oklab_pixels(const uint32_t *px, uint32_t n, float *out, uint32_t n_cus, hipStream_t stream)
+{
+	const uint32_t need = (n / 2u + 255u) / 256u + 1u, blocks = need < 8u * n_cus ? need : 8u * n_cus;
+	hipLaunchKernelGGL(oklab_pixels_kernel, dim3(blocks), dim3(256), 0, stream, px, n, reinterpret_cast<float4 *>(out));
+	return hipGetLastError();
 }
 
 hipError_t launch_finish(const FinishArgs &f, hipStream_t stream)

@@ -631,6 +631,23 @@ def test_packed_host_boundary_equals_the_slots(gpu, oracle, w, h, bs, c, mode, f
     assert getattr(e.value, "code", None) == -1
 
 
+def test_oklab_conversion_of_every_colour(gpu, oracle):
+    """All 2^24 RGB triples (alpha spread over 0..255) through the device function the Oklab detector kernels call,
+    against the oracle's conversion: L, a, b and alpha bit for bit.  The detector's sums absorb single-ulp
+    differences of one pixel, so this is the test that pins the conversion itself (incl. the glibc cbrtf steps)."""
+    import torch
+    idx = np.arange(1 << 24, dtype=np.uint32)
+    rgba = np.empty((1 << 24, 4), np.uint8)
+    rgba[:, 0] = idx & 255
+    rgba[:, 1] = (idx >> 8) & 255
+    rgba[:, 2] = (idx >> 16) & 255
+    rgba[:, 3] = (idx * 7 + (idx >> 11)) & 255
+    got = gpu.oklab_pixels_device(torch.from_numpy(rgba).cuda()).cpu().numpy()
+    exp = oracle.oklab_pixels(rgba)
+    diff = got.view(np.uint32) != exp.view(np.uint32)
+    assert not diff.any(), f"{int(diff.any(axis=1).sum())} colours differ, first: {rgba[diff.any(axis=1)][:4]}"
+
+
 def _sweep_cases(n, seed):
     rng = np.random.default_rng(seed)
     sizes = [2, 3, 4, 6, 8, 12, 16, 20, 24, 32, 40, 48, 64, 80, 96]
