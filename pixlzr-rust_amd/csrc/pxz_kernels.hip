@@ -2600,10 +2600,8 @@ constexpr uint32_t kOkBand = kOkTiles * 4 * kOkPlane;  // floats per band buffer
 __device__ __forceinline__ double div_f64_oklab_domain(double n, double d)
 {
 	double r = __builtin_amdgcn_rcp(d);
-#if PXZ_EXP != 5
 	const double e = __builtin_fma(-d, r, 1.0);
 	r = __builtin_fma(r, e, r);
-#endif
 	return n * r;
 }
 
@@ -2612,18 +2610,42 @@ __device__ __forceinline__ double div_f64_oklab_domain(double n, double d)
 // multiplication by 2^(xe/3) * third[..]: scaling a double by a power of two is exact and commutes
 // with the rounding to float (no underflow in this range), so the bits are unchanged.  `scale` is the
 // LDS table of those 132 doubles indexed by xe + 130 (xe in [-130, 1]).
+template <bool ZERO_CHECK = true>
 __device__ __forceinline__ float cbrt_f32_lut(float x, const double *scale)
 {
 	int xe;
 	const float xm = frexpf(x, &xe);
-	const float u = (float)(0.492659620528969547 + (0.697570460207922770 - 0.191502161678719066 * (double)xm) * (double)xm);
+	// glibc: (float)(0.4926.. + (0.6975.. - 0.1915.. * xm) * xm) with separate double operations.  The fused form
+	// differs from it by at most a few 2^-53 before the rounding to float, and for none of this path's inputs
+	// does that cross a rounding boundary (same exhaustive test as for the quotient below).
+	const float u = (float)__builtin_fma(__builtin_fma(-0.191502161678719066, (double)xm, 0.697570460207922770), (double)xm, 0.492659620528969547);
 	const float t2 = u * u * u;
 	// t2 + 2 xm and 2 t2 + xm are exact in double (24-bit operands a few binades apart), so the fused forms give
 	// the same values as glibc's separate multiplications and additions
 	const double num = (double)u * __builtin_fma(2.0, (double)xm, (double)t2);
 	const double den = __builtin_fma(2.0, (double)t2, (double)xm);
 	const float y = (float)(div_f64_oklab_domain(num, den) * scale[xe + 130]);
+	if constexpr (!ZERO_CHECK) return y;  // (x == 0 is the caller's business)
 	return x == 0.0f ? 0.0f : y;
+}
+
+// byte BYTE of v, times 4: the byte offset of a 256-entry f32 table row, in one SDWA shift
+template <int BYTE>
+__device__ __forceinline__ uint32_t byte_times4(uint32_t v)
+{
+	uint32_t r;
+	const uint32_t two = 2u;
+	if constexpr (BYTE == 0)
+		asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(r) : "v"(two), "v"(v));
+	else if constexpr (BYTE == 1)
+		asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(r) : "v"(two), "v"(v));
+	else
+		asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(r) : "v"(two), "v"(v));
+	return r;
+}
+__device__ __forceinline__ float table_at(const float *table, uint32_t byte_offset)
+{
+	return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(table) + byte_offset);
 }
 
 // Srgba<u8> -> linear -> Oklab of two pixels (operations.rs:56-59; palette 0.7.6): LUT, then Ottosson's matrices
@@ -2632,21 +2654,24 @@ __device__ __forceinline__ float cbrt_f32_lut(float x, const double *scale)
 __device__ __forceinline__ void oklab_pair(uint32_t v0, uint32_t v1, const float *s_srgb, const double *s_scale,
                                            float (&out0)[3], float (&out1)[3])
 {
-	const f32x2 r = {s_srgb[v0 & 255u], s_srgb[v1 & 255u]};
-	const f32x2 g = {s_srgb[(v0 >> 8) & 255u], s_srgb[(v1 >> 8) & 255u]};
-	const f32x2 b = {s_srgb[(v0 >> 16) & 255u], s_srgb[(v1 >> 16) & 255u]};
+	const f32x2 r = {table_at(s_srgb, byte_times4<0>(v0)), table_at(s_srgb, byte_times4<0>(v1))};
+	const f32x2 g = {table_at(s_srgb, byte_times4<1>(v0)), table_at(s_srgb, byte_times4<1>(v1))};
+	const f32x2 b = {table_at(s_srgb, byte_times4<2>(v0)), table_at(s_srgb, byte_times4<2>(v1))};
 	const f32x2 l = 0.4122214708f * r + 0.5363325363f * g + 0.0514459929f * b;
 	const f32x2 m = 0.2119034982f * r + 0.6806995451f * g + 0.1073969566f * b;
 	const f32x2 s3 = 0.0883024619f * r + 0.2817188376f * g + 0.6299787005f * b;
-	const f32x2 l_ = {cbrt_f32_lut(l.x, s_scale), cbrt_f32_lut(l.y, s_scale)};
-	const f32x2 m_ = {cbrt_f32_lut(m.x, s_scale), cbrt_f32_lut(m.y, s_scale)};
-	const f32x2 s_ = {cbrt_f32_lut(s3.x, s_scale), cbrt_f32_lut(s3.y, s_scale)};
+	// l, m, s are zero only for black (every coefficient is positive, the table is zero at 0 only), and then all
+	// three are: one test per pixel on the colour bytes instead of one per cube root
+	const f32x2 l_ = {cbrt_f32_lut<false>(l.x, s_scale), cbrt_f32_lut<false>(l.y, s_scale)};
+	const f32x2 m_ = {cbrt_f32_lut<false>(m.x, s_scale), cbrt_f32_lut<false>(m.y, s_scale)};
+	const f32x2 s_ = {cbrt_f32_lut<false>(s3.x, s_scale), cbrt_f32_lut<false>(s3.y, s_scale)};
 	const f32x2 L = 0.2104542553f * l_ + 0.7936177850f * m_ - 0.0040720468f * s_;
 	const f32x2 A = 1.9779984951f * l_ - 2.4285922050f * m_ + 0.4505937099f * s_;
 	const f32x2 B = 0.0259040371f * l_ + 0.7827717662f * m_ - 0.8086757660f * s_;
-	out0[2] = L.x; out1[2] = L.y;
-	out0[0] = A.x; out1[0] = A.y;
-	out0[1] = B.x; out1[1] = B.y;
+	const bool black0 = (v0 & 0x00ffffffu) == 0u, black1 = (v1 & 0x00ffffffu) == 0u;  // cbrt(0) = 0 -> L = a = b = +0
+	out0[2] = black0 ? 0.0f : L.x; out1[2] = black1 ? 0.0f : L.y;
+	out0[0] = black0 ? 0.0f : A.x; out1[0] = black1 ? 0.0f : A.y;
+	out0[1] = black0 ? 0.0f : B.x; out1[1] = black1 ? 0.0f : B.y;
 }
 
 // The conversion tables of the Oklab kernels in LDS: sRGB u8 -> linear (256), a / 255 (256), and the 132 doubles
