@@ -276,7 +276,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": r["achieved_gbps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": r["achieved_gbps"] / HBM_PEAK_GBPS, "traffic": load_traffic(primary),
                          "kernel_ms": r["kernel_ms"], "algorithmic_bytes_per_launch": r["algo_bytes_per_launch"],
-                         "kernel": "pxz::shrink32_kernel<1>" if primary == "shrink_directionally" else "pxz::oklab_kernel<32> + pxz::shrink32_kernel<0>"},
+                         "kernel": "pxz::shrink32_kernel<1, true>" if primary == "shrink_directionally" else "pxz::oklab_kernel<32> + pxz::shrink32_kernel<0, true>"},
             "modes": {k: {kk: v[kk] for kk in ("ms_per_step", "mp_per_s_per_gpu", "kernel_ms", "achieved_gbps",
                                                 "algo_bytes_per_launch", "histogram")} for k, v in results.items()},
         }

@@ -1314,7 +1314,9 @@ __device__ __forceinline__ void list_push(uint32_t *buf, uint32_t &cnt, uint32_t
 // each, next tile's pixels prefetched into registers, table rows in LDS, lookups in kernarg.
 // MODE 1: directional detector here; MODE 0: value already in sums[] (oklab_kernel).
 // ---------------------------------------------------------------------------
-template <int MODE>
+// FULL: out_px, out_w and out_h are all there (the shrink entry points): no run-time tests of them in the loop --
+// kept as loop-invariant lane masks they cost scalar registers, and a spilled one two v_readlane per use.
+template <int MODE, bool FULL>
 __global__ void __launch_bounds__(1024) shrink32_kernel(const Fast32Args a)
 {
 	extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
@@ -1444,7 +1446,7 @@ __global__ void __launch_bounds__(1024) shrink32_kernel(const Fast32Args a)
 		}
 		PXZ_STAMP(0);  // wait for the prefetched pixels + staging
 		fast32_prefetch(a, tile_next, tid, pre, pre_valid);  // lands while this tile is processed
-		if (transparent && a.out_px != nullptr) {
+		if (transparent && (FULL || a.out_px != nullptr)) {
 			// transparency: the premultiplied convolution needs the alpha plane -- shrink32a_kernel (list A) when the
 			// caller announced transparent frames, else the generic kernel (list B).  (Detector-only launches do not
 			// care: the detector never looks at alpha.)
@@ -1462,6 +1464,7 @@ __global__ void __launch_bounds__(1024) shrink32_kernel(const Fast32Args a)
 
 		// ---- detector + level decision
 		uint32_t m0, m1;
+		uint32_t key0 = 0, key1 = 0;
 		if constexpr (MODE == 1) {
 			uint32_t sum_hz = 0, sum_vr = 0;
 			// 16 lanes (pixel pairs) per row group, 4 groups of 8 window rows (the last one 6).  Per
@@ -1469,6 +1472,12 @@ __global__ void __launch_bounds__(1024) shrink32_kernel(const Fast32Args a)
 			// c = t(y)+t(y+1) (2 adds), the neighbour pair's c by DPP, |vr| (sad).  Fully unrolled:
 			// every LDS address is a per-channel base + immediate, no loop-carried register moves.
 			const uint32_t q = tid & 15u, g = tid >> 4;
+			// (compared afresh where it is used: hoisted out of the tile loop the lane mask would sit in two scalar
+			// registers, and those are spilled -- two v_readlane per use instead of one v_cmp)
+			auto last_rows = [](uint32_t grp) -> bool {
+				asm volatile("" : "+v"(grp));
+				return grp != 3u;
+			};
 			const uint32_t two = 0x00020002u;
 			const uint32_t *pc[3];
 			pc[0] = s_pl + g * (8u * kRS32) + q;
@@ -1485,7 +1494,7 @@ __global__ void __launch_bounds__(1024) shrink32_kernel(const Fast32Args a)
 			}
 #pragma unroll
 			for (int st = 0; st < 4; ++st) {
-				if (st < 3 || g != 3u) {  // the last group has 6 window rows = 3 steps
+				if (st < 3 || last_rows(g)) {  // the last group has 6 window rows = 3 steps
 #pragma unroll
 					for (int c = 0; c < 3; ++c) {
 						const uint32_t *pr = pc[c] + (2 + 2 * st) * (int)kRS32;
@@ -1512,23 +1521,31 @@ __global__ void __launch_bounds__(1024) shrink32_kernel(const Fast32Args a)
 			sum_vr = wave_sum_sgpr(sum_vr);
 			m0 = level_of(sum_hz);
 			m1 = level_of(sum_vr);
-			if (tid == 0) reinterpret_cast<uint2 *>(a.sums)[tile_g] = make_uint2(sum_hz, sum_vr);
+			key0 = sum_hz;
+			key1 = sum_vr;
 		} else {
 			const uint32_t vb = __builtin_amdgcn_readfirstlane(given_bits);
 			m0 = m1 = level_of(__float_as_uint(parse_value(__uint_as_float(vb))));
 		}
 		const uint32_t nw = reduced_size(32u, m0), nh = reduced_size(32u, m1);
-		if (tid == 0) {
-			if (a.out_w) a.out_w[tile_g] = nw;
-			if (a.out_h) a.out_h[tile_g] = nh;
+		{
+			uint32_t lane = tid;
+			asm volatile("" : "+v"(lane));  // (as above: a fresh compare instead of a spilled lane mask)
+			if (lane == 0) {
+				if constexpr (MODE == 1) reinterpret_cast<uint2 *>(a.sums)[tile_g] = make_uint2(key0, key1);
+				if (FULL || a.out_w) a.out_w[tile_g] = nw;
+				if (FULL || a.out_h) a.out_h[tile_g] = nh;
+			}
 		}
 		PXZ_STAMP(2);  // detector + reduction + level decision + metadata
-		if (a.out_px != nullptr) {
+		if (FULL || a.out_px != nullptr) {
+			uint32_t filt = a.filter;
+			asm volatile("" : "+s"(filt));  // a scalar compare per use, not a hoisted (and spilled) mask
 			pend_dst = a.out_px + (size_t)tile_g * 4096u;
 			pend_px = nw * nh;
 			if (nw == 32u && nh == 32u) {
 				pend_kind = 2;  // the planes themselves, re-interleaved by the flush
-			} else if (nw != 32u && nh != 32u && a.filter != 0) {
+			} else if (nw != 32u && nh != 32u && filt != 0) {
 				const uint32_t lx = m0 < (uint32_t)kMaxLevel ? m0 : (uint32_t)kMaxLevel - 1;
 				const uint32_t ly = m1 < (uint32_t)kMaxLevel ? m1 : (uint32_t)kMaxLevel - 1;
 				if (a.tabs[lx].mf_off != 0 && a.tabs[ly].mf_off != 0 && nw >= 4u && nh >= 4u) {
@@ -1544,7 +1561,7 @@ __global__ void __launch_bounds__(1024) shrink32_kernel(const Fast32Args a)
 				} else {
 					defer();  // 16 x (2|1): its transposed planes would not fit the 16-waves-per-CU LDS image
 				}
-			} else if (a.filter == 0) {
+			} else if (filt == 0) {
 				// ResizeAlg::Nearest (mod.rs:277): source index = floor((o + 0.5) * 2^m), no alpha handling
 				const uint32_t lgx = 31u - (uint32_t)__builtin_clz(nw);
 				const uint32_t hx = m0 ? (1u << (m0 < 6u ? m0 - 1u : 4u)) : 0u, hy = m1 ? (1u << (m1 < 6u ? m1 - 1u : 4u)) : 0u;
@@ -4201,12 +4218,10 @@ hipError_t launch_shrink(const ShrinkArgs &a, uint32_t channels, uint32_t n_cus,
 				if (lds_bytes > 64u * 1024u && (e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)) != hipSuccess) return e;
 				hipLaunchKernelGGL(k, dim3(blocks), dim3(64u * wpb), lds_bytes, stream, f);
 			}
-		} else if (a.mode == 1) {
-			auto k = shrink32_kernel<1>;
-			if (lds_bytes > 64u * 1024u && (e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)) != hipSuccess) return e;
-			hipLaunchKernelGGL(k, dim3(blocks), dim3(64u * wpb), lds_bytes, stream, f);
 		} else {
-			auto k = shrink32_kernel<0>;
+			const bool full = a.out_px != nullptr && a.out_w != nullptr && a.out_h != nullptr;
+			void (*k)(const Fast32Args) = a.mode == 1 ? (full ? shrink32_kernel<1, true> : shrink32_kernel<1, false>)
+			                                          : (full ? shrink32_kernel<0, true> : shrink32_kernel<0, false>);
 			if (lds_bytes > 64u * 1024u && (e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)) != hipSuccess) return e;
 			hipLaunchKernelGGL(k, dim3(blocks), dim3(64u * wpb), lds_bytes, stream, f);
 		}
