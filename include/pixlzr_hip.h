@@ -265,9 +265,13 @@ int pxz_axis_table(uint32_t in_size, uint32_t out_size, uint32_t filter,
 
 /* Average device time (milliseconds) of the kernels launched by the last
  * *_device call on this handle, measured with HIP events on the handle's
- * stream; blocks until that work is done.  Enabled by pxz_enable_timing(h,1). */
+ * stream; blocks until that work is done.  Enabled by pxz_enable_timing(h, 1); pxz_enable_timing(h, n) with
+ * n > 1 brackets every n-th step only (three event records cost a 0.27 ms step about 2 %). */
 int pxz_enable_timing(pxz_handle *h, int on);
 int pxz_last_kernel_ms(pxz_handle *h, float *ms);
+/* The same average for the FIRST kernel of each step alone (shrink32/64/16_kernel; oklab_kernel in shrink_by
+ * steps): the figure a per-kernel profile shows for it.  Call before pxz_last_kernel_ms, which resets the record. */
+int pxz_last_first_kernel_ms(pxz_handle *h, float *ms);
 
 #ifdef __cplusplus
 }

@@ -18,7 +18,7 @@ EXPORTED_SYMBOLS = [
     "pxz_version", "pxz_device_count", "pxz_create", "pxz_destroy", "pxz_last_error", "pxz_set_stream",
     "pxz_synchronize", "pxz_grid", "pxz_shrink_image", "pxz_shrink_image_packed", "pxz_fetch_packed", "pxz_shrink_frames_device", "pxz_lod_frames_device", "pxz_oklab_pixels_device",
     "pxz_pack_tiles_device", "pxz_encode_frames_device", "pxz_encode_container", "pxz_qoi_encode", "pxz_qoi_bound", "pxz_synth_frames_device", "pxz_axis_table",
-    "pxz_enable_timing", "pxz_last_kernel_ms",
+    "pxz_enable_timing", "pxz_last_kernel_ms", "pxz_last_first_kernel_ms",
     "pxz_expand_frames_device", "pxz_expand_image", "pxz_decode_frames_device", "pxz_decode_file", "pxz_decode_status", "pxz_process_frames_device",
 ]
 
@@ -133,6 +133,8 @@ def load_library():
     L.pxz_axis_table.argtypes = [u32] * 3 + [vp] * 3 + [C.POINTER(C.c_int32)] * 2
     L.pxz_enable_timing.restype = C.c_int
     L.pxz_enable_timing.argtypes = [vp, C.c_int]
+    L.pxz_last_first_kernel_ms.restype = C.c_int
+    L.pxz_last_first_kernel_ms.argtypes = [vp, C.POINTER(f32)]
     L.pxz_last_kernel_ms.restype = C.c_int
     L.pxz_last_kernel_ms.argtypes = [vp, C.POINTER(f32)]
     _lib = L
@@ -230,8 +232,14 @@ class Handle:
     def synchronize(self):
         self._check(self._L.pxz_synchronize(self._h))
 
-    def enable_timing(self, on=True):
-        self._check(self._L.pxz_enable_timing(self._h, 1 if on else 0))
+    def enable_timing(self, on=True, every=1):
+        """every = n > 1: only every n-th step is bracketed by events."""
+        self._check(self._L.pxz_enable_timing(self._h, (max(int(every), 1) if on else 0)))
+
+    def last_first_kernel_ms(self):
+        ms = C.c_float()
+        self._check(self._L.pxz_last_first_kernel_ms(self._h, C.byref(ms)))
+        return ms.value
 
     def last_kernel_ms(self):
         ms = C.c_float()

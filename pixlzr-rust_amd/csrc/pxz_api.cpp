@@ -85,7 +85,9 @@ struct pxz_handle {
 	bool work_ready = false;   // both worklist counters are zero / consistent with work_slot
 	uint32_t work_slot = 0;    // the counter the next 32x32 launch uses
 	bool timing = false;
+	uint32_t timing_stride = 1, timing_count = 0;  // every stride-th step is bracketed by events
 	std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+	std::vector<hipEvent_t> mid_events;  // one per pair: behind the first kernel of the step
 	size_t events_used = 0;
 };
 
@@ -588,17 +590,23 @@ int timed_launch(pxz_handle *h, pxz::ShrinkArgs &a, uint32_t channels, float *va
 	}
 	const pxz::FinishArgs fin{a.sums, value, lod0, lod1, a.n_tiles, a.tiles_per_frame, a.cols, a.rows,
 	                          a.bw, a.bh, a.edge_w, a.edge_h, a.mode, a.factor};
-	hipEvent_t e0 = nullptr, e1 = nullptr;
-	if (h->timing) {
+	hipEvent_t e0 = nullptr, e1 = nullptr, emid = nullptr;
+	a.mid_event = nullptr;
+	const bool record = h->timing && (h->timing_count++ % h->timing_stride) == 0;
+	if (record) {
 		if (h->events_used == h->events.size()) {
 			PXZ_HIP(h, hipEventCreate(&e0));
 			PXZ_HIP(h, hipEventCreate(&e1));
+			PXZ_HIP(h, hipEventCreate(&emid));
 			h->events.emplace_back(e0, e1);
+			h->mid_events.push_back(emid);
 		}
 		e0 = h->events[h->events_used].first;
 		e1 = h->events[h->events_used].second;
+		emid = h->mid_events[h->events_used];
 		++h->events_used;
 		PXZ_HIP(h, hipEventRecord(e0, h->stream));
+		a.mid_event = emid;  // recorded behind the first kernel of the step (pxz_last_first_kernel_ms)
 	}
 	// shrink_by on the headline geometry: the block-cooperative Oklab detector first, then the
 	// fused kernel only stages + resamples (it still runs the generic detector on ragged-edge tiles)
@@ -612,6 +620,10 @@ int timed_launch(pxz_handle *h, pxz::ShrinkArgs &a, uint32_t channels, float *va
 		}
 		a.oklab_given = 1;
 		PXZ_HIP(h, pxz::launch_oklab(a, h->n_cus, h->stream));
+		if (a.mid_event) {
+			PXZ_HIP(h, hipEventRecord(static_cast<hipEvent_t>(a.mid_event), h->stream));
+			a.mid_event = nullptr;
+		}
 	}
 	// 32x32 RGBA flow: shrink32_kernel, then the worklist kernel, which also finishes every tile and
 	// zeroes the worklist counter of the next launch (two counters, used alternately)
@@ -632,13 +644,14 @@ int timed_launch(pxz_handle *h, pxz::ShrinkArgs &a, uint32_t channels, float *va
 		a.work_slot = h->work_slot;
 	}
 	PXZ_HIP(h, pxz::launch_shrink(a, channels, h->n_cus, h->stream));
+	if (!fast && a.mid_event) PXZ_HIP(h, hipEventRecord(static_cast<hipEvent_t>(a.mid_event), h->stream));  // the generic kernel is the step
 	if (fast) {
 		h->work_slot ^= 1u;
 		h->work_ready = true;
 	} else {
 		PXZ_HIP(h, pxz::launch_finish(fin, h->stream));
 	}
-	if (h->timing) PXZ_HIP(h, hipEventRecord(e1, h->stream));
+	if (record) PXZ_HIP(h, hipEventRecord(e1, h->stream));
 	return PXZ_OK;
 }
 
@@ -718,12 +731,13 @@ void pxz_destroy(pxz_handle *h)
 		(void)hipFree(kv.second.d_sizes);
 		(void)hipFree(kv.second.d_coeffs);
 	}
-	for (DeviceBuffer *b : {&h->in, &h->val, &h->ow, &h->oh, &h->out, &h->sums, &h->chunks, &h->work, &h->qscratch, &h->qmeta, &h->status, &h->dmeta, &h->okscratch, &h->rgba, &h->slots4})
+	for (DeviceBuffer *b : {&h->in, &h->val, &h->ow, &h->oh, &h->out, &h->sums, &h->chunks, &h->work, &h->qscratch, &h->qmeta, &h->status, &h->dmeta, &h->okscratch, &h->rgba, &h->slots4, &h->pk, &h->pkoff})
 		if (b->ptr) (void)hipFree(b->ptr);
 	for (auto &ev : h->events) {
 		(void)hipEventDestroy(ev.first);
 		(void)hipEventDestroy(ev.second);
 	}
+	for (hipEvent_t ev : h->mid_events) (void)hipEventDestroy(ev);
 	if (h->host_stats) {
 		(void)hipDeviceSynchronize();  // a queued launch may still write it
 		(void)hipHostFree(h->host_stats);
@@ -1307,6 +1321,8 @@ int pxz_enable_timing(pxz_handle *h, int on)
 {
 	if (!h) return PXZ_ERR_INVALID_ARG;
 	h->timing = on != 0;
+	h->timing_stride = on > 1 ? (uint32_t)on : 1u;  // on = n > 1: every n-th step only (an event costs ~2 us of stream time)
+	h->timing_count = 0;
 	h->events_used = 0;
 	return PXZ_OK;
 }
@@ -1325,6 +1341,23 @@ int pxz_last_kernel_ms(pxz_handle *h, float *ms)
 	}
 	*ms = (float)(total / (double)h->events_used);
 	h->events_used = 0;
+	return PXZ_OK;
+}
+
+// the same for the FIRST kernel of each recorded step alone (shrink32/64/16_kernel, or oklab_kernel in shrink_by
+// steps): what a per-kernel profile shows for it.  Call before pxz_last_kernel_ms (which resets the record).
+int pxz_last_first_kernel_ms(pxz_handle *h, float *ms)
+{
+	if (!h || !ms) return PXZ_ERR_INVALID_ARG;
+	if (!h->timing || h->events_used == 0) return fail(h, PXZ_ERR_INVALID_ARG, "no timed launches recorded");
+	PXZ_HIP(h, hipEventSynchronize(h->events[h->events_used - 1].second));
+	double total = 0.0;
+	for (size_t i = 0; i < h->events_used; ++i) {
+		float t = 0.f;
+		PXZ_HIP(h, hipEventElapsedTime(&t, h->events[i].first, h->mid_events[i]));
+		total += t;
+	}
+	*ms = (float)(total / (double)h->events_used);
 	return PXZ_OK;
 }
 

@@ -77,6 +77,7 @@ struct ShrinkArgs {
 	                                //   (full size, 16-byte aligned rows; 0/0 when the batch is not aligned)
 	uint32_t alpha_kernel;   // frames with transparency announced (pxz_params.reserved bit 0) or seen by the last launch
 	uint32_t list_a_too;     // worklist kernel: list A (full tiles with transparency) was not taken by shrink32a_kernel
+	void *mid_event;         // host side only: hipEvent_t to record behind the first kernel of the step, or null
 	uint32_t *stats;         // pinned host dword (device address) <- number of list-A tiles of this launch; may be null
 	uint32_t *work;          // worklist: [work_slot] = count, [2..] = tile ids (null: all tiles).  The two
 	uint32_t work_slot;      //   counters alternate between launches; a launch zeroes the other one

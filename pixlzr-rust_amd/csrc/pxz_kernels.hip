@@ -4125,6 +4125,8 @@ hipError_t launch_shrink(const ShrinkArgs &a, uint32_t channels, uint32_t n_cus,
 			hipLaunchKernelGGL(k, dim3(blocks), dim3(256), lds_bytes, stream, f);
 		}
 		if ((e = hipGetLastError()) != hipSuccess) return e;
+		if (a.mid_event && (e = hipEventRecord(static_cast<hipEvent_t>(a.mid_event), stream)) != hipSuccess) return e;
+		ga.mid_event = nullptr;
 		// full tiles with transparency are on list A: the four-plane instance takes it when transparency was
 		// announced or seen before, else the generic kernel walks it after list B
 		const bool run_alpha = a.out_px != nullptr && a.alpha_kernel != 0;
@@ -4226,6 +4228,8 @@ hipError_t launch_shrink(const ShrinkArgs &a, uint32_t channels, uint32_t n_cus,
 			hipLaunchKernelGGL(k, dim3(blocks), dim3(64u * wpb), lds_bytes, stream, f);
 		}
 		if ((e = hipGetLastError()) != hipSuccess) return e;
+		if (a.mid_event && (e = hipEventRecord(static_cast<hipEvent_t>(a.mid_event), stream)) != hipSuccess) return e;
+		ga.mid_event = nullptr;
 		if (run_alpha) {
 			// 1b) the full tiles with transparency that shrink32_kernel listed: four planes, no output region
 			Fast32Args fa = f;
