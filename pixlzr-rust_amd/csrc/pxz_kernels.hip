@@ -1818,7 +1818,8 @@ __global__ void __launch_bounds__(1024) shrink32a_kernel(const Fast32Args a)
 // tile, tiles with transparency and the one-pass classes (16 x n, n x 16) go to the worklist.
 // MODE 1: directional detector here; MODE 0: values already in sums[] (oklab_kernel<16>).
 // ---------------------------------------------------------------------------
-template <int MODE>
+// FULL: as in shrink32_kernel (all three output arrays are there; no run-time tests of them in the loop).
+template <int MODE, bool FULL>
 __global__ void __launch_bounds__(1024) shrink16_kernel(const Fast32Args a)
 {
 	extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
@@ -2011,20 +2012,26 @@ __global__ void __launch_bounds__(1024) shrink16_kernel(const Fast32Args a)
 			nh[k] = reduced_size(16u, m1[k]);
 		}
 		// ---- per tile: metadata, then clone / nearest / two-pass resample straight into its slot
+		uint32_t filt = a.filter;
+		asm volatile("" : "+s"(filt));  // scalar compares per use instead of a hoisted mask
 #pragma unroll
 		for (uint32_t k = 0; k < 4; ++k) {
 			const uint32_t t = tile_id(k);
-			const bool one_pass = a.out_px != nullptr && (nw[k] == 16u) != (nh[k] == 16u) && a.filter != 0;
+			const bool one_pass = (FULL || a.out_px != nullptr) && (nw[k] == 16u) != (nh[k] == 16u) && filt != 0;
 			if (one_pass) {  // 16 x n, n x 16: generic kernel (it writes the tile's metadata itself)
 				defer_tile(t);
 				continue;
 			}
-			if (tid == 0) {
-				reinterpret_cast<uint2 *>(a.sums)[t] = make_uint2(key0[k], key1[k]);
-				if (a.out_w) a.out_w[t] = nw[k];
-				if (a.out_h) a.out_h[t] = nh[k];
+			{
+				uint32_t lane = tid;
+				asm volatile("" : "+v"(lane));  // a fresh compare, not a hoisted (and spilled) lane mask
+				if (lane == 0) {
+					reinterpret_cast<uint2 *>(a.sums)[t] = make_uint2(key0[k], key1[k]);
+					if (FULL || a.out_w) a.out_w[t] = nw[k];
+					if (FULL || a.out_h) a.out_h[t] = nh[k];
+				}
 			}
-			if (a.out_px == nullptr) continue;
+			if (!FULL && a.out_px == nullptr) continue;
 			uint32_t *dst = reinterpret_cast<uint32_t *>(a.out_px + (size_t)t * 1024u);
 			const uint32_t *tile_pl = s_pl + (16u * (k >> 1)) * kRS32 + 8u * (k & 1u);  // first pixel pair of the tile
 			if (nw[k] == 16u && nh[k] == 16u) {
@@ -2042,7 +2049,7 @@ __global__ void __launch_bounds__(1024) shrink16_kernel(const Fast32Args a)
 				o.z = __builtin_amdgcn_perm(ba23, rg23, 0x05040100u);
 				o.w = __builtin_amdgcn_perm(ba23, rg23, 0x07060302u);
 				reinterpret_cast<uint4 *>(dst)[tid] = o;
-			} else if (a.filter == 0) {
+			} else if (filt == 0) {
 				// ResizeAlg::Nearest: source index = floor((o + 0.5) * 2^m); any (nw, nh)
 				const uint32_t mx = m0[k], my = m1[k];
 				const uint32_t lgx = 31u - (uint32_t)__builtin_clz(nw[k]);
@@ -4211,15 +4218,11 @@ hipError_t launch_shrink(const ShrinkArgs &a, uint32_t channels, uint32_t n_cus,
 		if (const char *e = getenv("PXZ_CHUNK_LG")) f.chunk_lg = (uint32_t)atoi(e) & 15u;
 		hipError_t e = hipSuccess;  // the worklist counter of this launch was zeroed by the previous one (or at allocation)
 		if (groups16) {
-			if (a.mode == 1) {
-				auto k = shrink16_kernel<1>;
-				if (lds_bytes > 64u * 1024u && (e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)) != hipSuccess) return e;
-				hipLaunchKernelGGL(k, dim3(blocks), dim3(64u * wpb), lds_bytes, stream, f);
-			} else {
-				auto k = shrink16_kernel<0>;
-				if (lds_bytes > 64u * 1024u && (e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)) != hipSuccess) return e;
-				hipLaunchKernelGGL(k, dim3(blocks), dim3(64u * wpb), lds_bytes, stream, f);
-			}
+			const bool full = a.out_px != nullptr && a.out_w != nullptr && a.out_h != nullptr;
+			void (*k)(const Fast32Args) = a.mode == 1 ? (full ? shrink16_kernel<1, true> : shrink16_kernel<1, false>)
+			                                          : (full ? shrink16_kernel<0, true> : shrink16_kernel<0, false>);
+			if (lds_bytes > 64u * 1024u && (e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)) != hipSuccess) return e;
+			hipLaunchKernelGGL(k, dim3(blocks), dim3(64u * wpb), lds_bytes, stream, f);
 		} else {
 			const bool full = a.out_px != nullptr && a.out_w != nullptr && a.out_h != nullptr;
 			void (*k)(const Fast32Args) = a.mode == 1 ? (full ? shrink32_kernel<1, true> : shrink32_kernel<1, false>)
