@@ -2105,7 +2105,8 @@ __device__ __forceinline__ bool fast64_tile_src(const Args &a, uint32_t tile_g, 
 // ALPHA: the full tiles WITH transparency the opaque kernel put on list A -- a fourth plane keeps the alpha
 // channel, the colours are premultiplied in place once the detector is done with them (fir's U8x4 path), all
 // four planes go through the passes and every output pixel is un-premultiplied.
-template <int MODE, bool ALPHA>
+// FULL: as in shrink32_kernel (out_px, out_w, out_h all there: no run-time tests of them in the tile loop).
+template <int MODE, bool ALPHA, bool FULL>
 __global__ void __launch_bounds__(256) shrink64_kernel(const Fast64Args a)
 {
 	constexpr uint32_t NCH = ALPHA ? 4u : 3u;
@@ -2153,7 +2154,7 @@ __global__ void __launch_bounds__(256) shrink64_kernel(const Fast64Args a)
 	prefetch(tile_g);
 	// detector-only launches: equal cost per tile, and an iteration is shorter than an atomic's round trip:
 	// there the "tickets" are simply this block's turn in a fixed rotation
-	const bool dynamic = !ALPHA && a.out_px != nullptr;
+	const bool dynamic = !ALPHA && (FULL || a.out_px != nullptr);
 	uint32_t turn = blockIdx.x / n_ctr;
 	uint32_t n_listb = 0, n_lista = 0;  // pending list-B entries in s_red[16..31], list-A entries in s_red[32..47]
 	for (; tile_g < a.n_tiles;) {
@@ -2211,7 +2212,7 @@ __global__ void __launch_bounds__(256) shrink64_kernel(const Fast64Args a)
 		if (lane == 0) s_red[8 + wave] = wave_transparent ? 1u : 0u;
 		prefetch(tile_next);  // lands while this tile is processed
 		__syncthreads();      // B1: the whole tile is staged
-		if (!ALPHA && a.out_px != nullptr && (s_red[8] | s_red[9] | s_red[10] | s_red[11]) != 0u) {
+		if (!ALPHA && (FULL || a.out_px != nullptr) && (s_red[8] | s_red[9] | s_red[10] | s_red[11]) != 0u) {
 			// transparency: the premultiplied convolution needs the alpha plane -- list A (the ALPHA instance of this
 			// kernel, or the generic kernel when that one is not launched).  Detector-only launches do not care.
 			list_push(s_red + 32, n_lista, tile_g, a.work + kWorkList + a.n_tiles, a.work + kWorkA + a.work_slot, threadIdx.x);
@@ -2295,10 +2296,10 @@ __global__ void __launch_bounds__(256) shrink64_kernel(const Fast64Args a)
 		const uint32_t nw = reduced_size(64u, m0), nh = reduced_size(64u, m1);
 		if (threadIdx.x == 0) {
 			reinterpret_cast<uint2 *>(a.sums)[this_tile] = make_uint2(sum_hz, sum_vr);
-			if (a.out_w) a.out_w[this_tile] = nw;
-			if (a.out_h) a.out_h[this_tile] = nh;
+			if (FULL || a.out_w) a.out_w[this_tile] = nw;
+			if (FULL || a.out_h) a.out_h[this_tile] = nh;
 		}
-		if (a.out_px == nullptr) {
+		if (!FULL && a.out_px == nullptr) {
 			__syncthreads();  // s_red is rewritten by the next tile
 			continue;
 		}
@@ -4122,12 +4123,10 @@ hipError_t launch_shrink(const ShrinkArgs &a, uint32_t channels, uint32_t n_cus,
 		const uint32_t resident = n_cus * per_cu;
 		const uint32_t blocks = a.n_tiles < resident ? a.n_tiles : resident;
 		hipError_t e;
-		if (a.mode == 1) {
-			auto k = shrink64_kernel<1, false>;
-			if (lds_bytes > 64u * 1024u && (e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)) != hipSuccess) return e;
-			hipLaunchKernelGGL(k, dim3(blocks), dim3(256), lds_bytes, stream, f);
-		} else {
-			auto k = shrink64_kernel<0, false>;
+		{
+			const bool full = a.out_px != nullptr && a.out_w != nullptr && a.out_h != nullptr;
+			void (*k)(const Fast64Args) = a.mode == 1 ? (full ? shrink64_kernel<1, false, true> : shrink64_kernel<1, false, false>)
+			                                          : (full ? shrink64_kernel<0, false, true> : shrink64_kernel<0, false, false>);
 			if (lds_bytes > 64u * 1024u && (e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)) != hipSuccess) return e;
 			hipLaunchKernelGGL(k, dim3(blocks), dim3(256), lds_bytes, stream, f);
 		}
@@ -4136,17 +4135,17 @@ hipError_t launch_shrink(const ShrinkArgs &a, uint32_t channels, uint32_t n_cus,
 		ga.mid_event = nullptr;
 		// full tiles with transparency are on list A: the four-plane instance takes it when transparency was
 		// announced or seen before, else the generic kernel walks it after list B
-		const bool run_alpha = a.out_px != nullptr && a.alpha_kernel != 0;
+		const bool run_alpha = a.out_px != nullptr && a.out_w != nullptr && a.out_h != nullptr && a.alpha_kernel != 0;
 		ga.list_a_too = a.out_px != nullptr && !run_alpha ? 1u : 0u;
 		if (run_alpha) {
 			const uint32_t lds_a = lds64_dwords(4) * 4u;
 			const uint32_t blocks_a = n_cus * (kLds / lds_a);
 			if (a.mode == 1) {
-				auto k = shrink64_kernel<1, true>;
+				auto k = shrink64_kernel<1, true, true>;
 				if (lds_a > 64u * 1024u && (e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a)) != hipSuccess) return e;
 				hipLaunchKernelGGL(k, dim3(blocks_a), dim3(256), lds_a, stream, f);
 			} else {
-				auto k = shrink64_kernel<0, true>;
+				auto k = shrink64_kernel<0, true, true>;
 				if (lds_a > 64u * 1024u && (e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a)) != hipSuccess) return e;
 				hipLaunchKernelGGL(k, dim3(blocks_a), dim3(256), lds_a, stream, f);
 			}
