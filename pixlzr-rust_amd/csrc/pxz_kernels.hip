@@ -3683,7 +3683,7 @@ hipError_t launch_qoi(const QoiArgs &a, hipStream_t stream)
 // ---------------------------------------------------------------------------
 // Decode side: Pixlzr::decode_from_vec (reference src/encoding/mod.rs:95-165) + decode_block (:202-242)
 // + the `qoi` decoder it calls, on the device.
-//   pixlzr_index_kernel  one lane per (file, tile row): header check, the row's start from the line-length
+//   pixlzr_index_kernel  one wave per (file, tile row): header check, the row's start from the line-length
 //                        table, then a walk over the row's records ("block", f32 BE value, u32 BE length,
 //                        QOI minus its magic) -> per tile value, size and body position
 //   qoi_decode_kernel    one lane per tile: the QOI op stream -> pixels in the tile's slot; the 64-entry
@@ -3694,22 +3694,31 @@ __device__ __forceinline__ uint32_t be32(const uint8_t *p)
 	return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | (uint32_t)p[3];
 }
 
+// One wave per (file, tile row).  The walk over a row's records is a dependent chain (each length gives the next
+// record's position): it runs on bytes staged in LDS, chunk by chunk, so a step costs an LDS round trip instead of
+// an HBM one.  Per chunk: all lanes load it (coalesced), lane 0 walks up to 64 records ahead using only the
+// length fields, then the lanes check and publish those records in parallel.
+constexpr uint32_t kIdxChunk = 8192;   // bytes of a row held in LDS at a time (per wave)
+constexpr uint32_t kIdxHeader = 23;    // "block" + value + length + QOI header minus its magic, up to the channel byte
 __global__ void __launch_bounds__(256) pixlzr_index_kernel(const DecodeArgs a)
 {
-	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+	__shared__ __attribute__((aligned(16))) uint32_t s_chunk[4][kIdxChunk / 4u + 4u];
+	__shared__ uint32_t s_pos[4][64];  // positions (relative to the chunk's first byte) of the records of a batch
+	const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+	const uint32_t i = blockIdx.x * 4u + wave;
 	if (i >= a.n_frames * a.rows) return;
 	const uint32_t f = i / a.rows, r = i - f * a.rows;
 	const unsigned long long f0 = a.file_offsets[f], f1 = a.file_offsets[f + 1];
 	const uint8_t *file = a.files + f0;
 	const unsigned long long flen = f1 - f0;
 	const unsigned long long hdr = 26ull + 4ull * a.rows;
-	auto bad_row = [&]() {
-		atomicOr(a.status, 2u);
-		for (uint32_t c = 0; c < a.cols; ++c) {
-			const uint32_t t = f * a.tiles_per_frame + r * a.cols + c;
-			a.rec_len[t] = 0u;
-			a.tile_w[t] = 0u;
-			a.tile_h[t] = 0u;
+	const uint32_t t_row = f * a.tiles_per_frame + r * a.cols;
+	auto bad_from = [&](uint32_t c0) {  // the row is unusable from column c0 on
+		if (lane == 0) atomicOr(a.status, 2u);
+		for (uint32_t c = c0 + lane; c < a.cols; c += 64u) {
+			a.rec_len[t_row + c] = 0u;
+			a.tile_w[t_row + c] = 0u;
+			a.tile_h[t_row + c] = 0u;
 		}
 	};
 	const uint8_t magic[9] = {'P', 'I', 'X', 'L', 'Z', 'R', 0, 0, 2};  // constants.rs:10-11: v0.0.2 (filter byte + line table)
@@ -3719,55 +3728,120 @@ __global__ void __launch_bounds__(256) pixlzr_index_kernel(const DecodeArgs a)
 		ok = ok && be32(file + 10) == a.width && be32(file + 14) == a.height && be32(file + 18) == a.bw && be32(file + 22) == a.bh;
 	}
 	if (!ok) {
-		bad_row();
+		bad_from(0);
 		return;
 	}
-	unsigned long long p = hdr, total = hdr;
-	for (uint32_t q = 0; q < a.rows; ++q) {
+	// the line-length table, lane-parallel: bytes before this row, and the length of all rows (mod.rs:141)
+	unsigned long long before = 0, total = 0;
+	for (uint32_t q = lane; q < a.rows; q += 64u) {
 		const uint32_t len = be32(file + 26 + 4 * q);
-		if (q < r) p += len;
+		if (q < r) before += len;
 		total += len;
 	}
-	if (total != flen) {  // mod.rs:141
-		bad_row();
+	for (int sh = 32; sh >= 1; sh >>= 1) {
+		before += __shfl_xor(before, sh, 64);
+		total += __shfl_xor(total, sh, 64);
+	}
+	if (hdr + total != flen) {
+		bad_from(0);
 		return;
 	}
+	unsigned long long p = hdr + before;
 	const unsigned long long row_end = p + be32(file + 26 + 4 * r);
-	for (uint32_t c = 0; c < a.cols; ++c) {
-		const uint32_t t = f * a.tiles_per_frame + r * a.cols + c;
-		const uint32_t fw = (c == a.cols - 1) ? a.edge_w : a.bw, fh = (r == a.rows - 1) ? a.edge_h : a.bh;
-		bool good = p + 13ull + 10ull + 8ull <= row_end;
-		if (good) {
-			const uint8_t *rec = file + p;
-			good = rec[0] == 'b' && rec[1] == 'l' && rec[2] == 'o' && rec[3] == 'c' && rec[4] == 'k';
-			const uint32_t qlen = be32(rec + 9);
-			good = good && qlen >= 18u && p + 13ull + qlen <= row_end;
-			if (good) {
-				const uint32_t w = be32(rec + 13), h = be32(rec + 17), ch = rec[21];
-				good = ch == a.channels && w >= 1 && h >= 1 && w <= fw && h <= fh;
-				if (good) {
-					a.value[t] = __uint_as_float(be32(rec + 5));
-					a.tile_w[t] = w;
-					a.tile_h[t] = h;
-					a.rec_off[t] = f0 + p + 13ull + 10ull;  // first op byte
-					a.rec_len[t] = qlen - 10u - 8u;         // ops only: without the header and the end marker
+	const uint8_t *cb = reinterpret_cast<const uint8_t *>(s_chunk[wave]);
+	uint32_t c = 0;
+	while (c < a.cols) {
+		// ---- stage file bytes [p, p + kIdxChunk) of the row (whole aligned dwords of the buffer, then the tail bytes)
+		const unsigned long long want = row_end - p < (unsigned long long)kIdxChunk ? row_end - p : (unsigned long long)kIdxChunk;
+		const uintptr_t g = reinterpret_cast<uintptr_t>(file + p);
+		const uint32_t skew = (uint32_t)(g & 3u);  // the chunk starts at the aligned dword below p
+		const uint32_t dwords = (skew + (uint32_t)want + 3u) / 4u;
+		const uintptr_t buf_end = reinterpret_cast<uintptr_t>(a.files) + a.file_offsets[a.n_frames];
+		for (uint32_t d = lane; d < dwords; d += 64u) {
+			const uintptr_t ga = (g - skew) + 4ull * d;
+			uint32_t v = 0;
+			if (ga + 4u <= buf_end) {
+				v = *reinterpret_cast<const uint32_t *>(ga);
+			} else {
+				for (uint32_t k = 0; k < 4u && ga + k < buf_end; ++k) v |= (uint32_t) * reinterpret_cast<const uint8_t *>(ga + k) << (8u * k);
+			}
+			s_chunk[wave][d] = v;
+		}
+		tile_sync<1>();
+		const uint32_t have = (uint32_t)want;  // valid bytes behind cb + skew
+		// ---- lane 0: positions of up to 64 records whose headers lie inside the chunk
+		uint32_t n_rec = 0, walked = 0;  // walked: bytes of the chunk consumed by the records found
+		bool broken = false;             // a record that cannot be walked past (it is the last of the batch)
+		if (lane == 0) {
+			uint32_t o = 0;
+			while (n_rec < 64u && c + n_rec < a.cols) {
+				if (p + o + 13ull + 10ull + 8ull > row_end) {  // no room for a record: broken row
+					s_pos[wave][n_rec++] = o;
+					broken = true;
+					break;
 				}
-				p += 13ull + qlen;
+				if (o + kIdxHeader > have) break;  // header not in this chunk: restage from here
+				const uint32_t qlen = be32(cb + skew + o + 9u);
+				s_pos[wave][n_rec++] = o;
+				if (qlen < 18u || p + o + 13ull + qlen > row_end) {
+					broken = true;
+					break;
+				}
+				o += 13u + qlen;
+				if (o >= have && p + o < row_end && c + n_rec < a.cols) break;  // next record starts beyond the chunk
+			}
+			walked = o;
+		}
+		n_rec = __builtin_amdgcn_readfirstlane(n_rec);
+		walked = __builtin_amdgcn_readfirstlane(walked);
+		broken = __builtin_amdgcn_readfirstlane(broken ? 1u : 0u) != 0u;
+		tile_sync<1>();
+		// ---- all lanes: check and publish the batch
+		bool good = true;
+		if (lane < n_rec) {
+			const uint32_t o = s_pos[wave][lane];
+			const uint32_t cc = c + lane;
+			const uint32_t fw = (cc == a.cols - 1) ? a.edge_w : a.bw, fh = (r == a.rows - 1) ? a.edge_h : a.bh;
+			good = p + o + 13ull + 10ull + 8ull <= row_end;
+			if (good) {
+				const uint8_t *rec = cb + skew + o;
+				good = rec[0] == 'b' && rec[1] == 'l' && rec[2] == 'o' && rec[3] == 'c' && rec[4] == 'k';
+				const uint32_t qlen = be32(rec + 9);
+				good = good && qlen >= 18u && p + o + 13ull + qlen <= row_end;
+				if (good) {
+					const uint32_t w = be32(rec + 13), h = be32(rec + 17), ch = rec[21];
+					good = ch == a.channels && w >= 1 && h >= 1 && w <= fw && h <= fh;
+					// (the walk used this record's length whether or not its other fields are sound, as the
+					// sequential reader does not: a bad record ends the row there, see below)
+					if (good) {
+						const uint32_t t = t_row + cc;
+						a.value[t] = __uint_as_float(be32(rec + 5));
+						a.tile_w[t] = w;
+						a.tile_h[t] = h;
+						a.rec_off[t] = f0 + p + o + 13ull + 10ull;  // first op byte
+						a.rec_len[t] = qlen - 10u - 8u;             // ops only: without the header and the end marker
+					}
+				}
 			}
 		}
-		if (!good) {
-			// the walk cannot continue past a broken record: the rest of the row is unusable
-			atomicOr(a.status, 2u);
-			for (uint32_t cc = c; cc < a.cols; ++cc) {
-				const uint32_t tt = f * a.tiles_per_frame + r * a.cols + cc;
-				a.rec_len[tt] = 0u;
-				a.tile_w[tt] = 0u;
-				a.tile_h[tt] = 0u;
-			}
+		const unsigned long long bad = __builtin_amdgcn_ballot_w64(!good);
+		if (bad != 0ull) {
+			// the walk cannot continue past a broken record: the rest of the row is unusable (records of this batch
+			// behind the first bad one were published above and are taken back here)
+			bad_from(c + (uint32_t)__builtin_ctzll(bad));
 			return;
 		}
+		(void)broken;  // (a broken record fails the checks above)
+		if (n_rec == 0) {
+			// a header that does not fit the rest of the row although a record is due: broken row
+			bad_from(c);
+			return;
+		}
+		c += n_rec;
+		p += walked;
+		tile_sync<1>();  // the chunk is restaged
 	}
-	if (p != row_end) atomicOr(a.status, 2u);
+	if (p != row_end && lane == 0) atomicOr(a.status, 2u);
 }
 
 template <int C>
@@ -3875,7 +3949,7 @@ hipError_t launch_decode(const DecodeArgs &a, hipStream_t stream)
 {
 	hipError_t e = hipMemsetAsync(a.bins, 0, 64 * sizeof(uint32_t), stream);
 	if (e != hipSuccess) return e;
-	hipLaunchKernelGGL(pixlzr_index_kernel, dim3((a.n_frames * a.rows + 255u) / 256u), dim3(256), 0, stream, a);
+	hipLaunchKernelGGL(pixlzr_index_kernel, dim3((a.n_frames * a.rows + 3u) / 4u), dim3(256), 0, stream, a);
 	const uint32_t tb = (a.n_tiles + 255u) / 256u;
 	QoiArgs q{};  // the encoder's binning by pixel count, on the sizes the index kernel has just read
 	q.w = a.tile_w;
