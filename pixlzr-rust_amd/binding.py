@@ -57,7 +57,7 @@ def build_library(force=False):
     if (not force and os.path.exists(_LIB_PATH)
             and all(os.path.getmtime(_LIB_PATH) >= os.path.getmtime(s) for s in srcs)):
         return _LIB_PATH
-    r = subprocess.run(["make", "-C", _CSRC, "all"], capture_output=True, text=True)
+    r = subprocess.run(["make", "-j8", "-C", _CSRC, "all"], capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("building libpixlzr_hip.so failed:\n" + r.stdout + r.stderr)
     return _LIB_PATH

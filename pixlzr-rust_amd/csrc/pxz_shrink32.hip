@@ -1,0 +1,884 @@
+// pxz_shrink32.hip -- the fast kernels for 32x32 RGBA tiles (shrink32_kernel, shrink32a_kernel for tiles with
+// transparency) and for 2x2 groups of 16x16 tiles (shrink16_kernel), and the first part of their launch.
+//
+// Compiled with -ffp-contract=off: the f32 results of the Oklab detector are
+// written into the bitstream, and the reference (Rust) never fuses a*b+c.
+#include "pxz_device.h"
+
+namespace pxz {
+
+
+// ---------------------------------------------------------------------------
+// shrink32_kernel: the common case on its own — full, 16-byte-aligned 32x32 RGBA tiles whose
+// resample is a clone, a nearest pick, or a two-pass convolution of an opaque tile.  Everything
+// else (ragged-edge tiles, tiles with transparency, one-pass resamples) is appended to a device
+// worklist that the generic kernel processes afterwards.  Persistent waves, one LDS tile image
+// each, next tile's pixels prefetched into registers, table rows in LDS, lookups in kernarg.
+// MODE 1: directional detector here; MODE 0: value already in sums[] (oklab_kernel).
+// ---------------------------------------------------------------------------
+// FULL: out_px, out_w and out_h are all there (the shrink entry points): no run-time tests of them in the loop --
+// kept as loop-invariant lane masks they cost scalar registers, and a spilled one two v_readlane per use.
+template <int MODE, bool FULL>
+__global__ void __launch_bounds__(1024) shrink32_kernel(const Fast32Args a)
+{
+	extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+	const uint32_t wpb = blockDim.x / 64u, sub = threadIdx.x / 64u, tid = threadIdx.x % 64u;
+	for (uint32_t i = threadIdx.x; i < a.tab_dw / 4u; i += blockDim.x)
+		reinterpret_cast<uint4 *>(lds)[i] = reinterpret_cast<const uint4 *>(a.trows)[i];
+	// Tiles are dealt to the waves of a block on demand (an LDS ticket counter): tile costs differ by 2x
+	// between size classes, and a static stride leaves the unluckiest wave of the chip running alone.
+	// Block b owns tiles b, b + blocks, b + 2*blocks, ...; ticket t is tile b + t*blocks.
+	uint32_t *s_ticket = lds + a.tab_dw + wpb * a.tile_dw;
+	if (threadIdx.x == 0) *s_ticket = wpb;  // tickets 0..wpb-1 are the waves' first tiles
+	__syncthreads();
+	const uint32_t *s_tab = lds;
+	// level breakpoints, one per lane (lanes >= kMaxLevel never count): the level exponent of a key is
+	// one lane-parallel compare + ballot + popcount instead of a scalar compare chain
+	const uint32_t brk_lane = tid < (uint32_t)kMaxLevel ? a.breaks[tid] : (a.breaks_asc ? 0xffffffffu : 0u);
+	auto level_of = [&](uint32_t key) -> uint32_t {
+		const unsigned long long lt = __builtin_amdgcn_ballot_w64(key < brk_lane);
+		const unsigned long long live = (1ull << kMaxLevel) - 1ull;
+		return (uint32_t)__builtin_popcountll((a.breaks_asc ? ~lt : lt) & live);
+	};
+	uint32_t *s_pl = lds + a.tab_dw + sub * a.tile_dw;
+	uint32_t *s_tmp = s_pl + 3 * kPD32;  // R, G, B planes only: tiles with transparency go to the worklist
+	uint32_t *s_batch = s_ticket + 4u + sub * (2u * kListBatch);  // this wave's pending list-B / list-A entries
+	uint32_t n_listb = 0, n_lista = 0;
+	auto tile_of_ticket = [&](uint32_t t) -> uint32_t {
+		// runs of 2^chunk_lg adjacent tiles per block: successive tickets walk along an image row
+		const unsigned long long run = (unsigned long long)(t >> a.chunk_lg) * gridDim.x + blockIdx.x;
+		const unsigned long long g = (run << a.chunk_lg) + (t & ((1u << a.chunk_lg) - 1u));
+		return g < (unsigned long long)a.n_tiles ? (uint32_t)g : 0xffffffffu;
+	};
+	auto next_ticket = [&]() -> uint32_t {
+		uint32_t t = 0;
+		if (tid == 0) t = atomicAdd(s_ticket, 1u);
+		return tile_of_ticket(__builtin_amdgcn_readfirstlane(t));
+	};
+	// The pixels of the next tile are requested right after the current one has been staged, and a
+	// tile's output pixels are parked in LDS and stored at the START of the next iteration, before
+	// that prefetch: loads and stores share one in-order counter (vmcnt), so the wait for the
+	// prefetched registers must not find younger stores or loads behind it.
+	uint4 pre[4];
+	bool pre_valid = false;
+	const uint32_t first = tile_of_ticket(__builtin_amdgcn_readfirstlane(sub));
+	fast32_prefetch(a, first, tid, pre, pre_valid);
+#ifdef PXZ_STAMPS
+	unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+	unsigned long long st_last = stamp_now();
+	const unsigned long long st_begin = wall_clock64();
+#endif
+	uint32_t pend_kind = 0;       // 0 nothing, 1 linear pixels in LDS, 2 clone (re-interleave the planes)
+	uint32_t pend_px = 0;         // pixels parked in LDS (kind 1)
+	const uint32_t *pend_src = nullptr;
+	uint8_t *pend_dst = nullptr;
+	auto flush = [&]() {
+		if (pend_kind == 1) {
+			uint32_t *d = reinterpret_cast<uint32_t *>(pend_dst);
+			if (pend_px >= 4u) {  // whole 16-byte groups (pixel counts are powers of two)
+				for (uint32_t i = tid; i < (pend_px >> 2); i += 64u)
+					reinterpret_cast<uint4 *>(d)[i] = reinterpret_cast<const uint4 *>(pend_src)[i];
+			} else if (tid < pend_px) {
+				d[tid] = pend_src[tid];
+			}
+		} else if (pend_kind == 2) {
+			// clone (block.rs:279-281): re-interleave the planes, one 16-byte store per 4 pixels
+#pragma unroll
+			for (int k = 0; k < 4; ++k) {
+				const uint32_t i = tid + 64u * (uint32_t)k;
+				const uint32_t *p = s_pl + (i >> 3) * kRS32 + (i & 7u) * 2u;
+				const uint2 r = *reinterpret_cast<const uint2 *>(p), g = *reinterpret_cast<const uint2 *>(p + kPD32);
+				const uint2 b = *reinterpret_cast<const uint2 *>(p + 2 * kPD32);
+				const uint32_t opq = 0x00ff00ffu;  // the tile is opaque: alpha pair (255, 255)
+				const uint32_t rg01 = __builtin_amdgcn_perm(g.x, r.x, 0x06020400u), ba01 = __builtin_amdgcn_perm(opq, b.x, 0x06020400u);
+				const uint32_t rg23 = __builtin_amdgcn_perm(g.y, r.y, 0x06020400u), ba23 = __builtin_amdgcn_perm(opq, b.y, 0x06020400u);
+				uint4 o;
+				o.x = __builtin_amdgcn_perm(ba01, rg01, 0x05040100u);
+				o.y = __builtin_amdgcn_perm(ba01, rg01, 0x07060302u);
+				o.z = __builtin_amdgcn_perm(ba23, rg23, 0x05040100u);
+				o.w = __builtin_amdgcn_perm(ba23, rg23, 0x07060302u);
+				reinterpret_cast<uint4 *>(pend_dst)[i] = o;
+			}
+		}
+		pend_kind = 0;
+	};
+	auto one_tile = [&](const uint32_t tile_g, const uint32_t tile_next) {
+		auto defer = [&]() {
+			list_push(s_batch, n_listb, tile_g, a.work + kWorkList, a.work + a.work_slot, tid);
+			if (tid == 0) {
+				bool keep = false;  // MODE 0: a value the block-cooperative detector left is final and stays
+				if constexpr (MODE == 0) {
+					const uint32_t t = tile_g - fastdiv(tile_g, a.div_tpf) * a.tiles_per_frame;
+					const uint32_t ty = fastdiv(t, a.div_cols), tx = t - ty * a.cols;
+					keep = tx < a.full_cols && ty < a.ok_rows;
+				}
+				if (!keep) reinterpret_cast<uint2 *>(a.sums)[tile_g] = make_uint2(kDeferredKey, kDeferredKey);  // not finished here
+			}
+		};
+		if (!pre_valid) {  // ragged edge / unaligned rows: generic kernel
+			flush();
+			defer();
+			fast32_prefetch(a, tile_next, tid, pre, pre_valid);
+			return;
+		}
+		uint32_t given_bits = 0;
+		if constexpr (MODE == 0) given_bits = a.sums[2 * tile_g];  // issued before the prefetch: its wait leaves the prefetch in flight
+		// ---- wait for the prefetched registers (the opacity test is their first use), then emit the
+		// previous tile's parked pixels, then stage: registers -> planar u16 pairs
+		uint32_t alpha_and = 0xffu;
+#pragma unroll
+		for (int k = 0; k < 4; ++k) alpha_and &= (pre[k].x & pre[k].y & pre[k].z & pre[k].w) >> 24;
+		const bool transparent = __builtin_amdgcn_ballot_w64(alpha_and != 0xffu) != 0ull;
+		__builtin_amdgcn_sched_barrier(0);
+		flush();
+		__builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+		for (int k = 0; k < 4; ++k) {
+			const uint32_t row = (tid >> 3) + 8u * (uint32_t)k, col = tid & 7u;
+			const uint4 v = pre[k];
+			uint32_t *d = s_pl + row * kRS32 + col * 2u;
+#pragma unroll
+			for (uint32_t c = 0; c < 3; ++c) {
+				const uint32_t sel = c | 0x0c000c00u | ((4u + c) << 16);
+				uint2 pr;
+				pr.x = __builtin_amdgcn_perm(v.y, v.x, sel);
+				pr.y = __builtin_amdgcn_perm(v.w, v.z, sel);
+				*reinterpret_cast<uint2 *>(d + c * kPD32) = pr;
+			}
+		}
+		PXZ_STAMP(0);  // wait for the prefetched pixels + staging
+		fast32_prefetch(a, tile_next, tid, pre, pre_valid);  // lands while this tile is processed
+		if (transparent && (FULL || a.out_px != nullptr)) {
+			// transparency: the premultiplied convolution needs the alpha plane -- shrink32a_kernel (list A) when the
+			// caller announced transparent frames, else the generic kernel (list B).  (Detector-only launches do not
+			// care: the detector never looks at alpha.)
+			if (a.alpha_list) {
+				list_push(s_batch + kListBatch, n_lista, tile_g, a.work + kWorkList + a.n_tiles, a.work + kWorkA + a.work_slot, tid);
+				if constexpr (MODE == 1)
+					if (tid == 0) reinterpret_cast<uint2 *>(a.sums)[tile_g] = make_uint2(kDeferredKey, kDeferredKey);
+			} else {
+				defer();
+			}
+			return;
+		}
+		tile_sync<1>();
+		PXZ_STAMP(1);  // prefetch issue
+
+		// ---- detector + level decision
+		uint32_t m0, m1;
+		uint32_t key0 = 0, key1 = 0;
+		if constexpr (MODE == 1) {
+			uint32_t sum_hz = 0, sum_vr = 0;
+			// 16 lanes (pixel pairs) per row group, 4 groups of 8 window rows (the last one 6).  Per
+			// channel and window row: r = 1-2-1 along x (perm, add, mad), |hz| (sad), column smoothing
+			// c = t(y)+t(y+1) (2 adds), the neighbour pair's c by DPP, |vr| (sad).  Fully unrolled:
+			// every LDS address is a per-channel base + immediate, no loop-carried register moves.
+			const uint32_t q = tid & 15u, g = tid >> 4;
+			// (compared afresh where it is used: hoisted out of the tile loop the lane mask would sit in two scalar
+			// registers, and those are spilled -- two v_readlane per use instead of one v_cmp)
+			auto last_rows = [](uint32_t grp) -> bool {
+				asm volatile("" : "+v"(grp));
+				return grp != 3u;
+			};
+			const uint32_t two = 0x00020002u;
+			const uint32_t *pc[3];
+			pc[0] = s_pl + g * (8u * kRS32) + q;
+			pc[1] = pc[0] + kPD32;
+			pc[2] = pc[1] + kPD32;
+			uint32_t rA[3], rB[3], tP[3], dP[3];
+#pragma unroll
+			for (int c = 0; c < 3; ++c) {
+				const uint32_t a0 = pc[c][0], a1 = pc[c][1], b0 = pc[c][kRS32], b1 = pc[c][kRS32 + 1];
+				rA[c] = pk_mad_u16(__builtin_amdgcn_alignbit(a1, a0, 16), two, u32(us2(a0) + us2(a1)));
+				rB[c] = pk_mad_u16(__builtin_amdgcn_alignbit(b1, b0, 16), two, u32(us2(b0) + us2(b1)));
+				tP[c] = u32(us2(a0) + us2(b0));
+				dP[c] = b0;
+			}
+#pragma unroll
+			for (int st = 0; st < 4; ++st) {
+				if (st < 3 || last_rows(g)) {  // the last group has 6 window rows = 3 steps
+#pragma unroll
+					for (int c = 0; c < 3; ++c) {
+						const uint32_t *pr = pc[c] + (2 + 2 * st) * (int)kRS32;
+						const uint32_t n0 = pr[0], n1 = pr[1], o0 = pr[kRS32], o1 = pr[kRS32 + 1];
+						const uint32_t rN = pk_mad_u16(__builtin_amdgcn_alignbit(n1, n0, 16), two, u32(us2(n0) + us2(n1)));
+						sum_hz = sad16(rN, rA[c], sum_hz);
+						const uint32_t tN = u32(us2(dP[c]) + us2(n0));
+						const uint32_t c0 = u32(us2(tP[c]) + us2(tN));
+						sum_vr = sad16(dpp_mov<0x101>(c0), c0, sum_vr);  // row_shl:1 = the pair to the right
+						const uint32_t rO = pk_mad_u16(__builtin_amdgcn_alignbit(o1, o0, 16), two, u32(us2(o0) + us2(o1)));
+						sum_hz = sad16(rO, rB[c], sum_hz);
+						const uint32_t tO = u32(us2(n0) + us2(o0));
+						const uint32_t e0 = u32(us2(tN) + us2(tO));
+						sum_vr = sad16(dpp_mov<0x101>(e0), e0, sum_vr);
+						rA[c] = rN;
+						rB[c] = rO;
+						tP[c] = tO;
+						dP[c] = o0;
+					}
+				}
+			}
+			if (q == 15u) sum_hz = sum_vr = 0;  // pair 15 starts no window (x = 30, 31)
+			sum_hz = wave_sum_sgpr(sum_hz);
+			sum_vr = wave_sum_sgpr(sum_vr);
+			m0 = level_of(sum_hz);
+			m1 = level_of(sum_vr);
+			key0 = sum_hz;
+			key1 = sum_vr;
+		} else {
+			const uint32_t vb = __builtin_amdgcn_readfirstlane(given_bits);
+			m0 = m1 = level_of(__float_as_uint(parse_value(__uint_as_float(vb))));
+		}
+		const uint32_t nw = reduced_size(32u, m0), nh = reduced_size(32u, m1);
+		{
+			uint32_t lane = tid;
+			asm volatile("" : "+v"(lane));  // (as above: a fresh compare instead of a spilled lane mask)
+			if (lane == 0) {
+				if constexpr (MODE == 1) reinterpret_cast<uint2 *>(a.sums)[tile_g] = make_uint2(key0, key1);
+				if (FULL || a.out_w) a.out_w[tile_g] = nw;
+				if (FULL || a.out_h) a.out_h[tile_g] = nh;
+			}
+		}
+		PXZ_STAMP(2);  // detector + reduction + level decision + metadata
+		if (FULL || a.out_px != nullptr) {
+			uint32_t filt = a.filter;
+			asm volatile("" : "+s"(filt));  // a scalar compare per use, not a hoisted (and spilled) mask
+			pend_dst = a.out_px + (size_t)tile_g * 4096u;
+			pend_px = nw * nh;
+			if (nw == 32u && nh == 32u) {
+				pend_kind = 2;  // the planes themselves, re-interleaved by the flush
+			} else if (nw != 32u && nh != 32u && filt != 0) {
+				const uint32_t lx = m0 < (uint32_t)kMaxLevel ? m0 : (uint32_t)kMaxLevel - 1;
+				const uint32_t ly = m1 < (uint32_t)kMaxLevel ? m1 : (uint32_t)kMaxLevel - 1;
+				if (a.tabs[lx].mf_off != 0 && a.tabs[ly].mf_off != 0 && nw >= 4u && nh >= 4u) {
+					// (2- and 1-px outputs have tables too -- shrink32a_kernel uses them -- but the dot2 form is cheaper there)
+					resample_mfma32<3>(s_tab, a.tabs[lx], a.tabs[ly], s_pl, tid, nw, nh, s_tmp);
+					pend_src = s_tmp;
+					pend_kind = 1;
+				} else if (nw <= 8u) {
+					// the vertical pass reads only the transposed planes: the R plane is free for the pixels
+					resample_fast32_hv(s_tab, a.tabs[lx], a.tabs[ly], s_pl, s_tmp, tid, nw, nh, s_pl);
+					pend_src = s_pl;
+					pend_kind = 1;
+				} else {
+					defer();  // 16 x (2|1): its transposed planes would not fit the 16-waves-per-CU LDS image
+				}
+			} else if (filt == 0) {
+				// ResizeAlg::Nearest (mod.rs:277): source index = floor((o + 0.5) * 2^m), no alpha handling
+				const uint32_t lgx = 31u - (uint32_t)__builtin_clz(nw);
+				const uint32_t hx = m0 ? (1u << (m0 < 6u ? m0 - 1u : 4u)) : 0u, hy = m1 ? (1u << (m1 < 6u ? m1 - 1u : 4u)) : 0u;
+				const uint16_t *pl16 = reinterpret_cast<const uint16_t *>(s_pl);
+				for (uint32_t i = tid; i < nw * nh; i += 64u) {
+					const uint32_t ox = i & (nw - 1u), oy = i >> lgx;
+					// 32 -> nw = 32 >> m (m <= 5): index (2o+1) * 2^(m-1); m >= 5 gives the single index 16
+					const uint32_t x = m0 == 0 ? ox : (m0 < 6u ? (2u * ox + 1u) * hx : 16u);
+					const uint32_t y = m1 == 0 ? oy : (m1 < 6u ? (2u * oy + 1u) * hy : 16u);
+					const uint32_t idx = y * (2u * kRS32) + x;
+					s_tmp[i] = (uint32_t)pl16[idx] | ((uint32_t)pl16[idx + 2u * kPD32] << 8) | ((uint32_t)pl16[idx + 4u * kPD32] << 16) | 0xff000000u;
+				}
+				pend_kind = 1;
+				pend_src = s_tmp;
+			} else if (nh != 32u) {
+				const uint32_t ly = m1 < (uint32_t)kMaxLevel ? m1 : (uint32_t)kMaxLevel - 1;
+				fast32_v_only(s_tab, a.tabs[ly], s_pl, tid, nh, s_tmp);  // width kept; the transposed planes are unused here
+				pend_kind = 1;
+				pend_src = s_tmp;
+			} else {
+				const uint32_t lx = m0 < (uint32_t)kMaxLevel ? m0 : (uint32_t)kMaxLevel - 1;
+				fast32_h_only(s_tab, a.tabs[lx], s_pl, tid, nw, s_tmp);  // height kept
+				pend_kind = 1;
+				pend_src = s_tmp;
+			}
+		}
+		tile_sync<1>();  // the next tile reuses this wave's LDS image
+		PXZ_STAMP(3);  // clone / resample / defer
+	};
+#ifdef PXZ_STAMPS
+	uint32_t st_tiles = 0;
+#endif
+	for (uint32_t tile_g = first; tile_g < a.n_tiles;) {
+#ifdef PXZ_STAMPS
+		++st_tiles;
+#endif
+		const uint32_t tile_next = next_ticket();
+		one_tile(tile_g, tile_next);
+		tile_g = tile_next;
+	}
+	flush();  // the last tile's pixels
+	list_flush(s_batch, n_listb, a.work + kWorkList, a.work + a.work_slot, tid);
+	list_flush(s_batch + kListBatch, n_lista, a.work + kWorkList + a.n_tiles, a.work + kWorkA + a.work_slot, tid);
+#ifdef PXZ_STAMPS
+	if (tid == 0) {
+		unsigned long long *out = reinterpret_cast<unsigned long long *>(a.work + ((2u * a.n_tiles + kWorkList + 1u + 1u) & ~1u));
+		for (int i = 0; i < 8; ++i) atomicAdd(out + i, st_acc[i]);
+		// per-wave run time (100 MHz ticks) | tiles processed << 48; last launch wins
+		out[8 + blockIdx.x * 16u + sub] = ((wall_clock64() - st_begin) & 0xffffffffffffull) | ((unsigned long long)st_tiles << 48);
+		if (sub == 0) out[8 + blockIdx.x * 16u + 15u] = st_begin;
+	}
+#endif
+}
+
+// ---------------------------------------------------------------------------
+// shrink32a_kernel: the full 32x32 RGBA tiles WITH transparency that shrink32_kernel set aside (list A of the
+// worklist buffer).  Same staging / detector / level decision, but a fourth LDS plane keeps the alpha channel
+// and the resample is fir's U8x4 path: colours premultiplied in place (packed u16 arithmetic), all four planes
+// through the matrix-core resample (every output size <= 16), every output pixel un-premultiplied.  Clone and
+// nearest pick from the four planes as they are; the one-pass classes (32 x n, n x 32) go on to the generic
+// kernel (list B).  13 waves per CU (four planes); outputs are stored directly.
+// ---------------------------------------------------------------------------
+template <int MODE>
+__global__ void __launch_bounds__(1024) shrink32a_kernel(const Fast32Args a)
+{
+	extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+	const uint32_t wpb = blockDim.x / 64u, sub = threadIdx.x / 64u, tid = threadIdx.x % 64u;
+	for (uint32_t i = threadIdx.x; i < a.tab_dw / 4u; i += blockDim.x)
+		reinterpret_cast<uint4 *>(lds)[i] = reinterpret_cast<const uint4 *>(a.trows)[i];
+	uint32_t *s_ticket = lds + a.tab_dw + wpb * a.tile_dw;
+	if (threadIdx.x == 0) *s_ticket = wpb;
+	__syncthreads();
+	const uint32_t *s_tab = lds;
+	const uint32_t brk_lane = tid < (uint32_t)kMaxLevel ? a.breaks[tid] : (a.breaks_asc ? 0xffffffffu : 0u);
+	auto level_of = [&](uint32_t key) -> uint32_t {
+		const unsigned long long lt = __builtin_amdgcn_ballot_w64(key < brk_lane);
+		const unsigned long long live = (1ull << kMaxLevel) - 1ull;
+		return (uint32_t)__builtin_popcountll((a.breaks_asc ? ~lt : lt) & live);
+	};
+	uint32_t *s_pl = lds + a.tab_dw + sub * a.tile_dw;  // four planes: R, G, B, A
+	uint32_t *s_batch = s_ticket + 4u + sub * kListBatch;  // this wave's pending list-B entries
+	uint32_t n_listb = 0;
+	const uint32_t count = __builtin_amdgcn_readfirstlane(a.work[kWorkA + a.work_slot]);
+	const uint32_t *list = a.work + kWorkList + a.n_tiles;
+	auto tile_of_ticket = [&](uint32_t t) -> uint32_t {
+		const unsigned long long i = (unsigned long long)blockIdx.x + (unsigned long long)t * gridDim.x;
+		return i < (unsigned long long)count ? list[(uint32_t)i] : 0xffffffffu;
+	};
+	auto next_ticket = [&]() -> uint32_t {
+		uint32_t t = 0;
+		if (tid == 0) t = atomicAdd(s_ticket, 1u);
+		return __builtin_amdgcn_readfirstlane(tile_of_ticket(__builtin_amdgcn_readfirstlane(t)));
+	};
+	uint4 pre[4];
+	bool pre_valid = false;
+	const uint32_t first = __builtin_amdgcn_readfirstlane(tile_of_ticket(__builtin_amdgcn_readfirstlane(sub)));
+	fast32_prefetch(a, first, tid, pre, pre_valid);
+	for (uint32_t tile_g = first; tile_g < a.n_tiles;) {
+		const uint32_t tile_next = next_ticket();
+		auto defer = [&]() {  // on to the generic kernel (list B); the marker in sums[] is there already (MODE 1) / not wanted (MODE 0)
+			list_push(s_batch, n_listb, tile_g, a.work + kWorkList, a.work + a.work_slot, tid);
+		};
+		uint32_t given_bits = 0;
+		if constexpr (MODE == 0) given_bits = a.sums[2 * tile_g];
+		// ---- stage: registers -> four planes of u16 pairs (only full, aligned tiles are ever listed)
+#pragma unroll
+		for (int k = 0; k < 4; ++k) {
+			const uint32_t row = (tid >> 3) + 8u * (uint32_t)k, col = tid & 7u;
+			const uint4 v = pre[k];
+			uint32_t *d = s_pl + row * kRS32 + col * 2u;
+#pragma unroll
+			for (uint32_t c = 0; c < 4; ++c) {
+				const uint32_t sel = c | 0x0c000c00u | ((4u + c) << 16);
+				uint2 pr;
+				pr.x = __builtin_amdgcn_perm(v.y, v.x, sel);
+				pr.y = __builtin_amdgcn_perm(v.w, v.z, sel);
+				*reinterpret_cast<uint2 *>(d + c * kPD32) = pr;
+			}
+		}
+		fast32_prefetch(a, tile_next, tid, pre, pre_valid);
+		tile_sync<1>();
+		// ---- detector + level decision (as shrink32_kernel: the colour planes are still as loaded)
+		uint32_t m0, m1;
+		if constexpr (MODE == 1) {
+			uint32_t sum_hz = 0, sum_vr = 0;
+			const uint32_t q = tid & 15u, g = tid >> 4;
+			const uint32_t two = 0x00020002u;
+			const uint32_t *pc[3];
+			pc[0] = s_pl + g * (8u * kRS32) + q;
+			pc[1] = pc[0] + kPD32;
+			pc[2] = pc[1] + kPD32;
+			uint32_t rA[3], rB[3], tP[3], dP[3];
+#pragma unroll
+			for (int c = 0; c < 3; ++c) {
+				const uint32_t a0 = pc[c][0], a1 = pc[c][1], b0 = pc[c][kRS32], b1 = pc[c][kRS32 + 1];
+				rA[c] = pk_mad_u16(__builtin_amdgcn_alignbit(a1, a0, 16), two, u32(us2(a0) + us2(a1)));
+				rB[c] = pk_mad_u16(__builtin_amdgcn_alignbit(b1, b0, 16), two, u32(us2(b0) + us2(b1)));
+				tP[c] = u32(us2(a0) + us2(b0));
+				dP[c] = b0;
+			}
+#pragma unroll
+			for (int st = 0; st < 4; ++st) {
+				if (st < 3 || g != 3u) {
+#pragma unroll
+					for (int c = 0; c < 3; ++c) {
+						const uint32_t *pr = pc[c] + (2 + 2 * st) * (int)kRS32;
+						const uint32_t n0 = pr[0], n1 = pr[1], o0 = pr[kRS32], o1 = pr[kRS32 + 1];
+						const uint32_t rN = pk_mad_u16(__builtin_amdgcn_alignbit(n1, n0, 16), two, u32(us2(n0) + us2(n1)));
+						sum_hz = sad16(rN, rA[c], sum_hz);
+						const uint32_t tN = u32(us2(dP[c]) + us2(n0));
+						const uint32_t c0 = u32(us2(tP[c]) + us2(tN));
+						sum_vr = sad16(dpp_mov<0x101>(c0), c0, sum_vr);
+						const uint32_t rO = pk_mad_u16(__builtin_amdgcn_alignbit(o1, o0, 16), two, u32(us2(o0) + us2(o1)));
+						sum_hz = sad16(rO, rB[c], sum_hz);
+						const uint32_t tO = u32(us2(n0) + us2(o0));
+						const uint32_t e0 = u32(us2(tN) + us2(tO));
+						sum_vr = sad16(dpp_mov<0x101>(e0), e0, sum_vr);
+						rA[c] = rN;
+						rB[c] = rO;
+						tP[c] = tO;
+						dP[c] = o0;
+					}
+				}
+			}
+			if (q == 15u) sum_hz = sum_vr = 0;
+			sum_hz = wave_sum_sgpr(sum_hz);
+			sum_vr = wave_sum_sgpr(sum_vr);
+			m0 = level_of(sum_hz);
+			m1 = level_of(sum_vr);
+			if (tid == 0) reinterpret_cast<uint2 *>(a.sums)[tile_g] = make_uint2(sum_hz, sum_vr);
+		} else {
+			const uint32_t vb = __builtin_amdgcn_readfirstlane(given_bits);
+			m0 = m1 = level_of(__float_as_uint(parse_value(__uint_as_float(vb))));
+		}
+		const uint32_t nw = reduced_size(32u, m0), nh = reduced_size(32u, m1);
+		const bool one_pass = (nw == 32u) != (nh == 32u) && a.filter != 0;
+		if (one_pass) {
+			// 32 x n / n x 32 with transparency: generic kernel.  MODE 1: it must not be finished from these sums
+			if constexpr (MODE == 1) {
+				if (tid == 0) reinterpret_cast<uint2 *>(a.sums)[tile_g] = make_uint2(kDeferredKey, kDeferredKey);
+			}
+			defer();
+			tile_sync<1>();
+			tile_g = tile_next;
+			continue;
+		}
+		if (tid == 0) {
+			if (a.out_w) a.out_w[tile_g] = nw;
+			if (a.out_h) a.out_h[tile_g] = nh;
+		}
+		uint32_t *dst = reinterpret_cast<uint32_t *>(a.out_px + (size_t)tile_g * 4096u);
+		if (nw == 32u && nh == 32u) {
+			// clone (block.rs:279-281): re-interleave the four planes
+#pragma unroll
+			for (int k = 0; k < 4; ++k) {
+				const uint32_t i = tid + 64u * (uint32_t)k;
+				const uint32_t *p = s_pl + (i >> 3) * kRS32 + (i & 7u) * 2u;
+				const uint2 r = *reinterpret_cast<const uint2 *>(p), g = *reinterpret_cast<const uint2 *>(p + kPD32);
+				const uint2 b = *reinterpret_cast<const uint2 *>(p + 2 * kPD32), al = *reinterpret_cast<const uint2 *>(p + 3 * kPD32);
+				const uint32_t rg01 = __builtin_amdgcn_perm(g.x, r.x, 0x06020400u), ba01 = __builtin_amdgcn_perm(al.x, b.x, 0x06020400u);
+				const uint32_t rg23 = __builtin_amdgcn_perm(g.y, r.y, 0x06020400u), ba23 = __builtin_amdgcn_perm(al.y, b.y, 0x06020400u);
+				uint4 o;
+				o.x = __builtin_amdgcn_perm(ba01, rg01, 0x05040100u);
+				o.y = __builtin_amdgcn_perm(ba01, rg01, 0x07060302u);
+				o.z = __builtin_amdgcn_perm(ba23, rg23, 0x05040100u);
+				o.w = __builtin_amdgcn_perm(ba23, rg23, 0x07060302u);
+				reinterpret_cast<uint4 *>(dst)[i] = o;
+			}
+		} else if (a.filter == 0) {
+			// ResizeAlg::Nearest (mod.rs:277): pick, no alpha handling
+			const uint32_t lgx = 31u - (uint32_t)__builtin_clz(nw);
+			const uint32_t hx = m0 ? (1u << (m0 < 6u ? m0 - 1u : 4u)) : 0u, hy = m1 ? (1u << (m1 < 6u ? m1 - 1u : 4u)) : 0u;
+			const uint16_t *pl16 = reinterpret_cast<const uint16_t *>(s_pl);
+			for (uint32_t i = tid; i < nw * nh; i += 64u) {
+				const uint32_t ox = i & (nw - 1u), oy = i >> lgx;
+				const uint32_t x = m0 == 0 ? ox : (m0 < 6u ? (2u * ox + 1u) * hx : 16u);
+				const uint32_t y = m1 == 0 ? oy : (m1 < 6u ? (2u * oy + 1u) * hy : 16u);
+				const uint32_t idx = y * (2u * kRS32) + x;
+				dst[i] = (uint32_t)pl16[idx] | ((uint32_t)pl16[idx + 2u * kPD32] << 8) | ((uint32_t)pl16[idx + 4u * kPD32] << 16) |
+				         ((uint32_t)pl16[idx + 6u * kPD32] << 24);
+			}
+		} else {
+			// fir, U8x4: premultiply the colour planes in place -- mul_div_255 on both pixels of a dword at once:
+			// t = v*a + 128 <= 65153, t + (t >> 8) <= 65407: nothing leaves its 16-bit half
+#pragma unroll
+			for (uint32_t it = 0; it < 8; ++it) {
+				const uint32_t i = tid + 64u * it;
+				uint32_t *p = s_pl + (i >> 4) * kRS32 + (i & 15u);
+				const ushort2v al = us2(p[3 * kPD32]);
+#pragma unroll
+				for (uint32_t c = 0; c < 3; ++c) {
+					ushort2v t = us2(p[c * kPD32]) * al + (ushort2v)(128);
+					t = t + (t >> (ushort2v)(8));
+					p[c * kPD32] = u32(t >> (ushort2v)(8));
+				}
+			}
+			tile_sync<1>();
+			const uint32_t lx = m0 < (uint32_t)kMaxLevel ? m0 : (uint32_t)kMaxLevel - 1;
+			const uint32_t ly = m1 < (uint32_t)kMaxLevel ? m1 : (uint32_t)kMaxLevel - 1;
+			resample_mfma32<4>(s_tab, a.tabs[lx], a.tabs[ly], s_pl, tid, nw, nh, dst);
+		}
+		tile_sync<1>();  // the next tile reuses this wave's LDS image
+		tile_g = tile_next;
+	}
+	list_flush(s_batch, n_listb, a.work + kWorkList, a.work + a.work_slot, tid);
+}
+
+// ---------------------------------------------------------------------------
+// shrink16_kernel: 16x16 RGBA tiles, four at a time -- a 2x2 group of tiles is one 32x32 region, loaded,
+// staged and scanned by the detector exactly like a tile of shrink32_kernel; only the windows that would
+// straddle two tiles are left out, the sums are kept per tile (segmented reduction), and each of the four
+// tiles then gets its own level decision and its own small resample out of the shared LDS image.
+// Groups are dealt to the waves of a block through the LDS ticket counter.  Groups with a ragged or missing
+// tile, tiles with transparency and the one-pass classes (16 x n, n x 16) go to the worklist.
+// MODE 1: directional detector here; MODE 0: values already in sums[] (oklab_kernel<16>).
+// ---------------------------------------------------------------------------
+// FULL: as in shrink32_kernel (all three output arrays are there; no run-time tests of them in the loop).
+template <int MODE, bool FULL>
+__global__ void __launch_bounds__(1024) shrink16_kernel(const Fast32Args a)
+{
+	extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+	const uint32_t wpb = blockDim.x / 64u, sub = threadIdx.x / 64u, tid = threadIdx.x % 64u;
+	for (uint32_t i = threadIdx.x; i < a.tab_dw / 4u; i += blockDim.x)
+		reinterpret_cast<uint4 *>(lds)[i] = reinterpret_cast<const uint4 *>(a.trows)[i];
+	uint32_t *s_ticket = lds + a.tab_dw + wpb * a.tile_dw;
+	if (threadIdx.x == 0) *s_ticket = wpb;
+	__syncthreads();
+	const uint32_t *s_tab = lds;
+	const uint32_t brk_lane = tid < (uint32_t)kMaxLevel ? a.breaks[tid] : (a.breaks_asc ? 0xffffffffu : 0u);
+	auto level_of = [&](uint32_t key) -> uint32_t {
+		const unsigned long long lt = __builtin_amdgcn_ballot_w64(key < brk_lane);
+		const unsigned long long live = (1ull << kMaxLevel) - 1ull;
+		return (uint32_t)__builtin_popcountll((a.breaks_asc ? ~lt : lt) & live);
+	};
+	uint32_t *s_pl = lds + a.tab_dw + sub * a.tile_dw;
+	uint32_t *s_tmp = s_pl + 3 * kPD32;
+	uint32_t *s_batch = s_ticket + 4u + sub * kListBatch;  // this wave's pending list-B entries
+	uint32_t n_listb = 0;
+	// groups of 2x2 tiles: gcols x grows per frame
+	const uint32_t gcols = (a.cols + 1u) >> 1, grows = (a.rows + 1u) >> 1, gpf = gcols * grows;
+	auto group_of_ticket = [&](uint32_t t) -> uint32_t {
+		const unsigned long long run = (unsigned long long)(t >> a.chunk_lg) * gridDim.x + blockIdx.x;
+		const unsigned long long g = (run << a.chunk_lg) + (t & ((1u << a.chunk_lg) - 1u));
+		return g < (unsigned long long)a.n_groups ? (uint32_t)g : 0xffffffffu;
+	};
+	auto next_ticket = [&]() -> uint32_t {
+		uint32_t t = 0;
+		if (tid == 0) t = atomicAdd(s_ticket, 1u);
+		return group_of_ticket(__builtin_amdgcn_readfirstlane(t));
+	};
+	// a group's place: frame, (gx, gy); full: all four tiles exist, are full-size and the batch is aligned
+	struct Place {
+		uint32_t frame, gx, gy;
+		bool full;
+		const uint8_t *src;
+	};
+	auto place_of = [&](uint32_t grp) -> Place {
+		Place p{0, 0, 0, false, nullptr};
+		if (grp >= a.n_groups) return p;
+		p.frame = fastdiv(grp, a.div_gpf);
+		const uint32_t r = grp - p.frame * gpf;
+		p.gy = fastdiv(r, a.div_gcols);
+		p.gx = r - p.gy * gcols;
+		p.src = a.src + (size_t)p.frame * a.frame_stride + (size_t)(p.gy * 32u) * a.pitch + (size_t)(p.gx * 32u) * 4u;
+		p.full = 2u * p.gx + 1u < a.full_cols && 2u * p.gy + 1u < a.full_rows;
+		return p;
+	};
+	uint4 pre[4];
+	bool pre_valid = false;
+	auto prefetch = [&](uint32_t grp) {
+		const Place p = place_of(grp);
+		pre_valid = p.full;
+		if (pre_valid) {
+			const uint8_t *q = p.src + (size_t)(tid >> 3) * a.pitch + (tid & 7u) * 16u;
+#pragma unroll
+			for (int k = 0; k < 4; ++k) pre[k] = *reinterpret_cast<const uint4 *>(q + (size_t)(8 * k) * a.pitch);
+		}
+	};
+	const uint32_t first = group_of_ticket(__builtin_amdgcn_readfirstlane(sub));
+	prefetch(first);
+	for (uint32_t grp = first; grp < a.n_groups;) {
+		const uint32_t grp_next = next_ticket();
+		const Place pl = place_of(grp);
+		// tile ids of the group: t(dx, dy) = frame * tiles_per_frame + (2 gy + dy) * cols + 2 gx + dx
+		const uint32_t t00 = pl.frame * a.tiles_per_frame + (2u * pl.gy) * a.cols + 2u * pl.gx;
+		auto tile_id = [&](uint32_t k) -> uint32_t { return t00 + (k & 1u) + (k >> 1) * a.cols; };
+		auto defer_tile = [&](uint32_t t) {
+			list_push(s_batch, n_listb, t, a.work + kWorkList, a.work + a.work_slot, tid);
+			if (tid == 0) {
+				bool keep = false;  // MODE 0: a value the block-cooperative detector left is final and stays
+				if constexpr (MODE == 0) {
+					const uint32_t tt = t - pl.frame * a.tiles_per_frame;
+					const uint32_t ty = fastdiv(tt, a.div_cols), tx = tt - ty * a.cols;
+					keep = tx < a.full_cols && ty < a.ok_rows;
+				}
+				if (!keep) reinterpret_cast<uint2 *>(a.sums)[t] = make_uint2(kDeferredKey, kDeferredKey);
+			}
+		};
+		if (!pre_valid) {
+			// a ragged or incomplete group (or an unaligned batch): its tiles one by one to the generic kernel
+#pragma unroll
+			for (uint32_t k = 0; k < 4; ++k)
+				if (2u * pl.gx + (k & 1u) < a.cols && 2u * pl.gy + (k >> 1) < a.rows) defer_tile(tile_id(k));
+			prefetch(grp_next);
+			grp = grp_next;
+			continue;
+		}
+		uint32_t given[4] = {0, 0, 0, 0};
+		if constexpr (MODE == 0) {
+#pragma unroll
+			for (uint32_t k = 0; k < 4; ++k) given[k] = a.sums[2 * tile_id(k)];
+		}
+		// ---- stage: registers -> planar u16 pairs (as shrink32_kernel)
+		uint32_t alpha_and = 0xffu;
+#pragma unroll
+		for (int k = 0; k < 4; ++k) alpha_and &= (pre[k].x & pre[k].y & pre[k].z & pre[k].w) >> 24;
+		const bool transparent = __builtin_amdgcn_ballot_w64(alpha_and != 0xffu) != 0ull;
+#pragma unroll
+		for (int k = 0; k < 4; ++k) {
+			const uint32_t row = (tid >> 3) + 8u * (uint32_t)k, col = tid & 7u;
+			const uint4 v = pre[k];
+			uint32_t *d = s_pl + row * kRS32 + col * 2u;
+#pragma unroll
+			for (uint32_t c = 0; c < 3; ++c) {
+				const uint32_t sel = c | 0x0c000c00u | ((4u + c) << 16);
+				uint2 pr;
+				pr.x = __builtin_amdgcn_perm(v.y, v.x, sel);
+				pr.y = __builtin_amdgcn_perm(v.w, v.z, sel);
+				*reinterpret_cast<uint2 *>(d + c * kPD32) = pr;
+			}
+		}
+		prefetch(grp_next);
+		if (transparent) {
+			// (one transparent tile sends the whole group: the generic kernel has the alpha plane)
+#pragma unroll
+			for (uint32_t k = 0; k < 4; ++k) defer_tile(tile_id(k));
+			grp = grp_next;
+			continue;
+		}
+		tile_sync<1>();
+		// ---- detector: as shrink32_kernel, minus the windows that would straddle two tiles
+		uint32_t m0[4], m1[4], key0[4], key1[4];
+		if constexpr (MODE == 1) {
+			uint32_t sum_hz = 0, sum_vr = 0;
+			const uint32_t q = tid & 15u, g = tid >> 4;
+			const uint32_t two = 0x00020002u;
+			const uint32_t *pc[3];
+			pc[0] = s_pl + g * (8u * kRS32) + q;
+			pc[1] = pc[0] + kPD32;
+			pc[2] = pc[1] + kPD32;
+			uint32_t rA[3], rB[3], tP[3], dP[3];
+#pragma unroll
+			for (int c = 0; c < 3; ++c) {
+				const uint32_t a0 = pc[c][0], a1 = pc[c][1], b0 = pc[c][kRS32], b1 = pc[c][kRS32 + 1];
+				rA[c] = pk_mad_u16(__builtin_amdgcn_alignbit(a1, a0, 16), two, u32(us2(a0) + us2(a1)));
+				rB[c] = pk_mad_u16(__builtin_amdgcn_alignbit(b1, b0, 16), two, u32(us2(b0) + us2(b1)));
+				tP[c] = u32(us2(a0) + us2(b0));
+				dP[c] = b0;
+			}
+#pragma unroll
+			for (int st = 0; st < 4; ++st) {
+				if (st < 3 || (g & 1u) == 0u) {  // groups 1 and 3 hold window rows 8 .. 13 of their tiles: 3 steps
+#pragma unroll
+					for (int c = 0; c < 3; ++c) {
+						const uint32_t *pr = pc[c] + (2 + 2 * st) * (int)kRS32;
+						const uint32_t n0 = pr[0], n1 = pr[1], o0 = pr[kRS32], o1 = pr[kRS32 + 1];
+						const uint32_t rN = pk_mad_u16(__builtin_amdgcn_alignbit(n1, n0, 16), two, u32(us2(n0) + us2(n1)));
+						sum_hz = sad16(rN, rA[c], sum_hz);
+						const uint32_t tN = u32(us2(dP[c]) + us2(n0));
+						const uint32_t c0 = u32(us2(tP[c]) + us2(tN));
+						sum_vr = sad16(dpp_mov<0x101>(c0), c0, sum_vr);
+						const uint32_t rO = pk_mad_u16(__builtin_amdgcn_alignbit(o1, o0, 16), two, u32(us2(o0) + us2(o1)));
+						sum_hz = sad16(rO, rB[c], sum_hz);
+						const uint32_t tO = u32(us2(n0) + us2(o0));
+						const uint32_t e0 = u32(us2(tN) + us2(tO));
+						sum_vr = sad16(dpp_mov<0x101>(e0), e0, sum_vr);
+						rA[c] = rN;
+						rB[c] = rO;
+						tP[c] = tO;
+						dP[c] = o0;
+					}
+				}
+			}
+			if ((q & 7u) == 7u) sum_hz = sum_vr = 0;  // pairs 7 and 15 start no window inside their tile
+			// per tile: 8 lanes (q >> 3) of two 16-lane rows (g >> 1): sum inside the 8-lane groups, then pick
+			sum_hz = (uint32_t)group_sum<8>((int32_t)sum_hz);
+			sum_vr = (uint32_t)group_sum<8>((int32_t)sum_vr);
+#pragma unroll
+			for (uint32_t k = 0; k < 4; ++k) {
+				const uint32_t l0 = 32u * (k >> 1) + 8u * (k & 1u);  // first lane of tile k's first row; its second row is 16 on
+				key0[k] = (uint32_t)__builtin_amdgcn_readlane((int)sum_hz, l0) + (uint32_t)__builtin_amdgcn_readlane((int)sum_hz, l0 + 16u);
+				key1[k] = (uint32_t)__builtin_amdgcn_readlane((int)sum_vr, l0) + (uint32_t)__builtin_amdgcn_readlane((int)sum_vr, l0 + 16u);
+				m0[k] = level_of(key0[k]);
+				m1[k] = level_of(key1[k]);
+			}
+		} else {
+#pragma unroll
+			for (uint32_t k = 0; k < 4; ++k) {
+				const uint32_t vb = __builtin_amdgcn_readfirstlane(given[k]);
+				key0[k] = key1[k] = vb;
+				m0[k] = m1[k] = level_of(__float_as_uint(parse_value(__uint_as_float(vb))));
+			}
+		}
+		uint32_t nw[4], nh[4];
+#pragma unroll
+		for (uint32_t k = 0; k < 4; ++k) {
+			nw[k] = reduced_size(16u, m0[k]);
+			nh[k] = reduced_size(16u, m1[k]);
+		}
+		// ---- per tile: metadata, then clone / nearest / two-pass resample straight into its slot
+		uint32_t filt = a.filter;
+		asm volatile("" : "+s"(filt));  // scalar compares per use instead of a hoisted mask
+#pragma unroll
+		for (uint32_t k = 0; k < 4; ++k) {
+			const uint32_t t = tile_id(k);
+			const bool one_pass = (FULL || a.out_px != nullptr) && (nw[k] == 16u) != (nh[k] == 16u) && filt != 0;
+			if (one_pass) {  // 16 x n, n x 16: generic kernel (it writes the tile's metadata itself)
+				defer_tile(t);
+				continue;
+			}
+			{
+				uint32_t lane = tid;
+				asm volatile("" : "+v"(lane));  // a fresh compare, not a hoisted (and spilled) lane mask
+				if (lane == 0) {
+					reinterpret_cast<uint2 *>(a.sums)[t] = make_uint2(key0[k], key1[k]);
+					if (FULL || a.out_w) a.out_w[t] = nw[k];
+					if (FULL || a.out_h) a.out_h[t] = nh[k];
+				}
+			}
+			if (!FULL && a.out_px == nullptr) continue;
+			uint32_t *dst = reinterpret_cast<uint32_t *>(a.out_px + (size_t)t * 1024u);
+			const uint32_t *tile_pl = s_pl + (16u * (k >> 1)) * kRS32 + 8u * (k & 1u);  // first pixel pair of the tile
+			if (nw[k] == 16u && nh[k] == 16u) {
+				// clone (block.rs:279-281): 64 groups of 4 pixels, one per lane
+				const uint32_t row = tid >> 2, c4 = tid & 3u;
+				const uint32_t *p = tile_pl + row * kRS32 + c4 * 2u;
+				const uint2 r = *reinterpret_cast<const uint2 *>(p), gch = *reinterpret_cast<const uint2 *>(p + kPD32);
+				const uint2 b = *reinterpret_cast<const uint2 *>(p + 2 * kPD32);
+				const uint32_t opq = 0x00ff00ffu;
+				const uint32_t rg01 = __builtin_amdgcn_perm(gch.x, r.x, 0x06020400u), ba01 = __builtin_amdgcn_perm(opq, b.x, 0x06020400u);
+				const uint32_t rg23 = __builtin_amdgcn_perm(gch.y, r.y, 0x06020400u), ba23 = __builtin_amdgcn_perm(opq, b.y, 0x06020400u);
+				uint4 o;
+				o.x = __builtin_amdgcn_perm(ba01, rg01, 0x05040100u);
+				o.y = __builtin_amdgcn_perm(ba01, rg01, 0x07060302u);
+				o.z = __builtin_amdgcn_perm(ba23, rg23, 0x05040100u);
+				o.w = __builtin_amdgcn_perm(ba23, rg23, 0x07060302u);
+				reinterpret_cast<uint4 *>(dst)[tid] = o;
+			} else if (filt == 0) {
+				// ResizeAlg::Nearest: source index = floor((o + 0.5) * 2^m); any (nw, nh)
+				const uint32_t mx = m0[k], my = m1[k];
+				const uint32_t lgx = 31u - (uint32_t)__builtin_clz(nw[k]);
+				const uint16_t *pl16 = reinterpret_cast<const uint16_t *>(tile_pl);
+				for (uint32_t i = tid; i < nw[k] * nh[k]; i += 64u) {
+					const uint32_t ox = i & (nw[k] - 1u), oy = i >> lgx;
+					const uint32_t x = mx == 0 ? ox : (mx < 5u ? (2u * ox + 1u) << (mx - 1u) : 8u);
+					const uint32_t y = my == 0 ? oy : (my < 5u ? (2u * oy + 1u) << (my - 1u) : 8u);
+					const uint32_t idx = y * (2u * kRS32) + x;
+					dst[i] = (uint32_t)pl16[idx] | ((uint32_t)pl16[idx + 2u * kPD32] << 8) | ((uint32_t)pl16[idx + 4u * kPD32] << 16) | 0xff000000u;
+				}
+			} else {
+				const uint32_t lx = m0[k] < (uint32_t)kMaxLevel ? m0[k] : (uint32_t)kMaxLevel - 1;
+				const uint32_t ly = m1[k] < (uint32_t)kMaxLevel ? m1[k] : (uint32_t)kMaxLevel - 1;
+				resample_fast16_hv(s_tab, a.tabs[lx], a.tabs[ly], tile_pl, s_tmp, tid, nw[k], nh[k], dst);
+			}
+		}
+		tile_sync<1>();  // the next group reuses this wave's LDS image
+		grp = grp_next;
+	}
+	list_flush(s_batch, n_listb, a.work + kWorkList, a.work + a.work_slot, tid);
+}
+
+// 32x32 / 16x16 flow, first part: shrink32_kernel (+ shrink32a_kernel) or shrink16_kernel; ga = the arguments of
+// the worklist kernel that follows (pxz_shrink_generic.hip: launch_shrink)
+hipError_t launch_fast32_16(const ShrinkArgs &a, ShrinkArgs &ga, uint32_t n_cus, hipStream_t stream)
+{
+	// 1) the lean kernel for full opaque tiles (32x32), or for 2x2 groups of them (16x16); it leaves the rest
+	// in the worklist
+	const bool groups16 = a.bw == 16;
+	Fast32Args f{};
+	f.n_groups = a.n_frames_x_groups;
+	f.div_gpf = a.div_gpf;
+	f.div_gcols = a.div_gcols;
+	f.src = a.src;
+	f.frame_stride = a.frame_stride;
+	f.pitch = a.pitch;
+	f.cols = a.cols;
+	f.rows = a.rows;
+	f.tiles_per_frame = a.tiles_per_frame;
+	f.n_tiles = a.n_tiles;
+	f.div_tpf = a.div_tpf;
+	f.div_cols = a.div_cols;
+	f.full_cols = a.full_cols;
+	f.full_rows = a.full_rows;
+	f.ok_rows = a.ok_rows;
+	f.filter = a.filter;
+	f.sums = a.sums;
+	f.out_w = a.out_w;
+	f.out_h = a.out_h;
+	f.out_px = a.out_px;
+	f.work = a.work;
+	f.work_slot = a.work_slot;
+	// full tiles with transparency always go to list A; shrink32a_kernel takes it when transparency was announced
+	// or seen before, else the worklist kernel walks it after list B
+	f.alpha_list = (!groups16 && a.out_px != nullptr && (a.filter == 0 || a.tab_dw != 0)) ? 1u : 0u;
+	const bool run_alpha = f.alpha_list != 0 && a.alpha_kernel != 0;
+	ga.list_a_too = f.alpha_list != 0 && !run_alpha ? 1u : 0u;
+	f.trows = a.trows;
+	f.tab_dw = a.out_px && a.filter != 0 ? a.tab_dw : 0u;
+	// only the x-axis tables of full tiles are used (the y axis of a 32x32 tile is identical): they
+	// are the first rows of the blob, up to where the y axis begins
+	const uint32_t y_begin = a.tabs[2 * kMaxLevel + 1].rows_off;
+	if (f.tab_dw != 0 && y_begin != 0 && y_begin < f.tab_dw) f.tab_dw = (y_begin + 3u) & ~3u;
+	for (int j = 0; j < kMaxLevel; ++j) {
+		f.breaks[j] = a.breaks[0][j];
+		f.tabs[j] = a.tabs[j];  // x axis, full class; identical to the y axis for 32x32
+	}
+	f.breaks_asc = a.breaks_asc[0];
+	// planes 3 x 576 dwords (R, G, B), output region (transposed planes 3 x 144 of the dot2 form / parked
+	// pixels of nearest, one-pass and matrix-core outputs: at most 32x16), slack for zero-weight over-reads
+	static_assert(3u * kTD32 <= kOut32, "transposed planes fit the output region");
+	f.tile_dw = f.out_px ? 3u * kPD32 + kOut32 + 2u * kRS32 : 3u * kPD32 + 4u * kRS32;
+	f.tile_dw = (f.tile_dw + 3u) & ~3u;
+	constexpr uint32_t kLds = 160u * 1024u;
+	constexpr uint32_t kTail = 16u + 16u * 2u * kListBatch * 4u;  // the ticket counter + every wave's list batches
+	uint32_t wpb = (kLds - f.tab_dw * 4u - kTail) / (f.tile_dw * 4u);
+	if (wpb > 16u) wpb = 16u;
+	if (const char *e = getenv("PXZ_WPB")) {
+		const uint32_t v = (uint32_t)atoi(e);
+		if (v >= 1 && v < wpb) wpb = v;
+	}
+	const uint32_t lds_bytes = f.tab_dw * 4u + wpb * f.tile_dw * 4u + kTail;
+	const uint32_t per_cu = kLds / lds_bytes > 0 ? kLds / lds_bytes : 1u;
+	const uint32_t resident = n_cus * (per_cu > 2u ? 2u : per_cu);
+	const uint32_t units = groups16 ? f.n_groups : a.n_tiles;
+	const uint32_t need = (units + wpb - 1u) / wpb;
+	const uint32_t blocks = need < resident ? need : resident;
+	f.chunk_lg = 3;
+	if (const char *e = getenv("PXZ_CHUNK_LG")) f.chunk_lg = (uint32_t)atoi(e) & 15u;
+	hipError_t e = hipSuccess;  // the worklist counter of this launch was zeroed by the previous one (or at allocation)
+	if (groups16) {
+		const bool full = a.out_px != nullptr && a.out_w != nullptr && a.out_h != nullptr;
+		void (*k)(const Fast32Args) = a.mode == 1 ? (full ? shrink16_kernel<1, true> : shrink16_kernel<1, false>)
+		                                          : (full ? shrink16_kernel<0, true> : shrink16_kernel<0, false>);
+		if (lds_bytes > 64u * 1024u && (e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)) != hipSuccess) return e;
+		hipLaunchKernelGGL(k, dim3(blocks), dim3(64u * wpb), lds_bytes, stream, f);
+	} else {
+		const bool full = a.out_px != nullptr && a.out_w != nullptr && a.out_h != nullptr;
+		void (*k)(const Fast32Args) = a.mode == 1 ? (full ? shrink32_kernel<1, true> : shrink32_kernel<1, false>)
+		                                          : (full ? shrink32_kernel<0, true> : shrink32_kernel<0, false>);
+		if (lds_bytes > 64u * 1024u && (e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)) != hipSuccess) return e;
+		hipLaunchKernelGGL(k, dim3(blocks), dim3(64u * wpb), lds_bytes, stream, f);
+	}
+	if ((e = hipGetLastError()) != hipSuccess) return e;
+	if (a.mid_event && (e = hipEventRecord(static_cast<hipEvent_t>(a.mid_event), stream)) != hipSuccess) return e;
+	ga.mid_event = nullptr;
+	if (run_alpha) {
+		// 1b) the full tiles with transparency that shrink32_kernel listed: four planes, no output region
+		Fast32Args fa = f;
+		fa.tile_dw = (4u * kPD32 + 2u * kRS32 + 3u) & ~3u;
+		uint32_t wa = (kLds - fa.tab_dw * 4u - kTail) / (fa.tile_dw * 4u);
+		if (wa > 16u) wa = 16u;
+		const uint32_t lds_a = fa.tab_dw * 4u + wa * fa.tile_dw * 4u + kTail;
+		if (a.mode == 1) {
+			auto k = shrink32a_kernel<1>;
+			if (lds_a > 64u * 1024u && (e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a)) != hipSuccess) return e;
+			hipLaunchKernelGGL(k, dim3(n_cus), dim3(64u * wa), lds_a, stream, fa);
+		} else {
+			auto k = shrink32a_kernel<0>;
+			if (lds_a > 64u * 1024u && (e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a)) != hipSuccess) return e;
+			hipLaunchKernelGGL(k, dim3(n_cus), dim3(64u * wa), lds_a, stream, fa);
+		}
+		if ((e = hipGetLastError()) != hipSuccess) return e;
+	}
+	// 2) the generic kernel walks the worklist (usually empty or a few percent of the tiles)
+	return hipSuccess;
+}
+
+}  // namespace pxz

@@ -1,0 +1,635 @@
+// pxz_stream.hip -- the byte-stream kernels: tile compaction (pack_*), the device .pixlzr writer (qoi_* encode kernels:
+// binning, one QOI stream per lane, splice, headers) and reader (pixlzr_index_kernel, qoi_decode_kernel).
+//
+// Compiled with -ffp-contract=off: the f32 results of the Oklab detector are
+// written into the bitstream, and the reference (Rust) never fuses a*b+c.
+#include "pxz_device.h"
+
+namespace pxz {
+
+
+// ---------------------------------------------------------------------------
+// block-stream compaction: the valid bytes of the fixed output slots, tile order,
+// into one contiguous stream (what a writer / the RCCL gather consumes).
+//   offsets[t] = sum_{u<t} w[u]*h[u]*C  (exclusive scan, u64), offsets[n] = total
+// Three launches: per-chunk scan (4096 tiles per block), scan of the chunk totals,
+// copy (one wave per tile, 16-byte reads from the slot, dword or byte writes).
+// ---------------------------------------------------------------------------
+constexpr uint32_t kPackChunk = 4096;  // tiles per block in the scan: 256 threads x 16
+
+__global__ void __launch_bounds__(256) pack_scan_local_kernel(const PackArgs a)
+{
+	__shared__ uint32_t s_wave[4];
+	const uint32_t base = blockIdx.x * kPackChunk + threadIdx.x * 16u;
+	uint32_t sz[16], run = 0;
+#pragma unroll
+	for (uint32_t i = 0; i < 16; ++i) {
+		const uint32_t t = base + i;
+		sz[i] = t < a.n_tiles ? (a.sizes ? a.sizes[t] : a.w[t] * a.h[t] * a.channels) : 0u;
+		run += sz[i];
+	}
+	// exclusive scan of the per-thread totals inside the block
+	uint32_t incl = run;
+#pragma unroll
+	for (int off = 1; off < 64; off <<= 1) {
+		const uint32_t v = __shfl_up(incl, off, 64);
+		if ((threadIdx.x & 63u) >= (uint32_t)off) incl += v;
+	}
+	if ((threadIdx.x & 63u) == 63u) s_wave[threadIdx.x >> 6] = incl;
+	__syncthreads();
+	uint32_t wave_off = 0;
+	for (uint32_t q = 0; q < (threadIdx.x >> 6); ++q) wave_off += s_wave[q];
+	uint32_t excl = wave_off + incl - run;
+#pragma unroll
+	for (uint32_t i = 0; i < 16; ++i) {
+		const uint32_t t = base + i;
+		if (t < a.n_tiles) a.offsets[t] = excl;  // chunk-local for now (a chunk holds < 2^32 bytes)
+		excl += sz[i];
+	}
+	if (threadIdx.x == 255) a.chunk_totals[blockIdx.x] = excl;
+}
+
+__global__ void __launch_bounds__(1024) pack_scan_chunks_kernel(const PackArgs a)
+{
+	// one block: exclusive scan of the chunk totals (u64), in place
+	__shared__ unsigned long long s_wave[16];
+	__shared__ unsigned long long s_carry;
+	if (threadIdx.x == 0) s_carry = 0;
+	__syncthreads();
+	for (uint32_t base = 0; base < a.n_chunks; base += 1024u) {
+		const uint32_t i = base + threadIdx.x;
+		const unsigned long long v = i < a.n_chunks ? a.chunk_totals[i] : 0ull;
+		unsigned long long incl = v;
+#pragma unroll
+		for (int off = 1; off < 64; off <<= 1) {
+			const unsigned long long u = __shfl_up(incl, off, 64);
+			if ((threadIdx.x & 63u) >= (uint32_t)off) incl += u;
+		}
+		if ((threadIdx.x & 63u) == 63u) s_wave[threadIdx.x >> 6] = incl;
+		__syncthreads();
+		unsigned long long wave_off = s_carry;
+		for (uint32_t q = 0; q < (threadIdx.x >> 6); ++q) wave_off += s_wave[q];
+		if (i < a.n_chunks) a.chunk_totals[i] = wave_off + incl - v;
+		__syncthreads();
+		if (threadIdx.x == 1023) s_carry = wave_off + incl;
+		__syncthreads();
+	}
+	if (threadIdx.x == 0) a.offsets[a.n_tiles] = s_carry;  // grand total
+}
+
+__global__ void __launch_bounds__(256) pack_copy_kernel(const PackArgs a)
+{
+	const uint32_t t = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+	if (t >= a.n_tiles) return;
+	const unsigned long long off = a.chunk_totals[t / kPackChunk] + a.offsets[t];
+	const uint32_t bytes = a.w[t] * a.h[t] * a.channels;
+	const uint8_t *src = a.slots + (size_t)t * a.slot_bytes;
+	uint8_t *dst = a.packed + off;
+	if (lane == 0) a.offsets[t] = off;  // chunk-local -> global (each tile is owned by exactly one wave)
+	if (off + bytes > a.capacity) return;
+	if (((off | bytes) & 3ull) == 0 && (a.slot_bytes & 3u) == 0) {
+		const uint32_t *s4 = reinterpret_cast<const uint32_t *>(src);
+		uint32_t *d4 = reinterpret_cast<uint32_t *>(dst);
+		for (uint32_t i = lane; i < (bytes >> 2); i += 64u) d4[i] = s4[i];
+	} else {
+		for (uint32_t i = lane; i < bytes; i += 64u) dst[i] = src[i];
+	}
+}
+
+hipError_t launch_pack(const PackArgs &a, hipStream_t stream)
+{
+	hipLaunchKernelGGL(pack_scan_local_kernel, dim3(a.n_chunks), dim3(256), 0, stream, a);
+	hipLaunchKernelGGL(pack_scan_chunks_kernel, dim3(1), dim3(1024), 0, stream, a);
+	hipLaunchKernelGGL(pack_copy_kernel, dim3((a.n_tiles + 3) / 4), dim3(256), 0, stream, a);
+	return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// .pixlzr bitstream on the GPU: Pixlzr::encode_to_vec (reference src/encoding/mod.rs:40-89) with
+// encode_block (:168-200) and the `qoi` crate 0.4.1 encoder it calls (:181-189).
+//
+// QOI is sequential per tile (previous pixel, run length, 64-entry index), tiles are independent:
+// one lane encodes one tile.  Tiles are first binned by pixel count (counting sort) so that the 64
+// tiles of a wave have the same length and the lanes stay busy together.  Each lane keeps its index
+// in LDS as table[slot][lane] (consecutive lanes -> consecutive banks), reads 4 pixels per 16-byte
+// load from its slot and appends bytes through a 64-bit accumulator (aligned 8-byte stores) into a
+// per-tile scratch record:  "block" | f32 BE value | u32 BE len | w,h BE | channels | 0 | ops | 0x00*7 0x01.
+// Then: scan of the record lengths, splice into the final files, header + per-row length table.
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) qoi_bin_count_kernel(const QoiArgs a)
+{
+	// per-block histogram in LDS, then one global atomic per non-empty class and block
+	__shared__ uint32_t s_hist[32];
+	if (threadIdx.x < 32) s_hist[threadIdx.x] = 0;
+	__syncthreads();
+	const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+	if (t < a.n_tiles) atomicAdd(&s_hist[31u - (uint32_t)__builtin_clz((a.w[t] * a.h[t]) | 1u)], 1u);
+	__syncthreads();
+	if (threadIdx.x < 32 && s_hist[threadIdx.x]) atomicAdd(&a.bins[threadIdx.x], s_hist[threadIdx.x]);
+}
+
+__global__ void qoi_bin_scan_kernel(const QoiArgs a)
+{
+	// largest tiles first (they set the tail): cursor[c] = start of class c in the permutation
+	uint32_t run = 0;
+	for (int c = 31; c >= 0; --c) {
+		const uint32_t n = a.bins[c];
+		a.bins[32 + c] = run;
+		run += n;
+	}
+}
+
+__global__ void __launch_bounds__(256) qoi_bin_scatter_kernel(const QoiArgs a)
+{
+	// the block reserves one range per class (one global atomic each), threads take slots inside it
+	__shared__ uint32_t s_hist[32], s_base[32];
+	if (threadIdx.x < 32) s_hist[threadIdx.x] = 0;
+	__syncthreads();
+	const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+	uint32_t cls = 0, local = 0;
+	if (t < a.n_tiles) {
+		cls = 31u - (uint32_t)__builtin_clz((a.w[t] * a.h[t]) | 1u);
+		local = atomicAdd(&s_hist[cls], 1u);
+	}
+	__syncthreads();
+	if (threadIdx.x < 32 && s_hist[threadIdx.x]) s_base[threadIdx.x] = atomicAdd(&a.bins[32u + threadIdx.x], s_hist[threadIdx.x]);
+	__syncthreads();
+	if (t < a.n_tiles) a.perm[s_base[cls] + local] = t;
+}
+
+struct ByteSink {
+	unsigned long long acc;
+	uint32_t cnt;        // bytes in acc
+	unsigned long long *out;
+	__device__ __forceinline__ void put(uint32_t b)
+	{
+		acc |= (unsigned long long)(b & 255u) << (8u * cnt);
+		if (++cnt == 8u) {
+			*out++ = acc;
+			acc = 0;
+			cnt = 0;
+		}
+	}
+};
+
+template <int C>
+__global__ void __launch_bounds__(256) qoi_tiles_kernel(const QoiArgs a)
+{
+	__shared__ uint32_t s_index[4][64][64];  // [wave][slot][lane]
+	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+	const bool live = i < a.n_tiles;
+	const uint32_t t = live ? a.perm[i] : 0u;
+	uint32_t(*index)[64] = s_index[wave];
+#pragma unroll 8
+	for (int sidx = 0; sidx < 64; ++sidx) index[sidx][lane] = 0u;  // qoi: index starts as zero pixels
+	if (!live) return;
+	const uint32_t w = a.w[t], h = a.h[t], n = w * h;
+	const uint8_t *src = a.slots + (size_t)t * a.slot_bytes;
+	uint8_t *rec = a.scratch + (size_t)t * a.stride;
+	ByteSink s{0ull, 0u, reinterpret_cast<unsigned long long *>(rec)};
+	// encode_block: magic, value, length placeholder (mod.rs:172-178,195)
+	const uint32_t vb = __float_as_uint(a.value[t]);
+	s.put('b'); s.put('l'); s.put('o'); s.put('c'); s.put('k');
+	s.put(vb >> 24); s.put(vb >> 16); s.put(vb >> 8); s.put(vb);
+	s.put(0); s.put(0); s.put(0); s.put(0);
+	// qoi header minus its 4-byte magic (mod.rs:191): width, height BE, channels, colourspace 0
+	s.put(w >> 24); s.put(w >> 16); s.put(w >> 8); s.put(w);
+	s.put(h >> 24); s.put(h >> 16); s.put(h >> 8); s.put(h);
+	s.put((uint32_t)C); s.put(0);
+
+	uint32_t prev = 0xff000000u, run = 0, last_slot = 0;
+	bool seen_op = false;
+	const bool aligned = C == 4 ? true : ((a.slot_bytes & 3u) == 0);
+	for (uint32_t base = 0; base < n; base += 4u) {
+		uint32_t px4[4];
+		if constexpr (C == 4) {
+			const uint4 v = *reinterpret_cast<const uint4 *>(src + (size_t)base * 4u);  // slots are 16-byte aligned
+			px4[0] = v.x; px4[1] = v.y; px4[2] = v.z; px4[3] = v.w;
+		} else {
+			if (aligned) {
+				const uint32_t *p = reinterpret_cast<const uint32_t *>(src + (size_t)base * 3u);
+				const uint32_t d0 = p[0], d1 = p[1], d2 = p[2];
+				px4[0] = d0 & 0xffffffu;
+				px4[1] = (d0 >> 24) | ((d1 & 0xffffu) << 8);
+				px4[2] = (d1 >> 16) | ((d2 & 0xffu) << 16);
+				px4[3] = d2 >> 8;
+			} else {
+				for (int j = 0; j < 4; ++j) {
+					const uint8_t *p = src + (size_t)(base + j) * 3u;
+					px4[j] = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16);
+				}
+			}
+#pragma unroll
+			for (int j = 0; j < 4; ++j) px4[j] |= 0xff000000u;
+		}
+#pragma unroll
+		for (int j = 0; j < 4; ++j) {
+			const uint32_t pi = base + (uint32_t)j;
+			if (pi >= n) break;
+			const uint32_t px = px4[j];
+			if (px == prev) {
+				if (++run == 62u || pi + 1u == n) {
+					s.put(0xc0u | (run - 1u));
+					run = 0;
+				}
+				continue;
+			}
+			if (run) {
+				// the crate writes a pending run of ONE as INDEX of the repeated pixel once any op was written
+				s.put(run == 1u && seen_op ? last_slot : (0xc0u | (run - 1u)));
+				run = 0;
+			}
+			seen_op = true;
+			last_slot = ((px & 255u) * 3u + ((px >> 8) & 255u) * 5u + ((px >> 16) & 255u) * 7u + (px >> 24) * 11u) & 63u;
+			if (index[last_slot][lane] == px) {
+				s.put(last_slot);  // QOI_OP_INDEX
+			} else {
+				index[last_slot][lane] = px;
+				const uint32_t dr = ((px & 255u) - (prev & 255u)) & 255u;
+				const uint32_t dg = (((px >> 8) & 255u) - ((prev >> 8) & 255u)) & 255u;
+				const uint32_t db = (((px >> 16) & 255u) - ((prev >> 16) & 255u)) & 255u;
+				if (C == 4 && (px >> 24) != (prev >> 24)) {
+					s.put(0xff); s.put(px); s.put(px >> 8); s.put(px >> 16); s.put(px >> 24);  // QOI_OP_RGBA
+				} else if (((dr + 2u) & 255u) < 4u && ((dg + 2u) & 255u) < 4u && ((db + 2u) & 255u) < 4u) {
+					s.put(0x40u | (((dr + 2u) & 3u) << 4) | (((dg + 2u) & 3u) << 2) | ((db + 2u) & 3u));  // QOI_OP_DIFF
+				} else if (((dg + 32u) & 255u) < 64u && ((dr - dg + 8u) & 255u) < 16u && ((db - dg + 8u) & 255u) < 16u) {
+					s.put(0x80u | ((dg + 32u) & 63u));  // QOI_OP_LUMA
+					s.put((((dr - dg + 8u) & 15u) << 4) | ((db - dg + 8u) & 15u));
+				} else {
+					s.put(0xfe); s.put(px); s.put(px >> 8); s.put(px >> 16);  // QOI_OP_RGB
+				}
+			}
+			prev = px;
+		}
+	}
+	s.put(0); s.put(0); s.put(0); s.put(0); s.put(0); s.put(0); s.put(0); s.put(1);  // QOI end marker
+	const uint32_t total = (uint32_t)(reinterpret_cast<uint8_t *>(s.out) - rec) + s.cnt;
+	if (s.cnt) *s.out = s.acc;  // partial tail (the record stride leaves room)
+	const uint32_t qlen = total - 13u;  // mod.rs:193-195
+	rec[9] = (uint8_t)(qlen >> 24);
+	rec[10] = (uint8_t)(qlen >> 16);
+	rec[11] = (uint8_t)(qlen >> 8);
+	rec[12] = (uint8_t)qlen;
+	a.rec_len[t] = total;
+}
+
+// splice: one wave per tile copies its record to (frame+1)*hdr + offset[t]
+__global__ void __launch_bounds__(256) qoi_splice_kernel(const QoiArgs a)
+{
+	const uint32_t t = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+	if (t >= a.n_tiles) return;
+	const unsigned long long off = a.chunk_totals[t / kPackChunk] + a.offsets[t];
+	if (lane == 0) a.offsets[t] = off;
+	const uint32_t frame = t / a.tiles_per_frame;
+	const unsigned long long dstoff = (unsigned long long)(frame + 1u) * a.hdr_bytes + off;
+	const uint32_t len = a.rec_len[t];
+	if (dstoff + len > a.capacity) return;
+	const uint8_t *src = a.scratch + (size_t)t * a.stride;
+	uint8_t *dst = a.out + dstoff;
+	for (uint32_t i = lane; i < len; i += 64u) dst[i] = src[i];
+}
+
+// file header + line-length table (mod.rs:50-57,77-82): one thread per (frame, tile row)
+__global__ void __launch_bounds__(256) qoi_headers_kernel(const QoiArgs a)
+{
+	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+	const uint32_t frames = a.n_tiles / a.tiles_per_frame;
+	if (i >= frames * a.rows) return;
+	const uint32_t f = i / a.rows, r = i - f * a.rows;
+	const uint32_t t0 = f * a.tiles_per_frame + r * a.cols;
+	// offsets[] already hold global record offsets (splice ran first); a row's length is a difference
+	const unsigned long long lo = a.offsets[t0];
+	const unsigned long long hi = (t0 + a.cols == a.n_tiles) ? a.offsets[a.n_tiles] : a.offsets[t0 + a.cols];
+	const unsigned long long file0 = (unsigned long long)f * a.hdr_bytes + a.offsets[f * a.tiles_per_frame];
+	if (file0 + a.hdr_bytes > a.capacity) return;
+	uint8_t *hd = a.out + file0;
+	const uint32_t len = (uint32_t)(hi - lo);
+	uint8_t *lt = hd + 26 + 4 * r;
+	lt[0] = (uint8_t)(len >> 24); lt[1] = (uint8_t)(len >> 16); lt[2] = (uint8_t)(len >> 8); lt[3] = (uint8_t)len;
+	if (r == 0) {
+		const uint8_t magic[10] = {'P', 'I', 'X', 'L', 'Z', 'R', 0, 0, 2, (uint8_t)a.filter_byte};
+		for (int k = 0; k < 10; ++k) hd[k] = magic[k];
+		const uint32_t v[4] = {a.width, a.height, a.bw, a.bh};
+		for (int k = 0; k < 4; ++k) {
+			hd[10 + 4 * k] = (uint8_t)(v[k] >> 24);
+			hd[11 + 4 * k] = (uint8_t)(v[k] >> 16);
+			hd[12 + 4 * k] = (uint8_t)(v[k] >> 8);
+			hd[13 + 4 * k] = (uint8_t)v[k];
+		}
+		a.file_offsets[f] = file0;
+		if (f + 1 == frames) a.file_offsets[frames] = (unsigned long long)frames * a.hdr_bytes + a.offsets[a.n_tiles];
+	}
+}
+
+hipError_t launch_qoi(const QoiArgs &a, hipStream_t stream)
+{
+	hipError_t e = hipMemsetAsync(a.bins, 0, 64 * sizeof(uint32_t), stream);
+	if (e != hipSuccess) return e;
+	const uint32_t tb = (a.n_tiles + 255u) / 256u;
+	hipLaunchKernelGGL(qoi_bin_count_kernel, dim3(tb), dim3(256), 0, stream, a);
+	hipLaunchKernelGGL(qoi_bin_scan_kernel, dim3(1), dim3(1), 0, stream, a);
+	hipLaunchKernelGGL(qoi_bin_scatter_kernel, dim3(tb), dim3(256), 0, stream, a);
+	if (a.channels == 4) hipLaunchKernelGGL(qoi_tiles_kernel<4>, dim3(tb), dim3(256), 0, stream, a);
+	else hipLaunchKernelGGL(qoi_tiles_kernel<3>, dim3(tb), dim3(256), 0, stream, a);
+	// exclusive scan of the record lengths (same chunked scan as the pixel pack, sizes given)
+	PackArgs p{};
+	p.sizes = a.rec_len;
+	p.offsets = a.offsets;
+	p.chunk_totals = a.chunk_totals;
+	p.n_tiles = a.n_tiles;
+	p.n_chunks = a.n_chunks;
+	hipLaunchKernelGGL(pack_scan_local_kernel, dim3(a.n_chunks), dim3(256), 0, stream, p);
+	hipLaunchKernelGGL(pack_scan_chunks_kernel, dim3(1), dim3(1024), 0, stream, p);
+	hipLaunchKernelGGL(qoi_splice_kernel, dim3((a.n_tiles + 3u) / 4u), dim3(256), 0, stream, a);
+	const uint32_t frames = a.n_tiles / a.tiles_per_frame;
+	hipLaunchKernelGGL(qoi_headers_kernel, dim3((frames * a.rows + 255u) / 256u), dim3(256), 0, stream, a);
+	return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// Decode side: Pixlzr::decode_from_vec (reference src/encoding/mod.rs:95-165) + decode_block (:202-242)
+// + the `qoi` decoder it calls, on the device.
+//   pixlzr_index_kernel  one wave per (file, tile row): header check, the row's start from the line-length
+//                        table, then a walk over the row's records ("block", f32 BE value, u32 BE length,
+//                        QOI minus its magic) -> per tile value, size and body position
+//   qoi_decode_kernel    one lane per tile: the QOI op stream -> pixels in the tile's slot; the 64-entry
+//                        index of every lane lives in LDS as in the encoder
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t be32(const uint8_t *p)
+{
+	return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | (uint32_t)p[3];
+}
+
+// One wave per (file, tile row).  The walk over a row's records is a dependent chain (each length gives the next
+// record's position): it runs on bytes staged in LDS, chunk by chunk, so a step costs an LDS round trip instead of
+// an HBM one.  Per chunk: all lanes load it (coalesced), lane 0 walks up to 64 records ahead using only the
+// length fields, then the lanes check and publish those records in parallel.
+constexpr uint32_t kIdxChunk = 8192;   // bytes of a row held in LDS at a time (per wave)
+constexpr uint32_t kIdxHeader = 23;    // "block" + value + length + QOI header minus its magic, up to the channel byte
+__global__ void __launch_bounds__(256) pixlzr_index_kernel(const DecodeArgs a)
+{
+	__shared__ __attribute__((aligned(16))) uint32_t s_chunk[4][kIdxChunk / 4u + 4u];
+	__shared__ uint32_t s_pos[4][64];  // positions (relative to the chunk's first byte) of the records of a batch
+	const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+	const uint32_t i = blockIdx.x * 4u + wave;
+	if (i >= a.n_frames * a.rows) return;
+	const uint32_t f = i / a.rows, r = i - f * a.rows;
+	const unsigned long long f0 = a.file_offsets[f], f1 = a.file_offsets[f + 1];
+	const uint8_t *file = a.files + f0;
+	const unsigned long long flen = f1 - f0;
+	const unsigned long long hdr = 26ull + 4ull * a.rows;
+	const uint32_t t_row = f * a.tiles_per_frame + r * a.cols;
+	auto bad_from = [&](uint32_t c0) {  // the row is unusable from column c0 on
+		if (lane == 0) atomicOr(a.status, 2u);
+		for (uint32_t c = c0 + lane; c < a.cols; c += 64u) {
+			a.rec_len[t_row + c] = 0u;
+			a.tile_w[t_row + c] = 0u;
+			a.tile_h[t_row + c] = 0u;
+		}
+	};
+	const uint8_t magic[9] = {'P', 'I', 'X', 'L', 'Z', 'R', 0, 0, 2};  // constants.rs:10-11: v0.0.2 (filter byte + line table)
+	bool ok = flen >= hdr;
+	if (ok) {
+		for (int k = 0; k < 9; ++k) ok = ok && file[k] == magic[k];
+		ok = ok && be32(file + 10) == a.width && be32(file + 14) == a.height && be32(file + 18) == a.bw && be32(file + 22) == a.bh;
+	}
+	if (!ok) {
+		bad_from(0);
+		return;
+	}
+	// the line-length table, lane-parallel: bytes before this row, and the length of all rows (mod.rs:141)
+	unsigned long long before = 0, total = 0;
+	for (uint32_t q = lane; q < a.rows; q += 64u) {
+		const uint32_t len = be32(file + 26 + 4 * q);
+		if (q < r) before += len;
+		total += len;
+	}
+	for (int sh = 32; sh >= 1; sh >>= 1) {
+		before += __shfl_xor(before, sh, 64);
+		total += __shfl_xor(total, sh, 64);
+	}
+	if (hdr + total != flen) {
+		bad_from(0);
+		return;
+	}
+	unsigned long long p = hdr + before;
+	const unsigned long long row_end = p + be32(file + 26 + 4 * r);
+	const uint8_t *cb = reinterpret_cast<const uint8_t *>(s_chunk[wave]);
+	uint32_t c = 0;
+	while (c < a.cols) {
+		// ---- stage file bytes [p, p + kIdxChunk) of the row (whole aligned dwords of the buffer, then the tail bytes)
+		const unsigned long long want = row_end - p < (unsigned long long)kIdxChunk ? row_end - p : (unsigned long long)kIdxChunk;
+		const uintptr_t g = reinterpret_cast<uintptr_t>(file + p);
+		const uint32_t skew = (uint32_t)(g & 3u);  // the chunk starts at the aligned dword below p
+		const uint32_t dwords = (skew + (uint32_t)want + 3u) / 4u;
+		const uintptr_t buf_end = reinterpret_cast<uintptr_t>(a.files) + a.file_offsets[a.n_frames];
+		for (uint32_t d = lane; d < dwords; d += 64u) {
+			const uintptr_t ga = (g - skew) + 4ull * d;
+			uint32_t v = 0;
+			if (ga + 4u <= buf_end) {
+				v = *reinterpret_cast<const uint32_t *>(ga);
+			} else {
+				for (uint32_t k = 0; k < 4u && ga + k < buf_end; ++k) v |= (uint32_t) * reinterpret_cast<const uint8_t *>(ga + k) << (8u * k);
+			}
+			s_chunk[wave][d] = v;
+		}
+		tile_sync<1>();
+		const uint32_t have = (uint32_t)want;  // valid bytes behind cb + skew
+		// ---- lane 0: positions of up to 64 records whose headers lie inside the chunk
+		uint32_t n_rec = 0, walked = 0;  // walked: bytes of the chunk consumed by the records found
+		bool broken = false;             // a record that cannot be walked past (it is the last of the batch)
+		if (lane == 0) {
+			uint32_t o = 0;
+			while (n_rec < 64u && c + n_rec < a.cols) {
+				if (p + o + 13ull + 10ull + 8ull > row_end) {  // no room for a record: broken row
+					s_pos[wave][n_rec++] = o;
+					broken = true;
+					break;
+				}
+				if (o + kIdxHeader > have) break;  // header not in this chunk: restage from here
+				const uint32_t qlen = be32(cb + skew + o + 9u);
+				s_pos[wave][n_rec++] = o;
+				if (qlen < 18u || p + o + 13ull + qlen > row_end) {
+					broken = true;
+					break;
+				}
+				o += 13u + qlen;
+				if (o >= have && p + o < row_end && c + n_rec < a.cols) break;  // next record starts beyond the chunk
+			}
+			walked = o;
+		}
+		n_rec = __builtin_amdgcn_readfirstlane(n_rec);
+		walked = __builtin_amdgcn_readfirstlane(walked);
+		broken = __builtin_amdgcn_readfirstlane(broken ? 1u : 0u) != 0u;
+		tile_sync<1>();
+		// ---- all lanes: check and publish the batch
+		bool good = true;
+		if (lane < n_rec) {
+			const uint32_t o = s_pos[wave][lane];
+			const uint32_t cc = c + lane;
+			const uint32_t fw = (cc == a.cols - 1) ? a.edge_w : a.bw, fh = (r == a.rows - 1) ? a.edge_h : a.bh;
+			good = p + o + 13ull + 10ull + 8ull <= row_end;
+			if (good) {
+				const uint8_t *rec = cb + skew + o;
+				good = rec[0] == 'b' && rec[1] == 'l' && rec[2] == 'o' && rec[3] == 'c' && rec[4] == 'k';
+				const uint32_t qlen = be32(rec + 9);
+				good = good && qlen >= 18u && p + o + 13ull + qlen <= row_end;
+				if (good) {
+					const uint32_t w = be32(rec + 13), h = be32(rec + 17), ch = rec[21];
+					good = ch == a.channels && w >= 1 && h >= 1 && w <= fw && h <= fh;
+					// (the walk used this record's length whether or not its other fields are sound, as the
+					// sequential reader does not: a bad record ends the row there, see below)
+					if (good) {
+						const uint32_t t = t_row + cc;
+						a.value[t] = __uint_as_float(be32(rec + 5));
+						a.tile_w[t] = w;
+						a.tile_h[t] = h;
+						a.rec_off[t] = f0 + p + o + 13ull + 10ull;  // first op byte
+						a.rec_len[t] = qlen - 10u - 8u;             // ops only: without the header and the end marker
+					}
+				}
+			}
+		}
+		const unsigned long long bad = __builtin_amdgcn_ballot_w64(!good);
+		if (bad != 0ull) {
+			// the walk cannot continue past a broken record: the rest of the row is unusable (records of this batch
+			// behind the first bad one were published above and are taken back here)
+			bad_from(c + (uint32_t)__builtin_ctzll(bad));
+			return;
+		}
+		(void)broken;  // (a broken record fails the checks above)
+		if (n_rec == 0) {
+			// a header that does not fit the rest of the row although a record is due: broken row
+			bad_from(c);
+			return;
+		}
+		c += n_rec;
+		p += walked;
+		tile_sync<1>();  // the chunk is restaged
+	}
+	if (p != row_end && lane == 0) atomicOr(a.status, 2u);
+}
+
+template <int C>
+__global__ void __launch_bounds__(256) qoi_decode_kernel(const DecodeArgs a)
+{
+	__shared__ uint32_t s_index[4][64][64];  // [wave][slot][lane]
+	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+	const uint32_t i0 = blockIdx.x * 256u + threadIdx.x;
+	uint32_t(*index)[64] = s_index[wave];
+#pragma unroll 8
+	for (int sidx = 0; sidx < 64; ++sidx) index[sidx][lane] = 0u;  // qoi: index starts as zero pixels
+	if (i0 >= a.n_tiles) return;
+	const uint32_t t = a.perm[i0];  // tiles of similar pixel count share a wave (the walk is serial per lane)
+	const uint32_t len = a.rec_len[t];
+	if (len == 0) {
+		a.tile_w[t] = 0;  // unusable record: the expand step skips and flags it
+		a.tile_h[t] = 0;
+		return;
+	}
+	// the op bytes, fetched 8 at a time through an aligned 64-bit window (a byte load per op byte would make
+	// every op wait for a memory round trip).  The window may run up to 7 bytes past the last op: those are
+	// bytes of the record's own 8-byte end marker, still inside the file.
+	const unsigned long long first_byte = a.rec_off[t];
+	const unsigned long long *wp = reinterpret_cast<const unsigned long long *>(a.files + (first_byte & ~7ull));
+	unsigned long long acc = *wp++ >> (8u * (uint32_t)(first_byte & 7ull));
+	uint32_t have = 8u - (uint32_t)(first_byte & 7ull);
+	int32_t left = (int32_t)len;
+	auto next_byte = [&]() -> uint32_t {
+		if (have == 0u) {
+			acc = *wp++;
+			have = 8u;
+		}
+		const uint32_t b = (uint32_t)acc & 255u;
+		acc >>= 8;
+		--have;
+		--left;
+		return b;
+	};
+	const uint32_t n = a.tile_w[t] * a.tile_h[t];
+	uint8_t *dst = a.slots + (size_t)t * a.slot_bytes;
+	uint32_t px = 0xff000000u, run = 0;
+	uint4 hold = make_uint4(0, 0, 0, 0);
+	for (uint32_t i = 0; i < n; ++i) {
+		if (run > 0) {
+			--run;
+		} else if (left > 0) {
+			// (as in the qoi crate, only the op's first byte is checked against the end of the stream; a truncated
+			// last op reads on into the end marker, which is inside the file)
+			const uint32_t b1 = next_byte();
+			if (b1 == 0xfeu) {  // QOI_OP_RGB
+				const uint32_t r = next_byte(), g = next_byte(), b = next_byte();
+				px = (px & 0xff000000u) | r | (g << 8) | (b << 16);
+			} else if (b1 == 0xffu) {  // QOI_OP_RGBA
+				const uint32_t r = next_byte(), g = next_byte(), b = next_byte(), al = next_byte();
+				px = r | (g << 8) | (b << 16) | (al << 24);
+			} else if ((b1 & 0xc0u) == 0x00u) {  // QOI_OP_INDEX
+				px = index[b1][lane];
+			} else if ((b1 & 0xc0u) == 0x40u) {  // QOI_OP_DIFF
+				const uint32_t r = ((px & 255u) + ((b1 >> 4) & 3u) - 2u) & 255u;
+				const uint32_t g = (((px >> 8) & 255u) + ((b1 >> 2) & 3u) - 2u) & 255u;
+				const uint32_t b = (((px >> 16) & 255u) + (b1 & 3u) - 2u) & 255u;
+				px = (px & 0xff000000u) | r | (g << 8) | (b << 16);
+			} else if ((b1 & 0xc0u) == 0x80u) {  // QOI_OP_LUMA
+				const uint32_t b2 = next_byte();
+				const uint32_t vg = (b1 & 0x3fu) - 32u;
+				const uint32_t r = ((px & 255u) + vg - 8u + ((b2 >> 4) & 15u)) & 255u;
+				const uint32_t g = (((px >> 8) & 255u) + vg) & 255u;
+				const uint32_t b = (((px >> 16) & 255u) + vg - 8u + (b2 & 15u)) & 255u;
+				px = (px & 0xff000000u) | r | (g << 8) | (b << 16);
+			} else {  // QOI_OP_RUN
+				run = b1 & 0x3fu;
+			}
+			index[((px & 255u) * 3u + ((px >> 8) & 255u) * 5u + ((px >> 16) & 255u) * 7u + (px >> 24) * 11u) & 63u][lane] = px;
+		} else {
+			atomicOr(a.status, 2u);  // the op stream ended before the tile was full
+			a.tile_w[t] = 0;
+			a.tile_h[t] = 0;
+			return;
+		}
+		if constexpr (C == 4) {
+			// four pixels per 16-byte store (slots are 16-byte aligned: bw*bh*4 bytes each)
+			const uint32_t k = i & 3u;
+			if (k == 0) hold.x = px;
+			else if (k == 1) hold.y = px;
+			else if (k == 2) hold.z = px;
+			else {
+				hold.w = px;
+				reinterpret_cast<uint4 *>(dst)[i >> 2] = hold;
+			}
+		} else {
+			dst[3 * i] = (uint8_t)px;
+			dst[3 * i + 1] = (uint8_t)(px >> 8);
+			dst[3 * i + 2] = (uint8_t)(px >> 16);
+		}
+	}
+	if constexpr (C == 4) {
+		const uint32_t tail = n & 3u, base = n & ~3u;  // 1x1, 2x1 ... tiles
+		if (tail >= 1) reinterpret_cast<uint32_t *>(dst)[base] = hold.x;
+		if (tail >= 2) reinterpret_cast<uint32_t *>(dst)[base + 1] = hold.y;
+		if (tail >= 3) reinterpret_cast<uint32_t *>(dst)[base + 2] = hold.z;
+	}
+}
+
+hipError_t launch_decode(const DecodeArgs &a, hipStream_t stream)
+{
+	hipError_t e = hipMemsetAsync(a.bins, 0, 64 * sizeof(uint32_t), stream);
+	if (e != hipSuccess) return e;
+	hipLaunchKernelGGL(pixlzr_index_kernel, dim3((a.n_frames * a.rows + 3u) / 4u), dim3(256), 0, stream, a);
+	const uint32_t tb = (a.n_tiles + 255u) / 256u;
+	QoiArgs q{};  // the encoder's binning by pixel count, on the sizes the index kernel has just read
+	q.w = a.tile_w;
+	q.h = a.tile_h;
+	q.n_tiles = a.n_tiles;
+	q.bins = a.bins;
+	q.perm = a.perm;
+	hipLaunchKernelGGL(qoi_bin_count_kernel, dim3(tb), dim3(256), 0, stream, q);
+	hipLaunchKernelGGL(qoi_bin_scan_kernel, dim3(1), dim3(1), 0, stream, q);
+	hipLaunchKernelGGL(qoi_bin_scatter_kernel, dim3(tb), dim3(256), 0, stream, q);
+	if (a.channels == 4) hipLaunchKernelGGL(qoi_decode_kernel<4>, dim3(tb), dim3(256), 0, stream, a);
+	else hipLaunchKernelGGL(qoi_decode_kernel<3>, dim3(tb), dim3(256), 0, stream, a);
+	return hipGetLastError();
+}
+
+}  // namespace pxz
