@@ -581,12 +581,19 @@ int timed_launch(pxz_handle *h, pxz::ShrinkArgs &a, uint32_t channels, float *va
 		a.alpha_kernel = 1;
 	// 32x32 fast path: which tiles are full-size, and whether every tile row of the batch is 16-byte aligned
 	a.full_cols = a.full_rows = a.ok_rows = 0;
-	if (a.bw == a.bh && (a.bw == 16 || a.bw == 32 || a.bw == 64) && channels == 4 &&
-	    ((reinterpret_cast<uintptr_t>(a.src) | a.pitch | (a.n_tiles > a.tiles_per_frame ? a.frame_stride : 0)) & 15u) == 0) {
+	const bool aligned16 = channels == 4 &&
+	    ((reinterpret_cast<uintptr_t>(a.src) | a.pitch | (a.n_tiles > a.tiles_per_frame ? a.frame_stride : 0)) & 15u) == 0;
+	const bool square_fast = a.bw == a.bh && (a.bw == 16 || a.bw == 32 || a.bw == 64);
+	// any other tile whose rows are whole pixel quads: the Oklab detector with run-time geometry takes the full tiles
+	// (64 .. 16384 pixels); the generic kernel then only stages and resamples them
+	const bool general_oklab = !square_fast && a.mode == PXZ_MODE_SHRINK_BY && a.bw % 4u == 0 && a.bw * a.bh >= 64u &&
+	                           a.bw * a.bh <= 16384u && !getenv("PXZ_NO_OKLAB_GENERAL");
+	a.ok_bands = (a.bw * a.bh + 255u) / 256u;
+	if (aligned16 && (square_fast || general_oklab)) {
 		a.full_cols = a.edge_w == a.bw ? a.cols : a.cols - 1;
 		a.full_rows = a.edge_h == a.bh ? a.rows : a.rows - 1;
-		// the Oklab detector also takes a ragged last row of whole bands (256 pixels = 256/bw rows)
-		a.ok_rows = a.edge_h % (256u / a.bw) == 0 ? a.rows : a.full_rows;
+		// the Oklab detector also takes a ragged last row of whole bands (256 pixels = 256/bw rows) of the square sizes
+		a.ok_rows = square_fast && a.edge_h % (256u / a.bw) == 0 ? a.rows : a.full_rows;
 	}
 	const pxz::FinishArgs fin{a.sums, value, lod0, lod1, a.n_tiles, a.tiles_per_frame, a.cols, a.rows,
 	                          a.bw, a.bh, a.edge_w, a.edge_h, a.mode, a.factor};
@@ -611,11 +618,12 @@ int timed_launch(pxz_handle *h, pxz::ShrinkArgs &a, uint32_t channels, float *va
 	// shrink_by on the headline geometry: the block-cooperative Oklab detector first, then the
 	// fused kernel only stages + resamples (it still runs the generic detector on ragged-edge tiles)
 	a.oklab_given = 0;
-	if (a.mode == PXZ_MODE_SHRINK_BY && channels == 4 && a.bw == a.bh && (a.bw == 16 || a.bw == 32 || a.bw == 64) &&
+	if (a.mode == PXZ_MODE_SHRINK_BY && channels == 4 && (square_fast || general_oklab) &&
 	    a.full_cols != 0 && a.full_rows != 0 && !getenv("PXZ_NO_OKLAB32")) {
-		if (a.bw == 64) {
-			// a 64x64 tile does not fit the registers between the detector's two passes: 13 dwords per pixel quad in HBM
-			if ((rc = ensure(h, h->okscratch, (size_t)a.n_tiles * 16u * 3328u)) != PXZ_OK) return rc;
+		if (a.ok_bands > 4u) {
+			// a tile of more than 1024 pixels does not fit the registers between the detector's two passes: 13 dwords
+			// per pixel quad in HBM
+			if ((rc = ensure(h, h->okscratch, (size_t)a.n_tiles * a.ok_bands * 3328u)) != PXZ_OK) return rc;
 			a.ok_scratch = (float *)h->okscratch.ptr;
 		}
 		a.oklab_given = 1;

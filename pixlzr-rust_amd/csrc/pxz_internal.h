@@ -69,6 +69,7 @@ struct ShrinkArgs {
 	                         //   pixlzr.rs:15,162; 1 with factor 1 = the identity closure of process(), process/mod.rs:107-121)
 	FastDiv div_gpf, div_gcols;  // shrink16_kernel: divisors for its 2x2 tile groups (groups per frame, group columns)
 	uint32_t n_frames_x_groups;  //   and the number of groups in the batch
+	uint32_t ok_bands;       // Oklab detector with run-time geometry: bands (256 pixels) per tile, ceil(bw * bh / 256)
 	float *ok_scratch;       // Oklab detector on 64x64 tiles: 16 floats per pixel quad between its passes (HBM)
 	const uint32_t *mf64;    // 64x64 fast path: matrix-core operand tables (global memory), see Fast64Args
 	uint32_t ok_rows;        // tile rows the block-cooperative Oklab detector takes: full_rows, plus the ragged last row

@@ -156,13 +156,15 @@ __global__ void __launch_bounds__(256) oklab_pixels_kernel(const uint32_t *px, u
 	}
 }
 
-// Tile geometry of the block-cooperative Oklab detector, T = 16 | 32 | 64 (square RGBA tiles).  A band is 256
-// pixels of a tile in row-major order = 4 consecutive pixels per lane: 64 / (T/4) rows of T pixels.
+// Tile geometry of the block-cooperative Oklab detector.  A band is 256 pixels of a tile in row-major order = 4
+// consecutive pixels per lane.  T = 16 | 32 | 64: square tiles, a band is 64 / (T/4) whole rows of T pixels.
+// T = 0: any tile whose width is a multiple of 4 (so that a lane's 4 pixels sit in one row, 16-byte aligned), sizes
+// at run time; NBR = 1..4: that many bands, kept in registers between the passes; NBR = 0: any number, parked.
 template <int T>
 struct OkGeom {
-	static constexpr uint32_t kBands = T * T / 256;   // 1 | 4 | 16
-	static constexpr uint32_t kLanesPerRow = T / 4;   // 4 | 8 | 16
-	static constexpr uint32_t kRowsPerBand = 256 / T; // 16 | 8 | 4
+	static constexpr uint32_t kBands = T > 0 ? T * T / 256 : 1;   // 1 | 4 | 16
+	static constexpr uint32_t kLanesPerRow = T > 0 ? T / 4 : 1;   // 4 | 8 | 16
+	static constexpr uint32_t kRowsPerBand = T > 0 ? 256 / T : 1; // 16 | 8 | 4
 	// up to 4 bands the converted tile stays in registers between the passes; a 64x64 tile (192 values per
 	// lane) parks it in a scratch buffer in HBM instead (13 dwords per lane and band: 12 values + the alpha bytes)
 	static constexpr bool kInRegs = kBands <= 4;
@@ -177,16 +179,22 @@ __device__ __forceinline__ uint32_t oklab_tile_src(const Args &a, uint32_t tile_
 	const uint32_t frame = fastdiv(tile_g, a.div_tpf);
 	const uint32_t t = tile_g - frame * a.tiles_per_frame;
 	const uint32_t ty = fastdiv(t, a.div_cols), tx = t - ty * a.cols;
-	src = a.src + (size_t)frame * a.frame_stride + (size_t)(ty * (uint32_t)T) * a.pitch + (size_t)(tx * (uint32_t)T) * 4u;
+	const uint32_t tw = T > 0 ? (uint32_t)T : a.bw, th = T > 0 ? (uint32_t)T : a.bh;
+	src = a.src + (size_t)frame * a.frame_stride + (size_t)(ty * th) * a.pitch + (size_t)(tx * tw) * 4u;
 	if (tx >= a.full_cols || ty >= a.ok_rows) return 0u;
-	return ty == a.rows - 1u ? a.edge_h : (uint32_t)T;
+	return ty == a.rows - 1u ? a.edge_h : th;  // (T = 0: only full tiles are eligible, so this is th)
 }
 
-template <int T>
+template <int T, int NBR = 0>
 __global__ void __launch_bounds__(1024) oklab_kernel(const ShrinkArgs a)
 {
 	using G = OkGeom<T>;
-	constexpr uint32_t NB = G::kBands;
+	constexpr bool kGeneral = T == 0;
+	constexpr bool kInRegs = kGeneral ? NBR > 0 : G::kInRegs;
+	constexpr uint32_t NBC = kGeneral ? (NBR > 0 ? (uint32_t)NBR : 1u) : G::kBands;  // band count where it is static
+	const uint32_t NB = (kGeneral && NBR == 0) ? a.ok_bands : NBC;
+	const uint32_t tile_w = kGeneral ? a.bw : (uint32_t)T;
+	const uint32_t tile_px = kGeneral ? a.bw * a.bh : (uint32_t)(T * T);
 	extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
 	float *s_srgb = reinterpret_cast<float *>(lds);          // 256: sRGB u8 -> linear
 	float *s_alpha = s_srgb + 256;                           // 256: a / 255
@@ -206,29 +214,43 @@ __global__ void __launch_bounds__(1024) oklab_kernel(const ShrinkArgs a)
 	if (wave < kOkTiles) {
 		// ---------------- producers ----------------
 		const uint32_t row_off = lane / G::kLanesPerRow, col_off = (lane % G::kLanesPerRow) * 16u;
-		// source pointers (lane's first group of band 0) of this wave's tiles in batches p, p+1, p+2; null: nothing there
+		const size_t band_step = (size_t)G::kRowsPerBand * a.pitch;
+		// this lane's 4 pixels of a band: do they exist (T = 0: the last band may be short), and where in the tile
+		auto lane_has = [&](uint32_t band) -> bool { return !kGeneral || 256u * band + 4u * lane < tile_px; };
+		auto lane_off = [&](uint32_t band) -> size_t {
+			if constexpr (kGeneral) {
+				const uint32_t first = 256u * band + 4u * lane, row = small_div(first, tile_w);  // (first < 2^20)
+				return (size_t)row * a.pitch + (size_t)(first - row * tile_w) * 4u;
+			} else {
+				return (size_t)row_off * a.pitch + col_off + (size_t)band * band_step;
+			}
+		};
+		auto load_band = [&](const uint8_t *tile, uint32_t band) -> uint4 {
+			if (!lane_has(band)) return make_uint4(0, 0, 0, 0);  // black, alpha 0: converts to exact zeros
+			return *reinterpret_cast<const uint4 *>(tile + lane_off(band));
+		};
+		// source pointers (first byte) of this wave's tiles in batches p, p+1, p+2; null: nothing there
 		auto batch_src = [&](uint32_t j, uint32_t &bands) -> const uint8_t * {
 			const uint8_t *src;
 			bands = 0;
 			if (j >= own) return nullptr;
 			const uint32_t th = oklab_tile_src<T>(a, (blockIdx.x + j * gridDim.x) * kOkTiles + wave, src);
 			if (th == 0) return nullptr;
-			bands = th / G::kRowsPerBand;  // (a ragged tile is only taken with a whole number of bands)
-			return src + (size_t)row_off * a.pitch + col_off;
+			bands = kGeneral ? NB : th / G::kRowsPerBand;  // (a ragged tile is only taken with a whole number of bands)
+			return src;
 		};
 		uint32_t nb0 = 0, nb1 = 0, nb2 = 0, nb_prev = 0;  // bands of this wave's tile in batches p, p+1, p+2, p-1
 		const uint8_t *src0 = nullptr, *src1 = batch_src(0, nb1), *src2 = batch_src(1, nb2);
-		const size_t band_step = (size_t)G::kRowsPerBand * a.pitch;
 		// raw pixels: the band being converted and the one after it (requested one interval ahead)
 		uint4 px_cur = make_uint4(0, 0, 0, 0), px_nxt = make_uint4(0, 0, 0, 0);
-		if (src1) px_cur = *reinterpret_cast<const uint4 *>(src1);
+		if (src1) px_cur = load_band(src1, 0);
 		if (NB > 1) {
-			if (src1 && nb1 > 1u) px_nxt = *reinterpret_cast<const uint4 *>(src1 + band_step);
+			if (src1 && nb1 > 1u) px_nxt = load_band(src1, 1);
 		} else if (src2) {
-			px_nxt = *reinterpret_cast<const uint4 *>(src2);
+			px_nxt = load_band(src2, 0);
 		}
-		float lab[G::kInRegs ? NB : 1][4][3];   // [band][pixel][a, b, l] of the batch whose pass 2 is being staged
-		uint32_t alpha_px[G::kInRegs ? NB : 1];  // its 4 alpha bytes per band
+		float lab[kInRegs ? NBC : 1][4][3];   // [band][pixel][a, b, l] of the batch whose pass 2 is being staged
+		uint32_t alpha_px[kInRegs ? NBC : 1];  // its 4 alpha bytes per band
 		bool have_prev = false, elig_cur = false;
 		uint32_t tile_prev = 0, tile_cur = 0;
 		for (uint32_t p = 0; p < periods; ++p) {
@@ -241,12 +263,12 @@ __global__ void __launch_bounds__(1024) oklab_kernel(const ShrinkArgs a)
 			nb1 = nb2;
 			src2 = batch_src(p + 2u, nb2);
 			elig_cur = src0 != nullptr;  // (false past the last batch and for tiles the detector does not take)
-			constexpr int kUnroll = G::kInRegs ? (int)NB : 1;  // register form: lab[k] must be a static index
+			constexpr int kUnroll = kInRegs ? (int)NBC : 1;  // register form: lab[k] must be a static index
 #pragma unroll kUnroll
 			for (uint32_t k = 0; k < NB; ++k) {
 				// ---- convert phase
 				float4 old[4];  // scratch form only: band k of the previous batch, back from HBM for pass 2
-				if constexpr (!G::kInRegs) {
+				if constexpr (!kInRegs) {
 					if (have_prev && k < nb_prev) {
 						// per (tile, band): three arrays of 64 float4 (the 12 values of a lane) + 64 alpha words = 3328 bytes
 						const float *sb = a.ok_scratch + ((size_t)tile_prev * NB + k) * 832u;
@@ -275,7 +297,7 @@ __global__ void __launch_bounds__(1024) oklab_kernel(const ShrinkArgs a)
 					const uint32_t ahead = k + 2u, bo = ahead / NB, band = ahead % NB;
 					const uint8_t *base = bo == 0 ? src0 : (bo == 1 ? src1 : src2);
 					const uint32_t nbb = bo == 0 ? nb0 : (bo == 1 ? nb1 : nb2);
-					if (base && band < nbb) px_nxt = *reinterpret_cast<const uint4 *>(base + band * band_step);
+					if (base && band < nbb) px_nxt = load_band(base, band);
 				}
 				__syncthreads();  // A: the chain has consumed the bands of the previous interval
 				// ---- write phase
@@ -287,7 +309,7 @@ __global__ void __launch_bounds__(1024) oklab_kernel(const ShrinkArgs a)
 					const float mean4[4] = {mean.x, mean.y, mean.z, mean.w};
 					float x[4][3];
 					uint32_t al4;
-					if constexpr (G::kInRegs) {
+					if constexpr (kInRegs) {
 #pragma unroll
 						for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -303,13 +325,18 @@ __global__ void __launch_bounds__(1024) oklab_kernel(const ShrinkArgs a)
 						al4 = __float_as_uint(old[3].x);
 					}
 					float *d = s_p2 + slot;
+					// (a lane beyond a short last band has no pixels: exact zeros leave the chain's sums as they are)
+					const float keep = lane_has(k) ? 1.0f : 0.0f;
 #pragma unroll
-					for (int c = 0; c < 3; ++c)
-						*reinterpret_cast<float4 *>(d + c * kOkPlane) =
-						    make_float4(x[0][c] - mean4[c], x[1][c] - mean4[c], x[2][c] - mean4[c], x[3][c] - mean4[c]);
-					*reinterpret_cast<float4 *>(d + 3 * kOkPlane) =
-					    make_float4(s_alpha[al4 & 255u] - mean4[3], s_alpha[(al4 >> 8) & 255u] - mean4[3],
-					                s_alpha[(al4 >> 16) & 255u] - mean4[3], s_alpha[al4 >> 24] - mean4[3]);
+					for (int c = 0; c < 3; ++c) {
+						float4 v = make_float4(x[0][c] - mean4[c], x[1][c] - mean4[c], x[2][c] - mean4[c], x[3][c] - mean4[c]);
+						if constexpr (kGeneral) v = keep != 0.0f ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+						*reinterpret_cast<float4 *>(d + c * kOkPlane) = v;
+					}
+					float4 va = make_float4(s_alpha[al4 & 255u] - mean4[3], s_alpha[(al4 >> 8) & 255u] - mean4[3],
+					                        s_alpha[(al4 >> 16) & 255u] - mean4[3], s_alpha[al4 >> 24] - mean4[3]);
+					if constexpr (kGeneral) va = keep != 0.0f ? va : make_float4(0.f, 0.f, 0.f, 0.f);
+					*reinterpret_cast<float4 *>(d + 3 * kOkPlane) = va;
 				}
 				if (elig_cur && k < nb0) {
 					float *d = s_p1 + slot;
@@ -319,7 +346,7 @@ __global__ void __launch_bounds__(1024) oklab_kernel(const ShrinkArgs a)
 					*reinterpret_cast<float4 *>(d + 3 * kOkPlane) =
 					    make_float4(s_alpha[fresh_alpha & 255u], s_alpha[(fresh_alpha >> 8) & 255u], s_alpha[(fresh_alpha >> 16) & 255u],
 					                s_alpha[fresh_alpha >> 24]);
-					if constexpr (G::kInRegs) {
+					if constexpr (kInRegs) {
 #pragma unroll
 						for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -397,18 +424,19 @@ __global__ void __launch_bounds__(1024) oklab_kernel(const ShrinkArgs a)
 				const bool p1_valid = any && pp < own;                   // pass 1 of batch pp
 				const bool p2_valid = any && pp >= 1u && pp - 1u < own;  // pass 2 of batch pp - 1
 				const uint32_t h1 = k > 0 ? h0 : hm1, h2 = k > 0 ? hm1 : hm2;  // tile heights of those two batches
-				if (p1_valid && kk * G::kRowsPerBand < h1) acc1 = walk(s_p1, acc1, false);
-				if (p2_valid && kk * G::kRowsPerBand < h2) acc2 = walk(s_p2, acc2, true);
+				// (T = 0: a tile that is taken has all its bands; a short last band is padded with exact zeros)
+				if (p1_valid && (kGeneral ? h1 != 0u : kk * G::kRowsPerBand < h1)) acc1 = walk(s_p1, acc1, false);
+				if (p2_valid && (kGeneral ? h2 != 0u : kk * G::kRowsPerBand < h2)) acc2 = walk(s_p2, acc2, true);
 				if (kk == NB - 1u) {
 					if (p1_valid) {
-						s_mean[lane] = __fdiv_rn(acc1, (float)((uint32_t)T * h1));  // operations.rs:65-68; read after barrier A
+						s_mean[lane] = __fdiv_rn(acc1, (float)(tile_w * h1));  // operations.rs:65-68; read after barrier A
 						acc1 = 0.0f;
 					}
 					if (p2_valid) {
 						const float d0 = __shfl(acc2, (int)(lane & ~3u) + 0, 64), d1 = __shfl(acc2, (int)(lane & ~3u) + 1, 64);
 						const float d2 = __shfl(acc2, (int)(lane & ~3u) + 2, 64), d3 = __shfl(acc2, (int)(lane & ~3u) + 3, 64);
 						const float total = d0 + d1 + d2 + d3;  // :89
-						const float value = __fdiv_rn(total, (float)((uint32_t)T * h2)) * a.factor * a.scale2;  // pixlzr.rs:162
+						const float value = __fdiv_rn(total, (float)(tile_w * h2)) * a.factor * a.scale2;  // pixlzr.rs:162
 						const uint32_t tg = (blockIdx.x + (pp - 1u) * gridDim.x) * kOkTiles + ct;
 						if (live && cc == 0 && h2 != 0u)
 							reinterpret_cast<uint2 *>(a.sums)[tg] = make_uint2(__float_as_uint(value), __float_as_uint(value));
@@ -433,11 +461,22 @@ hipError_t launch_oklab(const ShrinkArgs &a, uint32_t n_cus, hipStream_t stream)
 		hipLaunchKernelGGL(kernel, dim3(blocks), dim3(1024), lds_bytes, stream, a);
 		return hipGetLastError();
 	};
-	switch (a.bw) {
-	case 16: return go(oklab_kernel<16>);
-	case 32: return go(oklab_kernel<32>);
-	case 64: return go(oklab_kernel<64>);
-	default: return hipErrorInvalidValue;
+	if (a.bw == a.bh) {
+		switch (a.bw) {
+		case 16: return go(oklab_kernel<16>);
+		case 32: return go(oklab_kernel<32>);
+		case 64: return go(oklab_kernel<64>);
+		default: break;
+		}
+	}
+	// any other tile with a width of whole pixel quads: run-time geometry
+	if (a.bw % 4u != 0u || a.ok_bands == 0u) return hipErrorInvalidValue;
+	switch (a.ok_bands) {
+	case 1: return go(oklab_kernel<0, 1>);
+	case 2: return go(oklab_kernel<0, 2>);
+	case 3: return go(oklab_kernel<0, 3>);
+	case 4: return go(oklab_kernel<0, 4>);
+	default: return go(oklab_kernel<0, 0>);
 	}
 }
 

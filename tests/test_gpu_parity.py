@@ -648,6 +648,24 @@ def test_oklab_conversion_of_every_colour(gpu, oracle):
     assert not diff.any(), f"{int(diff.any(axis=1).sum())} colours differ, first: {rgba[diff.any(axis=1)][:4]}"
 
 
+@pytest.mark.parametrize("bw,bh", [(8, 8), (12, 8), (24, 24), (40, 12), (48, 48), (32, 16), (16, 32), (64, 32), (96, 64),
+                                   (80, 80), (4, 16), (20, 36), (128, 48), (36, 28)])
+def test_oklab_detector_with_run_time_geometry(gpu, oracle, bw, bh):
+    """shrink_by on tiles that are not 16/32/64 squares: oklab_kernel<0, NBR> (tile width a multiple of 4, rows
+    16-byte aligned) takes the full tiles -- 1..4 bands in registers or any number parked, a short last band padded
+    with exact zeros -- and the generic kernel the ragged edge.  Two frames in one batch, values bit for bit."""
+    w, h = 5 * bw + 8, 3 * bh + (bh // 2 or 1)   # ragged right column and bottom row; w is a multiple of 4
+    frames = gpu.synth_frames_device(2, h, w, 4, first_frame=21, dist=1)
+    f = frames.cpu().numpy()
+    for filt, factor in ((4, 1.0), (2, 0.25)):
+        vals, ow, oh, slots = gpu.shrink_frames_device(frames, bw, bh, 0, filt, factor)
+        for n in range(2):
+            exp = oracle.shrink_image(f[n], bw, bh, 0, filt, factor, nthreads=8)
+            got = (vals[n].cpu().numpy(), ow[n].cpu().numpy().astype(np.uint32), oh[n].cpu().numpy().astype(np.uint32),
+                   slots[n].cpu().numpy())
+            assert_same_tiles(got, exp, 4, f"{bw}x{bh} f{filt} k={factor} frame {n}")
+
+
 def _sweep_cases(n, seed):
     rng = np.random.default_rng(seed)
     sizes = [2, 3, 4, 6, 8, 12, 16, 20, 24, 32, 40, 48, 64, 80, 96]
