@@ -796,7 +796,10 @@ static int run_shrink(pxz_handle *h, const pxz_frames *frames, const pxz_params 
 	pxz::ShrinkArgs a{};
 	int rc = prepare(h, frames, params, d_out_pixels != nullptr, &a);
 	if (rc != PXZ_OK) return rc;
-	bool widen = frames->channels == 3 && a.bw == a.bh && (a.bw == 16 || a.bw == 32 || a.bw == 64) && !getenv("PXZ_NO_WIDEN");
+	// (also shrink_by on the tile sizes the run-time-geometry Oklab detector takes: it only exists for RGBA)
+	const bool square_fast = a.bw == a.bh && (a.bw == 16 || a.bw == 32 || a.bw == 64);
+	const bool general_oklab = a.mode == PXZ_MODE_SHRINK_BY && a.bw % 4u == 0 && a.bw * a.bh >= 64u && a.bw * a.bh <= 16384u;
+	bool widen = frames->channels == 3 && (square_fast || general_oklab) && !getenv("PXZ_NO_WIDEN");
 	if (widen && d_out_pixels && params->filter != PXZ_FILTER_NEAREST) {
 		const TableSet *tsp = nullptr;
 		if ((rc = get_tables(h, a.bw, a.bh, a.edge_w, a.edge_h, params->filter, &tsp)) != PXZ_OK) return rc;
@@ -809,6 +812,10 @@ static int run_shrink(pxz_handle *h, const pxz_frames *frames, const pxz_params 
 		f4.channels = 4;
 		f4.pitch_bytes = (frames->width * 4u + 15u) & ~15u;
 		f4.frame_stride_bytes = (uint64_t)f4.pitch_bytes * frames->height;
+		pxz::ShrinkArgs probe{};
+		if (prepare(h, &f4, params, d_out_pixels != nullptr, &probe) != PXZ_OK) widen = false;  // e.g. four planes of a large tile exceed LDS
+	}
+	if (widen) {
 		if ((rc = ensure(h, h->rgba, (size_t)f4.frame_stride_bytes * frames->n_frames)) != PXZ_OK) return rc;
 		const pxz::WidenArgs w{d_pixels, (uint8_t *)h->rgba.ptr,
 		                       frames->n_frames > 1 ? frames->frame_stride_bytes : (uint64_t)frames->pitch_bytes * frames->height,

@@ -666,6 +666,22 @@ def test_oklab_detector_with_run_time_geometry(gpu, oracle, bw, bh):
             assert_same_tiles(got, exp, 4, f"{bw}x{bh} f{filt} k={factor} frame {n}")
 
 
+@pytest.mark.parametrize("bw,bh", [(24, 24), (48, 32), (8, 8), (80, 80)])
+def test_rgb_frames_ride_the_run_time_geometry_detector(gpu, oracle, bw, bh):
+    """RGB batches, shrink_by, tile sizes off the square fast paths: widened to RGBA for the run-time-geometry Oklab
+    detector and the generic RGBA kernel, slots narrowed back -- the same bits as the oracle's RGB path."""
+    w, h = 4 * bw + 12, 2 * bh + 5
+    frames = gpu.synth_frames_device(2, h, w, 3, first_frame=31, dist=0)
+    f = frames.cpu().numpy()
+    for filt, factor in ((4, 1.0), (1, 0.3)):
+        vals, ow, oh, slots = gpu.shrink_frames_device(frames, bw, bh, 0, filt, factor)
+        for n in range(2):
+            exp = oracle.shrink_image(f[n], bw, bh, 0, filt, factor, nthreads=8)
+            got = (vals[n].cpu().numpy(), ow[n].cpu().numpy().astype(np.uint32), oh[n].cpu().numpy().astype(np.uint32),
+                   slots[n].cpu().numpy())
+            assert_same_tiles(got, exp, 3, f"rgb {bw}x{bh} f{filt} k={factor} frame {n}")
+
+
 def _sweep_cases(n, seed):
     rng = np.random.default_rng(seed)
     sizes = [2, 3, 4, 6, 8, 12, 16, 20, 24, 32, 40, 48, 64, 80, 96]
