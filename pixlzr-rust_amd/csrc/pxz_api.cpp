@@ -668,6 +668,24 @@ int timed_launch(pxz_handle *h, pxz::ShrinkArgs &a, uint32_t channels, float *va
 namespace {
 // The pixels are here on the host: a sparse look at the alpha channel (one pixel in 61 per sampled row, every 7th
 // row) decides whether the kernels for transparent tiles are worth their launch (> 2 % of the samples).
+// Upload of a host image for the host-buffer entry points.  The device copy gets rows of a 16-byte multiple when the
+// caller's do not have one (tight rows of an RGBA image whose width is not a multiple of 4): the fast kernels and
+// the block-cooperative Oklab detector want aligned rows, and the copy engine does the re-pitching for free.
+int upload_image(pxz_handle *h, const uint8_t *pixels, uint32_t width, uint32_t height, uint32_t channels, uint32_t pitch_bytes,
+                 uint32_t *device_pitch)
+{
+	const size_t row_bytes = (size_t)width * channels;
+	uint32_t dp = pitch_bytes;
+	if (channels == 4 && (pitch_bytes & 15u) != 0) dp = (uint32_t)((row_bytes + 15u) & ~(size_t)15u);
+	const size_t bytes = (size_t)dp * (height - 1) + row_bytes;
+	int rc = ensure(h, h->in, bytes);
+	if (rc != PXZ_OK) return rc;
+	if (dp == pitch_bytes) PXZ_HIP(h, hipMemcpyAsync(h->in.ptr, pixels, bytes, hipMemcpyHostToDevice, h->stream));
+	else PXZ_HIP(h, hipMemcpy2DAsync(h->in.ptr, dp, pixels, pitch_bytes, row_bytes, height, hipMemcpyHostToDevice, h->stream));
+	*device_pitch = dp;
+	return PXZ_OK;
+}
+
 bool host_image_has_transparency(const uint8_t *pixels, uint32_t width, uint32_t height, uint32_t pitch_bytes)
 {
 	uint32_t seen = 0, looked = 0;
@@ -1124,14 +1142,12 @@ int pxz_shrink_image(pxz_handle *h, const uint8_t *pixels, uint32_t width, uint3
 	uint32_t cols, rows;
 	pxz_grid(width, height, block_w, block_h, &cols, &rows);
 	const size_t tiles = (size_t)cols * rows;
-	const size_t in_bytes = (size_t)pitch_bytes * (height - 1) + (size_t)width * channels;
 	const size_t slot = (size_t)block_w * block_h * channels;
-	if ((rc = ensure(h, h->in, in_bytes)) != PXZ_OK) return rc;
 	if ((rc = ensure(h, h->val, tiles * 4)) != PXZ_OK) return rc;
 	if ((rc = ensure(h, h->ow, tiles * 4)) != PXZ_OK) return rc;
 	if ((rc = ensure(h, h->oh, tiles * 4)) != PXZ_OK) return rc;
 	if (out_pixels && (rc = ensure(h, h->out, tiles * slot)) != PXZ_OK) return rc;
-	PXZ_HIP(h, hipMemcpyAsync(h->in.ptr, pixels, in_bytes, hipMemcpyHostToDevice, h->stream));
+	if ((rc = upload_image(h, pixels, width, height, channels, pitch_bytes, &f.pitch_bytes)) != PXZ_OK) return rc;
 	rc = pxz_shrink_frames_device(h, &f, &p, (const uint8_t *)h->in.ptr, (float *)h->val.ptr, (uint32_t *)h->ow.ptr,
 	                              (uint32_t *)h->oh.ptr, out_pixels ? (uint8_t *)h->out.ptr : nullptr);
 	if (rc != PXZ_OK) return rc;
@@ -1160,17 +1176,15 @@ int pxz_shrink_image_packed(pxz_handle *h, const uint8_t *pixels, uint32_t width
 	uint32_t cols, rows;
 	pxz_grid(width, height, block_w, block_h, &cols, &rows);
 	const size_t tiles = (size_t)cols * rows;
-	const size_t in_bytes = (size_t)pitch_bytes * (height - 1) + (size_t)width * channels;
 	const size_t slot = (size_t)block_w * block_h * channels;
 	const size_t most = (size_t)width * height * channels;  // no tile grows
-	if ((rc = ensure(h, h->in, in_bytes)) != PXZ_OK) return rc;
 	if ((rc = ensure(h, h->val, tiles * 4)) != PXZ_OK) return rc;
 	if ((rc = ensure(h, h->ow, tiles * 4)) != PXZ_OK) return rc;
 	if ((rc = ensure(h, h->oh, tiles * 4)) != PXZ_OK) return rc;
 	if ((rc = ensure(h, h->out, tiles * slot)) != PXZ_OK) return rc;
 	if ((rc = ensure(h, h->pk, most)) != PXZ_OK) return rc;
 	if ((rc = ensure(h, h->pkoff, (tiles + 1) * 8)) != PXZ_OK) return rc;
-	PXZ_HIP(h, hipMemcpyAsync(h->in.ptr, pixels, in_bytes, hipMemcpyHostToDevice, h->stream));
+	if ((rc = upload_image(h, pixels, width, height, channels, pitch_bytes, &f.pitch_bytes)) != PXZ_OK) return rc;
 	rc = pxz_shrink_frames_device(h, &f, &p, (const uint8_t *)h->in.ptr, (float *)h->val.ptr, (uint32_t *)h->ow.ptr,
 	                              (uint32_t *)h->oh.ptr, (uint8_t *)h->out.ptr);
 	if (rc != PXZ_OK) return rc;
