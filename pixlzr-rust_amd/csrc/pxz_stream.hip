@@ -159,7 +159,7 @@ __global__ void __launch_bounds__(256) qoi_bin_scatter_kernel(const QoiArgs a)
 
 struct ByteSink {
 	unsigned long long acc;
-	uint32_t cnt;        // bytes in acc
+	uint32_t cnt;        // bytes in acc (0..7)
 	unsigned long long *out;
 	__device__ __forceinline__ void put(uint32_t b)
 	{
@@ -170,14 +170,30 @@ struct ByteSink {
 			cnt = 0;
 		}
 	}
+	// n <= 8 bytes at once, first byte in the low bits of v (bits above 8n must be zero)
+	__device__ __forceinline__ void append(unsigned long long v, uint32_t n)
+	{
+		acc |= v << (8u * cnt);
+		const uint32_t total = cnt + n;
+		if (total >= 8u) {
+			*out++ = acc;
+			acc = cnt ? v >> (64u - 8u * cnt) : 0ull;  // the bytes that did not fit
+			cnt = total - 8u;
+		} else {
+			cnt = total;
+		}
+	}
 };
 
+// One wave per block: the 16 KB index table of a wave is what limits residency (ten waves per CU), and the lanes'
+// pixel loops are latency chains that only other waves can hide.
+constexpr uint32_t kQoiWaves = 1;
 template <int C>
-__global__ void __launch_bounds__(256) qoi_tiles_kernel(const QoiArgs a)
+__global__ void __launch_bounds__(64 * kQoiWaves) qoi_tiles_kernel(const QoiArgs a)
 {
-	__shared__ uint32_t s_index[4][64][64];  // [wave][slot][lane]
+	__shared__ uint32_t s_index[kQoiWaves][65][64];  // [wave][slot][lane]; row 64 takes the writes of lanes that have none
 	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+	const uint32_t i = blockIdx.x * (64u * kQoiWaves) + threadIdx.x;
 	const bool live = i < a.n_tiles;
 	const uint32_t t = live ? a.perm[i] : 0u;
 	uint32_t(*index)[64] = s_index[wave];
@@ -190,21 +206,26 @@ __global__ void __launch_bounds__(256) qoi_tiles_kernel(const QoiArgs a)
 	ByteSink s{0ull, 0u, reinterpret_cast<unsigned long long *>(rec)};
 	// encode_block: magic, value, length placeholder (mod.rs:172-178,195)
 	const uint32_t vb = __float_as_uint(a.value[t]);
-	s.put('b'); s.put('l'); s.put('o'); s.put('c'); s.put('k');
-	s.put(vb >> 24); s.put(vb >> 16); s.put(vb >> 8); s.put(vb);
-	s.put(0); s.put(0); s.put(0); s.put(0);
-	// qoi header minus its 4-byte magic (mod.rs:191): width, height BE, channels, colourspace 0
-	s.put(w >> 24); s.put(w >> 16); s.put(w >> 8); s.put(w);
-	s.put(h >> 24); s.put(h >> 16); s.put(h >> 8); s.put(h);
-	s.put((uint32_t)C); s.put(0);
+	// then the qoi header minus its 4-byte magic (mod.rs:191): width, height BE, channels, colourspace 0 -- 23 bytes
+	auto be = [](uint32_t v) -> unsigned long long { return (unsigned long long)__builtin_bswap32(v); };  // BE bytes, first one lowest
+	s.append(0x6b636f6c62ull | (be(vb) << 40), 8);                   // "block", value bytes 0..2
+	s.append((be(vb) >> 24) | (be(w) << 40), 8);                      // value byte 3, four zero bytes (length, patched below), w bytes 0..2
+	s.append((be(w) >> 24) | (be(h) << 8) | ((unsigned long long)C << 40), 7);  // w byte 3, h, channels, colourspace 0
 
 	uint32_t prev = 0xff000000u, run = 0, last_slot = 0;
 	bool seen_op = false;
 	const bool aligned = C == 4 ? true : ((a.slot_bytes & 3u) == 0);
+	// (RGBA: the next four pixels are requested before the current four are encoded -- a lane's pixel loop is one
+	// dependent chain, and a memory round trip every four pixels was most of its time.  The request may run past the
+	// tile's pixels, never past its slot.)
+	uint4 ahead = make_uint4(0, 0, 0, 0);
+	if constexpr (C == 4) ahead = *reinterpret_cast<const uint4 *>(src);
+	const uint32_t slot_px = a.slot_bytes / 4u;
 	for (uint32_t base = 0; base < n; base += 4u) {
 		uint32_t px4[4];
 		if constexpr (C == 4) {
-			const uint4 v = *reinterpret_cast<const uint4 *>(src + (size_t)base * 4u);  // slots are 16-byte aligned
+			const uint4 v = ahead;  // slots are 16-byte aligned
+			if (base + 4u < slot_px) ahead = *reinterpret_cast<const uint4 *>(src + (size_t)(base + 4u) * 4u);
 			px4[0] = v.x; px4[1] = v.y; px4[2] = v.z; px4[3] = v.w;
 		} else {
 			if (aligned) {
@@ -227,43 +248,60 @@ __global__ void __launch_bounds__(256) qoi_tiles_kernel(const QoiArgs a)
 		for (int j = 0; j < 4; ++j) {
 			const uint32_t pi = base + (uint32_t)j;
 			if (pi >= n) break;
+			// One pixel, without branches: the lanes of a wave sit in different ops at every pixel, and a wave that
+			// takes every branch in turn spends its time in the ones its lanes did not want.  Every candidate op is
+			// worked out, selects pick the bytes (a pending run byte first), one append writes them.
 			const uint32_t px = px4[j];
-			if (px == prev) {
-				if (++run == 62u || pi + 1u == n) {
-					s.put(0xc0u | (run - 1u));
-					run = 0;
-				}
-				continue;
+			const bool same = px == prev;
+			// (a) the pixel repeats: count it; the run is written at 62 or at the end of the tile
+			const uint32_t run_if_same = run + 1u;
+			const bool flush_same = run_if_same == 62u || pi + 1u == n;
+			// (b) it differs: a pending run first -- as INDEX of the repeated pixel when it is a run of ONE and any op was
+			// written before (the crate's quirk), else as RUN
+			const uint32_t pre_byte = (run == 1u && seen_op) ? last_slot : (0xc0u | (run - 1u));
+			const uint32_t pre_len = run ? 1u : 0u;
+			const uint32_t slot = ((px & 255u) * 3u + ((px >> 8) & 255u) * 5u + ((px >> 16) & 255u) * 7u + (px >> 24) * 11u) & 63u;
+			const bool hit = index[slot][lane] == px;
+			index[same ? 64u : slot][lane] = px;  // (a hit rewrites the same value)
+			const uint32_t dr = ((px & 255u) - (prev & 255u)) & 255u;
+			const uint32_t dg = (((px >> 8) & 255u) - ((prev >> 8) & 255u)) & 255u;
+			const uint32_t db = (((px >> 16) & 255u) - ((prev >> 16) & 255u)) & 255u;
+			const bool alpha_moves = C == 4 && (px >> 24) != (prev >> 24);
+			const bool diff_ok = ((dr + 2u) & 255u) < 4u && ((dg + 2u) & 255u) < 4u && ((db + 2u) & 255u) < 4u;
+			const bool luma_ok = ((dg + 32u) & 255u) < 64u && ((dr - dg + 8u) & 255u) < 16u && ((db - dg + 8u) & 255u) < 16u;
+			const unsigned long long rgb = (unsigned long long)(px & 0x00ffffffu);
+			unsigned long long op = 0xfeull | (rgb << 8);  // QOI_OP_RGB
+			uint32_t op_len = 4u;
+			if (luma_ok) {
+				op = (0x80u | ((dg + 32u) & 63u)) | (((((dr - dg + 8u) & 15u) << 4) | ((db - dg + 8u) & 15u)) << 8);  // QOI_OP_LUMA
+				op_len = 2u;
 			}
-			if (run) {
-				// the crate writes a pending run of ONE as INDEX of the repeated pixel once any op was written
-				s.put(run == 1u && seen_op ? last_slot : (0xc0u | (run - 1u)));
-				run = 0;
+			if (diff_ok) {
+				op = 0x40u | (((dr + 2u) & 3u) << 4) | (((dg + 2u) & 3u) << 2) | ((db + 2u) & 3u);  // QOI_OP_DIFF
+				op_len = 1u;
 			}
-			seen_op = true;
-			last_slot = ((px & 255u) * 3u + ((px >> 8) & 255u) * 5u + ((px >> 16) & 255u) * 7u + (px >> 24) * 11u) & 63u;
-			if (index[last_slot][lane] == px) {
-				s.put(last_slot);  // QOI_OP_INDEX
-			} else {
-				index[last_slot][lane] = px;
-				const uint32_t dr = ((px & 255u) - (prev & 255u)) & 255u;
-				const uint32_t dg = (((px >> 8) & 255u) - ((prev >> 8) & 255u)) & 255u;
-				const uint32_t db = (((px >> 16) & 255u) - ((prev >> 16) & 255u)) & 255u;
-				if (C == 4 && (px >> 24) != (prev >> 24)) {
-					s.put(0xff); s.put(px); s.put(px >> 8); s.put(px >> 16); s.put(px >> 24);  // QOI_OP_RGBA
-				} else if (((dr + 2u) & 255u) < 4u && ((dg + 2u) & 255u) < 4u && ((db + 2u) & 255u) < 4u) {
-					s.put(0x40u | (((dr + 2u) & 3u) << 4) | (((dg + 2u) & 3u) << 2) | ((db + 2u) & 3u));  // QOI_OP_DIFF
-				} else if (((dg + 32u) & 255u) < 64u && ((dr - dg + 8u) & 255u) < 16u && ((db - dg + 8u) & 255u) < 16u) {
-					s.put(0x80u | ((dg + 32u) & 63u));  // QOI_OP_LUMA
-					s.put((((dr - dg + 8u) & 15u) << 4) | ((db - dg + 8u) & 15u));
-				} else {
-					s.put(0xfe); s.put(px); s.put(px >> 8); s.put(px >> 16);  // QOI_OP_RGB
-				}
+			if (alpha_moves) {
+				op = 0xffull | ((unsigned long long)px << 8);  // QOI_OP_RGBA
+				op_len = 5u;
 			}
-			prev = px;
+			if (hit) {
+				op = slot;  // QOI_OP_INDEX
+				op_len = 1u;
+			}
+			unsigned long long bytes = pre_len ? ((unsigned long long)pre_byte | (op << 8)) : op;
+			uint32_t n_bytes = pre_len + op_len;
+			if (same) {
+				bytes = flush_same ? (0xc0u | (run_if_same - 1u)) : 0u;
+				n_bytes = flush_same ? 1u : 0u;
+			}
+			s.append(bytes, n_bytes);
+			run = same ? (flush_same ? 0u : run_if_same) : 0u;
+			seen_op = seen_op || !same;
+			last_slot = same ? last_slot : slot;
+			prev = px;  // (unchanged when the pixel repeats)
 		}
 	}
-	s.put(0); s.put(0); s.put(0); s.put(0); s.put(0); s.put(0); s.put(0); s.put(1);  // QOI end marker
+	s.append(0x0100000000000000ull, 8);  // QOI end marker: seven zero bytes and a one
 	const uint32_t total = (uint32_t)(reinterpret_cast<uint8_t *>(s.out) - rec) + s.cnt;
 	if (s.cnt) *s.out = s.acc;  // partial tail (the record stride leaves room)
 	const uint32_t qlen = total - 13u;  // mod.rs:193-195
@@ -285,9 +323,25 @@ __global__ void __launch_bounds__(256) qoi_splice_kernel(const QoiArgs a)
 	const unsigned long long dstoff = (unsigned long long)(frame + 1u) * a.hdr_bytes + off;
 	const uint32_t len = a.rec_len[t];
 	if (dstoff + len > a.capacity) return;
-	const uint8_t *src = a.scratch + (size_t)t * a.stride;
+	const uint8_t *src = a.scratch + (size_t)t * a.stride;  // 8-byte aligned (records sit at a stride of whole qwords)
 	uint8_t *dst = a.out + dstoff;
-	for (uint32_t i = lane; i < len; i += 64u) dst[i] = src[i];
+	// whole aligned dwords of the destination, each from two aligned dwords of the record; the bytes before the first
+	// and after the last one (shared with the neighbouring records' dwords) one by one
+	const uint32_t head = (uint32_t)((4u - (uint32_t)(reinterpret_cast<uintptr_t>(dst) & 3u)) & 3u);
+	if (len < 8u + head) {
+		for (uint32_t i = lane; i < len; i += 64u) dst[i] = src[i];
+		return;
+	}
+	if (lane < head) dst[lane] = src[lane];
+	const uint32_t n_dw = (len - head) / 4u, tail = head + 4u * n_dw;
+	const uint32_t *s32 = reinterpret_cast<const uint32_t *>(src);
+	uint32_t *d32 = reinterpret_cast<uint32_t *>(dst + head);
+	const uint32_t sh = head & 3u;  // source byte offset of destination dword j is head + 4j
+	for (uint32_t j = lane; j < n_dw; j += 64u) {
+		const uint32_t lo = s32[j + (head >> 2)], hi = sh ? s32[j + (head >> 2) + 1u] : 0u;  // (the record's stride leaves room behind it)
+		d32[j] = sh ? __builtin_amdgcn_alignbyte(hi, lo, sh) : lo;
+	}
+	if (lane < len - tail) dst[tail + lane] = src[tail + lane];
 }
 
 // file header + line-length table (mod.rs:50-57,77-82): one thread per (frame, tile row)
@@ -330,8 +384,9 @@ hipError_t launch_qoi(const QoiArgs &a, hipStream_t stream)
 	hipLaunchKernelGGL(qoi_bin_count_kernel, dim3(tb), dim3(256), 0, stream, a);
 	hipLaunchKernelGGL(qoi_bin_scan_kernel, dim3(1), dim3(1), 0, stream, a);
 	hipLaunchKernelGGL(qoi_bin_scatter_kernel, dim3(tb), dim3(256), 0, stream, a);
-	if (a.channels == 4) hipLaunchKernelGGL(qoi_tiles_kernel<4>, dim3(tb), dim3(256), 0, stream, a);
-	else hipLaunchKernelGGL(qoi_tiles_kernel<3>, dim3(tb), dim3(256), 0, stream, a);
+	const uint32_t qb = (a.n_tiles + 64u * kQoiWaves - 1u) / (64u * kQoiWaves);
+	if (a.channels == 4) hipLaunchKernelGGL(qoi_tiles_kernel<4>, dim3(qb), dim3(64u * kQoiWaves), 0, stream, a);
+	else hipLaunchKernelGGL(qoi_tiles_kernel<3>, dim3(qb), dim3(64u * kQoiWaves), 0, stream, a);
 	// exclusive scan of the record lengths (same chunked scan as the pixel pack, sizes given)
 	PackArgs p{};
 	p.sizes = a.rec_len;
@@ -512,11 +567,11 @@ __global__ void __launch_bounds__(256) pixlzr_index_kernel(const DecodeArgs a)
 }
 
 template <int C>
-__global__ void __launch_bounds__(256) qoi_decode_kernel(const DecodeArgs a)
+__global__ void __launch_bounds__(64 * kQoiWaves) qoi_decode_kernel(const DecodeArgs a)
 {
-	__shared__ uint32_t s_index[4][64][64];  // [wave][slot][lane]
+	__shared__ uint32_t s_index[kQoiWaves][64][64];  // [wave][slot][lane]
 	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-	const uint32_t i0 = blockIdx.x * 256u + threadIdx.x;
+	const uint32_t i0 = blockIdx.x * (64u * kQoiWaves) + threadIdx.x;
 	uint32_t(*index)[64] = s_index[wave];
 #pragma unroll 8
 	for (int sidx = 0; sidx < 64; ++sidx) index[sidx][lane] = 0u;  // qoi: index starts as zero pixels
@@ -536,9 +591,15 @@ __global__ void __launch_bounds__(256) qoi_decode_kernel(const DecodeArgs a)
 	unsigned long long acc = *wp++ >> (8u * (uint32_t)(first_byte & 7ull));
 	uint32_t have = 8u - (uint32_t)(first_byte & 7ull);
 	int32_t left = (int32_t)len;
+	// the window after the current one is already on its way (a lane's op loop is one dependent chain); it is only
+	// requested while op bytes remain beyond the current window, so it never leaves the file
+	const unsigned long long *w_end = reinterpret_cast<const unsigned long long *>(a.files + ((first_byte + len + 7ull) & ~7ull));
+	unsigned long long spare = wp < w_end ? *wp : 0ull;
 	auto next_byte = [&]() -> uint32_t {
 		if (have == 0u) {
-			acc = *wp++;
+			acc = spare;
+			++wp;
+			spare = wp < w_end ? *wp : 0ull;
 			have = 8u;
 		}
 		const uint32_t b = (uint32_t)acc & 255u;
@@ -627,8 +688,9 @@ hipError_t launch_decode(const DecodeArgs &a, hipStream_t stream)
 	hipLaunchKernelGGL(qoi_bin_count_kernel, dim3(tb), dim3(256), 0, stream, q);
 	hipLaunchKernelGGL(qoi_bin_scan_kernel, dim3(1), dim3(1), 0, stream, q);
 	hipLaunchKernelGGL(qoi_bin_scatter_kernel, dim3(tb), dim3(256), 0, stream, q);
-	if (a.channels == 4) hipLaunchKernelGGL(qoi_decode_kernel<4>, dim3(tb), dim3(256), 0, stream, a);
-	else hipLaunchKernelGGL(qoi_decode_kernel<3>, dim3(tb), dim3(256), 0, stream, a);
+	const uint32_t qb = (a.n_tiles + 64u * kQoiWaves - 1u) / (64u * kQoiWaves);
+	if (a.channels == 4) hipLaunchKernelGGL(qoi_decode_kernel<4>, dim3(qb), dim3(64u * kQoiWaves), 0, stream, a);
+	else hipLaunchKernelGGL(qoi_decode_kernel<3>, dim3(qb), dim3(64u * kQoiWaves), 0, stream, a);
 	return hipGetLastError();
 }
 
