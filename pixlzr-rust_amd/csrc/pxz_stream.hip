@@ -569,7 +569,7 @@ __global__ void __launch_bounds__(256) pixlzr_index_kernel(const DecodeArgs a)
 template <int C>
 __global__ void __launch_bounds__(64 * kQoiWaves) qoi_decode_kernel(const DecodeArgs a)
 {
-	__shared__ uint32_t s_index[kQoiWaves][64][64];  // [wave][slot][lane]
+	__shared__ uint32_t s_index[kQoiWaves][65][64];  // [wave][slot][lane]; row 64 takes the writes of lanes that have none
 	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
 	const uint32_t i0 = blockIdx.x * (64u * kQoiWaves) + threadIdx.x;
 	uint32_t(*index)[64] = s_index[wave];
@@ -583,71 +583,72 @@ __global__ void __launch_bounds__(64 * kQoiWaves) qoi_decode_kernel(const Decode
 		a.tile_h[t] = 0;
 		return;
 	}
-	// the op bytes, fetched 8 at a time through an aligned 64-bit window (a byte load per op byte would make
-	// every op wait for a memory round trip).  The window may run up to 7 bytes past the last op: those are
-	// bytes of the record's own 8-byte end marker, still inside the file.
+	// The op bytes come through two aligned 64-bit windows (the current one and the next, already on its way): the five
+	// bytes an op can have are cut out at the stream position with one funnel shift.  Windows are only requested while
+	// op bytes remain beyond them -- what lies past the last op is the record's own end marker (zeros where an op could
+	// still reach), so zeros stand in for it and no load leaves the file.  As in the encoder there are no branches per
+	// op: every op's result is worked out and selects keep the right one.
 	const unsigned long long first_byte = a.rec_off[t];
 	const unsigned long long *wp = reinterpret_cast<const unsigned long long *>(a.files + (first_byte & ~7ull));
-	unsigned long long acc = *wp++ >> (8u * (uint32_t)(first_byte & 7ull));
-	uint32_t have = 8u - (uint32_t)(first_byte & 7ull);
-	int32_t left = (int32_t)len;
-	// the window after the current one is already on its way (a lane's op loop is one dependent chain); it is only
-	// requested while op bytes remain beyond the current window, so it never leaves the file
 	const unsigned long long *w_end = reinterpret_cast<const unsigned long long *>(a.files + ((first_byte + len + 7ull) & ~7ull));
-	unsigned long long spare = wp < w_end ? *wp : 0ull;
-	auto next_byte = [&]() -> uint32_t {
-		if (have == 0u) {
-			acc = spare;
-			++wp;
-			spare = wp < w_end ? *wp : 0ull;
-			have = 8u;
-		}
-		const uint32_t b = (uint32_t)acc & 255u;
-		acc >>= 8;
-		--have;
-		--left;
-		return b;
-	};
+	unsigned long long w0 = *wp++;                          // (len > 0: the first window holds op bytes)
+	unsigned long long w1 = wp < w_end ? *wp : 0ull;
+	unsigned long long w2 = wp + 1 < w_end ? wp[1] : 0ull;  // one more ahead: its round trip overlaps a window's worth of ops
+	uint32_t pos = (uint32_t)(first_byte & 7ull);           // byte position of the next op inside w0 (0..7)
+	uint32_t left = len;                                    // op bytes not yet consumed
 	const uint32_t n = a.tile_w[t] * a.tile_h[t];
 	uint8_t *dst = a.slots + (size_t)t * a.slot_bytes;
 	uint32_t px = 0xff000000u, run = 0;
+	bool starved = false;
 	uint4 hold = make_uint4(0, 0, 0, 0);
 	for (uint32_t i = 0; i < n; ++i) {
-		if (run > 0) {
-			--run;
-		} else if (left > 0) {
-			// (as in the qoi crate, only the op's first byte is checked against the end of the stream; a truncated
-			// last op reads on into the end marker, which is inside the file)
-			const uint32_t b1 = next_byte();
-			if (b1 == 0xfeu) {  // QOI_OP_RGB
-				const uint32_t r = next_byte(), g = next_byte(), b = next_byte();
-				px = (px & 0xff000000u) | r | (g << 8) | (b << 16);
-			} else if (b1 == 0xffu) {  // QOI_OP_RGBA
-				const uint32_t r = next_byte(), g = next_byte(), b = next_byte(), al = next_byte();
-				px = r | (g << 8) | (b << 16) | (al << 24);
-			} else if ((b1 & 0xc0u) == 0x00u) {  // QOI_OP_INDEX
-				px = index[b1][lane];
-			} else if ((b1 & 0xc0u) == 0x40u) {  // QOI_OP_DIFF
-				const uint32_t r = ((px & 255u) + ((b1 >> 4) & 3u) - 2u) & 255u;
-				const uint32_t g = (((px >> 8) & 255u) + ((b1 >> 2) & 3u) - 2u) & 255u;
-				const uint32_t b = (((px >> 16) & 255u) + (b1 & 3u) - 2u) & 255u;
-				px = (px & 0xff000000u) | r | (g << 8) | (b << 16);
-			} else if ((b1 & 0xc0u) == 0x80u) {  // QOI_OP_LUMA
-				const uint32_t b2 = next_byte();
-				const uint32_t vg = (b1 & 0x3fu) - 32u;
-				const uint32_t r = ((px & 255u) + vg - 8u + ((b2 >> 4) & 15u)) & 255u;
-				const uint32_t g = (((px >> 8) & 255u) + vg) & 255u;
-				const uint32_t b = (((px >> 16) & 255u) + vg - 8u + (b2 & 15u)) & 255u;
-				px = (px & 0xff000000u) | r | (g << 8) | (b << 16);
-			} else {  // QOI_OP_RUN
-				run = b1 & 0x3fu;
-			}
-			index[((px & 255u) * 3u + ((px >> 8) & 255u) * 5u + ((px >> 16) & 255u) * 7u + (px >> 24) * 11u) & 63u][lane] = px;
-		} else {
-			atomicOr(a.status, 2u);  // the op stream ended before the tile was full
-			a.tile_w[t] = 0;
-			a.tile_h[t] = 0;
-			return;
+		// the (up to) 8 bytes at the stream position
+		const unsigned long long at = pos ? (w0 >> (8u * pos)) | (w1 << (64u - 8u * pos)) : w0;
+		const uint32_t b1 = (uint32_t)at & 255u, b2 = (uint32_t)(at >> 8) & 255u;
+		const uint32_t next4 = (uint32_t)(at >> 8);  // the four bytes behind the tag
+		const bool in_run = run > 0u;
+		starved = starved || (!in_run && left == 0u);  // the op stream ended before the tile was full
+		const bool take = !in_run && left != 0u;       // this pixel consumes an op
+		// (as in the qoi crate, only the op's first byte is checked against the end of the stream; a truncated last op
+		// reads on into the end marker)
+		const uint32_t tag = b1 & 0xc0u;
+		const uint32_t vg = (b1 & 0x3fu) - 32u;
+		const uint32_t d_r = ((px & 255u) + ((b1 >> 4) & 3u) - 2u) & 255u, d_g = (((px >> 8) & 255u) + ((b1 >> 2) & 3u) - 2u) & 255u,
+		               d_b = (((px >> 16) & 255u) + (b1 & 3u) - 2u) & 255u;
+		const uint32_t l_r = ((px & 255u) + vg - 8u + ((b2 >> 4) & 15u)) & 255u, l_g = (((px >> 8) & 255u) + vg) & 255u,
+		               l_b = (((px >> 16) & 255u) + vg - 8u + (b2 & 15u)) & 255u;
+		const uint32_t from_index = index[b1 & 63u][lane];
+		uint32_t cand = px, used = 1u, new_run = 0u;  // QOI_OP_RUN: the pixel repeats
+		if (tag == 0xc0u) new_run = b1 & 0x3fu;
+		if (tag == 0x80u) {  // QOI_OP_LUMA
+			cand = (px & 0xff000000u) | l_r | (l_g << 8) | (l_b << 16);
+			used = 2u;
+		}
+		if (tag == 0x40u) cand = (px & 0xff000000u) | d_r | (d_g << 8) | (d_b << 16);  // QOI_OP_DIFF
+		if (tag == 0x00u) cand = from_index;                                                 // QOI_OP_INDEX
+		if (b1 == 0xfeu) {  // QOI_OP_RGB
+			cand = (px & 0xff000000u) | (next4 & 0x00ffffffu);
+			used = 4u;
+			new_run = 0u;
+		}
+		if (b1 == 0xffu) {  // QOI_OP_RGBA
+			cand = next4;
+			used = 5u;
+			new_run = 0u;
+		}
+		px = take ? cand : px;
+		run = in_run ? run - 1u : (take ? new_run : 0u);
+		// every op (RUN included) stores its pixel in the index; the repeats of a run do not
+		index[take ? ((px & 255u) * 3u + ((px >> 8) & 255u) * 5u + ((px >> 16) & 255u) * 7u + (px >> 24) * 11u) & 63u : 64u][lane] = px;
+		const uint32_t step = take ? used : 0u;
+		left = left > step ? left - step : 0u;
+		pos += step;
+		if (pos >= 8u) {  // the window is used up: move on, request the one after next
+			pos -= 8u;
+			w0 = w1;
+			w1 = w2;
+			wp += 1;
+			w2 = wp + 1 < w_end ? wp[1] : 0ull;
 		}
 		if constexpr (C == 4) {
 			// four pixels per 16-byte store (slots are 16-byte aligned: bw*bh*4 bytes each)
@@ -664,6 +665,12 @@ __global__ void __launch_bounds__(64 * kQoiWaves) qoi_decode_kernel(const Decode
 			dst[3 * i + 1] = (uint8_t)(px >> 8);
 			dst[3 * i + 2] = (uint8_t)(px >> 16);
 		}
+	}
+	if (starved) {
+		atomicOr(a.status, 2u);
+		a.tile_w[t] = 0;
+		a.tile_h[t] = 0;
+		return;
 	}
 	if constexpr (C == 4) {
 		const uint32_t tail = n & 3u, base = n & ~3u;  // 1x1, 2x1 ... tiles
