@@ -2,6 +2,7 @@
 // handle, per-configuration table cache, HBM staging for the host-buffer entry
 // point, kernel launches on the caller's stream, HIP-event timing.
 #include <hip/hip_runtime.h>
+#include <algorithm>
 
 #include <cmath>
 #include <cstdarg>
@@ -589,6 +590,9 @@ int timed_launch(pxz_handle *h, pxz::ShrinkArgs &a, uint32_t channels, float *va
 	const bool general_oklab = !square_fast && a.mode == PXZ_MODE_SHRINK_BY && a.bw % 4u == 0 && a.bw * a.bh >= 64u &&
 	                           a.bw * a.bh <= 16384u && !getenv("PXZ_NO_OKLAB_GENERAL");
 	a.ok_bands = (a.bw * a.bh + 255u) / 256u;
+	a.ok_region = 0;
+	a.ok_count = a.n_tiles;
+	a.ok_edges = 0;
 	if (aligned16 && (square_fast || general_oklab)) {
 		a.full_cols = a.edge_w == a.bw ? a.cols : a.cols - 1;
 		a.full_rows = a.edge_h == a.bh ? a.rows : a.rows - 1;
@@ -620,10 +624,26 @@ int timed_launch(pxz_handle *h, pxz::ShrinkArgs &a, uint32_t channels, float *va
 	a.oklab_given = 0;
 	if (a.mode == PXZ_MODE_SHRINK_BY && channels == 4 && (square_fast || general_oklab) &&
 	    a.full_cols != 0 && a.full_rows != 0 && !getenv("PXZ_NO_OKLAB32")) {
-		if (a.ok_bands > 4u) {
+		// The ragged edge of the grid -- right column (edge_w x bh), bottom row (bw x edge_h), corner tile -- goes
+		// through the same detector with run-time geometry, one launch per region, where the region's tile rows are
+		// whole pixel quads (16-byte aligned like the full tiles).  What is left runs its chains in the generic kernel
+		// (four lanes per tile: ~0.1-0.5 ms of latency per launch whatever the batch).
+		const uint32_t n_frames = a.n_tiles / a.tiles_per_frame;
+		struct Region { uint32_t id, w, hh, per_frame, bit; bool wanted; } regions[3] = {
+		    {1u, a.edge_w, a.bh, a.full_rows, 1u, a.full_cols < a.cols},
+		    {2u, a.bw, a.edge_h, a.full_cols, 2u, a.full_rows < a.rows && a.ok_rows < a.rows},
+		    {3u, a.edge_w, a.edge_h, 1u, 4u, a.full_cols < a.cols && a.full_rows < a.rows}};
+		size_t scratch = a.ok_bands > 4u ? (size_t)a.n_tiles * a.ok_bands * 3328u : 0u;
+		for (Region &r : regions) {
+			r.wanted = r.wanted && r.per_frame != 0u && r.w % 4u == 0u && r.w * r.hh >= 16u && r.w * r.hh <= 16384u &&
+			           !getenv("PXZ_NO_OKLAB_EDGES");
+			const uint32_t bands = (r.w * r.hh + 255u) / 256u;
+			if (r.wanted && bands > 4u) scratch = std::max(scratch, (size_t)n_frames * r.per_frame * bands * 3328u);
+		}
+		if (scratch != 0) {
 			// a tile of more than 1024 pixels does not fit the registers between the detector's two passes: 13 dwords
 			// per pixel quad in HBM
-			if ((rc = ensure(h, h->okscratch, (size_t)a.n_tiles * a.ok_bands * 3328u)) != PXZ_OK) return rc;
+			if ((rc = ensure(h, h->okscratch, scratch)) != PXZ_OK) return rc;
 			a.ok_scratch = (float *)h->okscratch.ptr;
 		}
 		a.oklab_given = 1;
@@ -631,6 +651,15 @@ int timed_launch(pxz_handle *h, pxz::ShrinkArgs &a, uint32_t channels, float *va
 		if (a.mid_event) {
 			PXZ_HIP(h, hipEventRecord(static_cast<hipEvent_t>(a.mid_event), h->stream));
 			a.mid_event = nullptr;
+		}
+		for (const Region &r : regions) {
+			if (!r.wanted) continue;
+			pxz::ShrinkArgs e = a;
+			e.ok_region = r.id;
+			e.ok_bands = (r.w * r.hh + 255u) / 256u;
+			e.ok_count = n_frames * r.per_frame;
+			PXZ_HIP(h, pxz::launch_oklab(e, h->n_cus, h->stream));
+			a.ok_edges |= r.bit;
 		}
 	}
 	// 32x32 RGBA flow: shrink32_kernel, then the worklist kernel, which also finishes every tile and

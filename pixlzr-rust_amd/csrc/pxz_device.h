@@ -735,6 +735,18 @@ __device__ __forceinline__ void fast32_prefetch(const Args &a, uint32_t tile_g, 
 	}
 }
 
+// Does sums[] already hold this tile's Oklab value (left by an oklab_kernel launch)?  Interior: the full tiles, plus the
+// ragged last row of the square sizes when its height is a whole number of bands (ok_rows).  Edges: the regions a
+// run-time-geometry launch has taken (ok_edges: bit 0 right column, bit 1 bottom row, bit 2 corner tile).
+template <class Args>
+__device__ __forceinline__ bool oklab_value_given(const Args &a, uint32_t tx, uint32_t ty)
+{
+	const bool in_x = tx < a.full_cols, in_y = ty < a.full_rows;
+	if (in_x && ty < a.ok_rows) return true;  // (ok_rows >= full_rows)
+	const uint32_t bit = in_x ? 2u : (in_y ? 1u : 4u);
+	return (a.ok_edges & bit) != 0u;
+}
+
 // Detector result of one tile -> stored block value (and the raw detector outputs for pxz_lod_*):
 // the f64 part of get_block_variance_directionally (operations.rs:253-258), shrink_*'s closures
 // (pixlzr.rs:177-178, :199) and reduce_image_section's value (operations.rs:154).

@@ -69,7 +69,11 @@ struct ShrinkArgs {
 	                         //   pixlzr.rs:15,162; 1 with factor 1 = the identity closure of process(), process/mod.rs:107-121)
 	FastDiv div_gpf, div_gcols;  // shrink16_kernel: divisors for its 2x2 tile groups (groups per frame, group columns)
 	uint32_t n_frames_x_groups;  //   and the number of groups in the batch
-	uint32_t ok_bands;       // Oklab detector with run-time geometry: bands (256 pixels) per tile, ceil(bw * bh / 256)
+	uint32_t ok_bands;       // Oklab detector with run-time geometry: bands (256 pixels) per tile, ceil(w * h / 256)
+	uint32_t ok_region;      //   which tiles that launch takes: 0 the full ones, 1 the right column (edge_w x bh), 2 the bottom
+	                         //   row (bw x edge_h), 3 the corner tile (edge_w x edge_h)
+	uint32_t ok_count;       //   and how many items it enumerates (region 0: n_tiles)
+	uint32_t ok_edges;       // consumers: edge regions whose values are in sums[] already (bit 0 right, 1 bottom, 2 corner)
 	float *ok_scratch;       // Oklab detector on 64x64 tiles: 16 floats per pixel quad between its passes (HBM)
 	const uint32_t *mf64;    // 64x64 fast path: matrix-core operand tables (global memory), see Fast64Args
 	uint32_t ok_rows;        // tile rows the block-cooperative Oklab detector takes: full_rows, plus the ragged last row
@@ -119,7 +123,7 @@ struct Fast32Args {
 	FastDiv div_tpf, div_cols;
 	uint32_t n_groups;       // shrink16_kernel: 2x2 groups of tiles, ceil(cols/2) * ceil(rows/2) per frame
 	FastDiv div_gpf, div_gcols;
-	uint32_t full_cols, full_rows, ok_rows;  // as in ShrinkArgs
+	uint32_t full_cols, full_rows, ok_rows, ok_edges;  // as in ShrinkArgs
 	uint32_t filter;
 	uint32_t *sums;
 	uint32_t *out_w;
@@ -146,7 +150,7 @@ struct Fast64Args {
 	uint64_t frame_stride;
 	uint32_t pitch, cols, rows, tiles_per_frame, n_tiles;
 	FastDiv div_tpf, div_cols;
-	uint32_t full_cols, full_rows, ok_rows;
+	uint32_t full_cols, full_rows, ok_rows, ok_edges;
 	uint32_t filter;
 	uint32_t *sums;
 	uint32_t *out_w;

@@ -172,12 +172,24 @@ struct OkGeom {
 
 // Tiles the block-cooperative detector takes: full width, and a height of whole bands (every full tile; the
 // ragged last row of the grid when its height happens to be one).  tile_h = 0 when it does not.
+// item = the launch's running index: the tile number (region 0: every tile is asked, the full ones are taken), or the
+// index inside an edge region (T = 0 only: all of its tiles are taken).  tile_g = the tile's number in the batch.
 template <int T, class Args>
-__device__ __forceinline__ uint32_t oklab_tile_src(const Args &a, uint32_t tile_g, const uint8_t *&src)
+__device__ __forceinline__ uint32_t oklab_tile_src(const Args &a, uint32_t item, const uint8_t *&src, uint32_t &tile_g)
 {
-	if (tile_g >= a.n_tiles) return 0u;
-	const uint32_t frame = fastdiv(tile_g, a.div_tpf);
-	const uint32_t t = tile_g - frame * a.tiles_per_frame;
+	tile_g = item;
+	if (item >= a.ok_count) return 0u;
+	if (T == 0 && a.ok_region != 0u) {
+		// right column: full_rows tiles per frame; bottom row: full_cols; corner: one
+		const uint32_t per_frame = a.ok_region == 1u ? a.full_rows : (a.ok_region == 2u ? a.full_cols : 1u);
+		const uint32_t frame = item / per_frame, k = item - frame * per_frame;
+		const uint32_t tx = a.ok_region == 2u ? k : a.cols - 1u, ty = a.ok_region == 1u ? k : a.rows - 1u;
+		tile_g = frame * a.tiles_per_frame + ty * a.cols + tx;
+		src = a.src + (size_t)frame * a.frame_stride + (size_t)(ty * a.bh) * a.pitch + (size_t)(tx * a.bw) * 4u;
+		return a.ok_region == 1u ? a.bh : a.edge_h;
+	}
+	const uint32_t frame = fastdiv(item, a.div_tpf);
+	const uint32_t t = item - frame * a.tiles_per_frame;
 	const uint32_t ty = fastdiv(t, a.div_cols), tx = t - ty * a.cols;
 	const uint32_t tw = T > 0 ? (uint32_t)T : a.bw, th = T > 0 ? (uint32_t)T : a.bh;
 	src = a.src + (size_t)frame * a.frame_stride + (size_t)(ty * th) * a.pitch + (size_t)(tx * tw) * 4u;
@@ -193,8 +205,9 @@ __global__ void __launch_bounds__(1024) oklab_kernel(const ShrinkArgs a)
 	constexpr bool kInRegs = kGeneral ? NBR > 0 : G::kInRegs;
 	constexpr uint32_t NBC = kGeneral ? (NBR > 0 ? (uint32_t)NBR : 1u) : G::kBands;  // band count where it is static
 	const uint32_t NB = (kGeneral && NBR == 0) ? a.ok_bands : NBC;
-	const uint32_t tile_w = kGeneral ? a.bw : (uint32_t)T;
-	const uint32_t tile_px = kGeneral ? a.bw * a.bh : (uint32_t)(T * T);
+	// (T = 0: the tiles of this launch are a.bw x a.bh, or an edge region's smaller ones)
+	const uint32_t tile_w = kGeneral ? ((a.ok_region & 1u) ? a.edge_w : a.bw) : (uint32_t)T;
+	const uint32_t tile_px = kGeneral ? tile_w * ((a.ok_region & 2u) ? a.edge_h : a.bh) : (uint32_t)(T * T);
 	extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
 	float *s_srgb = reinterpret_cast<float *>(lds);          // 256: sRGB u8 -> linear
 	float *s_alpha = s_srgb + 256;                           // 256: a / 255
@@ -206,7 +219,7 @@ __global__ void __launch_bounds__(1024) oklab_kernel(const ShrinkArgs a)
 	oklab_fill_tables(s_srgb, s_alpha, s_scale, threadIdx.x);
 	__syncthreads();
 
-	const uint32_t n_batches = (a.n_tiles + kOkTiles - 1) / kOkTiles;
+	const uint32_t n_batches = (a.ok_count + kOkTiles - 1) / kOkTiles;
 	// batches of this block: blockIdx.x + j * gridDim.x, j < own; periods 0 .. own + 1 drain the pipeline
 	const uint32_t own = n_batches > blockIdx.x ? (n_batches - blockIdx.x + gridDim.x - 1) / gridDim.x : 0u;
 	const uint32_t periods = own + 2u;
@@ -234,7 +247,8 @@ __global__ void __launch_bounds__(1024) oklab_kernel(const ShrinkArgs a)
 			const uint8_t *src;
 			bands = 0;
 			if (j >= own) return nullptr;
-			const uint32_t th = oklab_tile_src<T>(a, (blockIdx.x + j * gridDim.x) * kOkTiles + wave, src);
+			uint32_t unused_tile;
+			const uint32_t th = oklab_tile_src<T>(a, (blockIdx.x + j * gridDim.x) * kOkTiles + wave, src, unused_tile);
 			if (th == 0) return nullptr;
 			bands = kGeneral ? NB : th / G::kRowsPerBand;  // (a ragged tile is only taken with a whole number of bands)
 			return src;
@@ -409,12 +423,15 @@ __global__ void __launch_bounds__(1024) oklab_kernel(const ShrinkArgs a)
 			return acc;
 		};
 		uint32_t h0 = 0, hm1 = 0, hm2 = 0;  // height of this lane's tile in batches p, p-1, p-2 (0: not taken)
+		uint32_t g0 = 0, gm1 = 0, gm2 = 0;  // and its number in the batch
 		for (uint32_t p = 0; p < periods; ++p) {
 			{
 				const uint8_t *unused;
 				hm2 = hm1;
 				hm1 = h0;
-				h0 = (live && p < own) ? oklab_tile_src<T>(a, (blockIdx.x + p * gridDim.x) * kOkTiles + ct, unused) : 0u;
+				gm2 = gm1;
+				gm1 = g0;
+				h0 = (live && p < own) ? oklab_tile_src<T>(a, (blockIdx.x + p * gridDim.x) * kOkTiles + ct, unused, g0) : 0u;
 			}
 #pragma unroll 1
 			for (uint32_t k = 0; k < NB; ++k) {
@@ -424,6 +441,7 @@ __global__ void __launch_bounds__(1024) oklab_kernel(const ShrinkArgs a)
 				const bool p1_valid = any && pp < own;                   // pass 1 of batch pp
 				const bool p2_valid = any && pp >= 1u && pp - 1u < own;  // pass 2 of batch pp - 1
 				const uint32_t h1 = k > 0 ? h0 : hm1, h2 = k > 0 ? hm1 : hm2;  // tile heights of those two batches
+				const uint32_t tg2 = k > 0 ? gm1 : gm2;                       // the tile whose pass 2 ends here
 				// (T = 0: a tile that is taken has all its bands; a short last band is padded with exact zeros)
 				if (p1_valid && (kGeneral ? h1 != 0u : kk * G::kRowsPerBand < h1)) acc1 = walk(s_p1, acc1, false);
 				if (p2_valid && (kGeneral ? h2 != 0u : kk * G::kRowsPerBand < h2)) acc2 = walk(s_p2, acc2, true);
@@ -437,9 +455,8 @@ __global__ void __launch_bounds__(1024) oklab_kernel(const ShrinkArgs a)
 						const float d2 = __shfl(acc2, (int)(lane & ~3u) + 2, 64), d3 = __shfl(acc2, (int)(lane & ~3u) + 3, 64);
 						const float total = d0 + d1 + d2 + d3;  // :89
 						const float value = __fdiv_rn(total, (float)(tile_w * h2)) * a.factor * a.scale2;  // pixlzr.rs:162
-						const uint32_t tg = (blockIdx.x + (pp - 1u) * gridDim.x) * kOkTiles + ct;
 						if (live && cc == 0 && h2 != 0u)
-							reinterpret_cast<uint2 *>(a.sums)[tg] = make_uint2(__float_as_uint(value), __float_as_uint(value));
+							reinterpret_cast<uint2 *>(a.sums)[tg2] = make_uint2(__float_as_uint(value), __float_as_uint(value));
 						acc2 = 0.0f;
 					}
 				}
@@ -453,7 +470,7 @@ __global__ void __launch_bounds__(1024) oklab_kernel(const ShrinkArgs a)
 hipError_t launch_oklab(const ShrinkArgs &a, uint32_t n_cus, hipStream_t stream)
 {
 	const uint32_t lds_bytes = (512u + 2u * 132u + 64u) * 4u + 2u * kOkBand * 4u;
-	const uint32_t n_batches = (a.n_tiles + kOkTiles - 1) / kOkTiles;
+	const uint32_t n_batches = (a.ok_count + kOkTiles - 1) / kOkTiles;
 	const uint32_t blocks = n_batches < n_cus ? n_batches : n_cus;
 	hipError_t e;
 	auto go = [&](auto kernel) -> hipError_t {
@@ -461,7 +478,7 @@ hipError_t launch_oklab(const ShrinkArgs &a, uint32_t n_cus, hipStream_t stream)
 		hipLaunchKernelGGL(kernel, dim3(blocks), dim3(1024), lds_bytes, stream, a);
 		return hipGetLastError();
 	};
-	if (a.bw == a.bh) {
+	if (a.bw == a.bh && a.ok_region == 0u) {
 		switch (a.bw) {
 		case 16: return go(oklab_kernel<16>);
 		case 32: return go(oklab_kernel<32>);
@@ -470,7 +487,7 @@ hipError_t launch_oklab(const ShrinkArgs &a, uint32_t n_cus, hipStream_t stream)
 		}
 	}
 	// any other tile with a width of whole pixel quads: run-time geometry
-	if (a.bw % 4u != 0u || a.ok_bands == 0u) return hipErrorInvalidValue;
+	if (((a.ok_region & 1u) ? a.edge_w : a.bw) % 4u != 0u || a.ok_bands == 0u || a.ok_count == 0u) return hipErrorInvalidValue;
 	switch (a.ok_bands) {
 	case 1: return go(oklab_kernel<0, 1>);
 	case 2: return go(oklab_kernel<0, 2>);

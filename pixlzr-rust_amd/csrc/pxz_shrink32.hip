@@ -110,7 +110,7 @@ __global__ void __launch_bounds__(1024) shrink32_kernel(const Fast32Args a)
 				if constexpr (MODE == 0) {
 					const uint32_t t = tile_g - fastdiv(tile_g, a.div_tpf) * a.tiles_per_frame;
 					const uint32_t ty = fastdiv(t, a.div_cols), tx = t - ty * a.cols;
-					keep = tx < a.full_cols && ty < a.ok_rows;
+					keep = oklab_value_given(a, tx, ty);
 				}
 				if (!keep) reinterpret_cast<uint2 *>(a.sums)[tile_g] = make_uint2(kDeferredKey, kDeferredKey);  // not finished here
 			}
@@ -597,7 +597,7 @@ __global__ void __launch_bounds__(1024) shrink16_kernel(const Fast32Args a)
 				if constexpr (MODE == 0) {
 					const uint32_t tt = t - pl.frame * a.tiles_per_frame;
 					const uint32_t ty = fastdiv(tt, a.div_cols), tx = tt - ty * a.cols;
-					keep = tx < a.full_cols && ty < a.ok_rows;
+					keep = oklab_value_given(a, tx, ty);
 				}
 				if (!keep) reinterpret_cast<uint2 *>(a.sums)[t] = make_uint2(kDeferredKey, kDeferredKey);
 			}
@@ -798,6 +798,7 @@ hipError_t launch_fast32_16(const ShrinkArgs &a, ShrinkArgs &ga, uint32_t n_cus,
 	f.full_cols = a.full_cols;
 	f.full_rows = a.full_rows;
 	f.ok_rows = a.ok_rows;
+	f.ok_edges = a.ok_edges;
 	f.filter = a.filter;
 	f.sums = a.sums;
 	f.out_w = a.out_w;

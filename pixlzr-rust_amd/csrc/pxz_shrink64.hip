@@ -112,7 +112,7 @@ __global__ void __launch_bounds__(256) shrink64_kernel(const Fast64Args a)
 				if constexpr (MODE == 0) {
 					const uint32_t t = tile_g - fastdiv(tile_g, a.div_tpf) * a.tiles_per_frame;
 					const uint32_t ty = fastdiv(t, a.div_cols), tx = t - ty * a.cols;
-					keep = tx < a.full_cols && ty < a.ok_rows;
+					keep = oklab_value_given(a, tx, ty);
 				}
 				if (!keep) reinterpret_cast<uint2 *>(a.sums)[tile_g] = make_uint2(kDeferredKey, kDeferredKey);
 			}
@@ -450,6 +450,7 @@ hipError_t launch_fast64(const ShrinkArgs &a, ShrinkArgs &ga, uint32_t n_cus, hi
 	f.full_cols = a.full_cols;
 	f.full_rows = a.full_rows;
 	f.ok_rows = a.ok_rows;
+	f.ok_edges = a.ok_edges;
 	f.filter = a.filter;
 	f.sums = a.sums;
 	f.out_w = a.out_w;

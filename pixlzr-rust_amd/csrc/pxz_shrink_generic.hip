@@ -181,7 +181,7 @@ __device__ __forceinline__ void process_tile(const ShrinkArgs &a, const uint32_t
 			m0 = level_count(sum_hz, a.breaks[cls], a.breaks_asc[cls]);
 			m1 = level_count(sum_vr, a.breaks[cls], a.breaks_asc[cls]);
 		}
-	} else if (a.oklab_given && tx < a.full_cols && ty < a.ok_rows) {
+	} else if (a.oklab_given && oklab_value_given(a, tx, ty)) {
 		// full tile of a batch the block-cooperative detector (oklab_kernel) has already been over
 		const float value = __uint_as_float(a.sums[2u * tile_g]);
 		key0 = key1 = __float_as_uint(value);
