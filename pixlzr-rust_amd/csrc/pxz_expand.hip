@@ -26,15 +26,33 @@ __global__ void __launch_bounds__(256) expand_kernel(const ExpandArgs a)
 	__syncthreads();
 	uint32_t *s_src = lds + sub * a.tile_dw;
 	uint32_t *s_tmp = s_src + a.bw * a.bh;
-	uint32_t ticket = sub;
-	for (;;) {
-		const unsigned long long tl = (unsigned long long)blockIdx.x + (unsigned long long)ticket * gridDim.x;
-		if (tl >= (unsigned long long)a.n_tiles) break;
-		const uint32_t t = (uint32_t)tl;
+	// A tile's stored size and its first 64 pixels (all of them for most tiles) are requested one tile ahead: the
+	// size -> pixels -> windows chain of dependent memory round trips was most of a tile's time.
+	auto tile_of = [&](uint32_t tk) -> uint32_t {
+		const unsigned long long tl = (unsigned long long)blockIdx.x + (unsigned long long)tk * gridDim.x;
+		return tl < (unsigned long long)a.n_tiles ? (uint32_t)tl : 0xffffffffu;
+	};
+	uint32_t p_tw = 0, p_th = 0, p_px = 0;
+	auto prefetch = [&](uint32_t tn) {
+		if (tn == 0xffffffffu) return;
+		p_tw = a.tile_w[tn];
+		p_th = a.tile_h[tn];
+		if constexpr (C == 4) {
+			if (lane < a.bw * a.bh) p_px = reinterpret_cast<const uint32_t *>(a.slots + (size_t)tn * a.slot_bytes)[lane];
+		}
+	};
+	uint32_t t = tile_of(sub);
+	prefetch(t);
+	while (t != 0xffffffffu) {
+		uint32_t nt = 0;
+		if (lane == 0) nt = atomicAdd(s_ticket, 1u);
+		const uint32_t t_next = tile_of(__builtin_amdgcn_readfirstlane(nt));
+		const uint32_t tw = __builtin_amdgcn_readfirstlane(p_tw), th = __builtin_amdgcn_readfirstlane(p_th);
+		const uint32_t first_px = p_px;
+		prefetch(t_next);  // in flight while this tile is expanded
 		const uint32_t frame = t / a.tiles_per_frame, tf = t - frame * a.tiles_per_frame;
 		const uint32_t ty = tf / a.cols, tx = tf - ty * a.cols;
 		const uint32_t fw = (tx == a.cols - 1) ? a.edge_w : a.bw, fh = (ty == a.rows - 1) ? a.edge_h : a.bh;
-		const uint32_t tw = a.tile_w[t], th = a.tile_h[t];
 		const bool widen = C == 3 && a.out_channels == 4;  // RGB tiles into an RGBA frame (process())
 		const uint32_t opx = widen ? 4u : (uint32_t)C;
 		uint8_t *dst = a.dst + (size_t)frame * a.frame_stride + (size_t)(ty * a.bh) * a.pitch + (size_t)(tx * a.bw) * opx;
@@ -58,7 +76,7 @@ __global__ void __launch_bounds__(256) expand_kernel(const ExpandArgs a)
 			for (uint32_t i = lane; i < n; i += 64u) {
 				uint32_t px;
 				if constexpr (C == 4) {
-					px = reinterpret_cast<const uint32_t *>(src)[i];
+					px = i == lane ? first_px : reinterpret_cast<const uint32_t *>(src)[i];
 					if (conv) px = premultiply(px);  // fir: U8x4 is alpha-premultiplied before a convolution
 				} else {
 					px = (uint32_t)src[3 * i] | ((uint32_t)src[3 * i + 1] << 8) | ((uint32_t)src[3 * i + 2] << 16) | 0xff000000u;
@@ -280,9 +298,7 @@ __global__ void __launch_bounds__(256) expand_kernel(const ExpandArgs a)
 				}
 			}
 		}
-		uint32_t nt = 0;
-		if (lane == 0) nt = atomicAdd(s_ticket, 1u);
-		ticket = __builtin_amdgcn_readfirstlane(nt);
+		t = t_next;
 		tile_sync<1>();  // the next tile reuses this wave's LDS
 	}
 }
