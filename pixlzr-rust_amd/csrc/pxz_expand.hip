@@ -115,9 +115,6 @@ __global__ void __launch_bounds__(256) expand_kernel(const ExpandArgs a)
 				if (tw != fw) stage_windows(s_wx, tab_x, fw);
 				if (th != fh) stage_windows(s_wy, tab_y, fh);
 				tile_sync<1>();
-				auto weight = [](const uint32_t (&kk)[4], uint32_t j) -> int32_t {
-					return (int32_t)(int16_t)(kk[j >> 1] >> (16u * (j & 1u)));
-				};
 				if (tw == fw && th == fh) {  // block.rs:279-281: clone
 					for (uint32_t i = lane; i < q4 * fh; i += 64u) {
 						const uint32_t oy = small_div(i, q4), q = i - oy * q4;
@@ -159,15 +156,17 @@ __global__ void __launch_bounds__(256) expand_kernel(const ExpandArgs a)
 							for (int r = 0; r < 4; ++r)
 #pragma unroll
 								for (int c = 0; c < 4; ++c) acc[r][c] = init;
-							for (uint32_t j = 0; j < cnt; ++j) {
-								const int32_t w = weight(kk, j);
+							// two taps per v_dot2_i32_i16: the weights are staged as i16 pairs (an odd count has a zero in the
+							// spare half, so the pixel read past the window -- still inside this wave's LDS -- counts for nothing)
+							for (uint32_t j = 0; j < cnt; j += 2u) {
+								const uint32_t w2 = kk[j >> 1];
 #pragma unroll
 								for (int r = 0; r < 4; ++r) {
-									const uint32_t p = s_src[yr[r] * tw + first + j];
-									acc[r][0] += (int32_t)(p & 255u) * w;
-									acc[r][1] += (int32_t)((p >> 8) & 255u) * w;
-									acc[r][2] += (int32_t)((p >> 16) & 255u) * w;
-									acc[r][3] += (int32_t)(p >> 24) * w;
+									const uint32_t *pp = s_src + yr[r] * tw + first + j;
+									const uint32_t p0 = pp[0], p1 = pp[1];
+#pragma unroll
+									for (uint32_t c = 0; c < 4; ++c)
+										acc[r][c] = dot2(__builtin_amdgcn_perm(p1, p0, c | 0x0c000c00u | ((4u + c) << 16)), w2, acc[r][c]);
 								}
 							}
 #pragma unroll
@@ -201,23 +200,29 @@ __global__ void __launch_bounds__(256) expand_kernel(const ExpandArgs a)
 							for (int r = 0; r < 4; ++r)
 #pragma unroll
 								for (int c = 0; c < 4; ++c) acc[r][c] = init;
-							for (uint32_t j = 0; j < cnt; ++j) {
-								const int32_t w = weight(kk, j);
-								const uint4 v = *reinterpret_cast<const uint4 *>(cur + (first + j) * fw + 4u * q);
-								const uint32_t p4[4] = {v.x, v.y, v.z, v.w};
+							for (uint32_t j = 0; j < cnt; j += 2u) {  // two taps (two source rows) per v_dot2_i32_i16, as above
+								const uint32_t w2 = kk[j >> 1];
+								const uint4 v0 = *reinterpret_cast<const uint4 *>(cur + (first + j) * fw + 4u * q);
+								const uint4 v1 = *reinterpret_cast<const uint4 *>(cur + (first + j + 1u) * fw + 4u * q);
+								const uint32_t a4[4] = {v0.x, v0.y, v0.z, v0.w}, b4[4] = {v1.x, v1.y, v1.z, v1.w};
 #pragma unroll
-								for (int r = 0; r < 4; ++r) {
-									acc[r][0] += (int32_t)(p4[r] & 255u) * w;
-									acc[r][1] += (int32_t)((p4[r] >> 8) & 255u) * w;
-									acc[r][2] += (int32_t)((p4[r] >> 16) & 255u) * w;
-									acc[r][3] += (int32_t)(p4[r] >> 24) * w;
-								}
+								for (int r = 0; r < 4; ++r)
+#pragma unroll
+									for (uint32_t c = 0; c < 4; ++c)
+										acc[r][c] = dot2(__builtin_amdgcn_perm(b4[r], a4[r], c | 0x0c000c00u | ((4u + c) << 16)), w2, acc[r][c]);
 							}
 							uint32_t o4[4];
 #pragma unroll
 							for (int r = 0; r < 4; ++r)
-								o4[r] = unpremultiply(clip8(acc[r][0], prec) | (clip8(acc[r][1], prec) << 8) | (clip8(acc[r][2], prec) << 16) |
-								                      (clip8(acc[r][3], prec) << 24));
+								o4[r] = clip8(acc[r][0], prec) | (clip8(acc[r][1], prec) << 8) | (clip8(acc[r][2], prec) << 16) |
+								        (clip8(acc[r][3], prec) << 24);
+							// un-premultiplying is the identity at alpha 255: skipped (table look-up and three divisions-by-
+							// multiplication per pixel) when no lane of the wave holds anything else
+							const uint32_t alpha_and = (o4[0] & o4[1] & o4[2] & o4[3]) >> 24;
+							if (__builtin_amdgcn_ballot_w64(alpha_and != 255u) != 0ull) {
+#pragma unroll
+								for (int r = 0; r < 4; ++r) o4[r] = unpremultiply(o4[r]);
+							}
 							put4(q, oy, make_uint4(o4[0], o4[1], o4[2], o4[3]));
 						}
 					}
