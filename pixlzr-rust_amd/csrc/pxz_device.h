@@ -186,6 +186,8 @@ __device__ __forceinline__ uint32_t premultiply(uint32_t px)
 __device__ __forceinline__ uint32_t unpremultiply(uint32_t px)
 {
 	uint32_t al = px >> 24;
+	// the identity at alpha 255 (recip = 256): no table look-up when every lane that is here holds an opaque pixel
+	if (__builtin_amdgcn_ballot_w64(al != 255u) == 0ull) return px;
 	uint32_t rc = kRecipAlpha.v[al];
 	uint32_t r = ((px & 255u) * rc + 128u) >> 8;
 	uint32_t g = (((px >> 8) & 255u) * rc + 128u) >> 8;
