@@ -536,6 +536,7 @@ int prepare(pxz_handle *h, const pxz_frames *f, const pxz_params *p, bool want_p
 	a->scale2 = 10.0f;  // BASE_FACTOR, pixlzr.rs:15
 	a->alpha_kernel = (p->reserved & PXZ_HINT_TRANSPARENCY) != 0 && !getenv("PXZ_NO_ALPHA_KERNEL");
 	a->list_a_too = 0;
+	a->finish_scan = 1;
 	a->stats = nullptr;
 	a->slot_bytes = bw * bh * f->channels;
 	build_breaks(h, a);

@@ -81,6 +81,8 @@ struct ShrinkArgs {
 	uint32_t full_cols, full_rows;  // 32x32 fast path: tile (tx, ty) is eligible iff tx < full_cols && ty < full_rows
 	                                //   (full size, 16-byte aligned rows; 0/0 when the batch is not aligned)
 	uint32_t alpha_kernel;   // frames with transparency announced (pxz_params.reserved bit 0) or seen by the last launch
+	uint32_t finish_scan;    // worklist kernel: 1 = finish every tile the fast kernel completed (scan of all sums); 0 = the fast
+	                         //   kernel did that itself, only the tiles of list A are left (when shrink32a_kernel took them)
 	uint32_t list_a_too;     // worklist kernel: list A (full tiles with transparency) was not taken by shrink32a_kernel
 	void *mid_event;         // host side only: hipEvent_t to record behind the first kernel of the step, or null
 	uint32_t *stats;         // pinned host dword (device address) <- number of list-A tiles of this launch; may be null
@@ -135,6 +137,9 @@ struct Fast32Args {
 	const uint32_t *trows;
 	uint32_t tab_dw, tile_dw;
 	uint32_t chunk_lg;       // tickets deal runs of 2^chunk_lg adjacent tiles
+	uint32_t finish_here;    // shrink32_kernel: every block finishes the tiles it completed (value / lod outputs) at its end
+	float factor;            //   with these, as the worklist kernel's scan over all tiles would
+	float *value, *lod0, *lod1;
 	uint32_t breaks[kMaxLevel];
 	uint32_t breaks_asc;
 	AxisTab tabs[kMaxLevel];

@@ -307,6 +307,21 @@ __global__ void __launch_bounds__(1024) shrink32_kernel(const Fast32Args a)
 	flush();  // the last tile's pixels
 	list_flush(s_batch, n_listb, a.work + kWorkList, a.work + a.work_slot, tid);
 	list_flush(s_batch + kListBatch, n_lista, a.work + kWorkList + a.n_tiles, a.work + kWorkA + a.work_slot, tid);
+	if (a.finish_here) {
+		// Detector sums -> stored value (f64 normalisation, hypot: finish_tile), one tile per thread, for the tiles this
+		// block dealt to its waves -- instead of a scan over every tile of the batch in the worklist kernel.  Tiles handed
+		// to a list carry the marker and are finished by whoever completes them.
+		__threadfence_block();  // the sums were written by other waves of this block
+		__syncthreads();
+		for (uint32_t i = threadIdx.x;; i += blockDim.x) {
+			const unsigned long long run = (unsigned long long)(i >> a.chunk_lg) * gridDim.x + blockIdx.x;
+			const unsigned long long g = (run << a.chunk_lg) + (i & ((1u << a.chunk_lg) - 1u));
+			if (g >= (unsigned long long)a.n_tiles) break;  // (g grows with i)
+			const uint2 key = reinterpret_cast<const uint2 *>(a.sums)[g];
+			if (key.x == kDeferredKey && key.y == kDeferredKey) continue;
+			finish_tile(key, 32u, 32u, (uint32_t)MODE, a.factor, a.value, a.lod0, a.lod1, (uint32_t)g);
+		}
+	}
 #ifdef PXZ_STAMPS
 	if (tid == 0) {
 		unsigned long long *out = reinterpret_cast<unsigned long long *>(a.work + ((2u * a.n_tiles + kWorkList + 1u + 1u) & ~1u));
@@ -806,6 +821,12 @@ hipError_t launch_fast32_16(const ShrinkArgs &a, ShrinkArgs &ga, uint32_t n_cus,
 	f.out_px = a.out_px;
 	f.work = a.work;
 	f.work_slot = a.work_slot;
+	f.finish_here = groups16 ? 0u : 1u;
+	f.factor = a.factor;
+	f.value = a.value;
+	f.lod0 = a.lod0;
+	f.lod1 = a.lod1;
+	ga.finish_scan = groups16 ? 1u : 0u;
 	// full tiles with transparency always go to list A; shrink32a_kernel takes it when transparency was announced
 	// or seen before, else the worklist kernel walks it after list B
 	f.alpha_list = (!groups16 && a.out_px != nullptr && (a.filter == 0 || a.tab_dw != 0)) ? 1u : 0u;

@@ -533,13 +533,23 @@ __global__ void __launch_bounds__(NW == 1 ? 768 : 64 * NW) shrink_kernel(const S
 			// worklist mode = second and last launch of the 32x32 flow: finish, lane-parallel, the tiles
 			// shrink32_kernel completed (it left kDeferredKey in the others, which process_tile finishes
 			// itself), and zero the worklist counter of the NEXT launch
-			for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < a.n_tiles; t += gridDim.x * blockDim.x) {
-				const uint2 key = reinterpret_cast<const uint2 *>(a.sums)[t];
-				if (key.x == kDeferredKey && key.y == kDeferredKey) continue;
-				const uint32_t tf = t % a.tiles_per_frame;
-				const uint32_t ty = tf / a.cols, tx = tf - ty * a.cols;
-				finish_tile(key, (tx == a.cols - 1) ? a.edge_w : a.bw, (ty == a.rows - 1) ? a.edge_h : a.bh, (uint32_t)MODE, a.factor,
-				            a.value, a.lod0, a.lod1, t);
+			if (a.finish_scan) {
+				for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < a.n_tiles; t += gridDim.x * blockDim.x) {
+					const uint2 key = reinterpret_cast<const uint2 *>(a.sums)[t];
+					if (key.x == kDeferredKey && key.y == kDeferredKey) continue;
+					const uint32_t tf = t % a.tiles_per_frame;
+					const uint32_t ty = tf / a.cols, tx = tf - ty * a.cols;
+					finish_tile(key, (tx == a.cols - 1) ? a.edge_w : a.bw, (ty == a.rows - 1) ? a.edge_h : a.bh, (uint32_t)MODE, a.factor,
+					            a.value, a.lod0, a.lod1, t);
+				}
+			} else if (!a.list_a_too) {
+				// shrink32_kernel finished its own tiles; the ones shrink32a_kernel completed (list A: full tiles) are left
+				for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count_a; i += gridDim.x * blockDim.x) {
+					const uint32_t t = a.work[kWorkList + a.n_tiles + i];
+					const uint2 key = reinterpret_cast<const uint2 *>(a.sums)[t];
+					if (key.x == kDeferredKey && key.y == kDeferredKey) continue;  // (went on to list B: finished above)
+					finish_tile(key, a.bw, a.bh, (uint32_t)MODE, a.factor, a.value, a.lod0, a.lod1, t);
+				}
 			}
 			if (blockIdx.x == 0) {  // the other set of counters is the next launch's
 				if (threadIdx.x == 0) {
