@@ -125,10 +125,16 @@ __global__ void __launch_bounds__(1024) shrink32_kernel(const Fast32Args a)
 		if constexpr (MODE == 0) given_bits = a.sums[2 * tile_g];  // issued before the prefetch: its wait leaves the prefetch in flight
 		// ---- wait for the prefetched registers (the opacity test is their first use), then emit the
 		// previous tile's parked pixels, then stage: registers -> planar u16 pairs
-		uint32_t alpha_and = 0xffu;
-#pragma unroll
-		for (int k = 0; k < 4; ++k) alpha_and &= (pre[k].x & pre[k].y & pre[k].z & pre[k].w) >> 24;
-		const bool transparent = __builtin_amdgcn_ballot_w64(alpha_and != 0xffu) != 0ull;
+		// every alpha byte is 255 iff the smallest of the 16 pixel dwords is >= 0xff000000 (alpha is the top byte): eight
+		// three-way minima instead of sixteen ANDs and a shift
+		uint32_t least;
+		{
+			const uint32_t m0 = min(min(pre[0].x, pre[0].y), pre[0].z), m1 = min(min(pre[0].w, pre[1].x), pre[1].y);
+			const uint32_t m2 = min(min(pre[1].z, pre[1].w), pre[2].x), m3 = min(min(pre[2].y, pre[2].z), pre[2].w);
+			const uint32_t m4 = min(min(pre[3].x, pre[3].y), pre[3].z);
+			least = min(min(min(m0, m1), m2), min(min(m3, m4), pre[3].w));
+		}
+		const bool transparent = __builtin_amdgcn_ballot_w64(least < 0xff000000u) != 0ull;
 		__builtin_amdgcn_sched_barrier(0);
 		flush();
 		__builtin_amdgcn_sched_barrier(0);
@@ -632,10 +638,16 @@ __global__ void __launch_bounds__(1024) shrink16_kernel(const Fast32Args a)
 			for (uint32_t k = 0; k < 4; ++k) given[k] = a.sums[2 * tile_id(k)];
 		}
 		// ---- stage: registers -> planar u16 pairs (as shrink32_kernel)
-		uint32_t alpha_and = 0xffu;
-#pragma unroll
-		for (int k = 0; k < 4; ++k) alpha_and &= (pre[k].x & pre[k].y & pre[k].z & pre[k].w) >> 24;
-		const bool transparent = __builtin_amdgcn_ballot_w64(alpha_and != 0xffu) != 0ull;
+		// every alpha byte is 255 iff the smallest of the 16 pixel dwords is >= 0xff000000 (alpha is the top byte): eight
+		// three-way minima instead of sixteen ANDs and a shift
+		uint32_t least;
+		{
+			const uint32_t m0 = min(min(pre[0].x, pre[0].y), pre[0].z), m1 = min(min(pre[0].w, pre[1].x), pre[1].y);
+			const uint32_t m2 = min(min(pre[1].z, pre[1].w), pre[2].x), m3 = min(min(pre[2].y, pre[2].z), pre[2].w);
+			const uint32_t m4 = min(min(pre[3].x, pre[3].y), pre[3].z);
+			least = min(min(min(m0, m1), m2), min(min(m3, m4), pre[3].w));
+		}
+		const bool transparent = __builtin_amdgcn_ballot_w64(least < 0xff000000u) != 0ull;
 #pragma unroll
 		for (int k = 0; k < 4; ++k) {
 			const uint32_t row = (tid >> 3) + 8u * (uint32_t)k, col = tid & 7u;

@@ -126,9 +126,14 @@ __global__ void __launch_bounds__(256) shrink64_kernel(const Fast64Args a)
 			continue;
 		}
 		// ---- stage: registers -> planar u16 pairs
-		uint32_t alpha_and = 0xffu;
-#pragma unroll
-		for (int k = 0; k < 4; ++k) alpha_and &= (pre[k].x & pre[k].y & pre[k].z & pre[k].w) >> 24;
+		// (every alpha byte is 255 iff the smallest of the 16 pixel dwords is >= 0xff000000: three-way minima)
+		uint32_t least;
+		{
+			const uint32_t m0 = min(min(pre[0].x, pre[0].y), pre[0].z), m1 = min(min(pre[0].w, pre[1].x), pre[1].y);
+			const uint32_t m2 = min(min(pre[1].z, pre[1].w), pre[2].x), m3 = min(min(pre[2].y, pre[2].z), pre[2].w);
+			const uint32_t m4 = min(min(pre[3].x, pre[3].y), pre[3].z);
+			least = min(min(min(m0, m1), m2), min(min(m3, m4), pre[3].w));
+		}
 #pragma unroll
 		for (int k = 0; k < 4; ++k) {
 			const uint32_t row = 16u * wave + (lane >> 4) + 4u * (uint32_t)k, col = lane & 15u;
@@ -143,7 +148,7 @@ __global__ void __launch_bounds__(256) shrink64_kernel(const Fast64Args a)
 				*reinterpret_cast<uint2 *>(d + c * kPD64) = pr;
 			}
 		}
-		const bool wave_transparent = __builtin_amdgcn_ballot_w64(alpha_and != 0xffu) != 0ull;
+		const bool wave_transparent = __builtin_amdgcn_ballot_w64(least < 0xff000000u) != 0ull;
 		if (lane == 0) s_red[8 + wave] = wave_transparent ? 1u : 0u;
 		prefetch(tile_next);  // lands while this tile is processed
 		__syncthreads();      // B1: the whole tile is staged
