@@ -626,9 +626,9 @@ int timed_launch(pxz_handle *h, pxz::ShrinkArgs &a, uint32_t channels, float *va
 	if (a.mode == PXZ_MODE_SHRINK_BY && channels == 4 && (square_fast || general_oklab) &&
 	    a.full_cols != 0 && a.full_rows != 0 && !getenv("PXZ_NO_OKLAB32")) {
 		// The ragged edge of the grid -- right column (edge_w x bh), bottom row (bw x edge_h), corner tile -- goes
-		// through the same detector with run-time geometry, one launch per region, where the region's tile rows are
-		// whole pixel quads (16-byte aligned like the full tiles).  What is left runs its chains in the generic kernel
-		// (four lanes per tile: ~0.1-0.5 ms of latency per launch whatever the batch).
+		// through the same detector with run-time geometry, one launch per region (tile rows that are not whole
+		// pixel quads are walked padded).  Without it the edge runs its chains in the generic kernel: four lanes per tile,
+		// ~0.1-0.5 ms of latency per launch whatever the batch.
 		const uint32_t n_frames = a.n_tiles / a.tiles_per_frame;
 		struct Region { uint32_t id, w, hh, per_frame, bit; bool wanted; } regions[3] = {
 		    {1u, a.edge_w, a.bh, a.full_rows, 1u, a.full_cols < a.cols},
@@ -636,9 +636,9 @@ int timed_launch(pxz_handle *h, pxz::ShrinkArgs &a, uint32_t channels, float *va
 		    {3u, a.edge_w, a.edge_h, 1u, 4u, a.full_cols < a.cols && a.full_rows < a.rows}};
 		size_t scratch = a.ok_bands > 4u ? (size_t)a.n_tiles * a.ok_bands * 3328u : 0u;
 		for (Region &r : regions) {
-			r.wanted = r.wanted && r.per_frame != 0u && r.w % 4u == 0u && r.w * r.hh >= 16u && r.w * r.hh <= 16384u &&
-			           !getenv("PXZ_NO_OKLAB_EDGES");
-			const uint32_t bands = (r.w * r.hh + 255u) / 256u;
+			const uint32_t wp = (r.w + 3u) & ~3u;  // rows are walked in whole quads (the padding counts as zeros)
+			r.wanted = r.wanted && r.per_frame != 0u && a.bw % 4u == 0u && wp * r.hh <= 16384u && !getenv("PXZ_NO_OKLAB_EDGES");
+			const uint32_t bands = (wp * r.hh + 255u) / 256u;
 			if (r.wanted && bands > 4u) scratch = std::max(scratch, (size_t)n_frames * r.per_frame * bands * 3328u);
 		}
 		if (scratch != 0) {
@@ -657,7 +657,7 @@ int timed_launch(pxz_handle *h, pxz::ShrinkArgs &a, uint32_t channels, float *va
 			if (!r.wanted) continue;
 			pxz::ShrinkArgs e = a;
 			e.ok_region = r.id;
-			e.ok_bands = (r.w * r.hh + 255u) / 256u;
+			e.ok_bands = (((r.w + 3u) & ~3u) * r.hh + 255u) / 256u;
 			e.ok_count = n_frames * r.per_frame;
 			PXZ_HIP(h, pxz::launch_oklab(e, h->n_cus, h->stream));
 			a.ok_edges |= r.bit;

@@ -207,7 +207,10 @@ __global__ void __launch_bounds__(1024) oklab_kernel(const ShrinkArgs a)
 	const uint32_t NB = (kGeneral && NBR == 0) ? a.ok_bands : NBC;
 	// (T = 0: the tiles of this launch are a.bw x a.bh, or an edge region's smaller ones)
 	const uint32_t tile_w = kGeneral ? ((a.ok_region & 1u) ? a.edge_w : a.bw) : (uint32_t)T;
-	const uint32_t tile_px = kGeneral ? tile_w * ((a.ok_region & 2u) ? a.edge_h : a.bh) : (uint32_t)(T * T);
+	// (a width that is not a multiple of 4 -- the ragged right column of any image -- is walked with rows padded to whole
+	// quads: the padding pixels are exact zeros in both passes, which leave the f32 sums of the real ones as they are)
+	const uint32_t tile_wp = kGeneral ? (tile_w + 3u) & ~3u : (uint32_t)T;
+	const uint32_t tile_px = kGeneral ? tile_wp * ((a.ok_region & 2u) ? a.edge_h : a.bh) : (uint32_t)(T * T);
 	extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
 	float *s_srgb = reinterpret_cast<float *>(lds);          // 256: sRGB u8 -> linear
 	float *s_alpha = s_srgb + 256;                           // 256: a / 255
@@ -228,19 +231,35 @@ __global__ void __launch_bounds__(1024) oklab_kernel(const ShrinkArgs a)
 		// ---------------- producers ----------------
 		const uint32_t row_off = lane / G::kLanesPerRow, col_off = (lane % G::kLanesPerRow) * 16u;
 		const size_t band_step = (size_t)G::kRowsPerBand * a.pitch;
-		// this lane's 4 pixels of a band: do they exist (T = 0: the last band may be short), and where in the tile
-		auto lane_has = [&](uint32_t band) -> bool { return !kGeneral || 256u * band + 4u * lane < tile_px; };
+		// this lane's 4 pixels of a band: how many exist (T = 0: short last band, padded rows), and where in the tile
+		// real pixels among the lane's four of a band (4, or fewer in the last quad of a padded row; 0: none)
+		auto lane_px = [&](uint32_t band) -> uint32_t {
+			if constexpr (!kGeneral) return 4u;
+			const uint32_t first = 256u * band + 4u * lane;
+			if (first >= tile_px) return 0u;
+			const uint32_t col = first - small_div(first, tile_wp) * tile_wp;  // (first < 2^20)
+			return tile_w - col < 4u ? tile_w - col : 4u;
+		};
 		auto lane_off = [&](uint32_t band) -> size_t {
 			if constexpr (kGeneral) {
-				const uint32_t first = 256u * band + 4u * lane, row = small_div(first, tile_w);  // (first < 2^20)
-				return (size_t)row * a.pitch + (size_t)(first - row * tile_w) * 4u;
+				const uint32_t first = 256u * band + 4u * lane, row = small_div(first, tile_wp);
+				return (size_t)row * a.pitch + (size_t)(first - row * tile_wp) * 4u;
 			} else {
 				return (size_t)row_off * a.pitch + col_off + (size_t)band * band_step;
 			}
 		};
 		auto load_band = [&](const uint8_t *tile, uint32_t band) -> uint4 {
-			if (!lane_has(band)) return make_uint4(0, 0, 0, 0);  // black, alpha 0: converts to exact zeros
-			return *reinterpret_cast<const uint4 *>(tile + lane_off(band));
+			const uint32_t have = lane_px(band);
+			uint4 v = make_uint4(0, 0, 0, 0);  // black, alpha 0: converts to exact zeros
+			if (have == 4u) {
+				v = *reinterpret_cast<const uint4 *>(tile + lane_off(band));
+			} else if (have != 0u) {  // the last quad of a padded row: nothing is read past the row's real pixels
+				const uint32_t *p = reinterpret_cast<const uint32_t *>(tile + lane_off(band));
+				v.x = p[0];
+				if (have > 1u) v.y = p[1];
+				if (have > 2u) v.z = p[2];
+			}
+			return v;
 		};
 		// source pointers (first byte) of this wave's tiles in batches p, p+1, p+2; null: nothing there
 		auto batch_src = [&](uint32_t j, uint32_t &bands) -> const uint8_t * {
@@ -339,17 +358,17 @@ __global__ void __launch_bounds__(1024) oklab_kernel(const ShrinkArgs a)
 						al4 = __float_as_uint(old[3].x);
 					}
 					float *d = s_p2 + slot;
-					// (a lane beyond a short last band has no pixels: exact zeros leave the chain's sums as they are)
-					const float keep = lane_has(k) ? 1.0f : 0.0f;
+					// (pixels that do not exist -- beyond a short last band, or the padding of a row -- are exact zeros here too)
+					const uint32_t have = lane_px(k);
 #pragma unroll
 					for (int c = 0; c < 3; ++c) {
 						float4 v = make_float4(x[0][c] - mean4[c], x[1][c] - mean4[c], x[2][c] - mean4[c], x[3][c] - mean4[c]);
-						if constexpr (kGeneral) v = keep != 0.0f ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+						if constexpr (kGeneral) v = make_float4(have > 0u ? v.x : 0.f, have > 1u ? v.y : 0.f, have > 2u ? v.z : 0.f, have > 3u ? v.w : 0.f);
 						*reinterpret_cast<float4 *>(d + c * kOkPlane) = v;
 					}
 					float4 va = make_float4(s_alpha[al4 & 255u] - mean4[3], s_alpha[(al4 >> 8) & 255u] - mean4[3],
 					                        s_alpha[(al4 >> 16) & 255u] - mean4[3], s_alpha[al4 >> 24] - mean4[3]);
-					if constexpr (kGeneral) va = keep != 0.0f ? va : make_float4(0.f, 0.f, 0.f, 0.f);
+					if constexpr (kGeneral) va = make_float4(have > 0u ? va.x : 0.f, have > 1u ? va.y : 0.f, have > 2u ? va.z : 0.f, have > 3u ? va.w : 0.f);
 					*reinterpret_cast<float4 *>(d + 3 * kOkPlane) = va;
 				}
 				if (elig_cur && k < nb0) {
@@ -487,7 +506,7 @@ hipError_t launch_oklab(const ShrinkArgs &a, uint32_t n_cus, hipStream_t stream)
 		}
 	}
 	// any other tile with a width of whole pixel quads: run-time geometry
-	if (((a.ok_region & 1u) ? a.edge_w : a.bw) % 4u != 0u || a.ok_bands == 0u || a.ok_count == 0u) return hipErrorInvalidValue;
+	if (a.bw % 4u != 0u || a.ok_bands == 0u || a.ok_count == 0u) return hipErrorInvalidValue;  // (tile origins are 16-byte aligned)
 	switch (a.ok_bands) {
 	case 1: return go(oklab_kernel<0, 1>);
 	case 2: return go(oklab_kernel<0, 2>);

@@ -654,16 +654,18 @@ def test_oklab_detector_with_run_time_geometry(gpu, oracle, bw, bh):
     """shrink_by on tiles that are not 16/32/64 squares: oklab_kernel<0, NBR> (tile width a multiple of 4, rows
     16-byte aligned) takes the full tiles -- 1..4 bands in registers or any number parked, a short last band padded
     with exact zeros -- and the generic kernel the ragged edge.  Two frames in one batch, values bit for bit."""
-    w, h = 5 * bw + 8, 3 * bh + (bh // 2 or 1)   # ragged right column and bottom row; w is a multiple of 4
-    frames = gpu.synth_frames_device(2, h, w, 4, first_frame=21, dist=1)
-    f = frames.cpu().numpy()
-    for filt, factor in ((4, 1.0), (2, 0.25)):
+    # ragged right column and bottom row; edge widths of whole quads (8) and not (6, 1, 3: rows walked padded, and the
+    # batch's rows are no 16-byte multiples, so it is re-pitched first)
+    for extra, (filt, factor) in zip((8, 6, 1, 3), ((4, 1.0), (2, 0.25), (4, 0.5), (1, 2.0))):
+        w, h = 5 * bw + extra, 3 * bh + (bh // 2 or 1)
+        frames = gpu.synth_frames_device(2, h, w, 4, first_frame=21 + extra, dist=1)
+        f = frames.cpu().numpy()
         vals, ow, oh, slots = gpu.shrink_frames_device(frames, bw, bh, 0, filt, factor)
         for n in range(2):
             exp = oracle.shrink_image(f[n], bw, bh, 0, filt, factor, nthreads=8)
             got = (vals[n].cpu().numpy(), ow[n].cpu().numpy().astype(np.uint32), oh[n].cpu().numpy().astype(np.uint32),
                    slots[n].cpu().numpy())
-            assert_same_tiles(got, exp, 4, f"{bw}x{bh} f{filt} k={factor} frame {n}")
+            assert_same_tiles(got, exp, 4, f"{bw}x{bh} +{extra} f{filt} k={factor} frame {n}")
 
 
 @pytest.mark.parametrize("bw,bh", [(24, 24), (48, 32), (8, 8), (80, 80)])

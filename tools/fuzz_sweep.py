@@ -28,7 +28,8 @@ rng = np.random.default_rng(seed)
 cases = 0
 for _ in range(int(os.environ.get("NB", "60"))):
     bw = int(rng.choice([8, 12, 16, 20, 24, 32, 48, 64, 96])); bh = bw if rng.random() < 0.6 else int(rng.choice([8, 16, 24, 32, 48, 64]))
-    w = (int(rng.integers(bw, 5 * bw + 64)) & ~3) or 4; h = int(rng.integers(bh, 4 * bh + 50))
+    w = int(rng.integers(bw, 5 * bw + 64)); h = int(rng.integers(bh, 4 * bh + 50))
+    if rng.random() < 0.5: w = (w & ~3) or 4  # half of the batches with 16-byte-multiple rows, half re-pitched
     c = int(rng.choice([3, 4])); mode = int(rng.integers(0, 2)); filt = int(rng.integers(0, 5))
     if mode == 0 and bw * bh > 7168: continue
     if mode == 1 and min(w % bw or bw, h % bh or bh) == 1: continue
