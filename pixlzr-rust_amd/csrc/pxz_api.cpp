@@ -569,7 +569,7 @@ int timed_launch(pxz_handle *h, pxz::ShrinkArgs &a, uint32_t channels, float *va
 	if (rc != PXZ_OK) return rc;
 	a.sums = (uint32_t *)h->sums.ptr;
 	const void *work_before = h->work.ptr;
-	if ((rc = ensure(h, h->work, (2u * (size_t)a.n_tiles + pxz::kWorkList + 4u) * 4u + 64u + 4096u * 8u)) != PXZ_OK) return rc;  // + diagnostic stamps
+	if ((rc = ensure(h, h->work, (2u * (size_t)a.n_tiles + pxz::kWorkList + 4u) * 4u + 64u + 4608u * 8u)) != PXZ_OK) return rc;  // + diagnostic stamps (8 phase sums + 256 blocks x 17 qwords)
 	if (h->work.ptr != work_before) h->work_ready = false;
 	a.work = (uint32_t *)h->work.ptr;
 	a.value = value;

@@ -310,6 +310,10 @@ __global__ void __launch_bounds__(1024) shrink32_kernel(const Fast32Args a)
 		one_tile(tile_g, tile_next);
 		tile_g = tile_next;
 	}
+#ifdef PXZ_STAMPS
+	unsigned long long st_loop_end;
+	asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_loop_end)::"memory");
+#endif
 	flush();  // the last tile's pixels
 	list_flush(s_batch, n_listb, a.work + kWorkList, a.work + a.work_slot, tid);
 	list_flush(s_batch + kListBatch, n_lista, a.work + kWorkList + a.n_tiles, a.work + kWorkA + a.work_slot, tid);
@@ -333,8 +337,8 @@ __global__ void __launch_bounds__(1024) shrink32_kernel(const Fast32Args a)
 		unsigned long long *out = reinterpret_cast<unsigned long long *>(a.work + ((2u * a.n_tiles + kWorkList + 1u + 1u) & ~1u));
 		for (int i = 0; i < 8; ++i) atomicAdd(out + i, st_acc[i]);
 		// per-wave run time (100 MHz ticks) | tiles processed << 48; last launch wins
-		out[8 + blockIdx.x * 16u + sub] = ((wall_clock64() - st_begin) & 0xffffffffffffull) | ((unsigned long long)st_tiles << 48);
-		if (sub == 0) out[8 + blockIdx.x * 16u + 15u] = st_begin;
+		out[8 + blockIdx.x * 17u + sub] = ((st_loop_end - st_begin) & 0xffffffffffffull) | ((unsigned long long)st_tiles << 48);  // when the wave ran out of tiles
+		if (sub == 0) out[8 + blockIdx.x * 17u + 16u] = st_begin;
 	}
 #endif
 }

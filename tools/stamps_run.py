@@ -35,13 +35,13 @@ print("total per tile (wave cycles):", tot / 5 / n_tiles)
 
 # per-wave run times of the last launch (100 MHz wall clock) and per-block start times (slot 15)
 import numpy as np
-buf = (C.c_uint64 * 4096)()
+buf = (C.c_uint64 * (256 * 17))()
 off = ((2 * n_tiles + 132 + 2) & ~1) * 4 + 64
-assert L.pxz_debug_read_work(h._h, buf, off, 4096 * 8) == 0
-raw = np.array(list(buf), dtype=np.uint64).reshape(256, 16)
-start = raw[:, 15].astype(np.float64) / 100
-dur = (raw[:, :15] & np.uint64(0xffffffffffff)).astype(np.float64) / 100
-cnt = (raw[:, :15] >> np.uint64(48)).astype(np.int64)
+assert L.pxz_debug_read_work(h._h, buf, off, 256 * 17 * 8) == 0
+raw = np.array(list(buf), dtype=np.uint64).reshape(256, 17)  # 16 waves per block + the block's start time
+start = raw[:, 16].astype(np.float64) / 100
+dur = (raw[:, :16] & np.uint64(0xffffffffffff)).astype(np.float64) / 100
+cnt = (raw[:, :16] >> np.uint64(48)).astype(np.int64)
 print("tiles per wave: min %d median %d max %d; per block sum min %d max %d" % (cnt.min(), np.median(cnt), cnt.max(), cnt.sum(axis=1).min(), cnt.sum(axis=1).max()))
 print("corr(run time, tiles) = %.3f" % np.corrcoef(dur.ravel(), cnt.ravel())[0, 1])
 print("block start spread (us): %.1f" % (start.max() - start.min()))
@@ -53,3 +53,5 @@ print("within-block finish spread (us): min %.1f median %.1f max %.1f" % (spread
 eb = end.max(axis=1)
 print("block finish (us): min %.1f median %.1f max %.1f" % (eb.min(), np.median(eb), eb.max()))
 print("mean block finish per XCD (block % 8):", ["%.1f" % eb[x::8].mean() for x in range(8)])
+print("block 0 waves: run time us", ["%.1f" % x for x in dur[0]], "tiles", cnt[0].tolist())
+print("block 100 waves: run time us", ["%.1f" % x for x in dur[100]], "tiles", cnt[100].tolist())
