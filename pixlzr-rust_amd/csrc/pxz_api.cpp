@@ -484,7 +484,7 @@ int check_frames(pxz_handle *h, const pxz_frames *f, const pxz_params *p)
 }
 
 // Fills the kernel arguments for a batch; returns the LDS bytes needed per block.
-int prepare(pxz_handle *h, const pxz_frames *f, const pxz_params *p, bool want_pixels, pxz::ShrinkArgs *a)
+int prepare(pxz_handle *h, const pxz_frames *f, const pxz_params *p, bool want_pixels, pxz::ShrinkArgs *a, bool no_lab = false)
 {
 	int rc = check_frames(h, f, p);
 	if (rc != PXZ_OK) return rc;
@@ -506,7 +506,9 @@ int prepare(pxz_handle *h, const pxz_frames *f, const pxz_params *p, bool want_p
 	a->plane_dw = a->rs * bh;
 	a->hps = skew(round2(ceil_div(bh, 2)));
 	a->tmp_dw = conv ? ceil_div(bw, 2) * a->hps : 0;
-	a->lab_dw = p->mode == PXZ_MODE_SHRINK_BY ? 3 * bw * bh : 0;
+	// (no_lab: every tile's Oklab value will come from oklab_kernel launches -- the generic kernel then needs no f32
+	// planes of its own, which is what limits shrink_by to ~7000-pixel tiles otherwise)
+	a->lab_dw = p->mode == PXZ_MODE_SHRINK_BY && !no_lab ? 3 * bw * bh : 0;
 	// planes | max(transposed planes, Oklab scratch) | slack for zero-weight over-reads past the last row
 	const uint32_t scratch = 4 * a->tmp_dw > a->lab_dw ? 4 * a->tmp_dw : a->lab_dw;
 	a->tile_dw = (4 * a->plane_dw + scratch + 4 * a->rs + 4 * a->hps + 3u) & ~3u;
@@ -662,6 +664,12 @@ int timed_launch(pxz_handle *h, pxz::ShrinkArgs &a, uint32_t channels, float *va
 			PXZ_HIP(h, pxz::launch_oklab(e, h->n_cus, h->stream));
 			a.ok_edges |= r.bit;
 		}
+	}
+	if (a.mode == PXZ_MODE_SHRINK_BY && a.lab_dw == 0) {
+		// the generic kernel was sized without its own detector planes: every tile must have its value by now
+		const bool right = a.full_cols < a.cols, bottom = a.full_rows < a.rows && a.ok_rows < a.rows, corner = a.full_cols < a.cols && a.full_rows < a.rows;
+		const bool covered = a.oklab_given && (!right || (a.ok_edges & 1u)) && (!bottom || (a.ok_edges & 2u)) && (!corner || (a.ok_edges & 4u));
+		if (!covered) return fail(h, PXZ_ERR_UNSUPPORTED, "internal: Oklab values missing for a layout sized without detector planes");
 	}
 	// 32x32 RGBA flow: shrink32_kernel, then the worklist kernel, which also finishes every tile and
 	// zeroes the worklist counter of the next launch (two counters, used alternately)
@@ -842,7 +850,14 @@ static int run_shrink(pxz_handle *h, const pxz_frames *frames, const pxz_params 
 {
 	PXZ_HIP(h, hipSetDevice(h->device));
 	pxz::ShrinkArgs a{};
-	int rc = prepare(h, frames, params, d_out_pixels != nullptr, &a);
+	// RGBA, shrink_by, a tile shape the block-cooperative detector takes and at least one full tile each way: interior
+	// and edge launches of oklab_kernel cover every tile (rows are re-pitched below if they are not aligned)
+	const uint32_t pbw = params ? params->block_w : 0, pbh = params ? params->block_h : 0;
+	const bool oklab_covers_all = frames && params && frames->channels == 4 && params->mode == PXZ_MODE_SHRINK_BY && pbw != 0 && pbh != 0 &&
+	                              pbw % 4u == 0 && (uint64_t)pbw * pbh >= 64u && (uint64_t)pbw * pbh <= 16384u &&
+	                              frames->width >= pbw && frames->height >= pbh && !getenv("PXZ_NO_OKLAB32") &&
+	                              !getenv("PXZ_NO_OKLAB_GENERAL") && !getenv("PXZ_NO_OKLAB_EDGES") && !getenv("PXZ_NO_REPITCH");
+	int rc = prepare(h, frames, params, d_out_pixels != nullptr, &a, oklab_covers_all);
 	if (rc != PXZ_OK) return rc;
 	// (also shrink_by on the tile sizes the run-time-geometry Oklab detector takes: it only exists for RGBA)
 	const bool square_fast = a.bw == a.bh && (a.bw == 16 || a.bw == 32 || a.bw == 64);
@@ -892,7 +907,7 @@ static int run_shrink(pxz_handle *h, const pxz_frames *frames, const pxz_params 
 				PXZ_HIP(h, hipMemcpy2DAsync((uint8_t *)h->rgba.ptr + (size_t)n * fa.frame_stride_bytes, fa.pitch_bytes,
 				                            d_pixels + (size_t)n * fstride, frames->pitch_bytes, (size_t)frames->width * 4u,
 				                            frames->height, hipMemcpyDeviceToDevice, h->stream));
-			if ((rc = prepare(h, &fa, params, d_out_pixels != nullptr, &a)) != PXZ_OK) return rc;
+			if ((rc = prepare(h, &fa, params, d_out_pixels != nullptr, &a, oklab_covers_all)) != PXZ_OK) return rc;
 			src = (const uint8_t *)h->rgba.ptr;
 		}
 	}

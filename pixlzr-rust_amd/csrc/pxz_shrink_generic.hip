@@ -186,6 +186,11 @@ __device__ __forceinline__ void process_tile(const ShrinkArgs &a, const uint32_t
 		const float value = __uint_as_float(a.sums[2u * tile_g]);
 		key0 = key1 = __float_as_uint(value);
 		m0 = m1 = level_count(__float_as_uint(parse_value(value)), a.breaks[cls], a.breaks_asc[cls]);
+	} else if (a.lab_dw == 0) {
+		// (never reached: the host sizes the LDS image without detector planes only when oklab_kernel covers every tile,
+		// and refuses the launch otherwise -- but no tile may write planes that are not there)
+		key0 = key1 = 0u;
+		m0 = m1 = (uint32_t)kMaxLevel;
 	} else {
 		// get_block_variance, operations.rs:26-126 with shrink_by's closures
 		// (pixlzr.rs:160-162).  Colours are computed once, in parallel, into LDS

@@ -649,11 +649,12 @@ def test_oklab_conversion_of_every_colour(gpu, oracle):
 
 
 @pytest.mark.parametrize("bw,bh", [(8, 8), (12, 8), (24, 24), (40, 12), (48, 48), (32, 16), (16, 32), (64, 32), (96, 64),
-                                   (80, 80), (4, 16), (20, 36), (128, 48), (36, 28)])
+                                   (80, 80), (4, 16), (20, 36), (128, 48), (36, 28), (128, 64), (100, 100), (96, 112)])
 def test_oklab_detector_with_run_time_geometry(gpu, oracle, bw, bh):
     """shrink_by on tiles that are not 16/32/64 squares: oklab_kernel<0, NBR> (tile width a multiple of 4, rows
     16-byte aligned) takes the full tiles -- 1..4 bands in registers or any number parked, a short last band padded
-    with exact zeros -- and the generic kernel the ragged edge.  Two frames in one batch, values bit for bit."""
+    with exact zeros -- and, region by region, the ragged edge.  Tiles beyond ~7000 pixels only work because of it:
+    the generic kernel's LDS image is then sized without detector planes.  Two frames in one batch, bit for bit."""
     # ragged right column and bottom row; edge widths of whole quads (8) and not (6, 1, 3: rows walked padded, and the
     # batch's rows are no 16-byte multiples, so it is re-pitched first)
     for extra, (filt, factor) in zip((8, 6, 1, 3), ((4, 1.0), (2, 0.25), (4, 0.5), (1, 2.0))):
