@@ -853,11 +853,26 @@ static int run_shrink(pxz_handle *h, const pxz_frames *frames, const pxz_params 
 	// RGBA, shrink_by, a tile shape the block-cooperative detector takes and at least one full tile each way: interior
 	// and edge launches of oklab_kernel cover every tile (rows are re-pitched below if they are not aligned)
 	const uint32_t pbw = params ? params->block_w : 0, pbh = params ? params->block_h : 0;
-	const bool oklab_covers_all = frames && params && frames->channels == 4 && params->mode == PXZ_MODE_SHRINK_BY && pbw != 0 && pbh != 0 &&
-	                              pbw % 4u == 0 && (uint64_t)pbw * pbh >= 64u && (uint64_t)pbw * pbh <= 16384u &&
-	                              frames->width >= pbw && frames->height >= pbh && !getenv("PXZ_NO_OKLAB32") &&
-	                              !getenv("PXZ_NO_OKLAB_GENERAL") && !getenv("PXZ_NO_OKLAB_EDGES") && !getenv("PXZ_NO_REPITCH");
+	const bool covers_if_rgba = frames && params && params->mode == PXZ_MODE_SHRINK_BY && pbw != 0 && pbh != 0 &&
+	                            pbw % 4u == 0 && (uint64_t)pbw * pbh >= 64u && (uint64_t)pbw * pbh <= 16384u &&
+	                            frames->width >= pbw && frames->height >= pbh && !getenv("PXZ_NO_OKLAB32") &&
+	                            !getenv("PXZ_NO_OKLAB_GENERAL") && !getenv("PXZ_NO_OKLAB_EDGES") && !getenv("PXZ_NO_REPITCH");
+	const bool oklab_covers_all = covers_if_rgba && frames->channels == 4;
 	int rc = prepare(h, frames, params, d_out_pixels != nullptr, &a, oklab_covers_all);
+	bool rgb_must_widen = false;
+	if (rc == PXZ_ERR_UNSUPPORTED && covers_if_rgba && frames->channels == 3 && !getenv("PXZ_NO_WIDEN")) {
+		// the RGB layout with its own detector planes does not fit LDS; the widened RGBA one without them might
+		pxz_frames fw = *frames;
+		fw.channels = 4;
+		fw.pitch_bytes = (frames->width * 4u + 15u) & ~15u;
+		fw.frame_stride_bytes = (uint64_t)fw.pitch_bytes * frames->height;
+		if (prepare(h, &fw, params, d_out_pixels != nullptr, &a, true) == PXZ_OK) {
+			rc = PXZ_OK;
+			rgb_must_widen = true;
+		} else {
+			(void)prepare(h, frames, params, d_out_pixels != nullptr, &a, false);  // (restore the first error text)
+		}
+	}
 	if (rc != PXZ_OK) return rc;
 	// (also shrink_by on the tile sizes the run-time-geometry Oklab detector takes: it only exists for RGBA)
 	const bool square_fast = a.bw == a.bh && (a.bw == 16 || a.bw == 32 || a.bw == 64);
@@ -868,6 +883,8 @@ static int run_shrink(pxz_handle *h, const pxz_frames *frames, const pxz_params 
 		if ((rc = get_tables(h, a.bw, a.bh, a.edge_w, a.edge_h, params->filter, &tsp)) != PXZ_OK) return rc;
 		widen = tsp->opaque_stays;
 	}
+	if (rgb_must_widen && !widen)
+		return fail(h, PXZ_ERR_UNSUPPORTED, "a %ux%u RGB tile needs more LDS than there is (and this filter cannot run it as RGBA)", a.bw, a.bh);
 	pxz_frames f4 = *frames;
 	const uint8_t *src = d_pixels;
 	uint8_t *out_px = d_out_pixels;
@@ -876,7 +893,7 @@ static int run_shrink(pxz_handle *h, const pxz_frames *frames, const pxz_params 
 		f4.pitch_bytes = (frames->width * 4u + 15u) & ~15u;
 		f4.frame_stride_bytes = (uint64_t)f4.pitch_bytes * frames->height;
 		pxz::ShrinkArgs probe{};
-		if (prepare(h, &f4, params, d_out_pixels != nullptr, &probe) != PXZ_OK) widen = false;  // e.g. four planes of a large tile exceed LDS
+		if (prepare(h, &f4, params, d_out_pixels != nullptr, &probe, covers_if_rgba) != PXZ_OK) widen = false;  // e.g. four planes of a large tile exceed LDS
 	}
 	if (widen) {
 		if ((rc = ensure(h, h->rgba, (size_t)f4.frame_stride_bytes * frames->n_frames)) != PXZ_OK) return rc;
@@ -885,7 +902,7 @@ static int run_shrink(pxz_handle *h, const pxz_frames *frames, const pxz_params 
 		                       f4.frame_stride_bytes, frames->pitch_bytes, f4.pitch_bytes, frames->width, frames->height,
 		                       frames->n_frames};
 		PXZ_HIP(h, pxz::launch_widen(w, h->stream));
-		if ((rc = prepare(h, &f4, params, d_out_pixels != nullptr, &a)) != PXZ_OK) return rc;
+		if ((rc = prepare(h, &f4, params, d_out_pixels != nullptr, &a, covers_if_rgba)) != PXZ_OK) return rc;
 		src = (const uint8_t *)h->rgba.ptr;
 		if (d_out_pixels) {
 			if ((rc = ensure(h, h->slots4, (size_t)a.n_tiles * a.bw * a.bh * 4u)) != PXZ_OK) return rc;

@@ -669,7 +669,7 @@ def test_oklab_detector_with_run_time_geometry(gpu, oracle, bw, bh):
             assert_same_tiles(got, exp, 4, f"{bw}x{bh} +{extra} f{filt} k={factor} frame {n}")
 
 
-@pytest.mark.parametrize("bw,bh", [(24, 24), (48, 32), (8, 8), (80, 80)])
+@pytest.mark.parametrize("bw,bh", [(24, 24), (48, 32), (8, 8), (80, 80), (100, 100), (128, 64)])
 def test_rgb_frames_ride_the_run_time_geometry_detector(gpu, oracle, bw, bh):
     """RGB batches, shrink_by, tile sizes off the square fast paths: widened to RGBA for the run-time-geometry Oklab
     detector and the generic RGBA kernel, slots narrowed back -- the same bits as the oracle's RGB path."""

@@ -32,7 +32,7 @@ for _ in range(int(os.environ.get("NB", "60"))):
     w = int(rng.integers(bw, 5 * bw + 64)); h = int(rng.integers(bh, 4 * bh + 50))
     if rng.random() < 0.5: w = (w & ~3) or 4  # half of the batches with 16-byte-multiple rows, half re-pitched
     c = int(rng.choice([3, 4])); mode = int(rng.integers(0, 2)); filt = int(rng.integers(0, 5))
-    if mode == 0 and bw * bh > 7168 and (c == 3 or bw % 4): continue  # RGBA tiles of whole quads go through oklab_kernel
+    if mode == 0 and bw * bh > 7168 and bw % 4: continue  # tiles of whole quads go through oklab_kernel (RGB widened)
     if mode == 1 and min(w % bw or bw, h % bh or bh) == 1: continue
     dist = int(rng.choice([0, 1])) if c == 4 else 0
     factor = float(rng.choice([0.5, 4.0, 16.0, 64.0])) if mode == 1 else float(rng.choice([0.1, 0.5, 1.0, 3.0]))
