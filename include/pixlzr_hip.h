@@ -273,6 +273,11 @@ int pxz_last_kernel_ms(pxz_handle *h, float *ms);
  * steps): the figure a per-kernel profile shows for it.  Call before pxz_last_kernel_ms, which resets the record. */
 int pxz_last_first_kernel_ms(pxz_handle *h, float *ms);
 
+/* Diagnostics: copies `bytes` bytes at byte `offset` of the handle's worklist buffer to `dst` after waiting for the
+ * handle's stream (the in-kernel phase stamps of the -DPXZ_STAMPS build land there; tools/stamps_run.py).  Not part of
+ * the path; PXZ_ERR_INVALID_ARG when the range lies outside the buffer. */
+int pxz_debug_read_work(pxz_handle *h, void *dst, size_t offset, size_t bytes);
+
 #ifdef __cplusplus
 }
 #endif

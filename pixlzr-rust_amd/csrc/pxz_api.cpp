@@ -536,7 +536,7 @@ int prepare(pxz_handle *h, const pxz_frames *f, const pxz_params *p, bool want_p
 	a->filter = p->filter;
 	a->factor = p->factor;
 	a->scale2 = 10.0f;  // BASE_FACTOR, pixlzr.rs:15
-	a->alpha_kernel = (p->reserved & PXZ_HINT_TRANSPARENCY) != 0 && !getenv("PXZ_NO_ALPHA_KERNEL");
+	a->alpha_kernel = (p->reserved & PXZ_HINT_TRANSPARENCY) != 0 && !pxz::knobs().no_alpha_kernel;
 	a->list_a_too = 0;
 	a->finish_scan = 1;
 	a->stats = nullptr;
@@ -581,7 +581,7 @@ int timed_launch(pxz_handle *h, pxz::ShrinkArgs &a, uint32_t channels, float *va
 	// (one dword in pinned memory, written by the worklist kernel).  Past ~2000 tiles shrink32a_kernel pays for
 	// its launch.  Either way the results are the same; only the kernel that produces them differs.
 	a.stats = h->dev_stats;
-	if (!a.alpha_kernel && h->host_stats && *const_cast<volatile uint32_t *>(h->host_stats) >= 2048u && !getenv("PXZ_NO_ALPHA_KERNEL"))
+	if (!a.alpha_kernel && h->host_stats && *const_cast<volatile uint32_t *>(h->host_stats) >= 2048u && !pxz::knobs().no_alpha_kernel)
 		a.alpha_kernel = 1;
 	// 32x32 fast path: which tiles are full-size, and whether every tile row of the batch is 16-byte aligned
 	a.full_cols = a.full_rows = a.ok_rows = 0;
@@ -591,7 +591,7 @@ int timed_launch(pxz_handle *h, pxz::ShrinkArgs &a, uint32_t channels, float *va
 	// any other tile whose rows are whole pixel quads: the Oklab detector with run-time geometry takes the full tiles
 	// (64 .. 16384 pixels); the generic kernel then only stages and resamples them
 	const bool general_oklab = !square_fast && a.mode == PXZ_MODE_SHRINK_BY && a.bw % 4u == 0 && a.bw * a.bh >= 64u &&
-	                           a.bw * a.bh <= 16384u && !getenv("PXZ_NO_OKLAB_GENERAL");
+	                           a.bw * a.bh <= 16384u && !pxz::knobs().no_oklab_general;
 	a.ok_bands = (a.bw * a.bh + 255u) / 256u;
 	a.ok_region = 0;
 	a.ok_count = a.n_tiles;
@@ -626,7 +626,7 @@ int timed_launch(pxz_handle *h, pxz::ShrinkArgs &a, uint32_t channels, float *va
 	// fused kernel only stages + resamples (it still runs the generic detector on ragged-edge tiles)
 	a.oklab_given = 0;
 	if (a.mode == PXZ_MODE_SHRINK_BY && channels == 4 && (square_fast || general_oklab) &&
-	    a.full_cols != 0 && a.full_rows != 0 && !getenv("PXZ_NO_OKLAB32")) {
+	    a.full_cols != 0 && a.full_rows != 0 && !pxz::knobs().no_oklab32) {
 		// The ragged edge of the grid -- right column (edge_w x bh), bottom row (bw x edge_h), corner tile -- goes
 		// through the same detector with run-time geometry, one launch per region (tile rows that are not whole
 		// pixel quads are walked padded).  Without it the edge runs its chains in the generic kernel: four lanes per tile,
@@ -639,7 +639,7 @@ int timed_launch(pxz_handle *h, pxz::ShrinkArgs &a, uint32_t channels, float *va
 		size_t scratch = a.ok_bands > 4u ? (size_t)a.n_tiles * a.ok_bands * 3328u : 0u;
 		for (Region &r : regions) {
 			const uint32_t wp = (r.w + 3u) & ~3u;  // rows are walked in whole quads (the padding counts as zeros)
-			r.wanted = r.wanted && r.per_frame != 0u && a.bw % 4u == 0u && wp * r.hh <= 16384u && !getenv("PXZ_NO_OKLAB_EDGES");
+			r.wanted = r.wanted && r.per_frame != 0u && a.bw % 4u == 0u && wp * r.hh <= 16384u && !pxz::knobs().no_oklab_edges;
 			const uint32_t bands = (wp * r.hh + 255u) / 256u;
 			if (r.wanted && bands > 4u) scratch = std::max(scratch, (size_t)n_frames * r.per_frame * bands * 3328u);
 		}
@@ -855,12 +855,12 @@ static int run_shrink(pxz_handle *h, const pxz_frames *frames, const pxz_params 
 	const uint32_t pbw = params ? params->block_w : 0, pbh = params ? params->block_h : 0;
 	const bool covers_if_rgba = frames && params && params->mode == PXZ_MODE_SHRINK_BY && pbw != 0 && pbh != 0 &&
 	                            pbw % 4u == 0 && (uint64_t)pbw * pbh >= 64u && (uint64_t)pbw * pbh <= 16384u &&
-	                            frames->width >= pbw && frames->height >= pbh && !getenv("PXZ_NO_OKLAB32") &&
-	                            !getenv("PXZ_NO_OKLAB_GENERAL") && !getenv("PXZ_NO_OKLAB_EDGES") && !getenv("PXZ_NO_REPITCH");
+	                            frames->width >= pbw && frames->height >= pbh && !pxz::knobs().no_oklab32 &&
+	                            !pxz::knobs().no_oklab_general && !pxz::knobs().no_oklab_edges && !pxz::knobs().no_repitch;
 	const bool oklab_covers_all = covers_if_rgba && frames->channels == 4;
 	int rc = prepare(h, frames, params, d_out_pixels != nullptr, &a, oklab_covers_all);
 	bool rgb_must_widen = false;
-	if (rc == PXZ_ERR_UNSUPPORTED && covers_if_rgba && frames->channels == 3 && !getenv("PXZ_NO_WIDEN")) {
+	if (rc == PXZ_ERR_UNSUPPORTED && covers_if_rgba && frames->channels == 3 && !pxz::knobs().no_widen) {
 		// the RGB layout with its own detector planes does not fit LDS; the widened RGBA one without them might
 		pxz_frames fw = *frames;
 		fw.channels = 4;
@@ -877,7 +877,7 @@ static int run_shrink(pxz_handle *h, const pxz_frames *frames, const pxz_params 
 	// (also shrink_by on the tile sizes the run-time-geometry Oklab detector takes: it only exists for RGBA)
 	const bool square_fast = a.bw == a.bh && (a.bw == 16 || a.bw == 32 || a.bw == 64);
 	const bool general_oklab = a.mode == PXZ_MODE_SHRINK_BY && a.bw % 4u == 0 && a.bw * a.bh >= 64u && a.bw * a.bh <= 16384u;
-	bool widen = frames->channels == 3 && (square_fast || general_oklab) && !getenv("PXZ_NO_WIDEN");
+	bool widen = frames->channels == 3 && (square_fast || general_oklab) && !pxz::knobs().no_widen;
 	if (widen && d_out_pixels && params->filter != PXZ_FILTER_NEAREST) {
 		const TableSet *tsp = nullptr;
 		if ((rc = get_tables(h, a.bw, a.bh, a.edge_w, a.edge_h, params->filter, &tsp)) != PXZ_OK) return rc;
@@ -912,7 +912,7 @@ static int run_shrink(pxz_handle *h, const pxz_frames *frames, const pxz_params 
 	// RGBA frames whose rows (or first byte, or frame stride) are not 16-byte multiples would miss the fast kernels and
 	// the block-cooperative Oklab detector: one device-to-device 2D copy into aligned scratch first (0.4 ms per GB
 	// against 5-50x on the kernels)
-	if (!widen && frames->channels == 4 && (square_fast || general_oklab) && !getenv("PXZ_NO_REPITCH")) {
+	if (!widen && frames->channels == 4 && (square_fast || general_oklab) && !pxz::knobs().no_repitch) {
 		const uint64_t fstride = frames->n_frames > 1 ? frames->frame_stride_bytes : (uint64_t)frames->pitch_bytes * frames->height;
 		const bool misaligned = ((reinterpret_cast<uintptr_t>(d_pixels) | frames->pitch_bytes | (frames->n_frames > 1 ? fstride : 0)) & 15u) != 0;
 		if (misaligned) {

@@ -170,6 +170,21 @@ struct Fast64Args {
 	uint32_t breaks_asc;
 };
 
+// Diagnostic switches (PXZ_* environment variables), read ONCE per process -- never on the call path.  Every one of
+// them only picks between kernels that produce the same bytes (the tests run both sides); none is part of the ABI.
+struct Knobs {
+	bool no_alpha_kernel;   // PXZ_NO_ALPHA_KERNEL: tiles with transparency stay on the generic kernel
+	bool no_oklab_general;  // PXZ_NO_OKLAB_GENERAL: no run-time-geometry Oklab detector
+	bool no_oklab32;        // PXZ_NO_OKLAB32: no block-cooperative Oklab detector at all
+	bool no_oklab_edges;    // PXZ_NO_OKLAB_EDGES: ragged edge tiles keep their four-lane chains
+	bool no_repitch;        // PXZ_NO_REPITCH: unaligned device batches are staged pixel by pixel
+	bool no_widen;          // PXZ_NO_WIDEN: RGB batches never ride the RGBA kernels
+	bool oklab_v1;          // PXZ_OKLAB_V1: round-1 detector (one chain wave, two barriers per band) for 16/32-px tiles
+	int wpb;                // PXZ_WPB: waves per block of the persistent kernels (0: default)
+	int chunk_lg;           // PXZ_CHUNK_LG: log2 of the ticket run length of shrink32_kernel (-1: default)
+};
+const Knobs &knobs();
+
 struct LaunchGeom {
 	uint32_t blocks, threads, lds_bytes;
 };

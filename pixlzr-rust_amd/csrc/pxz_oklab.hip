@@ -4,6 +4,7 @@
 // Compiled with -ffp-contract=off: the f32 results of the Oklab detector are
 // written into the bitstream, and the reference (Rust) never fuses a*b+c.
 #include "pxz_device.h"
+#include <cstdlib>
 
 namespace pxz {
 
@@ -37,120 +38,172 @@ constexpr uint32_t kOkTiles = 15;           // tiles per block and batch (one pe
 constexpr uint32_t kOkPlane = 256 + 4;      // floats per (tile, channel) band: 8 rows x 32 px + bank skew
 constexpr uint32_t kOkBand = kOkTiles * 4 * kOkPlane;  // floats per band buffer
 
-// The quotient of the Halley step inside cbrt_f32_lut: v_rcp_f64 (2^-23 or better) and ONE Newton step, i.e. a
-// quotient good to ~2^-46 instead of the correctly rounded one glibc's `/` produces.  That is enough here, and
-// provably so: the result is rounded to f32 right after, the inputs of this path are the l, m, s of the 2^24
-// possible RGB triples and nothing else, and tests/test_gpu_parity.py::test_oklab_conversion_of_every_colour runs
-// every one of them through this very function against the oracle's exact division: no bit differs.  (The
-// generic kernel's cbrt_f32, which sees the same inputs, keeps the exact division.)  4 instructions instead of 8.
-__device__ __forceinline__ double div_f64_oklab_domain(double n, double d)
+// glibc 2.35 cbrtf for the inputs of the Oklab detector, six at a time (l, m, s of two pixels).  Same arithmetic as
+// cbrt_f32 (pxz_device.h), in two parts (cbrt6_head, cbrt6_tail: LDS traffic of the caller goes between them), with these liberties, every one of them checked over the whole domain -- the conversion
+// is a pure function of the colour bytes, 2^24 inputs, and tests/test_gpu_parity.py::test_oklab_conversion_of_every_colour
+// runs all of them through this very function against the oracle's exact arithmetic, bit for bit:
+//  * frexpf by bit fields (the inputs are zero or normal, < 2): mantissa = fraction bits under the exponent of 0.5,
+//    exponent = the biased exponent field;
+//  * the tail `(float)(q * third[2 + xe % 3])` followed by `ldexpf(.., xe / 3)` is ONE multiplication by
+//    2^(xe/3) * third[..]: scaling a double by a power of two is exact and commutes with the rounding to float (no
+//    underflow in this range).  `scale` is the LDS table of those doubles indexed by the exponent field; entry 0 is
+//    0.0, which makes cbrt(0) = +0 fall out of the same instructions (no zero test, no select);
+//  * the seed polynomial and the sums t2 + 2 xm, 2 t2 + xm as FMAs (the sums are exact in double either way; the
+//    polynomial differs from glibc's separate operations by a few 2^-53 before the rounding to float);
+//  * the quotient of the Halley step is v_rcp_f64 + ONE Newton step times the numerator (4 instructions instead of the
+//    8 of a correctly rounded division; a raw v_rcp_f64 fails on 4.2 M colours, so the test bites).
+// Every liberty is a function of ONE input value, so the 2^24-colour test covers it completely.  (Sharing one
+// reciprocal among the six quotients -- Montgomery's trick, 2 instructions per root cheaper -- was tried and dropped
+// for that reason: the products make a root's last double bits depend on its neighbours, the exhaustive test then
+// samples 2^24 of 2^48 pairs, and with one partner per colour it already found a colour whose float flipped.)
+struct Cbrt6State {
+	double xmd[6];  // frexpf mantissas
+	double sc[6];   // 2^(xe/3) * third[xe % 3] (0 for x = 0)
+};
+// first part: mantissa and scale factor of each input (bit fields, one LDS read each)
+__device__ __forceinline__ void cbrt6_head(const float (&x)[6], const double *scale, Cbrt6State &st)
 {
-	double r = __builtin_amdgcn_rcp(d);
-	const double e = __builtin_fma(-d, r, 1.0);
-	r = __builtin_fma(r, e, r);
-	return n * r;
+#pragma unroll
+	for (int i = 0; i < 6; ++i) {
+		const uint32_t bits = __float_as_uint(x[i]);
+		uint32_t xmb;  // frexpf mantissa, [0.5, 1): one v_and_or_b32 (the compiler splits it in two)
+		asm("v_and_or_b32 %0, %1, %2, 0.5" : "=v"(xmb) : "v"(bits), "s"(0x007fffffu));
+		st.sc[i] = *reinterpret_cast<const double *>(reinterpret_cast<const char *>(scale) + ((bits >> 20) & 0x7f8u));
+		st.xmd[i] = (double)__uint_as_float(xmb);
+	}
+}
+// second part: seed, Halley step, scaling
+__device__ __forceinline__ void cbrt6_tail(const Cbrt6State &st, float (&y)[6])
+{
+	double den[6], num[6];
+	f32x2 u[3];
+#pragma unroll
+	for (int i = 0; i < 6; ++i) {
+		const float ui = (float)__builtin_fma(__builtin_fma(-0.191502161678719066, st.xmd[i], 0.697570460207922770), st.xmd[i], 0.492659620528969547);
+		if (i & 1) u[i >> 1].y = ui; else u[i >> 1].x = ui;
+	}
+#pragma unroll
+	for (int k = 0; k < 3; ++k) {
+		const f32x2 t2 = u[k] * u[k] * u[k];  // two f32 roundings, as glibc's float t2 = u * u * u
+#pragma unroll
+		for (int h = 0; h < 2; ++h) {
+			const int i = 2 * k + h;
+			const double ud = (double)(h ? u[k].y : u[k].x), t2d = (double)(h ? t2.y : t2.x);
+			den[i] = __builtin_fma(2.0, t2d, st.xmd[i]);
+			num[i] = ud * __builtin_fma(2.0, st.xmd[i], t2d);
+		}
+	}
+#pragma unroll
+	for (int i = 0; i < 6; ++i) {
+		double r = __builtin_amdgcn_rcp(den[i]);
+		r = __builtin_fma(r, __builtin_fma(-den[i], r, 1.0), r);
+		y[i] = (float)(num[i] * r * st.sc[i]);  // (u * N / D) * factor, glibc's order
+	}
 }
 
-// glibc 2.35 cbrtf for the inputs of the Oklab detector: same arithmetic as cbrt_f32 above with the quotient below.
-// The tail `(float)(q * third[2 + xe % 3])` followed by `ldexpf(.., xe / 3)` is folded into ONE
-// multiplication by 2^(xe/3) * third[..]: scaling a double by a power of two is exact and commutes
-// with the rounding to float (no underflow in this range), so the bits are unchanged.  `scale` is the
-// LDS table of those 132 doubles indexed by xe + 130 (xe in [-130, 1]).
-template <bool ZERO_CHECK = true>
-__device__ __forceinline__ float cbrt_f32_lut(float x, const double *scale)
-{
-	int xe;
-	const float xm = frexpf(x, &xe);
-	// glibc: (float)(0.4926.. + (0.6975.. - 0.1915.. * xm) * xm) with separate double operations.  The fused form
-	// differs from it by at most a few 2^-53 before the rounding to float, and for none of this path's inputs
-	// does that cross a rounding boundary (same exhaustive test as for the quotient below).
-	const float u = (float)__builtin_fma(__builtin_fma(-0.191502161678719066, (double)xm, 0.697570460207922770), (double)xm, 0.492659620528969547);
-	const float t2 = u * u * u;
-	// t2 + 2 xm and 2 t2 + xm are exact in double (24-bit operands a few binades apart), so the fused forms give
-	// the same values as glibc's separate multiplications and additions
-	const double num = (double)u * __builtin_fma(2.0, (double)xm, (double)t2);
-	const double den = __builtin_fma(2.0, (double)t2, (double)xm);
-	const float y = (float)(div_f64_oklab_domain(num, den) * scale[xe + 130]);
-	if constexpr (!ZERO_CHECK) return y;  // (x == 0 is the caller's business)
-	return x == 0.0f ? 0.0f : y;
-}
-
-// byte BYTE of v, times 4: the byte offset of a 256-entry f32 table row, in one SDWA shift
+// byte BYTE of v, times 16: the byte offset of a 256-entry float4 table row, in one SDWA shift
 template <int BYTE>
-__device__ __forceinline__ uint32_t byte_times4(uint32_t v)
+__device__ __forceinline__ uint32_t byte_times16(uint32_t v)
 {
 	uint32_t r;
-	const uint32_t two = 2u;
+	const uint32_t four = 4u;
 	if constexpr (BYTE == 0)
-		asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(r) : "v"(two), "v"(v));
+		asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(r) : "v"(four), "v"(v));
 	else if constexpr (BYTE == 1)
-		asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(r) : "v"(two), "v"(v));
+		asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(r) : "v"(four), "v"(v));
 	else
-		asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(r) : "v"(two), "v"(v));
+		asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(r) : "v"(four), "v"(v));
 	return r;
 }
-__device__ __forceinline__ float table_at(const float *table, uint32_t byte_offset)
+__device__ __forceinline__ float4 row_at(const float4 *table, uint32_t byte_offset)
 {
-	return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(table) + byte_offset);
+	return *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(table) + byte_offset);
+}
+
+__device__ __forceinline__ float add_f32_plain(float a, float b)
+{
+	float r;
+	asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+	return r;
 }
 
 // Srgba<u8> -> linear -> Oklab of two pixels (operations.rs:56-59; palette 0.7.6): LUT, then Ottosson's matrices
-// with left-to-right f32 sums; two pixels per packed-f32 instruction (same IEEE results per component).
-// out[k] = {a, b, l} of pixel k, the order the reference sums them in.
-__device__ __forceinline__ void oklab_pair(uint32_t v0, uint32_t v1, const float *s_srgb, const double *s_scale,
-                                           float (&out0)[3], float (&out1)[3])
+// with left-to-right f32 sums.  The first matrix's nine products per pixel come out of the table (s_lms[256 c + v] =
+// the three products of channel c's linear value: the same single-rounded f32 multiplications, done once per
+// block), which leaves its six additions; the second matrix runs two pixels per packed-f32 instruction (same IEEE
+// results per component).  out[k] = {a, b, l} of pixel k, the order the reference sums them in.
+__device__ __forceinline__ void oklab_pair_head(uint32_t v0, uint32_t v1, const float4 *s_lms, const double *s_scale, Cbrt6State &st)
 {
-	const f32x2 r = {table_at(s_srgb, byte_times4<0>(v0)), table_at(s_srgb, byte_times4<0>(v1))};
-	const f32x2 g = {table_at(s_srgb, byte_times4<1>(v0)), table_at(s_srgb, byte_times4<1>(v1))};
-	const f32x2 b = {table_at(s_srgb, byte_times4<2>(v0)), table_at(s_srgb, byte_times4<2>(v1))};
-	const f32x2 l = 0.4122214708f * r + 0.5363325363f * g + 0.0514459929f * b;
-	const f32x2 m = 0.2119034982f * r + 0.6806995451f * g + 0.1073969566f * b;
-	const f32x2 s3 = 0.0883024619f * r + 0.2817188376f * g + 0.6299787005f * b;
-	// l, m, s are zero only for black (every coefficient is positive, the table is zero at 0 only), and then all
-	// three are: one test per pixel on the colour bytes instead of one per cube root
-	const f32x2 l_ = {cbrt_f32_lut<false>(l.x, s_scale), cbrt_f32_lut<false>(l.y, s_scale)};
-	const f32x2 m_ = {cbrt_f32_lut<false>(m.x, s_scale), cbrt_f32_lut<false>(m.y, s_scale)};
-	const f32x2 s_ = {cbrt_f32_lut<false>(s3.x, s_scale), cbrt_f32_lut<false>(s3.y, s_scale)};
+	const float4 r0 = row_at(s_lms, byte_times16<0>(v0)), g0 = row_at(s_lms + 256, byte_times16<1>(v0)), b0 = row_at(s_lms + 512, byte_times16<2>(v0));
+	const float4 r1 = row_at(s_lms, byte_times16<0>(v1)), g1 = row_at(s_lms + 256, byte_times16<1>(v1)), b1 = row_at(s_lms + 512, byte_times16<2>(v1));
+	// l, m (packed) and s of each pixel: (r + g) + b, as 0.41.. * r + 0.53.. * g + 0.05.. * b evaluates
+	const f32x2 lm0 = f32x2{r0.x, r0.y} + f32x2{g0.x, g0.y} + f32x2{b0.x, b0.y};
+	const f32x2 lm1 = f32x2{r1.x, r1.y} + f32x2{g1.x, g1.y} + f32x2{b1.x, b1.y};
+	// (plain adds spelled out: left alone, the compiler gathers the two pixels' terms into register pairs with six
+	// moves in order to use two packed adds)
+	const float s0 = add_f32_plain(add_f32_plain(r0.z, g0.z), b0.z), s1 = add_f32_plain(add_f32_plain(r1.z, g1.z), b1.z);
+	// l, m, s are zero only for black (every coefficient is positive, the table is zero at 0 only); their cube roots
+	// are then +0 (entry 0 of the scale table) and so are L = (+0 + +0) - +0, a and b
+	const float x[6] = {lm0.x, lm1.x, lm0.y, lm1.y, s0, s1};
+	cbrt6_head(x, s_scale, st);
+}
+__device__ __forceinline__ void oklab_pair_tail(const Cbrt6State &st, float (&out0)[3], float (&out1)[3])
+{
+	float c[6];
+	cbrt6_tail(st, c);
+	const f32x2 l_ = {c[0], c[1]}, m_ = {c[2], c[3]}, s_ = {c[4], c[5]};
 	const f32x2 L = 0.2104542553f * l_ + 0.7936177850f * m_ - 0.0040720468f * s_;
 	const f32x2 A = 1.9779984951f * l_ - 2.4285922050f * m_ + 0.4505937099f * s_;
 	const f32x2 B = 0.0259040371f * l_ + 0.7827717662f * m_ - 0.8086757660f * s_;
-	const bool black0 = (v0 & 0x00ffffffu) == 0u, black1 = (v1 & 0x00ffffffu) == 0u;  // cbrt(0) = 0 -> L = a = b = +0
-	out0[2] = black0 ? 0.0f : L.x; out1[2] = black1 ? 0.0f : L.y;
-	out0[0] = black0 ? 0.0f : A.x; out1[0] = black1 ? 0.0f : A.y;
-	out0[1] = black0 ? 0.0f : B.x; out1[1] = black1 ? 0.0f : B.y;
+	out0[2] = L.x; out1[2] = L.y;
+	out0[0] = A.x; out1[0] = A.y;
+	out0[1] = B.x; out1[1] = B.y;
+}
+__device__ __forceinline__ void oklab_pair(uint32_t v0, uint32_t v1, const float4 *s_lms, const double *s_scale,
+                                           float (&out0)[3], float (&out1)[3])
+{
+	Cbrt6State st;
+	oklab_pair_head(v0, v1, s_lms, s_scale, st);
+	oklab_pair_tail(st, out0, out1);
 }
 
-// The conversion tables of the Oklab kernels in LDS: sRGB u8 -> linear (256), a / 255 (256), and the 132 doubles
-// 2^(xe/3) * cbrt(2)^(xe%3), xe = i - 130.  Call from the first 256 threads of a block, then a block barrier.
-__device__ __forceinline__ void oklab_fill_tables(float *s_srgb, float *s_alpha, double *s_scale, uint32_t t)
+// The conversion tables of the Oklab kernels in LDS: the products of the sRGB u8 -> linear values with the columns of
+// the first matrix (3 x 256 float4), a / 255 (256), and 128 doubles
+// 2^(xe/3) * cbrt(2)^(xe%3) indexed by the biased exponent field (xe = i - 126; entry 0 is 0.0).  Call from the first 256 threads of a block, then a block barrier.
+__device__ __forceinline__ void oklab_fill_tables(float4 *s_lms, float *s_alpha, double *s_scale, uint32_t t)
 {
 	if (t < 256) {
-		s_srgb[t] = __uint_as_float(kSrgbToLinearBits[t]);
+		const float x = __uint_as_float(kSrgbToLinearBits[t]);  // sRGB u8 -> linear
+		s_lms[t] = make_float4(0.4122214708f * x, 0.2119034982f * x, 0.0883024619f * x, 0.0f);        // red's share of l, m, s
+		s_lms[256 + t] = make_float4(0.5363325363f * x, 0.6806995451f * x, 0.2817188376f * x, 0.0f);  // green's
+		s_lms[512 + t] = make_float4(0.0514459929f * x, 0.1073969566f * x, 0.6299787005f * x, 0.0f);  // blue's
 		s_alpha[t] = __fdiv_rn((float)t, 255.0f);
 	}
-	if (t < 132) {
-		const int xe = (int)t - 130;
+	if (t < 128) {
+		// entry f: x = xm * 2^xe with xe = f - 126 (frexpf's convention); 0 for f = 0 (x = 0: its cube root is +0)
+		const int xe = (int)t - 126;
 		const int q3 = xe / 3, r3 = xe - 3 * q3;  // C semantics: the remainder carries the sign of xe
 		const double third = r3 == 0 ? 1.0
 		                   : r3 == 1 ? 1.2599210498948731648
 		                   : r3 == 2 ? 1.5874010519681994748
 		                   : r3 == -1 ? 1.0 / 1.2599210498948731648
 		                              : 1.0 / 1.5874010519681994748;
-		s_scale[t] = ldexp(third, q3);  // exact
+		s_scale[t] = t == 0 ? 0.0 : ldexp(third, q3);  // exact
 	}
 }
 
 // Per-pixel form of the same conversion (pxz_oklab_pixels_device): out[i] = {l, a, b, alpha} of RGBA pixel i.
 __global__ void __launch_bounds__(256) oklab_pixels_kernel(const uint32_t *px, uint32_t n, float4 *out)
 {
-	__shared__ float s_srgb[256], s_alpha[256];
-	__shared__ double s_scale[132];
-	oklab_fill_tables(s_srgb, s_alpha, s_scale, threadIdx.x);
+	__shared__ float4 s_lms[768];
+	__shared__ float s_alpha[256];
+	__shared__ double s_scale[128];
+	oklab_fill_tables(s_lms, s_alpha, s_scale, threadIdx.x);
 	__syncthreads();
 	for (uint32_t i = 2u * (blockIdx.x * blockDim.x + threadIdx.x); i < n; i += 2u * gridDim.x * blockDim.x) {
 		const uint32_t v0 = px[i], v1 = i + 1u < n ? px[i + 1u] : 0u;
 		float o0[3], o1[3];
-		oklab_pair(v0, v1, s_srgb, s_scale, o0, o1);
+		oklab_pair(v0, v1, s_lms, s_scale, o0, o1);
 		out[i] = make_float4(o0[2], o0[0], o0[1], s_alpha[v0 >> 24]);
 		if (i + 1u < n) out[i + 1u] = make_float4(o1[2], o1[0], o1[1], s_alpha[v1 >> 24]);
 	}
@@ -212,14 +265,14 @@ __global__ void __launch_bounds__(1024) oklab_kernel(const ShrinkArgs a)
 	const uint32_t tile_wp = kGeneral ? (tile_w + 3u) & ~3u : (uint32_t)T;
 	const uint32_t tile_px = kGeneral ? tile_wp * ((a.ok_region & 2u) ? a.edge_h : a.bh) : (uint32_t)(T * T);
 	extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-	float *s_srgb = reinterpret_cast<float *>(lds);          // 256: sRGB u8 -> linear
-	float *s_alpha = s_srgb + 256;                           // 256: a / 255
-	double *s_scale = reinterpret_cast<double *>(s_alpha + 256);  // 132: 2^(xe/3) * 2^((xe%3)/3), xe = i - 130
-	float *s_mean = reinterpret_cast<float *>(s_scale + 132);     // 64: per (tile, channel) means of the batch in pass 2
+	float4 *s_lms = reinterpret_cast<float4 *>(lds);         // 3 x 256: sRGB u8 -> linear, times the first matrix's columns
+	float *s_alpha = reinterpret_cast<float *>(s_lms + 768); // 256: a / 255
+	double *s_scale = reinterpret_cast<double *>(s_alpha + 256);  // 128: 2^(xe/3) * 2^((xe%3)/3) by exponent field
+	float *s_mean = reinterpret_cast<float *>(s_scale + 128);     // 64: per (tile, channel) means of the batch in pass 2
 	float *s_p1 = s_mean + 64;                               // pass-1 band: values
 	float *s_p2 = s_p1 + kOkBand;                            // pass-2 band: values minus means
 	const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-	oklab_fill_tables(s_srgb, s_alpha, s_scale, threadIdx.x);
+	oklab_fill_tables(s_lms, s_alpha, s_scale, threadIdx.x);
 	__syncthreads();
 
 	const uint32_t n_batches = (a.ok_count + kOkTiles - 1) / kOkTiles;
@@ -318,7 +371,11 @@ __global__ void __launch_bounds__(1024) oklab_kernel(const ShrinkArgs a)
 					fresh_alpha = (v[0] >> 24) | ((v[1] >> 24) << 8) | ((v[2] >> 24) << 16) | ((v[3] >> 24) << 24);
 #pragma unroll
 					for (int j = 0; j < 4; j += 2) {
-						oklab_pair(v[j], v[j + 1], s_srgb, s_scale, fresh[j], fresh[j + 1]);
+#if defined(PXZ_EXP) && (PXZ_EXP == 1 || PXZ_EXP == 3)
+						for (int c = 0; c < 3; ++c) { fresh[j][c] = __uint_as_float(v[j] >> (8 * c)); fresh[j + 1][c] = __uint_as_float(v[j + 1] >> (8 * c)); }
+#else
+						oklab_pair(v[j], v[j + 1], s_lms, s_scale, fresh[j], fresh[j + 1]);
+#endif
 						// two pixels (six cube-root chains) at a time: the register file also holds a whole tile of results
 						__builtin_amdgcn_sched_barrier(0);
 					}
@@ -462,8 +519,10 @@ __global__ void __launch_bounds__(1024) oklab_kernel(const ShrinkArgs a)
 				const uint32_t h1 = k > 0 ? h0 : hm1, h2 = k > 0 ? hm1 : hm2;  // tile heights of those two batches
 				const uint32_t tg2 = k > 0 ? gm1 : gm2;                       // the tile whose pass 2 ends here
 				// (T = 0: a tile that is taken has all its bands; a short last band is padded with exact zeros)
+#if !(defined(PXZ_EXP) && (PXZ_EXP == 2 || PXZ_EXP == 3))
 				if (p1_valid && (kGeneral ? h1 != 0u : kk * G::kRowsPerBand < h1)) acc1 = walk(s_p1, acc1, false);
 				if (p2_valid && (kGeneral ? h2 != 0u : kk * G::kRowsPerBand < h2)) acc2 = walk(s_p2, acc2, true);
+#endif
 				if (kk == NB - 1u) {
 					if (p1_valid) {
 						s_mean[lane] = __fdiv_rn(acc1, (float)(tile_w * h1));  // operations.rs:65-68; read after barrier A
@@ -486,9 +545,288 @@ __global__ void __launch_bounds__(1024) oklab_kernel(const ShrinkArgs a)
 	}
 }
 
+// ---------------------------------------------------------------------------
+// oklab2_kernel<T>, T = 16 | 32: the detector for square tiles whose converted pixels fit one wave's registers,
+// re-cut so that nothing waits for anything else (round 2):
+//   * 14 producer waves (one tile each per batch) and TWO chain waves: wave 14 walks pass 1 (the sums,
+//     operations.rs:55-64) of the batch being converted, wave 15 pass 2 (the sums of |x - mean|, :75-84) of the batch
+//     before it -- each chain has half the dependent adds of the single chain wave of oklab_kernel;
+//   * bands of 128 pixels (2 per producer lane) and ONE barrier per interval.  A producer issues its LDS stores at
+//     the START of an interval -- the band it converted in the interval before (pass 1) and the band of the previous
+//     batch that this interval's conversion is about to overwrite (pass 2) -- so they drain under the conversion
+//     instead of in front of the barrier (oklab_kernel: 17 % of its time in a store phase with the vector ALUs idle);
+//     the chains read a band two intervals after its conversion / re-delivery (pass-1 buffers x2, pass-2 buffers x3);
+//   * pass 2 is handed over as the raw values again and the chain wave subtracts its lane's mean itself (one
+//     independent v_sub per element beside the dependent v_add: that wave has the issue slots to spare) -- so a
+//     producer re-delivers band k of the previous batch just before it converts band k of the next one into the same
+//     registers: no spare register set, no moves, and the mean is only needed by the chain, two intervals later.
+// With g = p * NB + k the running interval number and s = q * NB + band the running number of a converted band:
+//   producers at g   store band s = g - 1 -> p1[g & 1]; store raw band g - NB (batch p - 1) -> p2[g % 3]; convert band g
+//   chain A at g     adds band s = g - 2 (p1[(g - 1) & 1]); after a batch's last band it publishes the means
+//   chain B at g     adds raw band s = g - 2 - NB (p2[(g - 2) % 3]); it picks the means up with a batch's first band
+//                    (published one barrier earlier) and writes the values after its last
+// ---------------------------------------------------------------------------
+constexpr uint32_t kOk2Prod = 14;                       // producer waves = tiles per batch
+constexpr uint32_t kOk2Plane = 128 + 4;                 // floats per (tile, channel) band + bank skew
+constexpr uint32_t kOk2Band = kOk2Prod * 4 * kOk2Plane; // floats per band buffer
+constexpr uint32_t kOk2Tables = 3072u + 256u + 2u * 128u + 64u; // dwords: matrix-column products, alpha, scale (doubles), means
+constexpr uint32_t kOk2LdsBytes = (kOk2Tables + 5u * kOk2Band) * 4u;
+
+template <int T>
+__global__ void __launch_bounds__(1024) oklab2_kernel(const ShrinkArgs a)
+{
+	constexpr uint32_t NB = T * T / 128;        // bands per tile: 2 | 8
+	constexpr uint32_t kLanesPerRow = T / 2;    // 8 | 16
+	constexpr uint32_t kRowsPerBand = 128 / T;  // 8 | 4
+	static_assert(NB % 2 == 0, "the pass-1 buffers alternate with the band index");
+	// (a static array: its address is a compile-time constant, so table and buffer offsets fold into the instructions'
+	// offset fields -- with `extern __shared__` every LDS access of the loop paid a v_add of the relocated base)
+	__shared__ __attribute__((aligned(16))) uint32_t lds[kOk2LdsBytes / 4u];
+	float4 *s_lms = reinterpret_cast<float4 *>(lds);
+	float *s_alpha = reinterpret_cast<float *>(s_lms + 768);
+	double *s_scale = reinterpret_cast<double *>(s_alpha + 256);
+	float *s_mean = reinterpret_cast<float *>(s_scale + 128);
+	float *s_p1 = s_mean + 64;                  // [2][kOk2Band]: converted values, pass 1
+	float *s_p2 = s_p1 + 2 * kOk2Band;          // [3][kOk2Band]: the same values of the batch before, pass 2
+	const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+#if defined(PXZ_EXP) && PXZ_EXP == 4
+	const uint64_t exp_c0 = clock64(), exp_w0 = wall_clock64();
+#endif
+	oklab_fill_tables(s_lms, s_alpha, s_scale, threadIdx.x);
+	__syncthreads();
+
+	const uint32_t n_batches = (a.ok_count + kOk2Prod - 1) / kOk2Prod;
+	const uint32_t own = n_batches > blockIdx.x ? (n_batches - blockIdx.x + gridDim.x - 1) / gridDim.x : 0u;
+	// batch q is converted in period q, re-delivered in period q + 1, and chain B adds its last band in interval 1 of
+	// period q + 2: the last period ends after two intervals
+	const uint32_t periods = own + 2u;
+	constexpr uint32_t kLastIntervals = 2u;
+
+	if (wave < kOk2Prod) {
+		// ---------------- producers ----------------
+		const size_t lane_off = (size_t)(lane / kLanesPerRow) * a.pitch + (lane % kLanesPerRow) * 8u;
+		const size_t band_step = (size_t)kRowsPerBand * a.pitch;
+		auto batch_src = [&](uint32_t j, uint32_t &bands) -> const uint8_t * {
+			const uint8_t *src;
+			bands = 0;
+			if (j >= own) return nullptr;
+			uint32_t unused_tile;
+			const uint32_t th = oklab_tile_src<T>(a, (blockIdx.x + j * gridDim.x) * kOk2Prod + wave, src, unused_tile);
+			if (th == 0) return nullptr;
+			bands = th / kRowsPerBand;  // (a ragged tile is only taken when its height is a multiple of 8 rows)
+			return src + lane_off;
+		};
+		uint32_t nb0 = 0, nb1 = 0, nb_prev = 0;
+		const uint8_t *src0 = nullptr, *src1 = batch_src(0, nb1);
+		// the pixel pairs of the next two bands in sequence, requested two intervals before their conversion; the band
+		// index picks the register pair (NB is even), so nothing is moved
+		uint2 q[2] = {make_uint2(0, 0), make_uint2(0, 0)};
+		auto request = [&](uint32_t ahead_of_k0, const uint8_t *s_a, uint32_t n_a, const uint8_t *s_b, uint32_t n_b, uint2 &dst) {
+			const uint32_t bo = ahead_of_k0 / NB, band = ahead_of_k0 % NB;
+			const uint8_t *base = bo == 0 ? s_a : s_b;
+			const uint32_t nbb = bo == 0 ? n_a : n_b;
+			if (base && band < nbb) dst = *reinterpret_cast<const uint2 *>(base + (size_t)band * band_step);
+		};
+		request(0, src1, nb1, nullptr, 0, q[0]);
+		request(1, src1, nb1, nullptr, 0, q[1]);
+		float lab[NB][2][3];  // [band][pixel][a, b, l]: this wave's tile of the batch in conversion / re-delivery
+		// Alpha.  An opaque band's alpha plane is the constant 1 (255 / 255): no bytes are kept and nothing is looked up.
+		// Only tiles with transparency keep their alpha bytes (two per band): al_cur for the tile in conversion, al_old for
+		// the one in re-delivery; the flags are wave-uniform.
+		uint32_t al_cur[NB / 2], al_old[NB / 2];
+#pragma unroll
+		for (uint32_t k = 0; k < NB / 2; ++k) al_cur[k] = al_old[k] = 0xffffffffu;
+		bool cur_opaque = true, old_opaque = true, band_opaque = true;  // tile in conversion / in re-delivery / band awaiting its store
+		const uint32_t slot = (wave * 4u) * kOk2Plane + lane * 2u;
+		// one band (two pixels per lane, three planes + alpha) into a band buffer
+		float2 ones;  // (kept in a register pair: as a constant it is re-made with two moves at each of its uses)
+		asm volatile("v_mov_b32 %0, 1.0\n\tv_mov_b32 %1, 1.0" : "=v"(ones.x), "=v"(ones.y));
+		auto store_band = [&](float *d, const float (&x)[2][3], bool opaque, uint32_t ab) {
+#pragma unroll
+			for (int c = 0; c < 3; ++c) *reinterpret_cast<float2 *>(d + c * kOk2Plane) = make_float2(x[0][c], x[1][c]);
+			// (a store in each branch: a value merged after the branch makes the compiler wait for every LDS operation in flight)
+			if (opaque) {
+				*reinterpret_cast<float2 *>(d + 3 * kOk2Plane) = ones;
+			} else {
+				*reinterpret_cast<float2 *>(d + 3 * kOk2Plane) = make_float2(s_alpha[ab & 255u], s_alpha[(ab >> 8) & 255u]);
+			}
+		};
+		bool have_prev = false, elig_cur = false, pending = false;  // pending: the band converted last interval awaits its store
+		uint32_t g3 = 0;  // interval number mod 3
+		// The conversion is cut in two (oklab_pair_head: table reads, first matrix, mantissas and scale factors;
+		// oklab_pair_tail: the cube roots' arithmetic and the second matrix) and the head of the NEXT band runs at the end of
+		// an interval, in front of the barrier: the waves of a block move in lock-step, so a table read at the start of an
+		// interval would be waited for by all of them at once, behind 112 stores, with nothing to issue meanwhile.
+		Cbrt6State st;          // head of the band about to be converted
+		bool st_opaque = true;  // and its alpha: all 255 (wave-uniform)?
+		uint32_t st_ab = 0;     //   the two alpha bytes of this lane
+		bool st_valid = false;
+		auto head = [&](bool valid, const uint2 &px) {
+			st_valid = valid;
+			if (valid) {
+				oklab_pair_head(px.x, px.y, s_lms, s_scale, st);
+				st_opaque = __all((px.x & px.y) >= 0xff000000u);
+				st_ab = (px.x >> 24) | ((px.y >> 24) << 8);
+			}
+		};
+		head(src1 != nullptr && nb1 > 0u, q[0]);
+		for (uint32_t p = 0; p < periods; ++p) {
+			src0 = src1;
+			nb_prev = nb0;
+			nb0 = nb1;
+			src1 = batch_src(p + 1u, nb1);
+			elig_cur = src0 != nullptr;
+#pragma unroll
+			for (uint32_t k = 0; k < NB; ++k) {
+				if (p + 1u == periods && k == kLastIntervals) break;  // (block-uniform)
+				const uint32_t kp = (k + NB - 1u) % NB;  // the band converted in the interval before (k = 0: of the batch before)
+				const bool convert = st_valid;  // (= elig_cur && k < nb0)
+				if (pending) store_band(s_p1 + (k & 1u) * kOk2Band + slot, lab[kp], band_opaque, al_cur[kp >> 1] >> (16u * (kp & 1u)));
+				if (k == 0u) {
+					// the tile converted last period is the one in re-delivery now
+					old_opaque = cur_opaque;
+					if (!cur_opaque) {
+#pragma unroll
+						for (uint32_t i = 0; i < NB / 2; ++i) { al_old[i] = al_cur[i]; al_cur[i] = 0xffffffffu; }
+					}
+					cur_opaque = true;
+				}
+				if (have_prev && k < nb_prev) store_band(s_p2 + g3 * kOk2Band + slot, lab[k], old_opaque, al_old[k >> 1] >> (16u * (k & 1u)));
+				__builtin_amdgcn_sched_barrier(0);
+				pending = convert;
+				if (convert) {
+#if defined(PXZ_EXP) && (PXZ_EXP == 1 || PXZ_EXP == 3)
+					for (int c = 0; c < 3; ++c) { lab[k][0][c] = (float)st.sc[c]; lab[k][1][c] = (float)st.xmd[c]; }
+#else
+					oklab_pair_tail(st, lab[k][0], lab[k][1]);
+#endif
+					band_opaque = st_opaque;
+					if (!st_opaque) {
+						al_cur[k >> 1] = (k & 1u) == 0u ? (al_cur[k >> 1] & 0xffff0000u) | st_ab : (al_cur[k >> 1] & 0x0000ffffu) | (st_ab << 16);
+						cur_opaque = false;
+					}
+				}
+				__builtin_amdgcn_sched_barrier(0);
+				// the head of the next band in sequence: band k + 1 of this batch, or band 0 of the next one
+				if (k + 1u < NB) head(elig_cur && k + 1u < nb0, q[(k + 1u) & 1u]);
+				else head(src1 != nullptr && nb1 > 0u, q[0]);
+				// (after the head: the wait for its pixels is a wait for every load in flight)
+				request(k + 2u, src0, nb0, src1, nb1, q[k & 1u]);
+				g3 = g3 == 2u ? 0u : g3 + 1u;
+				__syncthreads();
+			}
+			have_prev = elig_cur;
+		}
+	} else {
+		// ---------------- chain waves: lane = tile * 4 + channel (a, b, l, alpha) ----------------
+		const bool second = wave == kOk2Prod + 1u;  // pass 2
+		const uint32_t ct = lane >> 2, cc = lane & 3u;
+		const bool live = ct < kOk2Prod;
+		const float *plane = (second ? s_p2 : s_p1) + (live ? (ct * 4u + cc) * kOk2Plane : 0u);
+		float acc = 0.0f, mean = 0.0f;
+		__builtin_amdgcn_s_setprio(3);  // the serial part of every interval: first pick of its SIMD's issue slots
+		// one dependent add per element; 32 values in flight from LDS while 32 are added
+		auto walk = [&](const float *band, float sum, const bool deviation) -> float {
+			const float4 *x = reinterpret_cast<const float4 *>(band);
+			auto add32 = [&](const float4 (&v)[8]) {
+#pragma unroll
+				for (int q = 0; q < 8; ++q) {
+					if (deviation) {
+						sum += fabsf(v[q].x - mean);  // operations.rs:80-83 with `before` = |x - avg| (pixlzr.rs:160-161)
+						sum += fabsf(v[q].y - mean);
+						sum += fabsf(v[q].z - mean);
+						sum += fabsf(v[q].w - mean);
+					} else {
+						sum += v[q].x;  // operations.rs:60-63, row-major pixel order
+						sum += v[q].y;
+						sum += v[q].z;
+						sum += v[q].w;
+					}
+				}
+			};
+			float4 va[8], vb[8];
+#pragma unroll
+			for (int q = 0; q < 8; ++q) va[q] = x[q];
+#pragma unroll
+			for (int q = 0; q < 8; ++q) vb[q] = x[8 + q];
+			__builtin_amdgcn_sched_barrier(0);
+			add32(va);
+			__builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+			for (int q = 0; q < 8; ++q) va[q] = x[16 + q];
+			__builtin_amdgcn_sched_barrier(0);
+			add32(vb);
+			__builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+			for (int q = 0; q < 8; ++q) vb[q] = x[24 + q];
+			__builtin_amdgcn_sched_barrier(0);
+			add32(va);
+			__builtin_amdgcn_sched_barrier(0);
+			add32(vb);
+			return sum;
+		};
+		uint32_t h0 = 0, hm1 = 0, hm2 = 0;  // height of this lane's tile in batches p, p-1, p-2 (0: not taken)
+		uint32_t g0 = 0, gm1 = 0, gm2 = 0;  // and its number in the batch of frames
+		uint32_t g3 = 0;                    // interval number mod 3
+		for (uint32_t p = 0; p < periods; ++p) {
+			{
+				const uint8_t *unused;
+				hm2 = hm1;
+				hm1 = h0;
+				gm2 = gm1;
+				gm1 = g0;
+				h0 = (live && p < own) ? oklab_tile_src<T>(a, (blockIdx.x + p * gridDim.x) * kOk2Prod + ct, unused, g0) : 0u;
+			}
+#pragma unroll 1
+			for (uint32_t k = 0; k < NB; ++k) {
+				if (p + 1u == periods && k == kLastIntervals) break;
+				// the band converted (chain A) / re-delivered (chain B) two intervals ago
+				const bool same = k >= 2u;                           // it belongs to the period's own batch (A: p, B: p - 1)
+				const uint32_t kk = same ? k - 2u : k + NB - 2u;
+				if (!second) {
+					const uint32_t h = same ? h0 : hm1;
+					const float *band = plane + ((k + 1u) & 1u) * kOk2Band;  // stored in interval g - 1
+#if !(defined(PXZ_EXP) && (PXZ_EXP == 2 || PXZ_EXP == 3))
+					if (kk * kRowsPerBand < h) acc = walk(band, acc, false);
+#endif
+					if (kk == NB - 1u) {
+						s_mean[lane] = __fdiv_rn(acc, (float)((uint32_t)T * h));  // operations.rs:65-68 (h = 0: never read)
+						acc = 0.0f;
+					}
+				} else {
+					const uint32_t h = same ? hm1 : hm2;
+					const float *band = plane + (g3 == 0u ? 1u : (g3 == 1u ? 2u : 0u)) * kOk2Band;  // stored in interval g - 2
+					if (kk == 0u) mean = s_mean[lane];  // published by chain A during the interval before
+#if !(defined(PXZ_EXP) && (PXZ_EXP == 2 || PXZ_EXP == 3))
+					if (kk * kRowsPerBand < h) acc = walk(band, acc, true);
+#endif
+					if (kk == NB - 1u) {
+						const float d0 = __shfl(acc, (int)(lane & ~3u) + 0, 64), d1 = __shfl(acc, (int)(lane & ~3u) + 1, 64);
+						const float d2 = __shfl(acc, (int)(lane & ~3u) + 2, 64), d3 = __shfl(acc, (int)(lane & ~3u) + 3, 64);
+						const float total = d0 + d1 + d2 + d3;  // :89
+						const float value = __fdiv_rn(total, (float)((uint32_t)T * h)) * a.factor * a.scale2;  // pixlzr.rs:162
+						const uint32_t tg = same ? gm1 : gm2;
+						if (live && cc == 0 && h != 0u)
+							reinterpret_cast<uint2 *>(a.sums)[tg] = make_uint2(__float_as_uint(value), __float_as_uint(value));
+						acc = 0.0f;
+					}
+				}
+				g3 = g3 == 2u ? 0u : g3 + 1u;
+				__syncthreads();
+			}
+		}
+	}
+#if defined(PXZ_EXP) && PXZ_EXP == 4
+	if (threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == 100)) {
+		const uint64_t dc = clock64() - exp_c0, dw = wall_clock64() - exp_w0;
+		printf("block %u: %llu shader ticks in %llu x 10 ns = %.3f GHz\n", blockIdx.x, (unsigned long long)dc, (unsigned long long)dw, (double)dc / ((double)dw * 10.0));
+	}
+#endif
+}
+
 hipError_t launch_oklab(const ShrinkArgs &a, uint32_t n_cus, hipStream_t stream)
 {
-	const uint32_t lds_bytes = (512u + 2u * 132u + 64u) * 4u + 2u * kOkBand * 4u;
+	const uint32_t lds_bytes = (3072u + 256u + 2u * 128u + 64u) * 4u + 2u * kOkBand * 4u;
 	const uint32_t n_batches = (a.ok_count + kOkTiles - 1) / kOkTiles;
 	const uint32_t blocks = n_batches < n_cus ? n_batches : n_cus;
 	hipError_t e;
@@ -497,6 +835,14 @@ hipError_t launch_oklab(const ShrinkArgs &a, uint32_t n_cus, hipStream_t stream)
 		hipLaunchKernelGGL(kernel, dim3(blocks), dim3(1024), lds_bytes, stream, a);
 		return hipGetLastError();
 	};
+	if (a.bw == a.bh && a.ok_region == 0u && (a.bw == 16u || a.bw == 32u) && !knobs().oklab_v1) {
+		const uint32_t nb2 = (a.ok_count + kOk2Prod - 1) / kOk2Prod, blocks2 = nb2 < n_cus ? nb2 : n_cus;
+		auto go2 = [&](auto kernel) -> hipError_t {
+			hipLaunchKernelGGL(kernel, dim3(blocks2), dim3(1024), 0, stream, a);
+			return hipGetLastError();
+		};
+		return a.bw == 16u ? go2(oklab2_kernel<16>) : go2(oklab2_kernel<32>);
+	}
 	if (a.bw == a.bh && a.ok_region == 0u) {
 		switch (a.bw) {
 		case 16: return go(oklab_kernel<16>);

@@ -868,10 +868,7 @@ hipError_t launch_fast32_16(const ShrinkArgs &a, ShrinkArgs &ga, uint32_t n_cus,
 	constexpr uint32_t kTail = 16u + 16u * 2u * kListBatch * 4u;  // the ticket counter + every wave's list batches
 	uint32_t wpb = (kLds - f.tab_dw * 4u - kTail) / (f.tile_dw * 4u);
 	if (wpb > 16u) wpb = 16u;
-	if (const char *e = getenv("PXZ_WPB")) {
-		const uint32_t v = (uint32_t)atoi(e);
-		if (v >= 1 && v < wpb) wpb = v;
-	}
+	if (const uint32_t v = (uint32_t)knobs().wpb; v >= 1 && v < wpb) wpb = v;
 	const uint32_t lds_bytes = f.tab_dw * 4u + wpb * f.tile_dw * 4u + kTail;
 	const uint32_t per_cu = kLds / lds_bytes > 0 ? kLds / lds_bytes : 1u;
 	const uint32_t resident = n_cus * (per_cu > 2u ? 2u : per_cu);
@@ -879,7 +876,7 @@ hipError_t launch_fast32_16(const ShrinkArgs &a, ShrinkArgs &ga, uint32_t n_cus,
 	const uint32_t need = (units + wpb - 1u) / wpb;
 	const uint32_t blocks = need < resident ? need : resident;
 	f.chunk_lg = 3;
-	if (const char *e = getenv("PXZ_CHUNK_LG")) f.chunk_lg = (uint32_t)atoi(e) & 15u;
+	if (knobs().chunk_lg >= 0) f.chunk_lg = (uint32_t)knobs().chunk_lg;
 	hipError_t e = hipSuccess;  // the worklist counter of this launch was zeroed by the previous one (or at allocation)
 	if (groups16) {
 		const bool full = a.out_px != nullptr && a.out_w != nullptr && a.out_h != nullptr;

@@ -658,10 +658,7 @@ LaunchGeom plan_launch(const ShrinkArgs &a, uint32_t channels, uint32_t n_cus)
 	if (nw == 1) {
 		uint32_t wpb = (kLds - 16u) / tile_bytes;  // 16 bytes: the ticket counter
 		if (wpb > 12u) wpb = 12u;
-		if (const char *e = getenv("PXZ_WPB")) {  // tuning knob: waves per block
-			const uint32_t v = (uint32_t)atoi(e);
-			if (v >= 1 && v < wpb) wpb = v;
-		}
+		if (const uint32_t v = (uint32_t)knobs().wpb; v >= 1 && v < wpb) wpb = v;  // tuning knob: waves per block
 		if (wpb < 1u) wpb = 1u;
 		g.threads = 64u * wpb;
 		g.lds_bytes = wpb * tile_bytes + 16u;

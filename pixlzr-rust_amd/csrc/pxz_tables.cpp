@@ -11,6 +11,8 @@
 //    kernel compares v against the smallest float reaching each n, found here
 //    with the platform's own log2f (the one Rust's f32::log2 calls).
 #include "pxz_tables.h"
+#include "pxz_internal.h"
+#include <cstdlib>
 
 #include <cmath>
 #include <cstring>
@@ -189,6 +191,28 @@ bool build_level_thresholds(float *thresholds, int count)
 		thresholds[k] = from_bits(hi);
 	}
 	return true;
+}
+
+
+const Knobs &knobs()
+{
+	static const Knobs k = [] {
+		auto on = [](const char *name) { return getenv(name) != nullptr; };
+		Knobs v;
+		v.no_alpha_kernel = on("PXZ_NO_ALPHA_KERNEL");
+		v.no_oklab_general = on("PXZ_NO_OKLAB_GENERAL");
+		v.no_oklab32 = on("PXZ_NO_OKLAB32");
+		v.no_oklab_edges = on("PXZ_NO_OKLAB_EDGES");
+		v.no_repitch = on("PXZ_NO_REPITCH");
+		v.no_widen = on("PXZ_NO_WIDEN");
+		v.oklab_v1 = on("PXZ_OKLAB_V1");
+		const char *e = getenv("PXZ_WPB");
+		v.wpb = e ? atoi(e) : 0;
+		e = getenv("PXZ_CHUNK_LG");
+		v.chunk_lg = e ? (atoi(e) & 15) : -1;
+		return v;
+	}();
+	return k;
 }
 
 }  // namespace pxz
