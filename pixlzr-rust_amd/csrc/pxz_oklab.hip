@@ -120,10 +120,10 @@ __device__ __forceinline__ float4 row_at(const float4 *table, uint32_t byte_offs
 	return *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(table) + byte_offset);
 }
 
-__device__ __forceinline__ float add_f32_plain(float a, float b)
+__device__ __forceinline__ f32x2 pk_add_f32_asm(f32x2 a, f32x2 b)
 {
-	float r;
-	asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+	f32x2 r;
+	asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
 	return r;
 }
 
@@ -139,9 +139,12 @@ __device__ __forceinline__ void oklab_pair_head(uint32_t v0, uint32_t v1, const 
 	// l, m (packed) and s of each pixel: (r + g) + b, as 0.41.. * r + 0.53.. * g + 0.05.. * b evaluates
 	const f32x2 lm0 = f32x2{r0.x, r0.y} + f32x2{g0.x, g0.y} + f32x2{b0.x, b0.y};
 	const f32x2 lm1 = f32x2{r1.x, r1.y} + f32x2{g1.x, g1.y} + f32x2{b1.x, b1.y};
-	// (plain adds spelled out: left alone, the compiler gathers the two pixels' terms into register pairs with six
-	// moves in order to use two packed adds)
-	const float s0 = add_f32_plain(add_f32_plain(r0.z, g0.z), b0.z), s1 = add_f32_plain(add_f32_plain(r1.z, g1.z), b1.z);
+	// s on the (z, w) halves of the rows with spelled-out packed adds (w is zero padding).  Two reasons: left alone, the
+	// compiler gathers the two pixels' z terms into register pairs with six moves in order to pack the adds; and with
+	// all four components in use the rows are fetched by ds_read_b128 (4 LDS cycles, 16 lanes each) instead of
+	// ds_read_b96 (8 cycles, 8 lanes each).
+	const float s0 = pk_add_f32_asm(pk_add_f32_asm(f32x2{r0.z, r0.w}, f32x2{g0.z, g0.w}), f32x2{b0.z, b0.w}).x;
+	const float s1 = pk_add_f32_asm(pk_add_f32_asm(f32x2{r1.z, r1.w}, f32x2{g1.z, g1.w}), f32x2{b1.z, b1.w}).x;
 	// l, m, s are zero only for black (every coefficient is positive, the table is zero at 0 only); their cube roots
 	// are then +0 (entry 0 of the scale table) and so are L = (+0 + +0) - +0, a and b
 	const float x[6] = {lm0.x, lm1.x, lm0.y, lm1.y, s0, s1};
@@ -589,9 +592,6 @@ __global__ void __launch_bounds__(1024) oklab2_kernel(const ShrinkArgs a)
 	float *s_p1 = s_mean + 64;                  // [2][kOk2Band]: converted values, pass 1
 	float *s_p2 = s_p1 + 2 * kOk2Band;          // [3][kOk2Band]: the same values of the batch before, pass 2
 	const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-#if defined(PXZ_EXP) && PXZ_EXP == 4
-	const uint64_t exp_c0 = clock64(), exp_w0 = wall_clock64();
-#endif
 	oklab_fill_tables(s_lms, s_alpha, s_scale, threadIdx.x);
 	__syncthreads();
 
@@ -732,10 +732,14 @@ __global__ void __launch_bounds__(1024) oklab2_kernel(const ShrinkArgs a)
 #pragma unroll
 				for (int q = 0; q < 8; ++q) {
 					if (deviation) {
-						sum += fabsf(v[q].x - mean);  // operations.rs:80-83 with `before` = |x - avg| (pixlzr.rs:160-161)
-						sum += fabsf(v[q].y - mean);
-						sum += fabsf(v[q].z - mean);
-						sum += fabsf(v[q].w - mean);
+						// operations.rs:80-83 with `before` = |x - avg| (pixlzr.rs:160-161); the differences two per packed
+						// instruction (independent of the running sum), |.| as the add's source modifier
+						const f32x2 m2 = {mean, mean};
+						const f32x2 d0 = f32x2{v[q].x, v[q].y} - m2, d1 = f32x2{v[q].z, v[q].w} - m2;
+						sum += fabsf(d0.x);
+						sum += fabsf(d0.y);
+						sum += fabsf(d1.x);
+						sum += fabsf(d1.y);
 					} else {
 						sum += v[q].x;  // operations.rs:60-63, row-major pixel order
 						sum += v[q].y;
@@ -816,12 +820,6 @@ __global__ void __launch_bounds__(1024) oklab2_kernel(const ShrinkArgs a)
 			}
 		}
 	}
-#if defined(PXZ_EXP) && PXZ_EXP == 4
-	if (threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == 100)) {
-		const uint64_t dc = clock64() - exp_c0, dw = wall_clock64() - exp_w0;
-		printf("block %u: %llu shader ticks in %llu x 10 ns = %.3f GHz\n", blockIdx.x, (unsigned long long)dc, (unsigned long long)dw, (double)dc / ((double)dw * 10.0));
-	}
-#endif
 }
 
 hipError_t launch_oklab(const ShrinkArgs &a, uint32_t n_cus, hipStream_t stream)
