@@ -108,14 +108,36 @@ hipError_t launch_pack(const PackArgs &a, hipStream_t stream)
 // .pixlzr bitstream on the GPU: Pixlzr::encode_to_vec (reference src/encoding/mod.rs:40-89) with
 // encode_block (:168-200) and the `qoi` crate 0.4.1 encoder it calls (:181-189).
 //
-// QOI is sequential per tile (previous pixel, run length, 64-entry index), tiles are independent:
-// one lane encodes one tile.  Tiles are first binned by pixel count (counting sort) so that the 64
-// tiles of a wave have the same length and the lanes stay busy together.  Each lane keeps its index
-// in LDS as table[slot][lane] (consecutive lanes -> consecutive banks), reads 4 pixels per 16-byte
-// load from its slot and appends bytes through a 64-bit accumulator (aligned 8-byte stores) into a
-// per-tile scratch record:  "block" | f32 BE value | u32 BE len | w,h BE | channels | 0 | ops | 0x00*7 0x01.
-// Then: scan of the record lengths, splice into the final files, header + per-row length table.
+// QOI is sequential per tile (previous pixel, run length, 64-entry index) and a lane's pixel loop is one long
+// dependent chain (~900 cycles per pixel), so the longest tile of a launch used to set its duration: 1024 pixels on
+// one lane.  Round 2: a tile of n pixels is cut into G = 2^(class - 6) SEGMENTS (class = floor(log2 n); 64..128 pixels
+// each, G = 1 below 128 pixels) that consecutive lanes encode side by side.  What a segment needs from the pixels in
+// front of it is reconstructed exactly:
+//   previous pixel     the pixel before the segment;
+//   index table        a DRY pass over every segment writes its non-repeating pixels into the lane's table and notes the
+//                      written slots; then lane s, for slot s, walks the lanes of each tile in order and hands every
+//                      segment the last value written to that slot before it (the crate stores a pixel in the index
+//                      whenever it is not a repeat of its predecessor, hit or not);
+//   pending run        (pixels repeated so far, modulo the flush at 62) and "an op was written before" (the crate's
+//                      run-of-one INDEX quirk): a segment that is one repeat from end to end passes the count through,
+//                      any other ends with its trailing repeats -- a fixed point reached in as many rounds as there
+//                      are all-repeat segments in a row.
+// A pending run is written by the segment in which it ends, the end marker by the segment holding the last pixel.
+// Tiles are binned by class (counting sort, largest first) so that a wave holds segments of one class; the lanes' tables
+// live in LDS as table[lane][slot] (stride 65: conflict-free for the per-slot walk, random for the pixel loops).
+// Record of a tile in scratch: piece 0 = "block" | f32 BE value | u32 BE len | w,h BE | channels | 0 | ops of segment 0,
+// pieces 1.. = {u32 length, pad} + ops of the segment, at fixed distances; the last one ends with 0x00*7 0x01.
+// Then: scan of the record lengths, splice of the pieces into the final files, header + per-row length table.
 // ---------------------------------------------------------------------------
+constexpr uint32_t kBinCounts = 0, kBinCursor = 32, kBinUnits = 64, kBinTiles = 96, kBinTotal = 128;  // u32 offsets in bins[]
+
+__device__ __host__ __forceinline__ uint32_t qoi_class_segments(uint32_t cls) { return cls <= 6u ? 1u : (cls >= 12u ? 64u : 1u << (cls - 6u)); }
+// pixels per segment (a multiple of 4: the RGBA loads stay 16-byte aligned, the RGB ones dword aligned)
+__device__ __forceinline__ uint32_t qoi_segment_pixels(uint32_t n, uint32_t g) { return ((n + g - 1u) / g + 3u) & ~3u; }
+// scratch record: bytes of piece 0 (header + segment 0) and of every further piece (8-byte length header + segment)
+__device__ __host__ __forceinline__ uint32_t qoi_piece0_bytes(uint32_t seg_px, uint32_t c) { return (23u + seg_px * (c + 1u) + 8u + 8u + 7u) & ~7u; }
+__device__ __host__ __forceinline__ uint32_t qoi_piece_bytes(uint32_t seg_px, uint32_t c) { return (8u + seg_px * (c + 1u) + 8u + 8u + 7u) & ~7u; }
+
 __global__ void __launch_bounds__(256) qoi_bin_count_kernel(const QoiArgs a)
 {
 	// per-block histogram in LDS, then one global atomic per non-empty class and block
@@ -125,18 +147,23 @@ __global__ void __launch_bounds__(256) qoi_bin_count_kernel(const QoiArgs a)
 	const uint32_t t = blockIdx.x * 256u + threadIdx.x;
 	if (t < a.n_tiles) atomicAdd(&s_hist[31u - (uint32_t)__builtin_clz((a.w[t] * a.h[t]) | 1u)], 1u);
 	__syncthreads();
-	if (threadIdx.x < 32 && s_hist[threadIdx.x]) atomicAdd(&a.bins[threadIdx.x], s_hist[threadIdx.x]);
+	if (threadIdx.x < 32 && s_hist[threadIdx.x]) atomicAdd(&a.bins[kBinCounts + threadIdx.x], s_hist[threadIdx.x]);
 }
 
 __global__ void qoi_bin_scan_kernel(const QoiArgs a)
 {
-	// largest tiles first (they set the tail): cursor[c] = start of class c in the permutation
-	uint32_t run = 0;
+	// largest tiles first (they set the tail): where each class starts in the permutation of tiles, and in the run of
+	// segments ("units", a class starts a fresh wave)
+	uint32_t tiles = 0, units = 0;
 	for (int c = 31; c >= 0; --c) {
-		const uint32_t n = a.bins[c];
-		a.bins[32 + c] = run;
-		run += n;
+		const uint32_t n = a.bins[kBinCounts + c];
+		a.bins[kBinCursor + c] = tiles;
+		a.bins[kBinTiles + c] = tiles;
+		a.bins[kBinUnits + c] = units;
+		tiles += n;
+		units += (n * qoi_class_segments((uint32_t)c) + 63u) & ~63u;
 	}
+	a.bins[kBinTotal] = units;
 }
 
 __global__ void __launch_bounds__(256) qoi_bin_scatter_kernel(const QoiArgs a)
@@ -152,7 +179,7 @@ __global__ void __launch_bounds__(256) qoi_bin_scatter_kernel(const QoiArgs a)
 		local = atomicAdd(&s_hist[cls], 1u);
 	}
 	__syncthreads();
-	if (threadIdx.x < 32 && s_hist[threadIdx.x]) s_base[threadIdx.x] = atomicAdd(&a.bins[32u + threadIdx.x], s_hist[threadIdx.x]);
+	if (threadIdx.x < 32 && s_hist[threadIdx.x]) s_base[threadIdx.x] = atomicAdd(&a.bins[kBinCursor + threadIdx.x], s_hist[threadIdx.x]);
 	__syncthreads();
 	if (t < a.n_tiles) a.perm[s_base[cls] + local] = t;
 }
@@ -161,15 +188,6 @@ struct ByteSink {
 	unsigned long long acc;
 	uint32_t cnt;        // bytes in acc (0..7)
 	unsigned long long *out;
-	__device__ __forceinline__ void put(uint32_t b)
-	{
-		acc |= (unsigned long long)(b & 255u) << (8u * cnt);
-		if (++cnt == 8u) {
-			*out++ = acc;
-			acc = 0;
-			cnt = 0;
-		}
-	}
 	// n <= 8 bytes at once, first byte in the low bits of v (bits above 8n must be zero)
 	__device__ __forceinline__ void append(unsigned long long v, uint32_t n)
 	{
@@ -185,69 +203,180 @@ struct ByteSink {
 	}
 };
 
-// One wave per block: the 16 KB index table of a wave is what limits residency (ten waves per CU), and the lanes'
-// pixel loops are latency chains that only other waves can hide.
-constexpr uint32_t kQoiWaves = 1;
-template <int C>
-__global__ void __launch_bounds__(64 * kQoiWaves) qoi_tiles_kernel(const QoiArgs a)
+__device__ __forceinline__ uint32_t qoi_hash(uint32_t px)
 {
-	__shared__ uint32_t s_index[kQoiWaves][65][64];  // [wave][slot][lane]; row 64 takes the writes of lanes that have none
-	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-	const uint32_t i = blockIdx.x * (64u * kQoiWaves) + threadIdx.x;
-	const bool live = i < a.n_tiles;
-	const uint32_t t = live ? a.perm[i] : 0u;
-	uint32_t(*index)[64] = s_index[wave];
-#pragma unroll 8
-	for (int sidx = 0; sidx < 64; ++sidx) index[sidx][lane] = 0u;  // qoi: index starts as zero pixels
-	if (!live) return;
-	const uint32_t w = a.w[t], h = a.h[t], n = w * h;
-	const uint8_t *src = a.slots + (size_t)t * a.slot_bytes;
-	uint8_t *rec = a.scratch + (size_t)t * a.stride;
-	ByteSink s{0ull, 0u, reinterpret_cast<unsigned long long *>(rec)};
-	// encode_block: magic, value, length placeholder (mod.rs:172-178,195)
-	const uint32_t vb = __float_as_uint(a.value[t]);
-	// then the qoi header minus its 4-byte magic (mod.rs:191): width, height BE, channels, colourspace 0 -- 23 bytes
-	auto be = [](uint32_t v) -> unsigned long long { return (unsigned long long)__builtin_bswap32(v); };  // BE bytes, first one lowest
-	s.append(0x6b636f6c62ull | (be(vb) << 40), 8);                   // "block", value bytes 0..2
-	s.append((be(vb) >> 24) | (be(w) << 40), 8);                      // value byte 3, four zero bytes (length, patched below), w bytes 0..2
-	s.append((be(w) >> 24) | (be(h) << 8) | ((unsigned long long)C << 40), 7);  // w byte 3, h, channels, colourspace 0
+	return __builtin_amdgcn_udot4(px, 0x0b070503u, 0u, false) & 63u;  // r*3 + g*5 + b*7 + a*11: one v_dot4_u32_u8
+}
 
-	uint32_t prev = 0xff000000u, run = 0, last_slot = 0;
-	bool seen_op = false;
-	const bool aligned = C == 4 ? true : ((a.slot_bytes & 3u) == 0);
-	// (RGBA: the next four pixels are requested before the current four are encoded -- a lane's pixel loop is one
-	// dependent chain, and a memory round trip every four pixels was most of its time.  The request may run past the
-	// tile's pixels, never past its slot.)
-	uint4 ahead = make_uint4(0, 0, 0, 0);
-	if constexpr (C == 4) ahead = *reinterpret_cast<const uint4 *>(src);
-	const uint32_t slot_px = a.slot_bytes / 4u;
-	for (uint32_t base = 0; base < n; base += 4u) {
-		uint32_t px4[4];
-		if constexpr (C == 4) {
-			const uint4 v = ahead;  // slots are 16-byte aligned
-			if (base + 4u < slot_px) ahead = *reinterpret_cast<const uint4 *>(src + (size_t)(base + 4u) * 4u);
-			px4[0] = v.x; px4[1] = v.y; px4[2] = v.z; px4[3] = v.w;
+// pixel i of a tile's slot (RGB: alpha 255 added)
+template <int C>
+__device__ __forceinline__ uint32_t qoi_pixel(const uint8_t *src, uint32_t i)
+{
+	if constexpr (C == 4) return reinterpret_cast<const uint32_t *>(src)[i];
+	const uint8_t *p = src + (size_t)i * 3u;
+	return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | 0xff000000u;
+}
+
+// four pixels from pixel `base` on (base a multiple of 4); may run past the tile's pixels, never past its slot of
+// `slot_px` pixels (RGBA slots are whole pixel quads)
+template <int C>
+__device__ __forceinline__ void qoi_load4(const uint8_t *src, uint32_t base, bool dword_aligned, uint32_t slot_px, uint32_t (&px4)[4])
+{
+	if (C == 3 && base + 4u > slot_px) {
+		for (int j = 0; j < 4; ++j) px4[j] = base + (uint32_t)j < slot_px ? qoi_pixel<3>(src, base + (uint32_t)j) : 0u;
+		return;
+	}
+	if constexpr (C == 4) {
+		const uint4 v = *reinterpret_cast<const uint4 *>(src + (size_t)base * 4u);
+		px4[0] = v.x; px4[1] = v.y; px4[2] = v.z; px4[3] = v.w;
+	} else {
+		if (dword_aligned) {
+			const uint32_t *p = reinterpret_cast<const uint32_t *>(src + (size_t)base * 3u);
+			const uint32_t d0 = p[0], d1 = p[1], d2 = p[2];
+			px4[0] = d0 & 0xffffffu;
+			px4[1] = (d0 >> 24) | ((d1 & 0xffffu) << 8);
+			px4[2] = (d1 >> 16) | ((d2 & 0xffu) << 16);
+			px4[3] = d2 >> 8;
 		} else {
-			if (aligned) {
-				const uint32_t *p = reinterpret_cast<const uint32_t *>(src + (size_t)base * 3u);
-				const uint32_t d0 = p[0], d1 = p[1], d2 = p[2];
-				px4[0] = d0 & 0xffffffu;
-				px4[1] = (d0 >> 24) | ((d1 & 0xffffu) << 8);
-				px4[2] = (d1 >> 16) | ((d2 & 0xffu) << 16);
-				px4[3] = d2 >> 8;
-			} else {
-				for (int j = 0; j < 4; ++j) {
-					const uint8_t *p = src + (size_t)(base + j) * 3u;
-					px4[j] = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16);
-				}
+			for (int j = 0; j < 4; ++j) {
+				const uint8_t *p = src + (size_t)(base + j) * 3u;
+				px4[j] = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16);
 			}
-#pragma unroll
-			for (int j = 0; j < 4; ++j) px4[j] |= 0xff000000u;
 		}
+#pragma unroll
+		for (int j = 0; j < 4; ++j) px4[j] |= 0xff000000u;
+	}
+}
+
+// One wave per block: the 16 KB index table of a wave is what limits residency (nine waves per CU), and the lanes'
+// pixel loops are latency chains that only other waves can hide.
+constexpr uint32_t kQoiWaves = 1;  // waves per block of the decoder (one 16 KB table per wave)
+constexpr uint32_t kQoiRow = 65;  // table[lane][slot] row stride (dwords / bytes)
+template <int C>
+__global__ void __launch_bounds__(64) qoi_tiles_kernel(const QoiArgs a)
+{
+	__shared__ uint32_t s_index[64 * kQoiRow];
+	__shared__ uint32_t s_written[64][2];  // per lane: which slots its dry pass wrote (bit s of the 64-bit mask)
+	const uint32_t lane = threadIdx.x;
+	const uint32_t unit0 = blockIdx.x * 64u;
+	if (unit0 >= a.bins[kBinTotal]) return;  // (the grid covers the worst case: every tile in the largest class)
+	// this wave's class: the one whose run of units holds unit0 (classes in descending order, runs padded to whole waves)
+	// (lane c looks at class c: one round trip to the counters instead of a walk)
+	uint32_t cls = 0;
+	{
+		const uint32_t c = lane & 31u;
+		const uint32_t ub = a.bins[kBinUnits + c], nu = (a.bins[kBinCounts + c] * qoi_class_segments(c) + 63u) & ~63u;
+		const unsigned long long mine = __ballot(lane < 32u && unit0 >= ub && unit0 < ub + nu);
+		cls = (uint32_t)__builtin_ctzll(mine | (1ull << 63));
+	}
+	const uint32_t G = qoi_class_segments(cls);  // lanes per tile (a power of two)
+	const uint32_t rel = unit0 - a.bins[kBinUnits + cls] + lane;
+	const uint32_t rank = rel / G, seg = rel & (G - 1u);
+	const bool live = rank < a.bins[kBinCounts + cls];
+	const uint32_t t = live ? a.perm[a.bins[kBinTiles + cls] + rank] : 0u;
+	const uint32_t w = live ? a.w[t] : 0u, h = live ? a.h[t] : 0u, n = w * h;
+	const uint32_t seg_px = qoi_segment_pixels(n ? n : 1u, G);  // (the same value the splice kernel derives from n)
+	const uint32_t start = seg * seg_px, end = start + seg_px < n ? start + seg_px : n;
+	const uint32_t len = start < n ? end - start : 0u;
+	const uint8_t *src = a.slots + (size_t)t * a.slot_bytes;
+	const bool aligned = C == 4 ? true : ((a.slot_bytes & 3u) == 0);
+	const uint32_t slot_px = a.slot_bytes / (uint32_t)C;
+	uint32_t *index = s_index + lane * kQoiRow;
+#pragma unroll 8
+	for (int sidx = 0; sidx < 64; ++sidx) index[sidx] = 0u;  // qoi: the index starts as zero pixels
+	uint32_t wr_lo = 0u, wr_hi = 0u;
+	const uint32_t first_prev = (len && start) ? qoi_pixel<C>(src, start - 1u) : 0xff000000u;  // qoi: previous pixel starts as opaque black
+
+	// ---- dry pass (G > 1): what this segment leaves in the index, its trailing repeats, whether it is all repeats
+	uint32_t trail = 0;
+	bool all_same = true;
+	if (G > 1u) {
+		uint32_t prev = first_prev;
+		for (uint32_t base = start; base < end; base += 4u) {
+			uint32_t px4[4];
+			qoi_load4<C>(src, base, aligned, slot_px, px4);
+#pragma unroll
+			for (int j = 0; j < 4; ++j) {
+				if (base + (uint32_t)j >= end) break;
+				const uint32_t px = px4[j];
+				if (px != prev) {
+					const uint32_t slot = qoi_hash(px);
+					index[slot] = px;
+					const uint32_t bit = 1u << (slot & 31u);
+					wr_lo |= slot < 32u ? bit : 0u;
+					wr_hi |= slot < 32u ? 0u : bit;
+					trail = 0;
+					all_same = false;
+				} else {
+					++trail;
+				}
+				prev = px;
+			}
+		}
+	}
+	s_written[lane][0] = wr_lo;
+	s_written[lane][1] = wr_hi;
+	__syncthreads();
+	// ---- the index every segment starts from: lane s walks slot s over the lanes in order
+	if (G > 1u) {
+		uint32_t cur = 0u;
+		const uint32_t half = lane >> 5, bit = lane & 31u;
+#pragma unroll 8
+		for (uint32_t j = 0; j < 64u; ++j) {
+			if ((j & (G - 1u)) == 0u) cur = 0u;  // a new tile: zero pixels
+			const uint32_t v = s_index[j * kQoiRow + lane];
+			const uint32_t f = (s_written[j][half] >> bit) & 1u;
+			s_index[j * kQoiRow + lane] = cur;
+			cur = f ? v : cur;
+		}
+	}
+	__syncthreads();
+	// ---- pending run and "an op was written" at the start of every segment
+	uint32_t run_in = 0;
+	bool seen_in = false;
+	if (G > 1u) {
+		uint32_t run_out = all_same ? len % 62u : trail % 62u;
+		for (uint32_t round = 0; round < G; ++round) {
+			const uint32_t left = __shfl_up(run_out, 1, 64);
+			run_in = seg ? left : 0u;
+			const uint32_t next = all_same ? (run_in + len) % 62u : trail % 62u;
+			const bool changed = next != run_out;
+			run_out = next;
+			if (!__any(changed)) break;
+		}
+		const unsigned long long ops = __ballot(!all_same);  // segments that write at least one op
+		const uint32_t first_lane = lane - seg;
+		const unsigned long long before = (ops >> first_lane) & ((1ull << seg) - 1ull);
+		seen_in = before != 0ull;
+	}
+	if (!live) return;
+
+	// ---- the segment's ops
+	uint8_t *rec = a.scratch + (size_t)t * a.stride;
+	uint8_t *piece = seg ? rec + qoi_piece0_bytes(seg_px, C) + (size_t)(seg - 1u) * qoi_piece_bytes(seg_px, C) : rec;
+	ByteSink s{0ull, 0u, reinterpret_cast<unsigned long long *>(seg ? piece + 8 : piece)};
+	if (seg == 0u) {
+		// encode_block: magic, value, length placeholder (mod.rs:172-178,195), then the qoi header minus its 4-byte magic
+		// (mod.rs:191): width, height BE, channels, colourspace 0 -- 23 bytes
+		const uint32_t vb = __float_as_uint(a.value[t]);
+		auto be = [](uint32_t v) -> unsigned long long { return (unsigned long long)__builtin_bswap32(v); };  // BE bytes, first one lowest
+		s.append(0x6b636f6c62ull | (be(vb) << 40), 8);                   // "block", value bytes 0..2
+		s.append((be(vb) >> 24) | (be(w) << 40), 8);                      // value byte 3, four zero bytes (length, patched below), w bytes 0..2
+		s.append((be(w) >> 24) | (be(h) << 8) | ((unsigned long long)C << 40), 7);  // w byte 3, h, channels, colourspace 0
+	}
+	uint32_t prev = first_prev, run = run_in, last_slot = qoi_hash(first_prev);
+	bool seen_op = seen_in;
+	// (the next four pixels are requested before the current four are encoded -- a lane's pixel loop is one dependent
+	// chain, and a memory round trip every four pixels was most of its time)
+	uint32_t ahead[4] = {0, 0, 0, 0};
+	if (len) qoi_load4<C>(src, start, aligned, slot_px, ahead);
+	for (uint32_t base = start; base < end; base += 4u) {
+		uint32_t px4[4] = {ahead[0], ahead[1], ahead[2], ahead[3]};
+		if (base + 4u < end) qoi_load4<C>(src, base + 4u, aligned, slot_px, ahead);
 #pragma unroll
 		for (int j = 0; j < 4; ++j) {
 			const uint32_t pi = base + (uint32_t)j;
-			if (pi >= n) break;
+			if (pi >= end) break;
 			// One pixel, without branches: the lanes of a wave sit in different ops at every pixel, and a wave that
 			// takes every branch in turn spends its time in the ones its lanes did not want.  Every candidate op is
 			// worked out, selects pick the bytes (a pending run byte first), one append writes them.
@@ -260,9 +389,9 @@ __global__ void __launch_bounds__(64 * kQoiWaves) qoi_tiles_kernel(const QoiArgs
 			// written before (the crate's quirk), else as RUN
 			const uint32_t pre_byte = (run == 1u && seen_op) ? last_slot : (0xc0u | (run - 1u));
 			const uint32_t pre_len = run ? 1u : 0u;
-			const uint32_t slot = ((px & 255u) * 3u + ((px >> 8) & 255u) * 5u + ((px >> 16) & 255u) * 7u + (px >> 24) * 11u) & 63u;
-			const bool hit = index[slot][lane] == px;
-			index[same ? 64u : slot][lane] = px;  // (a hit rewrites the same value)
+			const uint32_t slot = qoi_hash(px);
+			const bool hit = index[slot] == px;
+			index[same ? 64u : slot] = px;  // (a hit rewrites the same value; slot 64 takes the writes of repeats)
 			const uint32_t dr = ((px & 255u) - (prev & 255u)) & 255u;
 			const uint32_t dg = (((px >> 8) & 255u) - ((prev >> 8) & 255u)) & 255u;
 			const uint32_t db = (((px >> 16) & 255u) - ((prev >> 16) & 255u)) & 255u;
@@ -301,18 +430,48 @@ __global__ void __launch_bounds__(64 * kQoiWaves) qoi_tiles_kernel(const QoiArgs
 			prev = px;  // (unchanged when the pixel repeats)
 		}
 	}
-	s.append(0x0100000000000000ull, 8);  // QOI end marker: seven zero bytes and a one
-	const uint32_t total = (uint32_t)(reinterpret_cast<uint8_t *>(s.out) - rec) + s.cnt;
-	if (s.cnt) *s.out = s.acc;  // partial tail (the record stride leaves room)
-	const uint32_t qlen = total - 13u;  // mod.rs:193-195
-	rec[9] = (uint8_t)(qlen >> 24);
-	rec[10] = (uint8_t)(qlen >> 16);
-	rec[11] = (uint8_t)(qlen >> 8);
-	rec[12] = (uint8_t)qlen;
-	a.rec_len[t] = total;
+	if (len && end == n) s.append(0x0100000000000000ull, 8);  // QOI end marker: seven zero bytes and a one
+	uint32_t bytes_here = (uint32_t)(reinterpret_cast<uint8_t *>(s.out) - (seg ? piece + 8 : piece)) + s.cnt;
+	if (s.cnt) *s.out = s.acc;  // partial tail (the piece leaves room)
+	if (seg) *reinterpret_cast<uint32_t *>(piece) = bytes_here;
+	// the record's length: every piece of the tile (a butterfly over the tile's lanes; all of them are here)
+	uint32_t total = bytes_here;
+	for (uint32_t d = 1; d < G; d <<= 1) total += __shfl_xor(total, (int)d, 64);
+	if (seg == 0u) {
+		const uint32_t qlen = total - 13u;  // mod.rs:193-195
+		rec[9] = (uint8_t)(qlen >> 24);
+		rec[10] = (uint8_t)(qlen >> 16);
+		rec[11] = (uint8_t)(qlen >> 8);
+		rec[12] = (uint8_t)qlen;
+		a.rec_len[t] = total;
+	}
 }
 
-// splice: one wave per tile copies its record to (frame+1)*hdr + offset[t]
+// bytes [0, len) from src (8-byte aligned) to dst (any alignment), by `width` lanes (lane = 0 .. width-1): whole aligned
+// dwords of the destination, each from two aligned dwords of the source; the bytes before the first and after the last
+// one (shared with the neighbouring pieces' dwords) one by one
+__device__ __forceinline__ void splice_piece(uint8_t *dst, const uint8_t *src, uint32_t len, uint32_t lane, uint32_t width)
+{
+	const uint32_t head = (uint32_t)((4u - (uint32_t)(reinterpret_cast<uintptr_t>(dst) & 3u)) & 3u);
+	if (len < 8u + head) {
+		for (uint32_t i = lane; i < len; i += width) dst[i] = src[i];
+		return;
+	}
+	if (lane < head) dst[lane] = src[lane];
+	const uint32_t n_dw = (len - head) / 4u, tail = head + 4u * n_dw;
+	const uint32_t *s32 = reinterpret_cast<const uint32_t *>(src);
+	uint32_t *d32 = reinterpret_cast<uint32_t *>(dst + head);
+	const uint32_t sh = head & 3u;  // source byte offset of destination dword j is head + 4j
+	for (uint32_t j = lane; j < n_dw; j += width) {
+		const uint32_t lo = s32[j + (head >> 2)], hi = sh ? s32[j + (head >> 2) + 1u] : 0u;  // (the piece leaves room behind it)
+		d32[j] = sh ? __builtin_amdgcn_alignbyte(hi, lo, sh) : lo;
+	}
+	if (lane < len - tail) dst[tail + lane] = src[tail + lane];
+}
+
+// splice: one wave per tile copies the pieces of its record to (frame+1)*hdr + offset[t]; the pieces of a segmented tile
+// four at a time, a quarter wave each.  (A quarter wave per TILE -- four times fewer waves -- was tried: 0.33 ms
+// against 0.25, the short records' byte copies then take three rounds of 16 lanes instead of one of 64.)
 __global__ void __launch_bounds__(256) qoi_splice_kernel(const QoiArgs a)
 {
 	const uint32_t t = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
@@ -323,25 +482,35 @@ __global__ void __launch_bounds__(256) qoi_splice_kernel(const QoiArgs a)
 	const unsigned long long dstoff = (unsigned long long)(frame + 1u) * a.hdr_bytes + off;
 	const uint32_t len = a.rec_len[t];
 	if (dstoff + len > a.capacity) return;
-	const uint8_t *src = a.scratch + (size_t)t * a.stride;  // 8-byte aligned (records sit at a stride of whole qwords)
+	const uint8_t *rec = a.scratch + (size_t)t * a.stride;  // 8-byte aligned (records sit at a stride of whole qwords)
 	uint8_t *dst = a.out + dstoff;
-	// whole aligned dwords of the destination, each from two aligned dwords of the record; the bytes before the first
-	// and after the last one (shared with the neighbouring records' dwords) one by one
-	const uint32_t head = (uint32_t)((4u - (uint32_t)(reinterpret_cast<uintptr_t>(dst) & 3u)) & 3u);
-	if (len < 8u + head) {
-		for (uint32_t i = lane; i < len; i += 64u) dst[i] = src[i];
+	const uint32_t n = a.w[t] * a.h[t];
+	const uint32_t G = qoi_class_segments(31u - (uint32_t)__builtin_clz(n | 1u));
+	if (G == 1u) {
+		splice_piece(dst, rec, len, lane, 64u);
 		return;
 	}
-	if (lane < head) dst[lane] = src[lane];
-	const uint32_t n_dw = (len - head) / 4u, tail = head + 4u * n_dw;
-	const uint32_t *s32 = reinterpret_cast<const uint32_t *>(src);
-	uint32_t *d32 = reinterpret_cast<uint32_t *>(dst + head);
-	const uint32_t sh = head & 3u;  // source byte offset of destination dword j is head + 4j
-	for (uint32_t j = lane; j < n_dw; j += 64u) {
-		const uint32_t lo = s32[j + (head >> 2)], hi = sh ? s32[j + (head >> 2) + 1u] : 0u;  // (the record's stride leaves room behind it)
-		d32[j] = sh ? __builtin_amdgcn_alignbyte(hi, lo, sh) : lo;
+	const uint32_t seg_px = qoi_segment_pixels(n, G), p0 = qoi_piece0_bytes(seg_px, a.channels), pn = qoi_piece_bytes(seg_px, a.channels);
+	// lane j holds the length of piece j (G <= 64; piece 0 is what the others leave of the record) and, after the scan,
+	// where it starts; quarter waves then copy pieces side by side
+	uint32_t mine = (lane >= 1u && lane < G) ? *reinterpret_cast<const uint32_t *>(rec + p0 + (size_t)(lane - 1u) * pn) : 0u;
+	if (mine > pn - 8u) mine = 0u;  // (cannot happen)
+	uint32_t others = mine;
+	for (uint32_t d = 1; d < 64u; d <<= 1) others += __shfl_xor(others, (int)d, 64);
+	if (others > len || len - others > p0) return;  // (cannot happen: the pieces add up to the record)
+	if (lane == 0u) mine = len - others;
+	uint32_t startpos = mine;  // inclusive scan, then minus own = exclusive
+	for (uint32_t d = 1; d < 64u; d <<= 1) {
+		const uint32_t up = __shfl_up(startpos, d, 64);
+		if (lane >= d) startpos += up;
 	}
-	if (lane < len - tail) dst[tail + lane] = src[tail + lane];
+	startpos -= mine;
+	const uint32_t quarter = lane >> 4, ql = lane & 15u;
+	for (uint32_t j0 = 0; j0 < G; j0 += 4u) {
+		const uint32_t j = j0 + quarter;
+		const uint32_t lj = __shfl(mine, (int)(j & 63u), 64), pj = __shfl(startpos, (int)(j & 63u), 64);
+		if (j < G && lj) splice_piece(dst + pj, j ? rec + p0 + (size_t)(j - 1u) * pn + 8u : rec, lj, ql, 16u);
+	}
 }
 
 // file header + line-length table (mod.rs:50-57,77-82): one thread per (frame, tile row)
@@ -378,15 +547,20 @@ __global__ void __launch_bounds__(256) qoi_headers_kernel(const QoiArgs a)
 
 hipError_t launch_qoi(const QoiArgs &a, hipStream_t stream)
 {
-	hipError_t e = hipMemsetAsync(a.bins, 0, 64 * sizeof(uint32_t), stream);
+	hipError_t e = hipMemsetAsync(a.bins, 0, 160 * sizeof(uint32_t), stream);
 	if (e != hipSuccess) return e;
 	const uint32_t tb = (a.n_tiles + 255u) / 256u;
 	hipLaunchKernelGGL(qoi_bin_count_kernel, dim3(tb), dim3(256), 0, stream, a);
 	hipLaunchKernelGGL(qoi_bin_scan_kernel, dim3(1), dim3(1), 0, stream, a);
 	hipLaunchKernelGGL(qoi_bin_scatter_kernel, dim3(tb), dim3(256), 0, stream, a);
-	const uint32_t qb = (a.n_tiles + 64u * kQoiWaves - 1u) / (64u * kQoiWaves);
-	if (a.channels == 4) hipLaunchKernelGGL(qoi_tiles_kernel<4>, dim3(qb), dim3(64u * kQoiWaves), 0, stream, a);
-	else hipLaunchKernelGGL(qoi_tiles_kernel<3>, dim3(qb), dim3(64u * kQoiWaves), 0, stream, a);
+	// one wave per 64 segments; the number of segments is only known on the device, so the grid covers the worst case
+	// (every tile in the class of a full slot, every class padded to a whole wave) and the surplus waves leave at once
+	const uint32_t slot_px = a.slot_bytes / a.channels, top = 31u - (uint32_t)__builtin_clz(slot_px | 1u);
+	const unsigned long long worst = ((unsigned long long)a.n_tiles * qoi_class_segments(top) + 63ull) / 64ull + 32ull;
+	if (worst > 0x7fffffffull) return hipErrorInvalidValue;
+	const uint32_t qb = (uint32_t)worst;
+	if (a.channels == 4) hipLaunchKernelGGL(qoi_tiles_kernel<4>, dim3(qb), dim3(64u), 0, stream, a);
+	else hipLaunchKernelGGL(qoi_tiles_kernel<3>, dim3(qb), dim3(64u), 0, stream, a);
 	// exclusive scan of the record lengths (same chunked scan as the pixel pack, sizes given)
 	PackArgs p{};
 	p.sizes = a.rec_len;
@@ -682,7 +856,7 @@ __global__ void __launch_bounds__(64 * kQoiWaves) qoi_decode_kernel(const Decode
 
 hipError_t launch_decode(const DecodeArgs &a, hipStream_t stream)
 {
-	hipError_t e = hipMemsetAsync(a.bins, 0, 64 * sizeof(uint32_t), stream);
+	hipError_t e = hipMemsetAsync(a.bins, 0, 160 * sizeof(uint32_t), stream);
 	if (e != hipSuccess) return e;
 	hipLaunchKernelGGL(pixlzr_index_kernel, dim3((a.n_frames * a.rows + 3u) / 4u), dim3(256), 0, stream, a);
 	const uint32_t tb = (a.n_tiles + 255u) / 256u;
