@@ -146,11 +146,14 @@ static int qoi_decode_body(const uint8_t *body, size_t len, uint32_t *w, uint32_
 			run--;
 		} else if (p < end) {
 			uint8_t b1 = *p++;
+			int is_run = 0;
 			if (b1 == QOI_OP_RGB) {
 				px[0] = *p++;
 				px[1] = *p++;
 				px[2] = *p++;
 			} else if (b1 == QOI_OP_RGBA) {
+				if (*c == 3)
+					return -4; /* the crate's 3-channel decoder has no arm for 0xff: malformed */
 				px[0] = *p++;
 				px[1] = *p++;
 				px[2] = *p++;
@@ -169,8 +172,12 @@ static int qoi_decode_body(const uint8_t *body, size_t len, uint32_t *w, uint32_
 				px[2] = (uint8_t)(px[2] + vg - 8 + (b2 & 0x0f));
 			} else {
 				run = b1 & 0x3f;
+				is_run = 1;
 			}
-			memcpy(index[(px[0] * 3 + px[1] * 5 + px[2] * 7 + px[3] * 11) % 64], px, 4);
+			/* qoi 0.4.1: the RUN (and INDEX) arms continue with the next op before the index store; only a
+			 * stream that opens with a run of the implicit opaque black can tell */
+			if (!is_run)
+				memcpy(index[(px[0] * 3 + px[1] * 5 + px[2] * 7 + px[3] * 11) % 64], px, 4);
 		} else {
 			return -3;
 		}

@@ -37,8 +37,14 @@ thread_local HandleCache g_handles;
 
 }  // namespace
 
-uint32_t Pixlzr::block_grid_width() const { return (uint32_t)std::ceil((float)width / (float)block_width); }
-uint32_t Pixlzr::block_grid_height() const { return (uint32_t)std::ceil((float)height / (float)block_height); }
+// (pixlzr.rs:36-46 rounds up in f32; pxz_grid is the integer ceiling, equal to it up to 2^24 and refusing larger sides)
+static void grid_of(const Pixlzr &p, uint32_t &cols, uint32_t &rows)
+{
+	if (pxz_grid(p.width, p.height, p.block_width, p.block_height, &cols, &rows) != PXZ_OK)
+		throw std::runtime_error("Pixlzr: zero block size or image side above 2^24");
+}
+uint32_t Pixlzr::block_grid_width() const { uint32_t c, r; grid_of(*this, c, r); return c; }
+uint32_t Pixlzr::block_grid_height() const { uint32_t c, r; grid_of(*this, c, r); return r; }
 
 Pixlzr Pixlzr::from_image(const ImageView &image, uint32_t bw, uint32_t bh)
 {

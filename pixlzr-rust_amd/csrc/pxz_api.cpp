@@ -68,6 +68,8 @@ struct DeviceBuffer {
 
 }  // namespace
 
+constexpr uint32_t kMaxImageSide = 1u << 24;  // see pxz_grid
+
 struct pxz_handle {
 	int device = 0;
 	uint32_t n_cus = 256;
@@ -472,6 +474,8 @@ int check_frames(pxz_handle *h, const pxz_frames *f, const pxz_params *p)
 	if (!h) return PXZ_ERR_INVALID_ARG;
 	if (!f || !p) return fail(h, PXZ_ERR_INVALID_ARG, "null descriptor");
 	if (f->width == 0 || f->height == 0 || f->n_frames == 0) return fail(h, PXZ_ERR_INVALID_ARG, "empty frame batch");
+	if (f->width > kMaxImageSide || f->height > kMaxImageSide)
+		return fail(h, PXZ_ERR_UNSUPPORTED, "image sides above 2^24 are not supported (the reference's f32 and f64 tile grids part there)");
 	if (f->channels != 3 && f->channels != 4) return fail(h, PXZ_ERR_INVALID_ARG, "channels must be 3 or 4, got %u", f->channels);
 	if ((uint64_t)f->pitch_bytes < (uint64_t)f->width * f->channels) return fail(h, PXZ_ERR_INVALID_ARG, "pitch smaller than a row");
 	if (f->n_frames > 1 && f->frame_stride_bytes < (uint64_t)f->pitch_bytes * f->height)
@@ -835,9 +839,13 @@ int pxz_synchronize(pxz_handle *h)
 int pxz_grid(uint32_t width, uint32_t height, uint32_t block_w, uint32_t block_h, uint32_t *cols, uint32_t *rows)
 {
 	if (!cols || !rows || block_w == 0 || block_h == 0) return PXZ_ERR_INVALID_ARG;
-	// ceil in f64 like iter.rs:38-41; exact for u32 operands
-	*cols = (uint32_t)std::ceil((double)width / (double)block_w);
-	*rows = (uint32_t)std::ceil((double)height / (double)block_h);
+	// The reference rounds up in f64 when it splits an image (iter.rs:38-41, split.rs:45-46) and in f32 when it writes
+	// and expands one (pixlzr.rs:36-46).  Up to 2^24 both are the integer ceiling; beyond, the f32 form can differ from
+	// it (and the reference's own two grids from each other), so larger images are refused here and by every entry
+	// point -- ONE grid, this one, is used throughout the library.
+	if (width > kMaxImageSide || height > kMaxImageSide) return PXZ_ERR_UNSUPPORTED;
+	*cols = (uint32_t)(((uint64_t)width + block_w - 1u) / block_w);
+	*rows = (uint32_t)(((uint64_t)height + block_h - 1u) / block_h);
 	return PXZ_OK;
 }
 
@@ -1337,9 +1345,9 @@ int pxz_encode_frames_device(pxz_handle *h, const pxz_frames *frames, const pxz_
 	if (frames->channels != 3 && frames->channels != 4) return fail(h, PXZ_ERR_INVALID_ARG, "channels must be 3 or 4");
 	if (params->block_w == 0 || params->block_h == 0 || frames->n_frames == 0) return fail(h, PXZ_ERR_INVALID_ARG, "bad geometry");
 	PXZ_HIP(h, hipSetDevice(h->device));
-	// grid in f32 like the container code (pixlzr.rs:36-46)
-	const uint32_t cols = (uint32_t)std::ceil((float)frames->width / (float)params->block_w);
-	const uint32_t rows = (uint32_t)std::ceil((float)frames->height / (float)params->block_h);
+	uint32_t cols, rows;
+	if (pxz_grid(frames->width, frames->height, params->block_w, params->block_h, &cols, &rows) != PXZ_OK)
+		return fail(h, PXZ_ERR_UNSUPPORTED, "image sides above 2^24 are not supported");
 	const uint64_t tiles64 = (uint64_t)cols * rows * frames->n_frames;
 	if (tiles64 > 0xffffffffull) return fail(h, PXZ_ERR_UNSUPPORTED, "too many tiles");
 	const uint32_t n_tiles = (uint32_t)tiles64, c = frames->channels;

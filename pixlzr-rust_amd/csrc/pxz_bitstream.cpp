@@ -116,12 +116,6 @@ size_t qoi_stream(const uint8_t *data, uint32_t w, uint32_t h, uint32_t channels
 	return (size_t)(s.p - out);
 }
 
-// f32 grid math of the container (reference src/data_types/pixlzr.rs:36-46)
-inline uint32_t grid_f32(uint32_t size, uint32_t block)
-{
-	return (uint32_t)std::ceil((float)size / (float)block);
-}
-
 }  // namespace
 
 extern "C" {
@@ -147,7 +141,9 @@ int64_t pxz_encode_container(uint32_t width, uint32_t height, uint32_t block_w, 
 	if (!block_value || !tile_w || !tile_h || (channels != 3 && channels != 4) || block_w == 0 || block_h == 0 ||
 	    width == 0 || height == 0)
 		return PXZ_ERR_INVALID_ARG;
-	const uint32_t cols = grid_f32(width, block_w), rows = grid_f32(height, block_h);
+	// the library's one grid (pxz_grid: integer ceiling = the reference's f32 and f64 forms up to 2^24, refused beyond)
+	uint32_t cols, rows;
+	if (pxz_grid(width, height, block_w, block_h, &cols, &rows) != PXZ_OK) return PXZ_ERR_UNSUPPORTED;
 	const size_t slot = (size_t)block_w * block_h * channels;
 
 	// per-row upper bounds -> each row of tiles is encoded into its own span

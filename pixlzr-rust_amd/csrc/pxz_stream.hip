@@ -812,8 +812,14 @@ __global__ void __launch_bounds__(64 * kQoiWaves) qoi_decode_kernel(const Decode
 		}
 		px = take ? cand : px;
 		run = in_run ? run - 1u : (take ? new_run : 0u);
-		// every op (RUN included) stores its pixel in the index; the repeats of a run do not
-		index[take ? ((px & 255u) * 3u + ((px >> 8) & 255u) * 5u + ((px >> 16) & 255u) * 7u + (px >> 24) * 11u) & 63u : 64u][lane] = px;
+		// The qoi crate stores the pixel in the index after RGB / RGBA / DIFF / LUMA ops only: its RUN and INDEX arms go
+		// on to the next op before the store (an INDEX op's pixel is in its slot already; a RUN's is too, except when the
+		// stream OPENS with a run of the implicit opaque black, which is never stored -- the encoder's run-of-one quirk
+		// has the same root).  A 3-channel stream has no RGBA op: the crate's decoder for 3 channels does not match 0xff,
+		// which ends in its error arm -- the record is flagged as malformed.
+		const bool is_run_op = tag == 0xc0u && b1 < 0xfeu;
+		if (C == 3 && take && b1 == 0xffu) starved = true;
+		index[(take && !is_run_op) ? qoi_hash(px) : 64u][lane] = px;
 		const uint32_t step = take ? used : 0u;
 		left = left > step ? left - step : 0u;
 		pos += step;

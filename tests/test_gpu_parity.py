@@ -738,3 +738,43 @@ def test_seeded_sweep_of_geometries(gpu, oracle, i, w, h, bw, bh, c, mode, filt)
     got = gpu.shrink_image(img, bw, bh, mode, filt, factor)
     exp = oracle.shrink_image(img, bw, bh, mode, filt, factor)
     assert_same_tiles(got, exp, c, f"case {i}: {w}x{h} b{bw}x{bh} c{c} mode{mode} f{filt} k={factor}")
+
+
+def _one_tile_file(w, h, c, ops):
+    """A .pixlzr file of one w x h tile whose QOI op stream is `ops` (bytes), laid out as encode_block does."""
+    import struct
+    body = struct.pack(">IIBB", w, h, c, 0) + bytes(ops) + bytes([0, 0, 0, 0, 0, 0, 0, 1])
+    rec = b"block" + struct.pack(">f", 0.5) + struct.pack(">I", len(body)) + body
+    head = b"PIXLZR" + bytes([0, 0, 2, 0]) + struct.pack(">IIII", w, h, w, h) + struct.pack(">I", len(rec))
+    return head + rec
+
+
+def test_decoder_on_streams_the_crate_encoder_never_writes(gpu, oracle):
+    """The qoi 0.4.1 decoder stores a pixel in its index after RGB / RGBA / DIFF / LUMA ops only: a stream that OPENS
+    with a run of the implicit opaque black and later names that slot with an INDEX op gets the zero pixel there, not
+    opaque black.  And a 3-channel stream has no RGBA op: 0xff is malformed.  Oracle and device decoder agree."""
+    import torch
+    # RUN of 3 (opaque black x3), INDEX 53 (= hash of opaque black: (255 * 11) % 64) -> zero pixel, then RGB
+    ops = [0xc0 | 2, 53, 0xfe, 10, 20, 30, 0xc0 | 0]
+    for c in (4, 3):
+        raw = _one_tile_file(3, 2, c, ops)
+        d = oracle.decode_container(raw)
+        exp = d["slots"][0][: 6 * c].reshape(6, c)
+        assert (exp[:3, :3] == 0).all() and (exp[3, :3] == 0).all()  # the INDEX op yields the zero pixel
+        if c == 4:
+            assert (exp[:3, 3] == 255).all() and exp[3, 3] == 0
+        files = torch.frombuffer(bytearray(raw), dtype=torch.uint8).cuda()
+        offs = torch.tensor([0, len(raw)], dtype=torch.int64).cuda()
+        vals, ow, oh, slots = gpu.decode_frames_device(files, offs, (1, 2, 3, c), 3, 2)
+        torch.cuda.synchronize()
+        assert gpu.decode_status() == 0
+        assert (slots.cpu().numpy()[0, 0, : 6 * c].reshape(6, c) == exp).all()
+    # an RGBA op in a 3-channel stream: flagged, the tile gets size 0x0
+    raw = _one_tile_file(2, 1, 3, [0xff, 1, 2, 3, 4, 0xc0])
+    with pytest.raises(Exception):
+        oracle.decode_container(raw)
+    files = torch.frombuffer(bytearray(raw), dtype=torch.uint8).cuda()
+    offs = torch.tensor([0, len(raw)], dtype=torch.int64).cuda()
+    vals, ow, oh, slots = gpu.decode_frames_device(files, offs, (1, 1, 2, 3), 2, 1)
+    torch.cuda.synchronize()
+    assert gpu.decode_status() == 2 and int(ow[0, 0]) == 0 and int(oh[0, 0]) == 0

@@ -99,3 +99,22 @@ def test_axis_tables_equal_oracle(product, oracle):
             a = product.axis_table(i, o, filt)
             b = oracle.fir_coeffs(i, o, filt)
             assert (a[0] == b[0]).all() and (a[1] == b[1]).all() and (a[2] == b[2]).all() and a[3] == b[3], (filt, i, o)
+
+
+def test_one_grid_and_its_limit(product):
+    """pxz_grid is the integer ceiling -- what the reference's f64 (iter.rs:38-41) and f32 (pixlzr.rs:36-46) forms both give
+    up to 2^24 -- and image sides beyond 2^24, where those two part, are refused by the grid and by the container writer."""
+    import ctypes as C
+    import numpy as np
+    assert product.grid(1080, 1617, 64, 64) == (17, 26) and product.grid(7680, 4320, 32, 32) == (240, 135)
+    assert product.grid(1 << 24, 1, 3, 1) == (5592406, 1) and product.grid(5, 5, 1 << 30, 7) == (1, 1)
+    with pytest.raises(product.PxzError) as e:
+        product.grid((1 << 24) + 1, 4, 32, 32)
+    assert e.value.code == -5
+    L = product.load_library()
+    one = np.ones(4, np.uint32)
+    v = np.zeros(4, np.float32)
+    px = np.zeros(4 * 4, np.uint8)
+    rc = L.pxz_encode_container((1 << 24) + 1, 1, 1 << 24, 1, 4, 0, C.c_void_p(v.ctypes.data), None, C.c_void_p(one.ctypes.data),
+                                C.c_void_p(one.ctypes.data), C.c_void_p(px.ctypes.data), None, 0)
+    assert rc == -5
