@@ -217,11 +217,7 @@ def run_strong(args, handle, product, frames_total, world, rank, dist_mod):
                 state["bytes"], state["files"] = int(o[-1]), int(o.numel()) - 1
 
     def loop(k):
-        produce(0)
-        for i in range(k):
-            if i + 1 < k:
-                produce(i + 1)   # enqueued first: runs while the files of step i travel
-            exchange(i)
+        pdist.run_pipelined(k, produce, exchange)  # produce(i + 1) is enqueued before exchange(i): the files travel under it
         torch.cuda.synchronize()
 
     ok, err, ms = True, "", 0.0

@@ -103,3 +103,18 @@ def gather_files(file_offsets, buf, dst=0, group=None):
     for req in dist.batch_isend_irecv(ops):
         req.wait()
     return None
+
+
+def run_pipelined(n_steps, produce, exchange):
+    """The strong-scaling step loop (bench.py `strong_scaling`, BASELINE configs[4]): produce(i) enqueues the shrink and
+    the device writer of step i into buffer set i & 1, exchange(i) ships that step's files to the writer rank.
+    produce(i + 1) is issued BEFORE exchange(i), so on a GPU (exchange on its own stream, behind an event of produce(i))
+    the files of step i travel while the kernels of step i + 1 run; two buffer sets are enough because exchange(i - 1)
+    has returned -- its sends are complete -- before produce(i + 1) overwrites its set."""
+    if n_steps <= 0:
+        return
+    produce(0)
+    for i in range(n_steps):
+        if i + 1 < n_steps:
+            produce(i + 1)
+        exchange(i)

@@ -141,3 +141,70 @@ def test_two_ranks_gather_files(tmp_path, product, oracle):
         assert blob[off:off + int(sizes[f])] == ref
         off += int(sizes[f])
     assert off == len(blob)
+
+
+def _worker_strong(rank, world, port, result_path, n_steps):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from tests.conftest import load_product
+    from oracle import binding as oracle
+    product = load_product()
+    from pixlzr_rust_amd import dist as pdist
+    mine = pdist.shard_frames(NF, world, rank)  # the fixed batch of NF frames, contiguous shards
+    bufs = [None, None]                         # two buffer sets, as in bench.py
+    got_steps = []
+
+    def produce(i):
+        # step i "shrinks" its frames with a step-dependent factor, so that a stale buffer set would be noticed
+        files = []
+        for f in mine:
+            img = oracle.synth_frame(W, H, 4, f, 1)
+            v, ow, oh, slots = oracle.shrink_image(img, B, B, 1, 4, 4.0 + 4.0 * i)
+            files.append(product.encode_container(W, H, B, B, 4, 0, v, None, ow, oh, slots))
+        offs = np.concatenate([[0], np.cumsum([len(x) for x in files])]).astype(np.int64)
+        bufs[i & 1] = (torch.from_numpy(offs), torch.from_numpy(np.frombuffer(b"".join(files) + bytes(16), np.uint8).copy()))
+
+    def exchange(i):
+        offs, buf = bufs[i & 1]
+        got = pdist.gather_files(offs, buf, dst=0)
+        if rank == 0:
+            blob = b""
+            for roffs, rbuf in got:
+                roffs = roffs.numpy()
+                blob += rbuf.numpy()[: roffs[-1]].tobytes()
+            got_steps.append(blob)
+        else:
+            assert got is None
+
+    pdist.run_pipelined(n_steps, produce, exchange)
+    if rank == 0:
+        with open(result_path, "wb") as fh:
+            for blob in got_steps:
+                fh.write(len(blob).to_bytes(8, "little") + blob)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_strong_scaling_loop_over_two_ranks(tmp_path, product, oracle):
+    """bench.py's strong-scaling leg on CPU: a fixed batch of 5 frames over 2 ranks (shards of 2 and 3), three steps
+    through run_pipelined with two buffer sets; at every step the writer rank holds all five files of THAT step, in
+    frame order, byte for byte what one process writes."""
+    result = str(tmp_path / "strong.bin")
+    port = 33500 + (os.getpid() % 2000)
+    n_steps = 3
+    mp.spawn(_worker_strong, args=(2, port, result, n_steps), nprocs=2, join=True)
+    data = open(result, "rb").read()
+    pos = 0
+    for i in range(n_steps):
+        n = int.from_bytes(data[pos:pos + 8], "little")
+        blob = data[pos + 8:pos + 8 + n]
+        pos += 8 + n
+        ref = b""
+        for f in range(NF):
+            img = oracle.synth_frame(W, H, 4, f, 1)
+            v, ow, oh, slots = oracle.shrink_image(img, B, B, 1, 4, 4.0 + 4.0 * i)
+            ref += oracle.encode_container(W, H, B, B, 4, 0, v, None, ow, oh, slots)
+        assert blob == ref, f"step {i}"
+    assert pos == len(data)
