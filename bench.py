@@ -61,6 +61,7 @@ def parse():
     ap.add_argument("--frames-total", type=int, default=0,
                     help="strong-scaling leg: a fixed batch of this many frames over all ranks (default: 64 when N > 1, off at N = 1)")
     ap.add_argument("--strong-steps", type=int, default=20)
+    ap.add_argument("--strong-timeout", type=float, default=240.0, help="seconds the strong-scaling leg may take before it is abandoned")
     ap.add_argument("--no-strong", action="store_true", help="N > 1: skip the strong-scaling leg (shrink + writer + gather to rank 0)")
     return ap.parse_args()
 
@@ -70,6 +71,12 @@ def histogram(ow, oh):
     key = ow.long() * 100000 + oh.long()
     uniq, counts = torch.unique(key, return_counts=True)
     return {f"{int(k) // 100000}x{int(k) % 100000}": int(c) for k, c in zip(uniq.tolist(), counts.tolist())}
+
+
+def note(msg):
+    """progress on stderr (rank 0): a run that stops can be placed"""
+    if int(os.environ.get("RANK", "0")) == 0:
+        print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
 
 def agree(dist_mod, world, device, ok):
@@ -222,7 +229,9 @@ def run_strong(args, handle, product, frames_total, world, rank, dist_mod):
 
     ok, err, ms = True, "", 0.0
     try:
+        note("strong scaling: buffers ready, warm-up exchange")
         loop(3)  # untimed: allocations, RCCL channels
+        note("strong scaling: timed loop")
         if world > 1:
             dist_mod.barrier()
         torch.cuda.synchronize()
@@ -328,8 +337,10 @@ def main():
     primary = args.primary if args.primary in names else names[0]
     results = {}
     for name in names:
+        note(f"{name}: {args.steps} steps")
         results[name] = run_mode(args, handle, frames, name, world, dist)
     if not args.no_encode_mode and "shrink_directionally" in names:
+        note(ENCODE_MODE)
         results[ENCODE_MODE] = run_mode(args, handle, frames, "shrink_directionally", world, dist, with_writer=True,
                                         steps=min(args.steps, 200))
 
@@ -350,13 +361,7 @@ def main():
                 others[f"{bs}x{bs} {name}"] = {"kernel_ms": ms, "mp_per_s": nf * args.width * args.height / 1e6 / (ms * 1e-3)}
                 del out
 
-    strong = None
-    frames_total = args.frames_total or (64 if world > 1 else 0)
-    if frames_total and not args.no_strong:
-        del frames
-        torch.cuda.empty_cache()
-        strong = run_strong(args, handle, product, frames_total, world, rank, dist)
-
+    line = None
     if rank == 0:
         r = results[primary]
         total_mp = world * nf * args.width * args.height / 1e6
@@ -376,7 +381,7 @@ def main():
                                    f"device-resident, one fused launch per step",
                        "mode": primary, "frames_per_gpu": nf, "tile": args.block,
                        "parallelism": f"{world} ranks x {nf} frames, frames sharded over ranks, no collective in the timed steps"
-                                      + ("; see strong_scaling for the fixed 64-frame batch with the gather to rank 0 in the step" if strong else ""),
+                                      + ("; see strong_scaling for the fixed 64-frame batch with the gather to rank 0 in the step" if world > 1 else ""),
                        "tile_size_histogram_frame0": r["histogram"]},
             "roofline": {"bound": "hbm", "achieved": r["achieved_gbps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": r["achieved_gbps"] / HBM_PEAK_GBPS, "traffic": load_traffic(primary),
@@ -390,10 +395,33 @@ def main():
         }
         if others:
             line["other_tile_sizes"] = others
-        if strong:
-            line["strong_scaling"] = strong
         if world == 1 and not args.no_cpu_baseline:
+            note("cpu baseline")
             line["cpu_baseline"] = cpu_baseline(args, primary, names)
+
+    # the strong-scaling leg comes last and under a watchdog: whatever happens to the exchange, the line above is printed
+    frames_total = args.frames_total or (64 if world > 1 else 0)
+    if frames_total and not args.no_strong:
+        import threading
+
+        def bail():
+            if rank == 0:
+                line["strong_scaling"] = {"error": f"no result within {args.strong_timeout} s; the leg was abandoned"}
+                print(json.dumps(line), flush=True)
+            os._exit(0)
+
+        dog = threading.Timer(args.strong_timeout, bail)
+        dog.daemon = True
+        dog.start()
+        del frames
+        torch.cuda.empty_cache()
+        note(f"strong scaling: {frames_total} frames over {world} ranks, {args.strong_steps} steps")
+        strong = run_strong(args, handle, product, frames_total, world, rank, dist)
+        dog.cancel()
+        note("strong scaling done")
+        if rank == 0:
+            line["strong_scaling"] = strong
+    if rank == 0:
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

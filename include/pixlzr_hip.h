@@ -212,6 +212,22 @@ int pxz_process_frames_device(pxz_handle *h, const pxz_frames *frames, const pxz
                               uint32_t filter_upscale, const uint8_t *d_pixels, uint8_t *d_out_rgba,
                               uint32_t out_pitch_bytes, uint64_t out_frame_stride_bytes);
 
+/* tree::process_custom (src/process/tree.rs:23-83) with the closures of tree::process (:89-109): per tile of the
+ * block_w x block_h grid get_block_variance (|x - avg|, identity); a tile with (value >= |threshold|) ^ (threshold >= 0)
+ * is pixelised as process() does it (reduce_image_section((v, v)) with params->filter, resized back with
+ * filter_upscale); any other tile is handed to the same function with both block sizes halved (|threshold| from
+ * there on, so only the outermost level can be inverted) until a block size reaches min(min_block_*, 4), where the
+ * tile keeps its pixels.  tree::process(image, n, k) is block_w = block_h = n, min 4 x 4, PXZ_FILTER_LANCZOS3 down,
+ * PXZ_FILTER_NEAREST up, threshold k.  Output RGBA8 (RGB input gains alpha 255; also in the degenerate case of a
+ * block size at or below the minimum, where the reference returns the image unchanged in its own colour type).
+ * One detector + shrink + expand pass per level over that level's regular grid; this needs block sizes that halve
+ * evenly down to the last level (64, 48, 40, ...: PXZ_ERR_UNSUPPORTED otherwise), and tiles that fit the kernels' LDS
+ * residency (about 128 x 96).  params->mode and factor are ignored.  Asynchronous on the handle's stream. */
+int pxz_tree_process_frames_device(pxz_handle *h, const pxz_frames *frames, const pxz_params *params,
+                                   uint32_t filter_upscale, float threshold, uint32_t min_block_w, uint32_t min_block_h,
+                                   const uint8_t *d_pixels, uint8_t *d_out_rgba, uint32_t out_pitch_bytes,
+                                   uint64_t out_frame_stride_bytes);
+
 /* Block-stream compaction (device): the valid out_w*out_h*channels bytes of every slot, in tile
  * order, into one contiguous stream -- the payload `encode_block` (src/encoding/mod.rs:168-200)
  * consumes tile after tile, and what one rank ships to the writer rank over RCCL.

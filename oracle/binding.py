@@ -273,6 +273,21 @@ def process_image(img, bw, bh, filter_down=4, filter_up=0):
     return out
 
 
+def tree_process_image(img, bw, bh, threshold, min_bw=4, min_bh=4, filter_down=4, filter_up=0):
+    """tree::process_custom with the closures of tree::process (tree.rs:23-109): (H, W, C) -> RGBA (H, W, 4)."""
+    H, W, Cc = img.shape
+    L = lib()
+    L.orc_tree_process_image.restype = C.c_int
+    L.orc_tree_process_image.argtypes = [C.c_void_p] + [C.c_uint32] * 8 + [C.c_float] + [C.c_uint32] * 2 + [C.c_void_p, C.c_uint32]
+    img = np.ascontiguousarray(img)
+    out = np.zeros((H, W, 4), np.uint8)
+    rc = L.orc_tree_process_image(_ptr(img), W, H, Cc, W * Cc, bw, bh, min_bw, min_bh, C.c_float(threshold), filter_down,
+                                  filter_up, _ptr(out), W * 4)
+    if rc != 0:
+        raise RuntimeError(f"orc_tree_process_image rc={rc}")
+    return out
+
+
 def synth_frame(width, height, channels=4, frame_index=0, dist=DIST_OPAQUE):
     img = np.empty((height, width, channels), np.uint8)
     lib().orc_synth_frame(_ptr(img), width, height, channels, width * channels, frame_index, dist)

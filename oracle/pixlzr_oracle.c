@@ -853,3 +853,86 @@ int orc_process_image(const uint8_t *pixels, uint32_t width, uint32_t height, ui
 	free(full);
 	return err;
 }
+
+
+/* tree::process_custom, src/process/tree.rs:23-83 (TEST INFRASTRUCTURE, as everything here).  `px` is the (sub-)image the
+ * call receives, `out` the RGBA image it returns (same size), both addressed from their own origin.
+ *   :32-36  min sizes are at least 4; a block no larger than the minimum on either axis returns image.clone()
+ *           (written here as RGBA: an RGB image gains alpha 255, which is what the caller's copy_from at :79 makes of it)
+ *   :37-38  is_positive from the sign of the threshold; the recursion passes |threshold| on, so only the outermost call
+ *           can be "inverted"
+ *   :47-58  per tile of the (bw, bh) grid: get_block_variance with |x - avg| and the identity
+ *   :60-69  (value >= threshold) ^ is_positive -> the tile is pixelised exactly as process() does it
+ *   :70-79  else -> the same function on the tile with halved block sizes */
+static int tree_rec(const uint8_t *px, uint32_t w, uint32_t h, uint32_t c, uint32_t pitch, uint32_t bw, uint32_t bh,
+                    uint32_t min_w, uint32_t min_h, float threshold, uint32_t filter_down, uint32_t filter_up,
+                    uint8_t *out, uint32_t out_pitch, uint8_t *small, uint8_t *full)
+{
+	const uint32_t mbw = min_w > 4 ? min_w : 4, mbh = min_h > 4 ? min_h : 4;
+	if (bw <= mbw || bh <= mbh) {
+		for (uint32_t y = 0; y < h; y++)
+			for (uint32_t x = 0; x < w; x++) {
+				const uint8_t *sp = px + (size_t)y * pitch + (size_t)x * c;
+				uint8_t *d = out + (size_t)y * out_pitch + (size_t)x * 4;
+				d[0] = sp[0];
+				d[1] = sp[1];
+				d[2] = sp[2];
+				d[3] = c == 4 ? sp[3] : 255;
+			}
+		return 0;
+	}
+	const int is_positive = threshold >= 0.0f;
+	const float thr = fabsf(threshold);
+	uint32_t cols, rows;
+	orc_grid(w, h, bw, bh, &cols, &rows);
+	for (uint32_t t = 0; t < cols * rows; t++) {
+		uint32_t x0, y0, tw, th;
+		orc_tile_rect(w, h, bw, bh, t, &x0, &y0, &tw, &th);
+		const uint8_t *tile = px + (size_t)y0 * pitch + (size_t)x0 * c;
+		uint8_t *dst = out + (size_t)y0 * out_pitch + (size_t)x0 * 4;
+		const float value = lod_oklab_scaled(tile, tw, th, c, pitch, 1.0f, 1.0f);
+		if ((value >= thr) ^ is_positive) {
+			uint32_t nw, nh;
+			float stored;
+			orc_reduce_dims(value, value, tw, th, &nw, &nh, &stored);
+			if (orc_resize(tile, tw, th, c, pitch, small, nw, nh, filter_down) != 0 ||
+			    orc_resize(small, nw, nh, c, nw * c, full, tw, th, filter_up) != 0)
+				return -3;
+			for (uint32_t y = 0; y < th; y++)
+				for (uint32_t x = 0; x < tw; x++) {
+					const uint8_t *sp = full + ((size_t)y * tw + x) * c;
+					uint8_t *d = dst + (size_t)y * out_pitch + (size_t)x * 4;
+					d[0] = sp[0];
+					d[1] = sp[1];
+					d[2] = sp[2];
+					d[3] = c == 4 ? sp[3] : 255;
+				}
+		} else {
+			const int rc = tree_rec(tile, tw, th, c, pitch, bw >> 1, bh >> 1, mbw, mbh, thr, filter_down, filter_up, dst,
+			                        out_pitch, small, full);
+			if (rc)
+				return rc;
+		}
+	}
+	return 0;
+}
+
+int orc_tree_process_image(const uint8_t *pixels, uint32_t width, uint32_t height, uint32_t channels, uint32_t pitch,
+                           uint32_t bw, uint32_t bh, uint32_t min_bw, uint32_t min_bh, float threshold,
+                           uint32_t filter_down, uint32_t filter_up, uint8_t *out_rgba, uint32_t out_pitch)
+{
+	if (!pixels || !out_rgba || (channels != 3 && channels != 4) || bw == 0 || bh == 0)
+		return -1;
+	uint8_t *small = (uint8_t *)malloc((size_t)bw * bh * channels);
+	uint8_t *full = (uint8_t *)malloc((size_t)bw * bh * channels);
+	if (!small || !full) {
+		free(small);
+		free(full);
+		return -2;
+	}
+	const int rc = tree_rec(pixels, width, height, channels, pitch, bw, bh, min_bw, min_bh, threshold, filter_down, filter_up,
+	                        out_rgba, out_pitch, small, full);
+	free(small);
+	free(full);
+	return rc;
+}

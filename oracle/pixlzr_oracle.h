@@ -98,6 +98,12 @@ int orc_expand_image(uint32_t width, uint32_t height, uint32_t bw, uint32_t bh, 
 int orc_process_image(const uint8_t *pixels, uint32_t width, uint32_t height, uint32_t channels, uint32_t pitch,
                       uint32_t bw, uint32_t bh, uint32_t filter_down, uint32_t filter_up, uint8_t *out_rgba,
                       uint32_t out_pitch);
+/* tree::process_custom (src/process/tree.rs:23-83) with the closures of tree::process (:89-109): recursive halving of
+ * the block while (value >= threshold) ^ is_positive fails; out is RGBA8.  process(image, n, k) = bw = bh = n,
+ * min 4 x 4, Lanczos3 down, Nearest up. */
+int orc_tree_process_image(const uint8_t *pixels, uint32_t width, uint32_t height, uint32_t channels, uint32_t pitch,
+                           uint32_t bw, uint32_t bh, uint32_t min_bw, uint32_t min_bh, float threshold,
+                           uint32_t filter_down, uint32_t filter_up, uint8_t *out_rgba, uint32_t out_pitch);
 
 size_t orc_qoi_bound(uint32_t w, uint32_t h, uint32_t c);
 /* full QOI stream incl. "qoif" magic; returns length */

@@ -19,7 +19,7 @@ EXPORTED_SYMBOLS = [
     "pxz_synchronize", "pxz_grid", "pxz_shrink_image", "pxz_shrink_image_packed", "pxz_fetch_packed", "pxz_shrink_frames_device", "pxz_lod_frames_device", "pxz_oklab_pixels_device",
     "pxz_pack_tiles_device", "pxz_encode_frames_device", "pxz_encode_container", "pxz_qoi_encode", "pxz_qoi_bound", "pxz_synth_frames_device", "pxz_axis_table",
     "pxz_enable_timing", "pxz_last_kernel_ms", "pxz_last_first_kernel_ms",
-    "pxz_debug_read_work", "pxz_expand_frames_device", "pxz_expand_image", "pxz_decode_frames_device", "pxz_decode_file", "pxz_decode_status", "pxz_process_frames_device",
+    "pxz_debug_read_work", "pxz_expand_frames_device", "pxz_expand_image", "pxz_decode_frames_device", "pxz_decode_file", "pxz_decode_status", "pxz_process_frames_device", "pxz_tree_process_frames_device",
 ]
 
 STATUS = {0: "PXZ_OK", -1: "PXZ_ERR_INVALID_ARG", -2: "PXZ_ERR_NO_DEVICE", -3: "PXZ_ERR_HIP",
@@ -121,6 +121,8 @@ def load_library():
     L.pxz_decode_file.argtypes = [vp, vp, C.c_size_t] + [C.POINTER(u32)] * 6 + [vp] * 4
     L.pxz_process_frames_device.restype = C.c_int
     L.pxz_process_frames_device.argtypes = [vp, C.POINTER(Frames), C.POINTER(Params), u32, vp, vp, u32, C.c_uint64]
+    L.pxz_tree_process_frames_device.restype = C.c_int
+    L.pxz_tree_process_frames_device.argtypes = [vp, C.POINTER(Frames), C.POINTER(Params), u32, f32, u32, u32, vp, vp, u32, C.c_uint64]
     L.pxz_decode_status.restype = C.c_int
     L.pxz_decode_status.argtypes = [vp, C.POINTER(u32)]
     L.pxz_decode_frames_device.restype = C.c_int
@@ -353,6 +355,18 @@ class Handle:
         self._check(self._L.pxz_process_frames_device(self._h, C.byref(fd), C.byref(pd), filter_up,
                                                       C.c_void_p(frames.data_ptr()), C.c_void_p(out.data_ptr()),
                                                       W * 4, W * 4 * H))
+        return out
+
+    def tree_process_frames_device(self, frames, bw, bh, threshold, min_bw=4, min_bh=4, filter_down=4, filter_up=0):
+        """tree::process_custom with |x - avg| / identity (process/tree.rs:23-109): frames [N,H,W,C] -> RGBA [N,H,W,4]."""
+        import torch
+        fd, (N, H, W, Cc) = self._frames_desc(frames)
+        out = torch.empty((N, H, W, 4), dtype=torch.uint8, device=frames.device)
+        pd = Params(bw, bh, 0, filter_down, 1.0, 0)
+        self.use_torch_stream()
+        self._check(self._L.pxz_tree_process_frames_device(self._h, C.byref(fd), C.byref(pd), filter_up, C.c_float(threshold),
+                                                           min_bw, min_bh, C.c_void_p(frames.data_ptr()),
+                                                           C.c_void_p(out.data_ptr()), W * 4, W * 4 * H))
         return out
 
     def decode_status(self):

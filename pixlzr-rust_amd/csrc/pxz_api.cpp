@@ -21,6 +21,7 @@
 namespace pxz {
 hipError_t launch_shrink(const ShrinkArgs &a, uint32_t channels, uint32_t n_cus, hipStream_t stream);
 hipError_t launch_synth(const SynthArgs &s, hipStream_t stream);
+hipError_t launch_tree_decide(const TreeArgs &a, hipStream_t stream);
 hipError_t launch_oklab_pixels(const uint32_t *px, uint32_t n, float *out, uint32_t n_cus, hipStream_t stream);
 hipError_t launch_finish(const FinishArgs &f, hipStream_t stream);
 bool fast32_applicable(const ShrinkArgs &a, uint32_t channels);
@@ -80,7 +81,7 @@ struct pxz_handle {
 	// level breakpoints per (mode, factor bits, bw, bh, edge_w, edge_h)
 	struct Breaks { uint32_t b[4][pxz::kMaxLevel]; uint32_t asc[4]; };
 	std::map<std::tuple<uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t>, Breaks> breaks;
-	DeviceBuffer in, val, ow, oh, out, sums, chunks, work, qscratch, qmeta, status, dmeta, okscratch, rgba, slots4, pk, pkoff;
+	DeviceBuffer in, val, ow, oh, out, sums, chunks, work, qscratch, qmeta, status, dmeta, okscratch, rgba, slots4, pk, pkoff, tree;
 	uint64_t packed_len = 0;   // bytes of the stream pxz_shrink_image_packed left in `pk` (0: none)
 	std::map<std::tuple<uint32_t, uint32_t, uint32_t, uint32_t, uint32_t>, ExpandTables> expand_tables;
 	uint32_t *host_stats = nullptr;  // pinned, device-visible: [0] = tiles with transparency the last finished 32x32 launch saw
@@ -799,7 +800,7 @@ void pxz_destroy(pxz_handle *h)
 		(void)hipFree(kv.second.d_sizes);
 		(void)hipFree(kv.second.d_coeffs);
 	}
-	for (DeviceBuffer *b : {&h->in, &h->val, &h->ow, &h->oh, &h->out, &h->sums, &h->chunks, &h->work, &h->qscratch, &h->qmeta, &h->status, &h->dmeta, &h->okscratch, &h->rgba, &h->slots4, &h->pk, &h->pkoff})
+	for (DeviceBuffer *b : {&h->in, &h->val, &h->ow, &h->oh, &h->out, &h->sums, &h->chunks, &h->work, &h->qscratch, &h->qmeta, &h->status, &h->dmeta, &h->okscratch, &h->rgba, &h->slots4, &h->pk, &h->pkoff, &h->tree})
 		if (b->ptr) (void)hipFree(b->ptr);
 	for (auto &ev : h->events) {
 		(void)hipEventDestroy(ev.first);
@@ -972,7 +973,8 @@ int pxz_lod_frames_device(pxz_handle *h, const pxz_frames *frames, const pxz_par
 
 // frames: the OUTPUT batch (its channels = bytes per output pixel); slot_channels: channels of the stored tiles
 static int expand_launch(pxz_handle *h, const pxz_frames *frames, uint32_t slot_channels, const pxz_params *params,
-                         const uint32_t *d_tile_w, const uint32_t *d_tile_h, const uint8_t *d_slots, uint8_t *d_out_pixels)
+                         const uint32_t *d_tile_w, const uint32_t *d_tile_h, const uint8_t *d_slots, uint8_t *d_out_pixels,
+                         bool quiet_empty = false)
 {
 	if (!h) return PXZ_ERR_INVALID_ARG;
 	if (!frames || !params) return fail(h, PXZ_ERR_INVALID_ARG, "null descriptor");
@@ -1013,6 +1015,7 @@ static int expand_launch(pxz_handle *h, const pxz_frames *frames, uint32_t slot_
 	a.slot_bytes = bw * bh * slot_channels;
 	a.filter = p.filter;
 	a.out_channels = frames->channels;
+	a.quiet_empty = quiet_empty ? 1u : 0u;
 	const ExpandTables *et = nullptr;
 	if ((rc = get_expand_tables(h, bw, bh, a.edge_w, a.edge_h, p.filter, &et)) != PXZ_OK) return rc;
 	a.tabs = et->d_dir;
@@ -1066,6 +1069,112 @@ int pxz_process_frames_device(pxz_handle *h, const pxz_frames *frames, const pxz
 	pxz_params up{params->block_w, params->block_h, 0, filter_upscale, 0.0f, 0};
 	return expand_launch(h, &of, frames->channels, &up, (const uint32_t *)h->ow.ptr, (const uint32_t *)h->oh.ptr,
 	                     (const uint8_t *)h->out.ptr, d_out_rgba);
+}
+
+int pxz_tree_process_frames_device(pxz_handle *h, const pxz_frames *frames, const pxz_params *params, uint32_t filter_upscale,
+                                   float threshold, uint32_t min_block_w, uint32_t min_block_h, const uint8_t *d_pixels,
+                                   uint8_t *d_out_rgba, uint32_t out_pitch_bytes, uint64_t out_frame_stride_bytes)
+{
+	if (!h) return PXZ_ERR_INVALID_ARG;
+	if (!frames || !params) return fail(h, PXZ_ERR_INVALID_ARG, "null descriptor");
+	if (!d_pixels || !d_out_rgba) return fail(h, PXZ_ERR_INVALID_ARG, "null device pointer");
+	if (filter_upscale > 4) return fail(h, PXZ_ERR_INVALID_ARG, "filter must be 0..4");
+	if (!std::isfinite(threshold)) return fail(h, PXZ_ERR_INVALID_ARG, "threshold must be finite");
+	pxz_params p = *params;
+	p.mode = PXZ_MODE_SHRINK_BY;
+	p.factor = 1.0f;
+	int rc = check_frames(h, frames, &p);
+	if (rc != PXZ_OK) return rc;
+	if ((uint64_t)out_pitch_bytes < (uint64_t)frames->width * 4u) return fail(h, PXZ_ERR_INVALID_ARG, "output pitch smaller than a row");
+	PXZ_HIP(h, hipSetDevice(h->device));
+	// the levels of the recursion (tree.rs:32-36): block sizes halve while both stay above the minimum (at least 4)
+	const uint32_t mbw = min_block_w > 4u ? min_block_w : 4u, mbh = min_block_h > 4u ? min_block_h : 4u;
+	std::vector<std::pair<uint32_t, uint32_t>> levels;
+	for (uint32_t bw = p.block_w, bh = p.block_h; bw > mbw && bh > mbh; bw >>= 1, bh >>= 1) levels.emplace_back(bw, bh);
+	// A level's tiles are the children of the level before: they form that level's regular grid over the frame as long as
+	// a block is exactly two of the next (the recursion splits every tile from its own corner).
+	for (size_t l = 0; l + 1 < levels.size(); ++l)
+		if ((levels[l].first & 1u) || (levels[l].second & 1u))
+			return fail(h, PXZ_ERR_UNSUPPORTED, "tree::process on the device needs block sizes that halve evenly down to the minimum (%ux%u does not)",
+			            levels[l].first, levels[l].second);
+	const uint64_t src_stride = frames->n_frames > 1 ? frames->frame_stride_bytes : (uint64_t)frames->pitch_bytes * frames->height;
+	const uint64_t dst_stride = frames->n_frames > 1 ? out_frame_stride_bytes : (uint64_t)out_pitch_bytes * frames->height;
+	pxz::TreeArgs t{};
+	t.src = d_pixels;
+	t.dst = d_out_rgba;
+	t.src_frame_stride = src_stride;
+	t.dst_frame_stride = dst_stride;
+	t.src_pitch = frames->pitch_bytes;
+	t.dst_pitch = out_pitch_bytes;
+	t.channels = frames->channels;
+	if (levels.empty()) {
+		// tree.rs:34-36: the image comes back as it is (as RGBA here).  One "level" of whole-image tiles, none pixelised.
+		levels.emplace_back(frames->width, frames->height);
+	}
+	uint32_t prev_cols = 0, prev_tpf = 0;
+	size_t max_tiles = 0;
+	for (auto &lv : levels) {
+		uint32_t c, r;
+		pxz_grid(frames->width, frames->height, lv.first, lv.second, &c, &r);
+		if ((uint64_t)c * r * frames->n_frames > 0xffffffffull) return fail(h, PXZ_ERR_UNSUPPORTED, "too many tiles");
+		max_tiles = std::max(max_tiles, (size_t)c * r * frames->n_frames);
+	}
+	// per tile: the detector's own output (the stored block value is hypot(v, v), operations.rs:154) + two sets of flags
+	if ((rc = ensure(h, h->tree, 4 * max_tiles + 2 * max_tiles)) != PXZ_OK) return rc;
+	float *raw_value = (float *)h->tree.ptr;
+	uint8_t *open_flags[2] = {(uint8_t *)h->tree.ptr + 4 * max_tiles, (uint8_t *)h->tree.ptr + 5 * max_tiles};
+	const bool whole = p.block_w <= mbw || p.block_h <= mbh;
+	for (size_t l = 0; l < levels.size(); ++l) {
+		const uint32_t bw = levels[l].first, bh = levels[l].second;
+		uint32_t cols, rows;
+		pxz_grid(frames->width, frames->height, bw, bh, &cols, &rows);
+		const size_t tiles = (size_t)cols * rows * frames->n_frames, slot = (size_t)bw * bh * frames->channels;
+		if ((rc = ensure(h, h->val, tiles * 4)) != PXZ_OK) return rc;
+		if ((rc = ensure(h, h->ow, tiles * 4)) != PXZ_OK) return rc;
+		if ((rc = ensure(h, h->oh, tiles * 4)) != PXZ_OK) return rc;
+		if (!whole) {
+			// get_block_variance + reduce_image_section((v, v)) of every tile of this level's grid (process/mod.rs:84-95); the
+			// tiles that do not take part are discarded by the decision below
+			if ((rc = ensure(h, h->out, tiles * slot)) != PXZ_OK) return rc;
+			pxz_params lp = p;
+			lp.block_w = bw;
+			lp.block_h = bh;
+			if ((rc = run_shrink(h, frames, &lp, d_pixels, (float *)h->val.ptr, (uint32_t *)h->ow.ptr, (uint32_t *)h->oh.ptr,
+			                     (uint8_t *)h->out.ptr, raw_value, nullptr, true)) != PXZ_OK)
+				return rc;
+		} else {
+			PXZ_HIP(h, hipMemsetAsync(raw_value, 0, tiles * 4, h->stream));
+		}
+		t.value = raw_value;
+		t.tile_w = (uint32_t *)h->ow.ptr;
+		t.tile_h = (uint32_t *)h->oh.ptr;
+		t.parent_open = l ? open_flags[(l - 1) & 1] : nullptr;
+		t.open = open_flags[l & 1];
+		t.bw = bw;
+		t.bh = bh;
+		t.cols = cols;
+		t.rows = rows;
+		t.tiles_per_frame = cols * rows;
+		t.n_tiles = (uint32_t)tiles;
+		t.edge_w = frames->width - (cols - 1) * bw;
+		t.edge_h = frames->height - (rows - 1) * bh;
+		t.parent_cols = prev_cols;
+		t.parent_tiles_per_frame = prev_tpf;
+		t.threshold = whole ? 1.0f : std::fabs(threshold);
+		t.positive = whole ? 0u : ((l == 0 ? threshold >= 0.0f : true) ? 1u : 0u);  // whole: (0 >= 1) ^ false = false: nothing is pixelised
+		t.last = l + 1 == levels.size() ? 1u : 0u;
+		PXZ_HIP(h, pxz::launch_tree_decide(t, h->stream));
+		if (!whole) {
+			pxz_frames of{frames->width, frames->height, 4, out_pitch_bytes, frames->n_frames, 0, out_frame_stride_bytes};
+			pxz_params up{bw, bh, 0, filter_upscale, 0.0f, 0};
+			if ((rc = expand_launch(h, &of, frames->channels, &up, (const uint32_t *)h->ow.ptr, (const uint32_t *)h->oh.ptr,
+			                        (const uint8_t *)h->out.ptr, d_out_rgba, true)) != PXZ_OK)
+				return rc;
+		}
+		prev_cols = cols;
+		prev_tpf = cols * rows;
+	}
+	return PXZ_OK;
 }
 
 int pxz_decode_frames_device(pxz_handle *h, const pxz_frames *frames, const pxz_params *params, const uint8_t *d_files,

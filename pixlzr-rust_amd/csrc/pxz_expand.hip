@@ -67,7 +67,7 @@ __global__ void __launch_bounds__(256) expand_kernel(const ExpandArgs a)
 			}
 		};
 		if (tw == 0 || th == 0 || tw > fw || th > fh) {
-			if (lane == 0) atomicOr(a.status, 1u);
+			if (lane == 0 && !(a.quiet_empty && tw == 0 && th == 0)) atomicOr(a.status, 1u);
 		} else {
 			// ---- stored pixels -> one dword per pixel
 			const uint8_t *src = a.slots + (size_t)t * a.slot_bytes;

@@ -118,6 +118,47 @@ __global__ void __launch_bounds__(256) synth_kernel(const SynthArgs s)
 }
 
 
+// ---------------------------------------------------------------------------
+// tree::process (reference src/process/tree.rs:23-83), one level: a quarter wave per tile of the level's grid.
+// A tile takes part if its parent went on to this level; it is pixelised here if (value >= threshold) ^ is_positive
+// (:60) -- then the expand step that follows writes it -- and otherwise goes on to the next level (:70-79), or, when
+// there is none, keeps its own pixels (the recursion's first lines, :34-36, return the block as it is).
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) tree_decide_kernel(const TreeArgs a)
+{
+	const uint32_t t = blockIdx.x * 16u + (threadIdx.x >> 4), ql = threadIdx.x & 15u;
+	if (t >= a.n_tiles) return;
+	const uint32_t frame = t / a.tiles_per_frame, tf = t - frame * a.tiles_per_frame;
+	const uint32_t ty = tf / a.cols, tx = tf - ty * a.cols;
+	bool active = true;
+	if (a.parent_open) active = a.parent_open[(size_t)frame * a.parent_tiles_per_frame + (size_t)(ty >> 1) * a.parent_cols + (tx >> 1)] != 0;
+	const float value = a.value[t];
+	const bool pixelise = active && ((value >= a.threshold) != (a.positive != 0u));
+	if (ql == 0) {
+		if (!pixelise) {
+			a.tile_w[t] = 0u;
+			a.tile_h[t] = 0u;
+		}
+		a.open[t] = (active && !pixelise && !a.last) ? 1u : 0u;
+	}
+	if (!(active && !pixelise && a.last)) return;
+	const uint32_t w = (tx == a.cols - 1) ? a.edge_w : a.bw, h = (ty == a.rows - 1) ? a.edge_h : a.bh;
+	const uint8_t *src = a.src + (size_t)frame * a.src_frame_stride + (size_t)(ty * a.bh) * a.src_pitch + (size_t)(tx * a.bw) * a.channels;
+	uint8_t *dst = a.dst + (size_t)frame * a.dst_frame_stride + (size_t)(ty * a.bh) * a.dst_pitch + (size_t)(tx * a.bw) * 4u;
+	for (uint32_t i = ql; i < w * h; i += 16u) {
+		const uint32_t y = i / w, x = i - y * w;
+		const uint8_t *p = src + (size_t)y * a.src_pitch + (size_t)x * a.channels;
+		const uint32_t px = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((a.channels == 4 ? (uint32_t)p[3] : 255u) << 24);
+		*reinterpret_cast<uint32_t *>(dst + (size_t)y * a.dst_pitch + (size_t)x * 4u) = px;
+	}
+}
+
+hipError_t launch_tree_decide(const TreeArgs &a, hipStream_t stream)
+{
+	hipLaunchKernelGGL(tree_decide_kernel, dim3((a.n_tiles + 15u) / 16u), dim3(256), 0, stream, a);
+	return hipGetLastError();
+}
+
 hipError_t launch_synth(const SynthArgs &s, hipStream_t stream)
 {
 	dim3 grid((s.width + 255) / 256, s.height, s.n_frames);

@@ -252,6 +252,7 @@ struct ExpandArgs {
 	const int16_t *coeffs;
 	uint32_t tile_dw;                 // LDS dwords per wave: source pixels + horizontal-pass result
 	uint32_t *status;                 // set to 1 when a tile's stored size is 0 or exceeds its full size
+	uint32_t quiet_empty;             // 1: tiles of stored size 0 x 0 are simply not written (tree::process: not this level's)
 };
 
 // Decode side: .pixlzr files -> tile values, sizes and pixel slots (pixlzr_index_kernel, qoi_decode_kernel)
@@ -281,6 +282,23 @@ struct NarrowArgs {
 	uint8_t *slots3;
 	const uint32_t *w, *h;
 	uint32_t n_tiles, slot4_bytes, slot3_bytes;
+};
+
+// tree::process (src/process/tree.rs:23-83), one level of the quad tree = the regular grid of that level's block size
+struct TreeArgs {
+	const uint8_t *src;           // the source frames (for the tiles that are handed back unchanged)
+	uint8_t *dst;                 // RGBA output frames
+	uint64_t src_frame_stride, dst_frame_stride;
+	uint32_t src_pitch, dst_pitch, channels;
+	const float *value;           // this level's grid: get_block_variance of every tile
+	uint32_t *tile_w, *tile_h;    //   reduced sizes; set to 0 for tiles that are not pixelised at this level
+	const uint8_t *parent_open;   // previous level's grid: 1 = the tile went on to this level (null at level 0: all tiles)
+	uint8_t *open;                // this level's grid: 1 = the tile goes on to the next level
+	uint32_t bw, bh, cols, rows, tiles_per_frame, n_tiles, edge_w, edge_h;
+	uint32_t parent_cols, parent_tiles_per_frame;
+	float threshold;              // |threshold|
+	uint32_t positive;            // tree.rs:37: threshold >= 0 (deeper levels: always)
+	uint32_t last;                // no further level: a tile that fails the test keeps its pixels (tree.rs:34-36)
 };
 
 struct SynthArgs {

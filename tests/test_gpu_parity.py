@@ -778,3 +778,45 @@ def test_decoder_on_streams_the_crate_encoder_never_writes(gpu, oracle):
     vals, ow, oh, slots = gpu.decode_frames_device(files, offs, (1, 1, 2, 3), 2, 1)
     torch.cuda.synchronize()
     assert gpu.decode_status() == 2 and int(ow[0, 0]) == 0 and int(oh[0, 0]) == 0
+
+
+# ---- legacy quad-tree filter: tree::process / tree::process_custom --------------------------------
+
+@pytest.mark.parametrize("c,dist", [(4, 0), (4, 1), (3, 0)])
+@pytest.mark.parametrize("bw,bh,down,up", [(64, 64, 4, 0), (32, 32, 2, 4), (48, 48, 4, 0), (64, 32, 3, 1), (40, 40, 4, 0)])
+def test_tree_process_matches_oracle(gpu, oracle, c, dist, bw, bh, down, up):
+    """tree::process(image, n, k) = Lanczos3 down / Nearest up, 4 x 4 minimum (tree.rs:89-109) and process_custom with other
+    filters / non-square blocks: per level the tiles under the threshold are pixelised, the others split in four until
+    the minimum block, where they keep their pixels.  Thresholds from "split everything" to "pixelise everything", and
+    a negative one (the outermost level inverted, tree.rs:37-38).  RGBA opaque / transparent, RGB; ragged grids."""
+    frames = gpu.synth_frames_device(2, 200, 328, c, first_frame=17, dist=dist)
+    f = frames.cpu().numpy()
+    split_some = False
+    for thr in (0.0, 0.012, 0.04, 0.15, 0.4, 50.0, -0.04):
+        out = gpu.tree_process_frames_device(frames, bw, bh, thr, 4, 4, down, up).cpu().numpy()
+        for n in range(2):
+            exp = oracle.tree_process_image(f[n], bw, bh, thr, 4, 4, down, up)
+            bad = (out[n] != exp).any(axis=2)
+            assert not bad.any(), f"thr {thr} frame {n}: {int(bad.sum())} pixels differ"
+            if 0.0 < thr < 1.0:
+                flat = oracle.process_image(f[n], bw, bh, down, up)
+                src = np.concatenate([f[n], np.full(f[n].shape[:2] + (1,), 255, np.uint8)], axis=2) if c == 3 else f[n]
+                split_some |= bool((exp != flat).any()) and bool((exp != src).any())
+    assert split_some  # some threshold gave a real mixture of levels
+    assert gpu.decode_status() == 0
+
+
+def test_tree_process_edge_cases(gpu, product, oracle):
+    """A block at or below the minimum hands the image back (tree.rs:34-36; as RGBA here); a larger minimum ends the
+    recursion earlier; block sizes that do not halve evenly down to the last level are refused on the device."""
+    frames = gpu.synth_frames_device(1, 96, 160, 3, first_frame=2, dist=0)
+    f = frames.cpu().numpy()[0]
+    out = gpu.tree_process_frames_device(frames, 4, 4, 0.05).cpu().numpy()[0]
+    assert (out[..., :3] == f).all() and (out[..., 3] == 255).all()
+    assert (out == oracle.tree_process_image(f, 4, 4, 0.05)).all()
+    out = gpu.tree_process_frames_device(frames, 64, 64, 0.02, 16, 16).cpu().numpy()[0]
+    assert (out == oracle.tree_process_image(f, 64, 64, 0.02, 16, 16)).all()
+    with pytest.raises(product.PxzError) as e:
+        gpu.tree_process_frames_device(frames, 50, 50, 0.05)  # 50 -> 25 -> 12: 25 does not halve evenly
+    assert e.value.code == -5
+    oracle.tree_process_image(f, 50, 50, 0.05)  # (the oracle takes any geometry)
