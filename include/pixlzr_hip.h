@@ -135,6 +135,21 @@ int pxz_shrink_image_packed(pxz_handle *h, const uint8_t *pixels, uint32_t width
                             float *block_value, uint32_t *out_w, uint32_t *out_h, uint64_t *packed_len);
 int pxz_fetch_packed(pxz_handle *h, uint8_t *dst, uint64_t capacity);
 
+/* pxz_shrink_image / pxz_shrink_image_packed over a LIST of equally sized host images (a folder of frames, what
+ * src/bin/whole-folder.rs:69-117 loops over): outputs as for the single-image calls, one set of caller-allocated arrays
+ * per image (out_pixels may be NULL, or hold NULLs, for detector + dimensions only; packed[k] needs packed_capacity
+ * bytes -- width*height*channels always suffices -- and packed_len[k] receives the stream's length).  The images go
+ * through a three-stage pipeline on the device -- upload of image k+1, kernels of image k, download of image k-1 at the
+ * same time -- so that a list costs about one PCIe direction per image rather than the sum of both.  Synchronous. */
+int pxz_shrink_images(pxz_handle *h, const uint8_t *const *pixels, uint32_t n_images, uint32_t width, uint32_t height,
+                      uint32_t channels, uint32_t pitch_bytes, uint32_t block_w, uint32_t block_h, uint32_t mode,
+                      uint32_t filter, float factor, float *const *block_value, uint32_t *const *out_w,
+                      uint32_t *const *out_h, uint8_t *const *out_pixels);
+int pxz_shrink_images_packed(pxz_handle *h, const uint8_t *const *pixels, uint32_t n_images, uint32_t width, uint32_t height,
+                             uint32_t channels, uint32_t pitch_bytes, uint32_t block_w, uint32_t block_h, uint32_t mode,
+                             uint32_t filter, float factor, float *const *block_value, uint32_t *const *out_w,
+                             uint32_t *const *out_h, uint8_t *const *packed, uint64_t packed_capacity, uint64_t *packed_len);
+
 /* Same over a batch of device-resident frames: the measured path (frames come
  * from a GPU decoder / stay in HBM).  All pointers are device pointers; outputs
  * are frame-major: index = frame*tiles + tile; out_pixels slot stride as above.

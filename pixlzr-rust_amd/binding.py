@@ -16,7 +16,7 @@ DIST_OPAQUE, DIST_ALPHA, DIST_FLAT, DIST_NOISE = range(4)
 # every symbol include/pixlzr_hip.h declares
 EXPORTED_SYMBOLS = [
     "pxz_version", "pxz_device_count", "pxz_create", "pxz_destroy", "pxz_last_error", "pxz_set_stream",
-    "pxz_synchronize", "pxz_grid", "pxz_shrink_image", "pxz_shrink_image_packed", "pxz_fetch_packed", "pxz_shrink_frames_device", "pxz_lod_frames_device", "pxz_oklab_pixels_device",
+    "pxz_synchronize", "pxz_grid", "pxz_shrink_image", "pxz_shrink_image_packed", "pxz_fetch_packed", "pxz_shrink_images", "pxz_shrink_images_packed", "pxz_shrink_frames_device", "pxz_lod_frames_device", "pxz_oklab_pixels_device",
     "pxz_pack_tiles_device", "pxz_encode_frames_device", "pxz_encode_container", "pxz_qoi_encode", "pxz_qoi_bound", "pxz_synth_frames_device", "pxz_axis_table",
     "pxz_enable_timing", "pxz_last_kernel_ms", "pxz_last_first_kernel_ms",
     "pxz_debug_read_work", "pxz_expand_frames_device", "pxz_expand_image", "pxz_decode_frames_device", "pxz_decode_file", "pxz_decode_status", "pxz_process_frames_device", "pxz_tree_process_frames_device",
@@ -97,6 +97,10 @@ def load_library():
     L.pxz_shrink_image.argtypes = [vp, vp] + [u32] * 8 + [f32] + [vp] * 4
     L.pxz_shrink_image_packed.restype = C.c_int
     L.pxz_shrink_image_packed.argtypes = [vp, vp] + [u32] * 8 + [f32] + [vp] * 4
+    L.pxz_shrink_images.restype = C.c_int
+    L.pxz_shrink_images.argtypes = [vp, vp] + [u32] * 9 + [f32] + [vp] * 4
+    L.pxz_shrink_images_packed.restype = C.c_int
+    L.pxz_shrink_images_packed.argtypes = [vp, vp] + [u32] * 9 + [f32] + [vp] * 4 + [C.c_uint64, vp]
     L.pxz_fetch_packed.restype = C.c_int
     L.pxz_fetch_packed.argtypes = [vp, vp, C.c_uint64]
     L.pxz_shrink_frames_device.restype = C.c_int
@@ -277,6 +281,32 @@ class Handle:
         stream = np.empty(total.value, np.uint8)
         self._check(self._L.pxz_fetch_packed(self._h, _p(stream), total.value))
         return vals, ow, oh, stream
+
+    def shrink_images(self, imgs, bw, bh, mode, filt, factor, want_pixels=True, packed=False):
+        """pxz_shrink_images[_packed]: a list of equally sized (H, W, C) uint8 images through the pipelined host boundary.
+        Returns a list of (values, w, h, slots | stream | None) per image."""
+        n = len(imgs)
+        H, W, Cc = imgs[0].shape
+        for im in imgs:
+            assert im.shape == (H, W, Cc) and im.dtype == np.uint8 and im.strides == imgs[0].strides and im.strides[2] == 1 and im.strides[1] == Cc
+        cols, rows = grid(W, H, bw, bh)
+        T = cols * rows
+        vals = [np.zeros(T, np.float32) for _ in range(n)]
+        ow = [np.zeros(T, np.uint32) for _ in range(n)]
+        oh = [np.zeros(T, np.uint32) for _ in range(n)]
+        ptrs = lambda arrs: (C.c_void_p * n)(*[a.ctypes.data for a in arrs])
+        src = ptrs(imgs)
+        if packed:
+            cap = H * W * Cc
+            px = [np.empty(cap, np.uint8) for _ in range(n)]
+            lens = np.zeros(n, np.uint64)
+            self._check(self._L.pxz_shrink_images_packed(self._h, src, n, W, H, Cc, imgs[0].strides[0], bw, bh, mode, filt, C.c_float(factor),
+                                                         ptrs(vals), ptrs(ow), ptrs(oh), ptrs(px), cap, _p(lens)))
+            return [(vals[k], ow[k], oh[k], px[k][: int(lens[k])]) for k in range(n)]
+        px = [np.zeros((T, bw * bh * Cc), np.uint8) for _ in range(n)] if want_pixels else None
+        self._check(self._L.pxz_shrink_images(self._h, src, n, W, H, Cc, imgs[0].strides[0], bw, bh, mode, filt, C.c_float(factor),
+                                              ptrs(vals), ptrs(ow), ptrs(oh), ptrs(px) if px else None))
+        return [(vals[k], ow[k], oh[k], px[k] if px else None) for k in range(n)]
 
     def oklab_pixels_device(self, rgba):
         """rgba: uint8 CUDA tensor [n, 4] -> float32 [n, 4] = (l, a, b, alpha) per pixel."""

@@ -3,6 +3,9 @@
 // point, kernel launches on the caller's stream, HIP-event timing.
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
 
 #include <cmath>
 #include <cstdarg>
@@ -83,6 +86,8 @@ struct pxz_handle {
 	std::map<std::tuple<uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t>, Breaks> breaks;
 	DeviceBuffer in, val, ow, oh, out, sums, chunks, work, qscratch, qmeta, status, dmeta, okscratch, rgba, slots4, pk, pkoff, tree;
 	uint64_t packed_len = 0;   // bytes of the stream pxz_shrink_image_packed left in `pk` (0: none)
+	static constexpr int kRing = 3;  // buffer sets of the pipelined host boundary (pxz_shrink_images*)
+	DeviceBuffer ring_in[kRing], ring_val[kRing], ring_ow[kRing], ring_oh[kRing], ring_out[kRing], ring_pk[kRing], ring_pkoff[kRing];
 	std::map<std::tuple<uint32_t, uint32_t, uint32_t, uint32_t, uint32_t>, ExpandTables> expand_tables;
 	uint32_t *host_stats = nullptr;  // pinned, device-visible: [0] = tiles with transparency the last finished 32x32 launch saw
 	uint32_t *dev_stats = nullptr;   //   (its device-side address); read without synchronisation, steers only the kernel choice
@@ -802,6 +807,9 @@ void pxz_destroy(pxz_handle *h)
 	}
 	for (DeviceBuffer *b : {&h->in, &h->val, &h->ow, &h->oh, &h->out, &h->sums, &h->chunks, &h->work, &h->qscratch, &h->qmeta, &h->status, &h->dmeta, &h->okscratch, &h->rgba, &h->slots4, &h->pk, &h->pkoff, &h->tree})
 		if (b->ptr) (void)hipFree(b->ptr);
+	for (int i = 0; i < pxz_handle::kRing; ++i)
+		for (DeviceBuffer *b : {&h->ring_in[i], &h->ring_val[i], &h->ring_ow[i], &h->ring_oh[i], &h->ring_out[i], &h->ring_pk[i], &h->ring_pkoff[i]})
+			if (b->ptr) (void)hipFree(b->ptr);
 	for (auto &ev : h->events) {
 		(void)hipEventDestroy(ev.first);
 		(void)hipEventDestroy(ev.second);
@@ -1399,6 +1407,178 @@ int pxz_shrink_image_packed(pxz_handle *h, const uint8_t *pixels, uint32_t width
 	h->packed_len = total;
 	*packed_len = total;
 	return PXZ_OK;
+}
+
+// pxz_shrink_images / pxz_shrink_images_packed: pxz_shrink_image[_packed] over a list of equally sized host images, as a
+// three-stage pipeline over three sets of device buffers -- the upload of image k + 1, the kernels of image k and the
+// download of image k - 1 run at the same time (two copy streams driven by two helper threads: a copy from or to pageable
+// host memory blocks its caller), so the list costs about one PCIe direction per image instead of the sum of both.
+static int shrink_images_impl(pxz_handle *h, const uint8_t *const *pixels, uint32_t n_images, uint32_t width, uint32_t height,
+                              uint32_t channels, uint32_t pitch_bytes, uint32_t block_w, uint32_t block_h, uint32_t mode,
+                              uint32_t filter, float factor, float *const *block_value, uint32_t *const *out_w,
+                              uint32_t *const *out_h, uint8_t *const *out_pixels, bool packed, uint64_t capacity,
+                              uint64_t *packed_len)
+{
+	if (!h) return PXZ_ERR_INVALID_ARG;
+	if (!pixels || !block_value || !out_w || !out_h || n_images == 0 || (packed && (!out_pixels || !packed_len)))
+		return fail(h, PXZ_ERR_INVALID_ARG, "null pointer or empty list");
+	for (uint32_t k = 0; k < n_images; ++k)
+		if (!pixels[k] || !block_value[k] || !out_w[k] || !out_h[k] || (packed && !out_pixels[k]))
+			return fail(h, PXZ_ERR_INVALID_ARG, "null pointer in the list (image %u)", k);
+	pxz_frames f{width, height, channels, pitch_bytes, 1, 0, 0};
+	pxz_params p{block_w, block_h, mode, filter, factor, 0};
+	int rc = check_frames(h, &f, &p);
+	if (rc != PXZ_OK) return rc;
+	PXZ_HIP(h, hipSetDevice(h->device));
+	uint32_t cols, rows;
+	pxz_grid(width, height, block_w, block_h, &cols, &rows);
+	const size_t tiles = (size_t)cols * rows, slot = (size_t)block_w * block_h * channels;
+	const size_t most = (size_t)width * height * channels;  // no tile grows
+	const size_t row_bytes = (size_t)width * channels;
+	uint32_t dp = pitch_bytes;
+	if (channels == 4 && (pitch_bytes & 15u) != 0) dp = (uint32_t)((row_bytes + 15u) & ~(size_t)15u);
+	const size_t in_bytes = (size_t)dp * (height - 1) + row_bytes;
+	const bool want_px = packed || out_pixels != nullptr;
+	constexpr int R = pxz_handle::kRing;
+	for (int i = 0; i < R; ++i) {
+		if ((rc = ensure(h, h->ring_in[i], in_bytes)) != PXZ_OK) return rc;
+		if ((rc = ensure(h, h->ring_val[i], tiles * 4)) != PXZ_OK) return rc;
+		if ((rc = ensure(h, h->ring_ow[i], tiles * 4)) != PXZ_OK) return rc;
+		if ((rc = ensure(h, h->ring_oh[i], tiles * 4)) != PXZ_OK) return rc;
+		if (want_px && (rc = ensure(h, h->ring_out[i], tiles * slot)) != PXZ_OK) return rc;
+		if (packed && (rc = ensure(h, h->ring_pk[i], most)) != PXZ_OK) return rc;
+		if (packed && (rc = ensure(h, h->ring_pkoff[i], (tiles + 1) * 8)) != PXZ_OK) return rc;
+	}
+	hipStream_t up = nullptr, down = nullptr;
+	PXZ_HIP(h, hipStreamCreateWithFlags(&up, hipStreamNonBlocking));
+	if (hipStreamCreateWithFlags(&down, hipStreamNonBlocking) != hipSuccess) {
+		(void)hipStreamDestroy(up);
+		return fail(h, PXZ_ERR_HIP, "hipStreamCreateWithFlags failed");
+	}
+	std::mutex m;
+	std::condition_variable cv;
+	uint32_t uploaded = 0, computed = 0, downloaded = 0;
+	hipError_t copy_error = hipSuccess;
+	bool stop = false;
+	const int device = h->device;
+
+	std::thread uploader([&] {
+		(void)hipSetDevice(device);
+		for (uint32_t k = 0; k < n_images; ++k) {
+			{
+				std::unique_lock<std::mutex> lk(m);
+				cv.wait(lk, [&] { return stop || k < downloaded + (uint32_t)R; });  // its buffer set is free again
+				if (stop) return;
+			}
+			void *dst = h->ring_in[k % R].ptr;
+			hipError_t e = dp == pitch_bytes ? hipMemcpyAsync(dst, pixels[k], in_bytes, hipMemcpyHostToDevice, up)
+			                                 : hipMemcpy2DAsync(dst, dp, pixels[k], pitch_bytes, row_bytes, height, hipMemcpyHostToDevice, up);
+			if (e == hipSuccess) e = hipStreamSynchronize(up);
+			std::lock_guard<std::mutex> lk(m);
+			if (e != hipSuccess) {
+				copy_error = e;
+				stop = true;
+			} else {
+				uploaded = k + 1;
+			}
+			cv.notify_all();
+			if (stop) return;
+		}
+	});
+	std::thread downloader([&] {
+		(void)hipSetDevice(device);
+		for (uint32_t k = 0; k < n_images; ++k) {
+			{
+				std::unique_lock<std::mutex> lk(m);
+				cv.wait(lk, [&] { return stop || computed > k; });
+				if (stop) return;
+			}
+			const int i = (int)(k % R);
+			hipError_t e = hipMemcpyAsync(block_value[k], h->ring_val[i].ptr, tiles * 4, hipMemcpyDeviceToHost, down);
+			if (e == hipSuccess) e = hipMemcpyAsync(out_w[k], h->ring_ow[i].ptr, tiles * 4, hipMemcpyDeviceToHost, down);
+			if (e == hipSuccess) e = hipMemcpyAsync(out_h[k], h->ring_oh[i].ptr, tiles * 4, hipMemcpyDeviceToHost, down);
+			if (e == hipSuccess && packed) {
+				uint64_t total = 0;
+				e = hipMemcpyAsync(&total, (const uint64_t *)h->ring_pkoff[i].ptr + tiles, 8, hipMemcpyDeviceToHost, down);
+				if (e == hipSuccess) e = hipStreamSynchronize(down);
+				packed_len[k] = total;
+				if (e == hipSuccess && total <= capacity && total <= most && total)
+					e = hipMemcpyAsync(out_pixels[k], h->ring_pk[i].ptr, total, hipMemcpyDeviceToHost, down);
+			} else if (e == hipSuccess && out_pixels && out_pixels[k]) {
+				e = hipMemcpyAsync(out_pixels[k], h->ring_out[i].ptr, tiles * slot, hipMemcpyDeviceToHost, down);
+			}
+			if (e == hipSuccess) e = hipStreamSynchronize(down);
+			std::lock_guard<std::mutex> lk(m);
+			if (e != hipSuccess) {
+				copy_error = e;
+				stop = true;
+			} else {
+				downloaded = k + 1;
+			}
+			cv.notify_all();
+			if (stop) return;
+		}
+	});
+	// this thread: the kernels, on the handle's stream
+	rc = PXZ_OK;
+	for (uint32_t k = 0; k < n_images && rc == PXZ_OK; ++k) {
+		{
+			std::unique_lock<std::mutex> lk(m);
+			cv.wait(lk, [&] { return stop || uploaded > k; });
+			if (stop) break;
+		}
+		const int i = (int)(k % R);
+		pxz_frames fk{width, height, channels, dp, 1, 0, 0};
+		pxz_params pk = p;
+		if (channels == 4 && host_image_has_transparency(pixels[k], width, height, pitch_bytes)) pk.reserved |= PXZ_HINT_TRANSPARENCY;
+		rc = pxz_shrink_frames_device(h, &fk, &pk, (const uint8_t *)h->ring_in[i].ptr, (float *)h->ring_val[i].ptr,
+		                              (uint32_t *)h->ring_ow[i].ptr, (uint32_t *)h->ring_oh[i].ptr,
+		                              want_px ? (uint8_t *)h->ring_out[i].ptr : nullptr);
+		if (rc == PXZ_OK && packed)
+			rc = pxz_pack_tiles_device(h, (uint32_t)tiles, channels, (uint32_t)slot, (const uint32_t *)h->ring_ow[i].ptr,
+			                           (const uint32_t *)h->ring_oh[i].ptr, (const uint8_t *)h->ring_out[i].ptr,
+			                           (uint64_t *)h->ring_pkoff[i].ptr, (uint8_t *)h->ring_pk[i].ptr, most);
+		if (rc == PXZ_OK && hipStreamSynchronize(h->stream) != hipSuccess) rc = fail(h, PXZ_ERR_HIP, "hipStreamSynchronize failed");
+		std::lock_guard<std::mutex> lk(m);
+		if (rc != PXZ_OK) stop = true;
+		else computed = k + 1;
+		cv.notify_all();
+	}
+	{
+		std::unique_lock<std::mutex> lk(m);
+		cv.wait(lk, [&] { return stop || downloaded == n_images; });
+		stop = true;  // (lets a helper that is still waiting go)
+		cv.notify_all();
+	}
+	uploader.join();
+	downloader.join();
+	(void)hipStreamDestroy(up);
+	(void)hipStreamDestroy(down);
+	if (rc != PXZ_OK) return rc;
+	if (copy_error != hipSuccess) return fail(h, PXZ_ERR_HIP, "host copy failed: %s", hipGetErrorString(copy_error));
+	if (packed)
+		for (uint32_t k = 0; k < n_images; ++k)
+			if (packed_len[k] > capacity) return fail(h, PXZ_ERR_BUFFER_TOO_SMALL, "image %u: packed stream of %llu bytes, capacity %llu", k,
+			                                          (unsigned long long)packed_len[k], (unsigned long long)capacity);
+	return PXZ_OK;
+}
+
+int pxz_shrink_images(pxz_handle *h, const uint8_t *const *pixels, uint32_t n_images, uint32_t width, uint32_t height,
+                      uint32_t channels, uint32_t pitch_bytes, uint32_t block_w, uint32_t block_h, uint32_t mode, uint32_t filter,
+                      float factor, float *const *block_value, uint32_t *const *out_w, uint32_t *const *out_h,
+                      uint8_t *const *out_pixels)
+{
+	return shrink_images_impl(h, pixels, n_images, width, height, channels, pitch_bytes, block_w, block_h, mode, filter, factor,
+	                          block_value, out_w, out_h, out_pixels, false, 0, nullptr);
+}
+
+int pxz_shrink_images_packed(pxz_handle *h, const uint8_t *const *pixels, uint32_t n_images, uint32_t width, uint32_t height,
+                             uint32_t channels, uint32_t pitch_bytes, uint32_t block_w, uint32_t block_h, uint32_t mode,
+                             uint32_t filter, float factor, float *const *block_value, uint32_t *const *out_w,
+                             uint32_t *const *out_h, uint8_t *const *packed, uint64_t packed_capacity, uint64_t *packed_len)
+{
+	return shrink_images_impl(h, pixels, n_images, width, height, channels, pitch_bytes, block_w, block_h, mode, filter, factor,
+	                          block_value, out_w, out_h, packed, true, packed_capacity, packed_len);
 }
 
 int pxz_fetch_packed(pxz_handle *h, uint8_t *dst, uint64_t capacity)

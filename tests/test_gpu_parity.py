@@ -820,3 +820,21 @@ def test_tree_process_edge_cases(gpu, product, oracle):
         gpu.tree_process_frames_device(frames, 50, 50, 0.05)  # 50 -> 25 -> 12: 25 does not halve evenly
     assert e.value.code == -5
     oracle.tree_process_image(f, 50, 50, 0.05)  # (the oracle takes any geometry)
+
+
+@pytest.mark.parametrize("c,mode,factor,bs", [(4, 1, 8.0, 32), (3, 0, 0.5, 64), (4, 0, 1.0, 16)])
+def test_pipelined_host_boundary_over_a_list_of_images(gpu, oracle, c, mode, factor, bs):
+    """pxz_shrink_images / pxz_shrink_images_packed: seven images through the three-stage pipeline (more images than
+    buffer sets, so every set is reused) give what pxz_shrink_image gives one by one -- and the oracle."""
+    imgs = [oracle.synth_frame(333 if c == 3 else 640, 217 if c == 3 else 360, c, 40 + k, (k % 2) if c == 4 else 0) for k in range(7)]
+    res = gpu.shrink_images(imgs, bs, bs, mode, 4, factor)
+    pk = gpu.shrink_images(imgs, bs, bs, mode, 4, factor, packed=True)
+    lod = gpu.shrink_images(imgs, bs, bs, mode, 4, factor, want_pixels=False)
+    for k, img in enumerate(imgs):
+        exp = oracle.shrink_image(img, bs, bs, mode, 4, factor)
+        assert_same_tiles(res[k], exp, c, f"list image {k}")
+        assert (lod[k][0].view(np.uint32) == exp[0].view(np.uint32)).all() and (lod[k][1] == exp[1]).all() and lod[k][3] is None
+        sizes = exp[1].astype(np.int64) * exp[2] * c
+        stream = np.concatenate([exp[3][t, :n] for t, n in enumerate(sizes.tolist())])
+        assert (pk[k][0].view(np.uint32) == exp[0].view(np.uint32)).all() and (pk[k][1] == exp[1]).all() and (pk[k][2] == exp[2]).all()
+        assert pk[k][3].size == stream.size and (pk[k][3] == stream).all()
