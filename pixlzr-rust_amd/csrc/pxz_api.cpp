@@ -606,6 +606,13 @@ int timed_launch(pxz_handle *h, pxz::ShrinkArgs &a, uint32_t channels, float *va
 	a.ok_region = 0;
 	a.ok_count = a.n_tiles;
 	a.ok_edges = 0;
+	// RGB frames on the 32x32 directional fast path (round 2): 12-byte pixel quads, rows 4-byte aligned
+	const bool rgb_native = channels == 3 && a.bw == 32 && a.bh == 32 && a.mode == PXZ_MODE_SHRINK_DIRECTIONALLY && !pxz::knobs().no_native_rgb &&
+	    ((reinterpret_cast<uintptr_t>(a.src) | a.pitch | (a.n_tiles > a.tiles_per_frame ? a.frame_stride : 0)) & 3u) == 0;
+	if (rgb_native) {
+		a.full_cols = a.edge_w == a.bw ? a.cols : a.cols - 1;
+		a.full_rows = a.ok_rows = a.edge_h == a.bh ? a.rows : a.rows - 1;
+	}
 	if (aligned16 && (square_fast || general_oklab)) {
 		a.full_cols = a.edge_w == a.bw ? a.cols : a.cols - 1;
 		a.full_rows = a.edge_h == a.bh ? a.rows : a.rows - 1;
@@ -895,6 +902,10 @@ static int run_shrink(pxz_handle *h, const pxz_frames *frames, const pxz_params 
 	const bool square_fast = a.bw == a.bh && (a.bw == 16 || a.bw == 32 || a.bw == 64);
 	const bool general_oklab = a.mode == PXZ_MODE_SHRINK_BY && a.bw % 4u == 0 && a.bw * a.bh >= 64u && a.bw * a.bh <= 16384u;
 	bool widen = frames->channels == 3 && (square_fast || general_oklab) && !pxz::knobs().no_widen;
+	// (32x32 tiles under the directional detector: shrink32_kernel reads RGB itself, when the rows are 4-byte aligned)
+	if (widen && a.bw == 32 && a.bh == 32 && a.mode == PXZ_MODE_SHRINK_DIRECTIONALLY && !pxz::knobs().no_native_rgb &&
+	    ((reinterpret_cast<uintptr_t>(d_pixels) | frames->pitch_bytes | (frames->n_frames > 1 ? frames->frame_stride_bytes : 0)) & 3u) == 0)
+		widen = false;
 	if (widen && d_out_pixels && params->filter != PXZ_FILTER_NEAREST) {
 		const TableSet *tsp = nullptr;
 		if ((rc = get_tables(h, a.bw, a.bh, a.edge_w, a.edge_h, params->filter, &tsp)) != PXZ_OK) return rc;

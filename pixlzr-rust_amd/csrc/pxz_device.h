@@ -714,26 +714,34 @@ __device__ __forceinline__ void resample_mfma32(const uint32_t *s_tab, const Axi
 }
 
 // Fast-path eligibility of a tile (full 32x32 RGBA, 16-byte aligned rows) and its first byte.
-template <class Args>
+template <int C = 4, class Args>
 __device__ __forceinline__ bool fast32_tile_src(const Args &a, uint32_t tile_g, const uint8_t *&src)
 {
 	if (tile_g >= a.n_tiles) return false;
 	const uint32_t frame = fastdiv(tile_g, a.div_tpf);
 	const uint32_t t = tile_g - frame * a.tiles_per_frame;
 	const uint32_t ty = fastdiv(t, a.div_cols), tx = t - ty * a.cols;
-	src = a.src + (size_t)frame * a.frame_stride + (size_t)(ty * 32u) * a.pitch + (size_t)(tx * 32u) * 4u;
+	src = a.src + (size_t)frame * a.frame_stride + (size_t)(ty * 32u) * a.pitch + (size_t)(tx * 32u) * (uint32_t)C;
 	return tx < a.full_cols && ty < a.full_rows;  // full size; the alignment of the batch is folded in by the host
 }
-// Issues the four 16-byte loads of a lane's share of a fast tile (rows l/8 + 8k, quad l%8).
-template <class Args>
+// Issues the four loads of a lane's share of a fast tile: rows l/8 + 8k, pixel quad l%8 -- 16 bytes of an RGBA row, 12
+// of an RGB one (pre[k].w unused).
+template <int C = 4, class Args>
 __device__ __forceinline__ void fast32_prefetch(const Args &a, uint32_t tile_g, uint32_t lane, uint4 (&pre)[4], bool &valid)
 {
 	const uint8_t *src;
-	valid = fast32_tile_src(a, tile_g, src);
+	valid = fast32_tile_src<C>(a, tile_g, src);
 	if (valid) {
-		const uint8_t *p = src + (size_t)(lane >> 3) * a.pitch + (lane & 7u) * 16u;
+		const uint8_t *p = src + (size_t)(lane >> 3) * a.pitch + (lane & 7u) * (4u * (uint32_t)C);
 #pragma unroll
-		for (int k = 0; k < 4; ++k) pre[k] = *reinterpret_cast<const uint4 *>(p + (size_t)(8 * k) * a.pitch);
+		for (int k = 0; k < 4; ++k) {
+			if constexpr (C == 4) {
+				pre[k] = *reinterpret_cast<const uint4 *>(p + (size_t)(8 * k) * a.pitch);
+			} else {
+				const uint3 v = *reinterpret_cast<const uint3 *>(p + (size_t)(8 * k) * a.pitch);  // rows are 4-byte aligned
+				pre[k] = make_uint4(v.x, v.y, v.z, 0u);
+			}
+		}
 	}
 }
 

@@ -179,6 +179,7 @@ struct Knobs {
 	bool no_oklab_edges;    // PXZ_NO_OKLAB_EDGES: ragged edge tiles keep their four-lane chains
 	bool no_repitch;        // PXZ_NO_REPITCH: unaligned device batches are staged pixel by pixel
 	bool no_widen;          // PXZ_NO_WIDEN: RGB batches never ride the RGBA kernels
+	bool no_native_rgb;     // PXZ_NO_NATIVE_RGB: RGB batches are widened to RGBA even where a kernel reads RGB itself
 	bool oklab_v1;          // PXZ_OKLAB_V1: round-1 detector (one chain wave, two barriers per band) for 16/32-px tiles
 	int wpb;                // PXZ_WPB: waves per block of the persistent kernels (0: default)
 	int chunk_lg;           // PXZ_CHUNK_LG: log2 of the ticket run length of shrink32_kernel (-1: default)

@@ -18,7 +18,9 @@ namespace pxz {
 // ---------------------------------------------------------------------------
 // FULL: out_px, out_w and out_h are all there (the shrink entry points): no run-time tests of them in the loop --
 // kept as loop-invariant lane masks they cost scalar registers, and a spilled one two v_readlane per use.
-template <int MODE, bool FULL>
+// C = 3: RGB frames read and RGB slots written directly (round 2) -- 12-byte pixel quads in, the same three LDS planes,
+// no opacity test (there is no alpha), outputs packed to 3 bytes per pixel by the flush.
+template <int MODE, bool FULL, int C = 4>
 __global__ void __launch_bounds__(1024) shrink32_kernel(const Fast32Args a)
 {
 	extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
@@ -62,7 +64,7 @@ __global__ void __launch_bounds__(1024) shrink32_kernel(const Fast32Args a)
 	uint4 pre[4];
 	bool pre_valid = false;
 	const uint32_t first = tile_of_ticket(__builtin_amdgcn_readfirstlane(sub));
-	fast32_prefetch(a, first, tid, pre, pre_valid);
+	fast32_prefetch<C>(a, first, tid, pre, pre_valid);
 #ifdef PXZ_STAMPS
 	unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 	unsigned long long st_last = stamp_now();
@@ -74,30 +76,58 @@ __global__ void __launch_bounds__(1024) shrink32_kernel(const Fast32Args a)
 	uint8_t *pend_dst = nullptr;
 	auto flush = [&]() {
 		if (pend_kind == 1) {
-			uint32_t *d = reinterpret_cast<uint32_t *>(pend_dst);
-			if (pend_px >= 4u) {  // whole 16-byte groups (pixel counts are powers of two)
-				for (uint32_t i = tid; i < (pend_px >> 2); i += 64u)
-					reinterpret_cast<uint4 *>(d)[i] = reinterpret_cast<const uint4 *>(pend_src)[i];
-			} else if (tid < pend_px) {
-				d[tid] = pend_src[tid];
+			if constexpr (C == 4) {
+				uint32_t *d = reinterpret_cast<uint32_t *>(pend_dst);
+				if (pend_px >= 4u) {  // whole 16-byte groups (pixel counts are powers of two)
+					for (uint32_t i = tid; i < (pend_px >> 2); i += 64u)
+						reinterpret_cast<uint4 *>(d)[i] = reinterpret_cast<const uint4 *>(pend_src)[i];
+				} else if (tid < pend_px) {
+					d[tid] = pend_src[tid];
+				}
+			} else {
+				// RGB slots: four parked pixels (dwords, alpha 255) -> 12 bytes
+				if (pend_px >= 4u) {
+					for (uint32_t i = tid; i < (pend_px >> 2); i += 64u) {
+						const uint4 v = reinterpret_cast<const uint4 *>(pend_src)[i];
+						uint3 o;
+						o.x = __builtin_amdgcn_perm(v.y, v.x, 0x04020100u);  // R0 G0 B0 R1
+						o.y = __builtin_amdgcn_perm(v.z, v.y, 0x05040201u);  // G1 B1 R2 G2
+						o.z = __builtin_amdgcn_perm(v.w, v.z, 0x06050402u);  // B2 R3 G3 B3
+						reinterpret_cast<uint3 *>(pend_dst)[i] = o;
+					}
+				} else if (tid < pend_px) {
+					const uint32_t v = pend_src[tid];
+					pend_dst[3u * tid] = (uint8_t)v;
+					pend_dst[3u * tid + 1u] = (uint8_t)(v >> 8);
+					pend_dst[3u * tid + 2u] = (uint8_t)(v >> 16);
+				}
 			}
 		} else if (pend_kind == 2) {
-			// clone (block.rs:279-281): re-interleave the planes, one 16-byte store per 4 pixels
+			// clone (block.rs:279-281): re-interleave the planes, one 16-byte (RGB: 12-byte) store per 4 pixels
 #pragma unroll
 			for (int k = 0; k < 4; ++k) {
 				const uint32_t i = tid + 64u * (uint32_t)k;
 				const uint32_t *p = s_pl + (i >> 3) * kRS32 + (i & 7u) * 2u;
 				const uint2 r = *reinterpret_cast<const uint2 *>(p), g = *reinterpret_cast<const uint2 *>(p + kPD32);
 				const uint2 b = *reinterpret_cast<const uint2 *>(p + 2 * kPD32);
-				const uint32_t opq = 0x00ff00ffu;  // the tile is opaque: alpha pair (255, 255)
-				const uint32_t rg01 = __builtin_amdgcn_perm(g.x, r.x, 0x06020400u), ba01 = __builtin_amdgcn_perm(opq, b.x, 0x06020400u);
-				const uint32_t rg23 = __builtin_amdgcn_perm(g.y, r.y, 0x06020400u), ba23 = __builtin_amdgcn_perm(opq, b.y, 0x06020400u);
-				uint4 o;
-				o.x = __builtin_amdgcn_perm(ba01, rg01, 0x05040100u);
-				o.y = __builtin_amdgcn_perm(ba01, rg01, 0x07060302u);
-				o.z = __builtin_amdgcn_perm(ba23, rg23, 0x05040100u);
-				o.w = __builtin_amdgcn_perm(ba23, rg23, 0x07060302u);
-				reinterpret_cast<uint4 *>(pend_dst)[i] = o;
+				const uint32_t rg01 = __builtin_amdgcn_perm(g.x, r.x, 0x06020400u), rg23 = __builtin_amdgcn_perm(g.y, r.y, 0x06020400u);
+				if constexpr (C == 4) {
+					const uint32_t opq = 0x00ff00ffu;  // the tile is opaque: alpha pair (255, 255)
+					const uint32_t ba01 = __builtin_amdgcn_perm(opq, b.x, 0x06020400u), ba23 = __builtin_amdgcn_perm(opq, b.y, 0x06020400u);
+					uint4 o;
+					o.x = __builtin_amdgcn_perm(ba01, rg01, 0x05040100u);
+					o.y = __builtin_amdgcn_perm(ba01, rg01, 0x07060302u);
+					o.z = __builtin_amdgcn_perm(ba23, rg23, 0x05040100u);
+					o.w = __builtin_amdgcn_perm(ba23, rg23, 0x07060302u);
+					reinterpret_cast<uint4 *>(pend_dst)[i] = o;
+				} else {
+					uint3 o;
+					o.x = __builtin_amdgcn_perm(b.x, rg01, 0x02040100u);                        // R0 G0 B0 R1
+					const uint32_t gb1 = __builtin_amdgcn_perm(b.x, rg01, 0x0c0c0603u);         // G1 B1 . .
+					o.y = __builtin_amdgcn_perm(rg23, gb1, 0x05040100u);                        // G1 B1 R2 G2
+					o.z = __builtin_amdgcn_perm(b.y, rg23, 0x06030204u);                        // B2 R3 G3 B3
+					reinterpret_cast<uint3 *>(pend_dst)[i] = o;
+				}
 			}
 		}
 		pend_kind = 0;
@@ -118,7 +148,7 @@ __global__ void __launch_bounds__(1024) shrink32_kernel(const Fast32Args a)
 		if (!pre_valid) {  // ragged edge / unaligned rows: generic kernel
 			flush();
 			defer();
-			fast32_prefetch(a, tile_next, tid, pre, pre_valid);
+			fast32_prefetch<C>(a, tile_next, tid, pre, pre_valid);
 			return;
 		}
 		uint32_t given_bits = 0;
@@ -127,14 +157,15 @@ __global__ void __launch_bounds__(1024) shrink32_kernel(const Fast32Args a)
 		// previous tile's parked pixels, then stage: registers -> planar u16 pairs
 		// every alpha byte is 255 iff the smallest of the 16 pixel dwords is >= 0xff000000 (alpha is the top byte): eight
 		// three-way minima instead of sixteen ANDs and a shift
-		uint32_t least;
-		{
+		bool transparent = false;
+		if constexpr (C == 4) {
+			uint32_t least;
 			const uint32_t m0 = min(min(pre[0].x, pre[0].y), pre[0].z), m1 = min(min(pre[0].w, pre[1].x), pre[1].y);
 			const uint32_t m2 = min(min(pre[1].z, pre[1].w), pre[2].x), m3 = min(min(pre[2].y, pre[2].z), pre[2].w);
 			const uint32_t m4 = min(min(pre[3].x, pre[3].y), pre[3].z);
 			least = min(min(min(m0, m1), m2), min(min(m3, m4), pre[3].w));
+			transparent = __builtin_amdgcn_ballot_w64(least < 0xff000000u) != 0ull;
 		}
-		const bool transparent = __builtin_amdgcn_ballot_w64(least < 0xff000000u) != 0ull;
 		__builtin_amdgcn_sched_barrier(0);
 		flush();
 		__builtin_amdgcn_sched_barrier(0);
@@ -143,17 +174,24 @@ __global__ void __launch_bounds__(1024) shrink32_kernel(const Fast32Args a)
 			const uint32_t row = (tid >> 3) + 8u * (uint32_t)k, col = tid & 7u;
 			const uint4 v = pre[k];
 			uint32_t *d = s_pl + row * kRS32 + col * 2u;
+			if constexpr (C == 4) {
 #pragma unroll
-			for (uint32_t c = 0; c < 3; ++c) {
-				const uint32_t sel = c | 0x0c000c00u | ((4u + c) << 16);
-				uint2 pr;
-				pr.x = __builtin_amdgcn_perm(v.y, v.x, sel);
-				pr.y = __builtin_amdgcn_perm(v.w, v.z, sel);
-				*reinterpret_cast<uint2 *>(d + c * kPD32) = pr;
+				for (uint32_t c = 0; c < 3; ++c) {
+					const uint32_t sel = c | 0x0c000c00u | ((4u + c) << 16);
+					uint2 pr;
+					pr.x = __builtin_amdgcn_perm(v.y, v.x, sel);
+					pr.y = __builtin_amdgcn_perm(v.w, v.z, sel);
+					*reinterpret_cast<uint2 *>(d + c * kPD32) = pr;
+				}
+			} else {
+				// bytes R0 G0 B0 R1 | G1 B1 R2 G2 | B2 R3 G3 B3 -> the u16 pairs (c0, c1), (c2, c3) of each plane
+				*reinterpret_cast<uint2 *>(d) = make_uint2(__builtin_amdgcn_perm(v.x, v.x, 0x0c070c00u), __builtin_amdgcn_perm(v.z, v.y, 0x0c050c02u));
+				*reinterpret_cast<uint2 *>(d + kPD32) = make_uint2(__builtin_amdgcn_perm(v.y, v.x, 0x0c040c01u), __builtin_amdgcn_perm(v.z, v.y, 0x0c060c03u));
+				*reinterpret_cast<uint2 *>(d + 2 * kPD32) = make_uint2(__builtin_amdgcn_perm(v.y, v.x, 0x0c050c02u), __builtin_amdgcn_perm(v.z, v.z, 0x0c070c00u));
 			}
 		}
 		PXZ_STAMP(0);  // wait for the prefetched pixels + staging
-		fast32_prefetch(a, tile_next, tid, pre, pre_valid);  // lands while this tile is processed
+		fast32_prefetch<C>(a, tile_next, tid, pre, pre_valid);  // lands while this tile is processed
 		if (transparent && (FULL || a.out_px != nullptr)) {
 			// transparency: the premultiplied convolution needs the alpha plane -- shrink32a_kernel (list A) when the
 			// caller announced transparent frames, else the generic kernel (list B).  (Detector-only launches do not
@@ -249,7 +287,7 @@ __global__ void __launch_bounds__(1024) shrink32_kernel(const Fast32Args a)
 		if (FULL || a.out_px != nullptr) {
 			uint32_t filt = a.filter;
 			asm volatile("" : "+s"(filt));  // a scalar compare per use, not a hoisted (and spilled) mask
-			pend_dst = a.out_px + (size_t)tile_g * 4096u;
+			pend_dst = a.out_px + (size_t)tile_g * (1024u * (uint32_t)C);
 			pend_px = nw * nh;
 			if (nw == 32u && nh == 32u) {
 				pend_kind = 2;  // the planes themselves, re-interleaved by the flush
@@ -808,7 +846,7 @@ __global__ void __launch_bounds__(1024) shrink16_kernel(const Fast32Args a)
 
 // 32x32 / 16x16 flow, first part: shrink32_kernel (+ shrink32a_kernel) or shrink16_kernel; ga = the arguments of
 // the worklist kernel that follows (pxz_shrink_generic.hip: launch_shrink)
-hipError_t launch_fast32_16(const ShrinkArgs &a, ShrinkArgs &ga, uint32_t n_cus, hipStream_t stream)
+hipError_t launch_fast32_16(const ShrinkArgs &a, ShrinkArgs &ga, uint32_t channels, uint32_t n_cus, hipStream_t stream)
 {
 	// 1) the lean kernel for full opaque tiles (32x32), or for 2x2 groups of them (16x16); it leaves the rest
 	// in the worklist
@@ -845,7 +883,7 @@ hipError_t launch_fast32_16(const ShrinkArgs &a, ShrinkArgs &ga, uint32_t n_cus,
 	ga.finish_scan = groups16 ? 1u : 0u;
 	// full tiles with transparency always go to list A; shrink32a_kernel takes it when transparency was announced
 	// or seen before, else the worklist kernel walks it after list B
-	f.alpha_list = (!groups16 && a.out_px != nullptr && (a.filter == 0 || a.tab_dw != 0)) ? 1u : 0u;
+	f.alpha_list = (!groups16 && channels == 4 && a.out_px != nullptr && (a.filter == 0 || a.tab_dw != 0)) ? 1u : 0u;
 	const bool run_alpha = f.alpha_list != 0 && a.alpha_kernel != 0;
 	ga.list_a_too = f.alpha_list != 0 && !run_alpha ? 1u : 0u;
 	f.trows = a.trows;
@@ -888,6 +926,8 @@ hipError_t launch_fast32_16(const ShrinkArgs &a, ShrinkArgs &ga, uint32_t n_cus,
 		const bool full = a.out_px != nullptr && a.out_w != nullptr && a.out_h != nullptr;
 		void (*k)(const Fast32Args) = a.mode == 1 ? (full ? shrink32_kernel<1, true> : shrink32_kernel<1, false>)
 		                                          : (full ? shrink32_kernel<0, true> : shrink32_kernel<0, false>);
+		if (channels == 3)  // RGB frames, directional detector: 12-byte pixel quads in, RGB slots out
+			k = full ? shrink32_kernel<1, true, 3> : shrink32_kernel<1, false, 3>;
 		if (lds_bytes > 64u * 1024u && (e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)) != hipSuccess) return e;
 		hipLaunchKernelGGL(k, dim3(blocks), dim3(64u * wpb), lds_bytes, stream, f);
 	}
