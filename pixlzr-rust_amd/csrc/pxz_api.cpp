@@ -35,7 +35,7 @@ hipError_t launch_decode(const DecodeArgs &a, hipStream_t stream);
 hipError_t launch_widen(const WidenArgs &a, hipStream_t stream);
 hipError_t launch_narrow(const NarrowArgs &a, hipStream_t stream);
 hipError_t launch_pack(const PackArgs &a, hipStream_t stream);
-hipError_t launch_oklab(const ShrinkArgs &a, uint32_t n_cus, hipStream_t stream);
+hipError_t launch_oklab(const ShrinkArgs &a, uint32_t n_cus, hipStream_t stream, uint32_t channels = 4);
 hipError_t launch_qoi(const QoiArgs &a, hipStream_t stream);
 uint32_t waves_per_tile(uint32_t bw, uint32_t bh);
 }  // namespace pxz
@@ -606,8 +606,8 @@ int timed_launch(pxz_handle *h, pxz::ShrinkArgs &a, uint32_t channels, float *va
 	a.ok_region = 0;
 	a.ok_count = a.n_tiles;
 	a.ok_edges = 0;
-	// RGB frames on the 32x32 directional fast path (round 2): 12-byte pixel quads, rows 4-byte aligned
-	const bool rgb_native = channels == 3 && a.bw == 32 && a.bh == 32 && a.mode == PXZ_MODE_SHRINK_DIRECTIONALLY && !pxz::knobs().no_native_rgb &&
+	// RGB frames on the 32x32 fast path (round 2; both callers): 12-byte pixel quads, rows 4-byte aligned
+	const bool rgb_native = channels == 3 && a.bw == 32 && a.bh == 32 && !pxz::knobs().no_native_rgb &&
 	    ((reinterpret_cast<uintptr_t>(a.src) | a.pitch | (a.n_tiles > a.tiles_per_frame ? a.frame_stride : 0)) & 3u) == 0;
 	if (rgb_native) {
 		a.full_cols = a.edge_w == a.bw ? a.cols : a.cols - 1;
@@ -680,6 +680,15 @@ int timed_launch(pxz_handle *h, pxz::ShrinkArgs &a, uint32_t channels, float *va
 			e.ok_count = n_frames * r.per_frame;
 			PXZ_HIP(h, pxz::launch_oklab(e, h->n_cus, h->stream));
 			a.ok_edges |= r.bit;
+		}
+	}
+	if (a.mode == PXZ_MODE_SHRINK_BY && rgb_native && a.full_cols != 0 && a.full_rows != 0 && !pxz::knobs().no_oklab32) {
+		// RGB, 32x32: oklab2_kernel<32, 3> for the full tiles; a ragged edge keeps its chains in the generic kernel
+		a.oklab_given = 1;
+		PXZ_HIP(h, pxz::launch_oklab(a, h->n_cus, h->stream, 3));
+		if (a.mid_event) {
+			PXZ_HIP(h, hipEventRecord(static_cast<hipEvent_t>(a.mid_event), h->stream));
+			a.mid_event = nullptr;
 		}
 	}
 	if (a.mode == PXZ_MODE_SHRINK_BY && a.lab_dw == 0) {
@@ -902,8 +911,8 @@ static int run_shrink(pxz_handle *h, const pxz_frames *frames, const pxz_params 
 	const bool square_fast = a.bw == a.bh && (a.bw == 16 || a.bw == 32 || a.bw == 64);
 	const bool general_oklab = a.mode == PXZ_MODE_SHRINK_BY && a.bw % 4u == 0 && a.bw * a.bh >= 64u && a.bw * a.bh <= 16384u;
 	bool widen = frames->channels == 3 && (square_fast || general_oklab) && !pxz::knobs().no_widen;
-	// (32x32 tiles under the directional detector: shrink32_kernel reads RGB itself, when the rows are 4-byte aligned)
-	if (widen && a.bw == 32 && a.bh == 32 && a.mode == PXZ_MODE_SHRINK_DIRECTIONALLY && !pxz::knobs().no_native_rgb &&
+	// (32x32 tiles: shrink32_kernel and oklab2_kernel read RGB themselves, when the rows are 4-byte aligned)
+	if (widen && a.bw == 32 && a.bh == 32 && !rgb_must_widen && !pxz::knobs().no_native_rgb &&
 	    ((reinterpret_cast<uintptr_t>(d_pixels) | frames->pitch_bytes | (frames->n_frames > 1 ? frames->frame_stride_bytes : 0)) & 3u) == 0)
 		widen = false;
 	if (widen && d_out_pixels && params->filter != PXZ_FILTER_NEAREST) {

@@ -230,7 +230,7 @@ struct OkGeom {
 // ragged last row of the grid when its height happens to be one).  tile_h = 0 when it does not.
 // item = the launch's running index: the tile number (region 0: every tile is asked, the full ones are taken), or the
 // index inside an edge region (T = 0 only: all of its tiles are taken).  tile_g = the tile's number in the batch.
-template <int T, class Args>
+template <int T, int C = 4, class Args>
 __device__ __forceinline__ uint32_t oklab_tile_src(const Args &a, uint32_t item, const uint8_t *&src, uint32_t &tile_g)
 {
 	tile_g = item;
@@ -248,7 +248,7 @@ __device__ __forceinline__ uint32_t oklab_tile_src(const Args &a, uint32_t item,
 	const uint32_t t = item - frame * a.tiles_per_frame;
 	const uint32_t ty = fastdiv(t, a.div_cols), tx = t - ty * a.cols;
 	const uint32_t tw = T > 0 ? (uint32_t)T : a.bw, th = T > 0 ? (uint32_t)T : a.bh;
-	src = a.src + (size_t)frame * a.frame_stride + (size_t)(ty * th) * a.pitch + (size_t)(tx * tw) * 4u;
+	src = a.src + (size_t)frame * a.frame_stride + (size_t)(ty * th) * a.pitch + (size_t)(tx * tw) * (uint32_t)C;
 	if (tx >= a.full_cols || ty >= a.ok_rows) return 0u;
 	return ty == a.rows - 1u ? a.edge_h : th;  // (T = 0: only full tiles are eligible, so this is th)
 }
@@ -575,7 +575,9 @@ constexpr uint32_t kOk2Band = kOk2Prod * 4 * kOk2Plane; // floats per band buffe
 constexpr uint32_t kOk2Tables = 3072u + 256u + 2u * 128u + 64u; // dwords: matrix-column products, alpha, scale (doubles), means
 constexpr uint32_t kOk2LdsBytes = (kOk2Tables + 5u * kOk2Band) * 4u;
 
-template <int T>
+// C = 3 (round 2): RGB frames read directly -- a lane's two pixels are six bytes inside an aligned eight (rows are 4-byte
+// aligned), cut out with two funnel shifts; there is no alpha (the plane is the constant 1).
+template <int T, int C = 4>
 __global__ void __launch_bounds__(1024) oklab2_kernel(const ShrinkArgs a)
 {
 	constexpr uint32_t NB = T * T / 128;        // bands per tile: 2 | 8
@@ -604,14 +606,17 @@ __global__ void __launch_bounds__(1024) oklab2_kernel(const ShrinkArgs a)
 
 	if (wave < kOk2Prod) {
 		// ---------------- producers ----------------
-		const size_t lane_off = (size_t)(lane / kLanesPerRow) * a.pitch + (lane % kLanesPerRow) * 8u;
+		// RGBA: the lane's two pixels are 8 aligned bytes.  RGB: bytes 6l .. 6l+5 of the row (l = lane in row) lie inside the
+		// aligned 8 bytes at 6l & ~3, shifted by 0 or 2 bytes
+		const uint32_t rgb_off = (lane % kLanesPerRow) * 6u, rgb_shift = (rgb_off & 3u) * 8u;
+		const size_t lane_off = (size_t)(lane / kLanesPerRow) * a.pitch + (C == 4 ? (lane % kLanesPerRow) * 8u : (rgb_off & ~3u));
 		const size_t band_step = (size_t)kRowsPerBand * a.pitch;
 		auto batch_src = [&](uint32_t j, uint32_t &bands) -> const uint8_t * {
 			const uint8_t *src;
 			bands = 0;
 			if (j >= own) return nullptr;
 			uint32_t unused_tile;
-			const uint32_t th = oklab_tile_src<T>(a, (blockIdx.x + j * gridDim.x) * kOk2Prod + wave, src, unused_tile);
+			const uint32_t th = oklab_tile_src<T, C>(a, (blockIdx.x + j * gridDim.x) * kOk2Prod + wave, src, unused_tile);
 			if (th == 0) return nullptr;
 			bands = th / kRowsPerBand;  // (a ragged tile is only taken when its height is a multiple of 8 rows)
 			return src + lane_off;
@@ -664,9 +669,16 @@ __global__ void __launch_bounds__(1024) oklab2_kernel(const ShrinkArgs a)
 		auto head = [&](bool valid, const uint2 &px) {
 			st_valid = valid;
 			if (valid) {
-				oklab_pair_head(px.x, px.y, s_lms, s_scale, st);
-				st_opaque = __all((px.x & px.y) >= 0xff000000u);
-				st_ab = (px.x >> 24) | ((px.y >> 24) << 8);
+				if constexpr (C == 4) {
+					oklab_pair_head(px.x, px.y, s_lms, s_scale, st);
+					st_opaque = __all((px.x & px.y) >= 0xff000000u);
+					st_ab = (px.x >> 24) | ((px.y >> 24) << 8);
+				} else {
+					const uint32_t w0 = __builtin_amdgcn_alignbit(px.y, px.x, rgb_shift);  // R0 G0 B0 R1
+					const uint32_t w1 = px.y >> rgb_shift;                                  // G1 B1 . .
+					oklab_pair_head(w0, __builtin_amdgcn_alignbit(w1, w0, 24), s_lms, s_scale, st);  // (byte 3 of either is not looked at)
+					st_opaque = true;
+				}
 			}
 		};
 		head(src1 != nullptr && nb1 > 0u, q[0]);
@@ -779,7 +791,7 @@ __global__ void __launch_bounds__(1024) oklab2_kernel(const ShrinkArgs a)
 				hm1 = h0;
 				gm2 = gm1;
 				gm1 = g0;
-				h0 = (live && p < own) ? oklab_tile_src<T>(a, (blockIdx.x + p * gridDim.x) * kOk2Prod + ct, unused, g0) : 0u;
+				h0 = (live && p < own) ? oklab_tile_src<T, C>(a, (blockIdx.x + p * gridDim.x) * kOk2Prod + ct, unused, g0) : 0u;
 			}
 #pragma unroll 1
 			for (uint32_t k = 0; k < NB; ++k) {
@@ -822,7 +834,7 @@ __global__ void __launch_bounds__(1024) oklab2_kernel(const ShrinkArgs a)
 	}
 }
 
-hipError_t launch_oklab(const ShrinkArgs &a, uint32_t n_cus, hipStream_t stream)
+hipError_t launch_oklab(const ShrinkArgs &a, uint32_t n_cus, hipStream_t stream, uint32_t channels)
 {
 	const uint32_t lds_bytes = (3072u + 256u + 2u * 128u + 64u) * 4u + 2u * kOkBand * 4u;
 	const uint32_t n_batches = (a.ok_count + kOkTiles - 1) / kOkTiles;
@@ -839,8 +851,10 @@ hipError_t launch_oklab(const ShrinkArgs &a, uint32_t n_cus, hipStream_t stream)
 			hipLaunchKernelGGL(kernel, dim3(blocks2), dim3(1024), 0, stream, a);
 			return hipGetLastError();
 		};
+		if (channels == 3) return a.bw == 16u ? go2(oklab2_kernel<16, 3>) : go2(oklab2_kernel<32, 3>);
 		return a.bw == 16u ? go2(oklab2_kernel<16>) : go2(oklab2_kernel<32>);
 	}
+	if (channels != 4) return hipErrorInvalidValue;  // (the round-1 kernels below read RGBA)
 	if (a.bw == a.bh && a.ok_region == 0u) {
 		switch (a.bw) {
 		case 16: return go(oklab_kernel<16>);

@@ -926,8 +926,9 @@ hipError_t launch_fast32_16(const ShrinkArgs &a, ShrinkArgs &ga, uint32_t channe
 		const bool full = a.out_px != nullptr && a.out_w != nullptr && a.out_h != nullptr;
 		void (*k)(const Fast32Args) = a.mode == 1 ? (full ? shrink32_kernel<1, true> : shrink32_kernel<1, false>)
 		                                          : (full ? shrink32_kernel<0, true> : shrink32_kernel<0, false>);
-		if (channels == 3)  // RGB frames, directional detector: 12-byte pixel quads in, RGB slots out
-			k = full ? shrink32_kernel<1, true, 3> : shrink32_kernel<1, false, 3>;
+		if (channels == 3)  // RGB frames: 12-byte pixel quads in, RGB slots out
+			k = a.mode == 1 ? (full ? shrink32_kernel<1, true, 3> : shrink32_kernel<1, false, 3>)
+			                : (full ? shrink32_kernel<0, true, 3> : shrink32_kernel<0, false, 3>);
 		if (lds_bytes > 64u * 1024u && (e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)) != hipSuccess) return e;
 		hipLaunchKernelGGL(k, dim3(blocks), dim3(64u * wpb), lds_bytes, stream, f);
 	}

@@ -690,8 +690,7 @@ bool fast16_applicable(const ShrinkArgs &a, uint32_t channels)
 
 bool fast32_applicable(const ShrinkArgs &a, uint32_t channels)
 {
-	// (RGB: the directional detector only -- the Oklab detector's values come from RGBA launches)
-	return (channels == 4 || (channels == 3 && a.mode == 1)) && a.bw == 32 && a.bh == 32 && a.work != nullptr &&
+	return (channels == 4 || channels == 3) && a.bw == 32 && a.bh == 32 && a.work != nullptr &&
 	       (a.out_px == nullptr || a.filter == 0 || a.tab_dw != 0) && !(a.mode == 0 && !a.oklab_given);
 }
 
