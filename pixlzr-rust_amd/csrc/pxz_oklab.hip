@@ -253,9 +253,11 @@ __device__ __forceinline__ uint32_t oklab_tile_src(const Args &a, uint32_t item,
 	return ty == a.rows - 1u ? a.edge_h : th;  // (T = 0: only full tiles are eligible, so this is th)
 }
 
-template <int T, int NBR = 0>
+// C = 3 (T = 64 only): RGB frames, a lane's 4 pixels are 12 bytes (rows 4-byte aligned), alpha 255.
+template <int T, int NBR = 0, int C = 4>
 __global__ void __launch_bounds__(1024) oklab_kernel(const ShrinkArgs a)
 {
+	static_assert(C == 4 || T > 0, "the run-time geometry reads RGBA");
 	using G = OkGeom<T>;
 	constexpr bool kGeneral = T == 0;
 	constexpr bool kInRegs = kGeneral ? NBR > 0 : G::kInRegs;
@@ -285,7 +287,7 @@ __global__ void __launch_bounds__(1024) oklab_kernel(const ShrinkArgs a)
 
 	if (wave < kOkTiles) {
 		// ---------------- producers ----------------
-		const uint32_t row_off = lane / G::kLanesPerRow, col_off = (lane % G::kLanesPerRow) * 16u;
+		const uint32_t row_off = lane / G::kLanesPerRow, col_off = (lane % G::kLanesPerRow) * (4u * (uint32_t)C);
 		const size_t band_step = (size_t)G::kRowsPerBand * a.pitch;
 		// this lane's 4 pixels of a band: how many exist (T = 0: short last band, padded rows), and where in the tile
 		// real pixels among the lane's four of a band (4, or fewer in the last quad of a padded row; 0: none)
@@ -307,7 +309,11 @@ __global__ void __launch_bounds__(1024) oklab_kernel(const ShrinkArgs a)
 		auto load_band = [&](const uint8_t *tile, uint32_t band) -> uint4 {
 			const uint32_t have = lane_px(band);
 			uint4 v = make_uint4(0, 0, 0, 0);  // black, alpha 0: converts to exact zeros
-			if (have == 4u) {
+			if constexpr (C == 3) {
+				const uint3 t = *reinterpret_cast<const uint3 *>(tile + lane_off(band));
+				v = make_uint4(t.x | 0xff000000u, __builtin_amdgcn_alignbit(t.y, t.x, 24) | 0xff000000u,
+				               __builtin_amdgcn_alignbit(t.z, t.y, 16) | 0xff000000u, (t.z >> 8) | 0xff000000u);
+			} else if (have == 4u) {
 				v = *reinterpret_cast<const uint4 *>(tile + lane_off(band));
 			} else if (have != 0u) {  // the last quad of a padded row: nothing is read past the row's real pixels
 				const uint32_t *p = reinterpret_cast<const uint32_t *>(tile + lane_off(band));
@@ -323,7 +329,7 @@ __global__ void __launch_bounds__(1024) oklab_kernel(const ShrinkArgs a)
 			bands = 0;
 			if (j >= own) return nullptr;
 			uint32_t unused_tile;
-			const uint32_t th = oklab_tile_src<T>(a, (blockIdx.x + j * gridDim.x) * kOkTiles + wave, src, unused_tile);
+			const uint32_t th = oklab_tile_src<T, C>(a, (blockIdx.x + j * gridDim.x) * kOkTiles + wave, src, unused_tile);
 			if (th == 0) return nullptr;
 			bands = kGeneral ? NB : th / G::kRowsPerBand;  // (a ragged tile is only taken with a whole number of bands)
 			return src;
@@ -510,7 +516,7 @@ __global__ void __launch_bounds__(1024) oklab_kernel(const ShrinkArgs a)
 				hm1 = h0;
 				gm2 = gm1;
 				gm1 = g0;
-				h0 = (live && p < own) ? oklab_tile_src<T>(a, (blockIdx.x + p * gridDim.x) * kOkTiles + ct, unused, g0) : 0u;
+				h0 = (live && p < own) ? oklab_tile_src<T, C>(a, (blockIdx.x + p * gridDim.x) * kOkTiles + ct, unused, g0) : 0u;
 			}
 #pragma unroll 1
 			for (uint32_t k = 0; k < NB; ++k) {
@@ -854,7 +860,8 @@ hipError_t launch_oklab(const ShrinkArgs &a, uint32_t n_cus, hipStream_t stream,
 		if (channels == 3) return a.bw == 16u ? go2(oklab2_kernel<16, 3>) : go2(oklab2_kernel<32, 3>);
 		return a.bw == 16u ? go2(oklab2_kernel<16>) : go2(oklab2_kernel<32>);
 	}
-	if (channels != 4) return hipErrorInvalidValue;  // (the round-1 kernels below read RGBA)
+	if (channels == 3 && a.bw == 64u && a.bh == 64u && a.ok_region == 0u) return go(oklab_kernel<64, 0, 3>);
+	if (channels != 4) return hipErrorInvalidValue;  // (the other round-1 kernels read RGBA)
 	if (a.bw == a.bh && a.ok_region == 0u) {
 		switch (a.bw) {
 		case 16: return go(oklab_kernel<16>);

@@ -26,14 +26,14 @@ constexpr uint32_t kTS64 = 20;                   // dwords per column of the hor
 constexpr uint32_t kRed64 = 48;                  // partial sums, flags, ticket, two worklist batches
 constexpr uint32_t lds64_dwords(uint32_t nch) { return nch * kPD64 + nch * 32u * kTS64 + kRed64; }  // planes + [channel][ox < 32][kTS64] + s_red
 
-template <class Args>
+template <int C = 4, class Args>
 __device__ __forceinline__ bool fast64_tile_src(const Args &a, uint32_t tile_g, const uint8_t *&src)
 {
 	if (tile_g >= a.n_tiles) return false;
 	const uint32_t frame = fastdiv(tile_g, a.div_tpf);
 	const uint32_t t = tile_g - frame * a.tiles_per_frame;
 	const uint32_t ty = fastdiv(t, a.div_cols), tx = t - ty * a.cols;
-	src = a.src + (size_t)frame * a.frame_stride + (size_t)(ty * 64u) * a.pitch + (size_t)(tx * 64u) * 4u;
+	src = a.src + (size_t)frame * a.frame_stride + (size_t)(ty * 64u) * a.pitch + (size_t)(tx * 64u) * (uint32_t)C;
 	return tx < a.full_cols && ty < a.full_rows;
 }
 
@@ -41,10 +41,23 @@ __device__ __forceinline__ bool fast64_tile_src(const Args &a, uint32_t tile_g, 
 // channel, the colours are premultiplied in place once the detector is done with them (fir's U8x4 path), all
 // four planes go through the passes and every output pixel is un-premultiplied.
 // FULL: as in shrink32_kernel (out_px, out_w, out_h all there: no run-time tests of them in the tile loop).
-template <int MODE, bool ALPHA, bool FULL>
+// C = 3 (round 2): RGB frames read (12-byte pixel quads) and RGB slots written directly; no opacity test, no ALPHA instance.
+template <int MODE, bool ALPHA, bool FULL, int C = 4>
 __global__ void __launch_bounds__(256) shrink64_kernel(const Fast64Args a)
 {
+	static_assert(C == 4 || !ALPHA, "RGB tiles have no alpha plane");
 	constexpr uint32_t NCH = ALPHA ? 4u : 3u;
+	// one output pixel (a dword R G B A) into a slot of C-byte pixels
+	auto store_px = [](uint8_t *slot, uint32_t index, uint32_t px) {
+		if constexpr (C == 4) {
+			reinterpret_cast<uint32_t *>(slot)[index] = px;
+		} else {
+			uint8_t *p = slot + 3u * index;
+			p[0] = (uint8_t)px;
+			p[1] = (uint8_t)(px >> 8);
+			p[2] = (uint8_t)(px >> 16);
+		}
+	};
 	extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
 	uint32_t *s_pl = lds;                       // NCH planes of u16 pairs
 	uint32_t *s_t = lds + NCH * kPD64;          // horizontal-pass results
@@ -61,11 +74,18 @@ __global__ void __launch_bounds__(256) shrink64_kernel(const Fast64Args a)
 	bool pre_valid = false;
 	auto prefetch = [&](uint32_t tile_g) {
 		const uint8_t *src;
-		pre_valid = fast64_tile_src(a, tile_g, src);
+		pre_valid = fast64_tile_src<C>(a, tile_g, src);
 		if (pre_valid) {
-			const uint8_t *p = src + (size_t)(16u * wave + (lane >> 4)) * a.pitch + (lane & 15u) * 16u;
+			const uint8_t *p = src + (size_t)(16u * wave + (lane >> 4)) * a.pitch + (lane & 15u) * (4u * (uint32_t)C);
 #pragma unroll
-			for (int k = 0; k < 4; ++k) pre[k] = *reinterpret_cast<const uint4 *>(p + (size_t)(4 * k) * a.pitch);
+			for (int k = 0; k < 4; ++k) {
+				if constexpr (C == 4) {
+					pre[k] = *reinterpret_cast<const uint4 *>(p + (size_t)(4 * k) * a.pitch);
+				} else {
+					const uint3 v = *reinterpret_cast<const uint3 *>(p + (size_t)(4 * k) * a.pitch);  // rows are 4-byte aligned
+					pre[k] = make_uint4(v.x, v.y, v.z, 0u);
+				}
+			}
 		}
 	};
 	// Tiles are dealt on demand: tile costs differ several times between size classes, and with ~64 tiles per
@@ -127,8 +147,8 @@ __global__ void __launch_bounds__(256) shrink64_kernel(const Fast64Args a)
 		}
 		// ---- stage: registers -> planar u16 pairs
 		// (every alpha byte is 255 iff the smallest of the 16 pixel dwords is >= 0xff000000: three-way minima)
-		uint32_t least;
-		{
+		uint32_t least = 0xffffffffu;
+		if constexpr (C == 4) {
 			const uint32_t m0 = min(min(pre[0].x, pre[0].y), pre[0].z), m1 = min(min(pre[0].w, pre[1].x), pre[1].y);
 			const uint32_t m2 = min(min(pre[1].z, pre[1].w), pre[2].x), m3 = min(min(pre[2].y, pre[2].z), pre[2].w);
 			const uint32_t m4 = min(min(pre[3].x, pre[3].y), pre[3].z);
@@ -139,16 +159,23 @@ __global__ void __launch_bounds__(256) shrink64_kernel(const Fast64Args a)
 			const uint32_t row = 16u * wave + (lane >> 4) + 4u * (uint32_t)k, col = lane & 15u;
 			const uint4 v = pre[k];
 			uint32_t *d = s_pl + row * kRS64 + col * 2u;
+			if constexpr (C == 4) {
 #pragma unroll
-			for (uint32_t c = 0; c < NCH; ++c) {
-				const uint32_t sel = c | 0x0c000c00u | ((4u + c) << 16);
-				uint2 pr;
-				pr.x = __builtin_amdgcn_perm(v.y, v.x, sel);
-				pr.y = __builtin_amdgcn_perm(v.w, v.z, sel);
-				*reinterpret_cast<uint2 *>(d + c * kPD64) = pr;
+				for (uint32_t c = 0; c < NCH; ++c) {
+					const uint32_t sel = c | 0x0c000c00u | ((4u + c) << 16);
+					uint2 pr;
+					pr.x = __builtin_amdgcn_perm(v.y, v.x, sel);
+					pr.y = __builtin_amdgcn_perm(v.w, v.z, sel);
+					*reinterpret_cast<uint2 *>(d + c * kPD64) = pr;
+				}
+			} else {
+				// bytes R0 G0 B0 R1 | G1 B1 R2 G2 | B2 R3 G3 B3 -> the u16 pairs (c0, c1), (c2, c3) of each plane
+				*reinterpret_cast<uint2 *>(d) = make_uint2(__builtin_amdgcn_perm(v.x, v.x, 0x0c070c00u), __builtin_amdgcn_perm(v.z, v.y, 0x0c050c02u));
+				*reinterpret_cast<uint2 *>(d + kPD64) = make_uint2(__builtin_amdgcn_perm(v.y, v.x, 0x0c040c01u), __builtin_amdgcn_perm(v.z, v.y, 0x0c060c03u));
+				*reinterpret_cast<uint2 *>(d + 2 * kPD64) = make_uint2(__builtin_amdgcn_perm(v.y, v.x, 0x0c050c02u), __builtin_amdgcn_perm(v.z, v.z, 0x0c070c00u));
 			}
 		}
-		const bool wave_transparent = __builtin_amdgcn_ballot_w64(least < 0xff000000u) != 0ull;
+		const bool wave_transparent = C == 4 && __builtin_amdgcn_ballot_w64(least < 0xff000000u) != 0ull;
 		if (lane == 0) s_red[8 + wave] = wave_transparent ? 1u : 0u;
 		prefetch(tile_next);  // lands while this tile is processed
 		__syncthreads();      // B1: the whole tile is staged
@@ -243,7 +270,7 @@ __global__ void __launch_bounds__(256) shrink64_kernel(const Fast64Args a)
 			__syncthreads();  // s_red is rewritten by the next tile
 			continue;
 		}
-		uint8_t *dst = a.out_px + (size_t)this_tile * (64u * 64u * 4u);
+		uint8_t *dst = a.out_px + (size_t)this_tile * (64u * 64u * (uint32_t)C);
 		if (nw == 64u && nh == 64u) {
 			// clone (block.rs:279-281): re-interleave this wave's 16 rows, 16 bytes per lane and step
 #pragma unroll
@@ -255,14 +282,23 @@ __global__ void __launch_bounds__(256) shrink64_kernel(const Fast64Args a)
 				const uint2 b = *reinterpret_cast<const uint2 *>(p + 2 * kPD64);
 				uint2 al = make_uint2(0x00ff00ffu, 0x00ff00ffu);
 				if constexpr (ALPHA) al = *reinterpret_cast<const uint2 *>(p + 3 * kPD64);
-				const uint32_t rg01 = __builtin_amdgcn_perm(g.x, r.x, 0x06020400u), ba01 = __builtin_amdgcn_perm(al.x, b.x, 0x06020400u);
-				const uint32_t rg23 = __builtin_amdgcn_perm(g.y, r.y, 0x06020400u), ba23 = __builtin_amdgcn_perm(al.y, b.y, 0x06020400u);
-				uint4 o;
-				o.x = __builtin_amdgcn_perm(ba01, rg01, 0x05040100u);
-				o.y = __builtin_amdgcn_perm(ba01, rg01, 0x07060302u);
-				o.z = __builtin_amdgcn_perm(ba23, rg23, 0x05040100u);
-				o.w = __builtin_amdgcn_perm(ba23, rg23, 0x07060302u);
-				reinterpret_cast<uint4 *>(dst)[row * 16u + c4] = o;
+				const uint32_t rg01 = __builtin_amdgcn_perm(g.x, r.x, 0x06020400u), rg23 = __builtin_amdgcn_perm(g.y, r.y, 0x06020400u);
+				if constexpr (C == 4) {
+					const uint32_t ba01 = __builtin_amdgcn_perm(al.x, b.x, 0x06020400u), ba23 = __builtin_amdgcn_perm(al.y, b.y, 0x06020400u);
+					uint4 o;
+					o.x = __builtin_amdgcn_perm(ba01, rg01, 0x05040100u);
+					o.y = __builtin_amdgcn_perm(ba01, rg01, 0x07060302u);
+					o.z = __builtin_amdgcn_perm(ba23, rg23, 0x05040100u);
+					o.w = __builtin_amdgcn_perm(ba23, rg23, 0x07060302u);
+					reinterpret_cast<uint4 *>(dst)[row * 16u + c4] = o;
+				} else {
+					uint3 o;
+					o.x = __builtin_amdgcn_perm(b.x, rg01, 0x02040100u);                  // R0 G0 B0 R1
+					const uint32_t gb1 = __builtin_amdgcn_perm(b.x, rg01, 0x0c0c0603u);   // G1 B1 . .
+					o.y = __builtin_amdgcn_perm(rg23, gb1, 0x05040100u);                  // G1 B1 R2 G2
+					o.z = __builtin_amdgcn_perm(b.y, rg23, 0x06030204u);                  // B2 R3 G3 B3
+					reinterpret_cast<uint3 *>(dst)[row * 16u + c4] = o;
+				}
 			}
 			__syncthreads();
 			continue;
@@ -382,7 +418,7 @@ __global__ void __launch_bounds__(256) shrink64_kernel(const Fast64Args a)
 #pragma unroll
 					for (uint32_t r = 0; r < 4; ++r) {
 						const uint32_t oy = 16u * mb + 4u * g + r;
-						if (oy < nh) reinterpret_cast<uint32_t *>(dst)[oy * row_w + ox0 + oxl] = pix[r];
+						if (oy < nh) store_px(dst, oy * row_w + ox0 + oxl, pix[r]);
 					}
 				}
 			}
@@ -427,7 +463,7 @@ __global__ void __launch_bounds__(256) shrink64_kernel(const Fast64Args a)
 					if constexpr (ALPHA) al = (a4 >> (8u * r)) & 255u;
 					uint32_t px = ((r4 >> (8u * r)) & 255u) | (((g4 >> (8u * r)) & 255u) << 8) | (((b4 >> (8u * r)) & 255u) << 16) | (al << 24);
 					if (al != 255u) px = unpremultiply(px);
-					reinterpret_cast<uint32_t *>(dst)[(4u * yq + r) * nw + ox] = px;
+					store_px(dst, (4u * yq + r) * nw + ox, px);
 				}
 			}
 			__syncthreads();
@@ -439,7 +475,7 @@ __global__ void __launch_bounds__(256) shrink64_kernel(const Fast64Args a)
 
 // 64x64 flow, first part: the four-wave kernel (and its four-plane instance); ga = the arguments of the worklist
 // kernel that follows (pxz_shrink_generic.hip: launch_shrink)
-hipError_t launch_fast64(const ShrinkArgs &a, ShrinkArgs &ga, uint32_t n_cus, hipStream_t stream)
+hipError_t launch_fast64(const ShrinkArgs &a, ShrinkArgs &ga, uint32_t channels, uint32_t n_cus, hipStream_t stream)
 {
 	// 64x64: the four-wave kernel for full opaque tiles; it leaves the rest in the worklist
 	Fast64Args f{};
@@ -480,6 +516,9 @@ hipError_t launch_fast64(const ShrinkArgs &a, ShrinkArgs &ga, uint32_t n_cus, hi
 		const bool full = a.out_px != nullptr && a.out_w != nullptr && a.out_h != nullptr;
 		void (*k)(const Fast64Args) = a.mode == 1 ? (full ? shrink64_kernel<1, false, true> : shrink64_kernel<1, false, false>)
 		                                          : (full ? shrink64_kernel<0, false, true> : shrink64_kernel<0, false, false>);
+		if (channels == 3)  // RGB frames: 12-byte pixel quads in, RGB slots out
+			k = a.mode == 1 ? (full ? shrink64_kernel<1, false, true, 3> : shrink64_kernel<1, false, false, 3>)
+			                : (full ? shrink64_kernel<0, false, true, 3> : shrink64_kernel<0, false, false, 3>);
 		if (lds_bytes > 64u * 1024u && (e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)) != hipSuccess) return e;
 		hipLaunchKernelGGL(k, dim3(blocks), dim3(256), lds_bytes, stream, f);
 	}
@@ -488,8 +527,8 @@ hipError_t launch_fast64(const ShrinkArgs &a, ShrinkArgs &ga, uint32_t n_cus, hi
 	ga.mid_event = nullptr;
 	// full tiles with transparency are on list A: the four-plane instance takes it when transparency was
 	// announced or seen before, else the generic kernel walks it after list B
-	const bool run_alpha = a.out_px != nullptr && a.out_w != nullptr && a.out_h != nullptr && a.alpha_kernel != 0;
-	ga.list_a_too = a.out_px != nullptr && !run_alpha ? 1u : 0u;
+	const bool run_alpha = channels == 4 && a.out_px != nullptr && a.out_w != nullptr && a.out_h != nullptr && a.alpha_kernel != 0;
+	ga.list_a_too = channels == 4 && a.out_px != nullptr && !run_alpha ? 1u : 0u;
 	if (run_alpha) {
 		const uint32_t lds_a = lds64_dwords(4) * 4u;
 		const uint32_t blocks_a = n_cus * (kLds / lds_a);

@@ -678,7 +678,7 @@ LaunchGeom plan_launch(const ShrinkArgs &a, uint32_t channels, uint32_t n_cus)
 
 bool fast64_applicable(const ShrinkArgs &a, uint32_t channels)
 {
-	return channels == 4 && a.bw == 64 && a.bh == 64 && (a.mode == 1 || a.oklab_given) && a.work != nullptr &&
+	return (channels == 4 || channels == 3) && a.bw == 64 && a.bh == 64 && (a.mode == 1 || a.oklab_given) && a.work != nullptr &&
 	       (a.out_px == nullptr || (a.filter != 0 && a.mf64 != nullptr));
 }
 
@@ -694,14 +694,14 @@ bool fast32_applicable(const ShrinkArgs &a, uint32_t channels)
 	       (a.out_px == nullptr || a.filter == 0 || a.tab_dw != 0) && !(a.mode == 0 && !a.oklab_given);
 }
 
-hipError_t launch_fast64(const ShrinkArgs &a, ShrinkArgs &ga, uint32_t n_cus, hipStream_t stream);     // pxz_shrink64.hip
+hipError_t launch_fast64(const ShrinkArgs &a, ShrinkArgs &ga, uint32_t channels, uint32_t n_cus, hipStream_t stream);     // pxz_shrink64.hip
 hipError_t launch_fast32_16(const ShrinkArgs &a, ShrinkArgs &ga, uint32_t channels, uint32_t n_cus, hipStream_t stream);  // pxz_shrink32.hip
 
 hipError_t launch_shrink(const ShrinkArgs &a, uint32_t channels, uint32_t n_cus, hipStream_t stream)
 {
 	ShrinkArgs ga = a;
 	hipError_t e = hipSuccess;
-	if (fast64_applicable(a, channels)) e = launch_fast64(a, ga, n_cus, stream);
+	if (fast64_applicable(a, channels)) e = launch_fast64(a, ga, channels, n_cus, stream);
 	else if (fast32_applicable(a, channels) || fast16_applicable(a, channels)) e = launch_fast32_16(a, ga, channels, n_cus, stream);
 	else ga.work = nullptr;
 	if (e != hipSuccess) return e;
