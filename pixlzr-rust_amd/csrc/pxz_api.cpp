@@ -606,8 +606,8 @@ int timed_launch(pxz_handle *h, pxz::ShrinkArgs &a, uint32_t channels, float *va
 	a.ok_region = 0;
 	a.ok_count = a.n_tiles;
 	a.ok_edges = 0;
-	// RGB frames on the 32x32 and 64x64 fast paths (round 2; both callers): 12-byte pixel quads, rows 4-byte aligned
-	const bool rgb_native = channels == 3 && a.bw == a.bh && (a.bw == 32 || a.bw == 64) && !pxz::knobs().no_native_rgb &&
+	// RGB frames on the square fast paths (round 2; both callers): 12-byte pixel quads, rows 4-byte aligned
+	const bool rgb_native = channels == 3 && square_fast && !pxz::knobs().no_native_rgb &&
 	    ((reinterpret_cast<uintptr_t>(a.src) | a.pitch | (a.n_tiles > a.tiles_per_frame ? a.frame_stride : 0)) & 3u) == 0;
 	if (rgb_native) {
 		a.full_cols = a.edge_w == a.bw ? a.cols : a.cols - 1;
@@ -684,8 +684,8 @@ int timed_launch(pxz_handle *h, pxz::ShrinkArgs &a, uint32_t channels, float *va
 		}
 	}
 	if (a.mode == PXZ_MODE_SHRINK_BY && rgb_native && a.full_cols != 0 && a.full_rows != 0 && !pxz::knobs().no_oklab32) {
-		// RGB, 32x32 / 64x64: oklab2_kernel<32, 3> / oklab_kernel<64, 0, 3> for the full tiles; a ragged edge keeps its
-		// chains in the generic kernel
+		// RGB, 16x16 / 32x32 / 64x64: oklab2_kernel<16 | 32, 3> / oklab_kernel<64, 0, 3> for the full tiles; a ragged edge
+		// keeps its chains in the generic kernel
 		if (a.ok_bands > 4u) {  // 64x64: the converted tile is parked in HBM between the passes
 			if ((rc = ensure(h, h->okscratch, (size_t)a.n_tiles * a.ok_bands * 3328u)) != PXZ_OK) return rc;
 			a.ok_scratch = (float *)h->okscratch.ptr;
@@ -917,8 +917,8 @@ static int run_shrink(pxz_handle *h, const pxz_frames *frames, const pxz_params 
 	const bool square_fast = a.bw == a.bh && (a.bw == 16 || a.bw == 32 || a.bw == 64);
 	const bool general_oklab = a.mode == PXZ_MODE_SHRINK_BY && a.bw % 4u == 0 && a.bw * a.bh >= 64u && a.bw * a.bh <= 16384u;
 	bool widen = frames->channels == 3 && (square_fast || general_oklab) && !pxz::knobs().no_widen;
-	// (32x32 tiles: shrink32_kernel and oklab2_kernel read RGB themselves, when the rows are 4-byte aligned)
-	if (widen && a.bw == a.bh && (a.bw == 32 || a.bw == 64) && !rgb_must_widen && !pxz::knobs().no_native_rgb &&
+	// (16x16, 32x32, 64x64 tiles: the fast kernels and the Oklab detector read RGB themselves, when the rows are 4-byte aligned)
+	if (widen && square_fast && !rgb_must_widen && !pxz::knobs().no_native_rgb &&
 	    ((reinterpret_cast<uintptr_t>(d_pixels) | frames->pitch_bytes | (frames->n_frames > 1 ? frames->frame_stride_bytes : 0)) & 3u) == 0)
 		widen = false;
 	if (widen && d_out_pixels && params->filter != PXZ_FILTER_NEAREST) {

@@ -372,7 +372,8 @@ __device__ __forceinline__ void fast32_h_rows(const uint32_t *trows, const AxisT
 
 // vertical pass over the transposed planes, window split over LPI lanes; item = (oy fastest, ox),
 // so that a lane keeps the same output row (= the same table row) across iterations
-template <int LPI>
+// C = 3: out is a slot of 3-byte pixels (shrink16_kernel on RGB frames)
+template <int LPI, int C = 4>
 __device__ __forceinline__ void fast32_v(const uint32_t *trows, const AxisTab &tx, const AxisTab &ty, const uint32_t *s_tmp,
                                          uint32_t lane, uint32_t nw, uint32_t nh, uint32_t *out)
 {
@@ -415,7 +416,14 @@ __device__ __forceinline__ void fast32_v(const uint32_t *trows, const AxisTab &t
 			const uint32_t al = clip8(iy + ah * (int32_t)hdr.z, py);
 			uint32_t px = clip8(a0 + iy, py) | (clip8(a1 + iy, py) << 8) | (clip8(a2 + iy, py) << 16) | (al << 24);
 			if (al != 255u) px = unpremultiply(px);
-			out[oy * nw + ox] = px;
+			if constexpr (C == 4) {
+				out[oy * nw + ox] = px;
+			} else {
+				uint8_t *o3 = reinterpret_cast<uint8_t *>(out) + 3u * (oy * nw + ox);
+				o3[0] = (uint8_t)px;
+				o3[1] = (uint8_t)(px >> 8);
+				o3[2] = (uint8_t)(px >> 16);
+			}
 		}
 	}
 }
@@ -573,6 +581,7 @@ __device__ __forceinline__ void resample_fast32_hv(const uint32_t *trows, const 
 
 // The same for a 16x16 tile that sits somewhere inside the 32x32 LDS image (s_pl points at its first pixel
 // pair): windows of at most 4 quads, 16 source rows, nw and nh in {8, 4, 2, 1}.
+template <int C = 4>
 __device__ __forceinline__ void resample_fast16_hv(const uint32_t *trows, const AxisTab &tx, const AxisTab &ty, const uint32_t *s_pl,
                                                    uint32_t *s_tmp, uint32_t lane, uint32_t nw, uint32_t nh, uint32_t *out)
 {
@@ -591,10 +600,10 @@ __device__ __forceinline__ void resample_fast16_hv(const uint32_t *trows, const 
 	}
 	tile_sync<1>();
 	const uint32_t items = nw * nh;
-	if (items >= 64u) fast32_v<1>(trows, tx, ty, s_tmp, lane, nw, nh, out);
-	else if (items >= 32u) fast32_v<2>(trows, tx, ty, s_tmp, lane, nw, nh, out);
-	else if (items >= 16u) fast32_v<4>(trows, tx, ty, s_tmp, lane, nw, nh, out);
-	else fast32_v<8>(trows, tx, ty, s_tmp, lane, nw, nh, out);
+	if (items >= 64u) fast32_v<1, C>(trows, tx, ty, s_tmp, lane, nw, nh, out);
+	else if (items >= 32u) fast32_v<2, C>(trows, tx, ty, s_tmp, lane, nw, nh, out);
+	else if (items >= 16u) fast32_v<4, C>(trows, tx, ty, s_tmp, lane, nw, nh, out);
+	else fast32_v<8, C>(trows, tx, ty, s_tmp, lane, nw, nh, out);
 	tile_sync<1>();  // the next tile of the group reuses the transposed planes
 }
 

@@ -584,7 +584,8 @@ __global__ void __launch_bounds__(1024) shrink32a_kernel(const Fast32Args a)
 // MODE 1: directional detector here; MODE 0: values already in sums[] (oklab_kernel<16>).
 // ---------------------------------------------------------------------------
 // FULL: as in shrink32_kernel (all three output arrays are there; no run-time tests of them in the loop).
-template <int MODE, bool FULL>
+// C = 3 (round 2): RGB frames read as 12-byte pixel quads, RGB slots written; no opacity test.
+template <int MODE, bool FULL, int C = 4>
 __global__ void __launch_bounds__(1024) shrink16_kernel(const Fast32Args a)
 {
 	extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
@@ -630,7 +631,7 @@ __global__ void __launch_bounds__(1024) shrink16_kernel(const Fast32Args a)
 		const uint32_t r = grp - p.frame * gpf;
 		p.gy = fastdiv(r, a.div_gcols);
 		p.gx = r - p.gy * gcols;
-		p.src = a.src + (size_t)p.frame * a.frame_stride + (size_t)(p.gy * 32u) * a.pitch + (size_t)(p.gx * 32u) * 4u;
+		p.src = a.src + (size_t)p.frame * a.frame_stride + (size_t)(p.gy * 32u) * a.pitch + (size_t)(p.gx * 32u) * (uint32_t)C;
 		p.full = 2u * p.gx + 1u < a.full_cols && 2u * p.gy + 1u < a.full_rows;
 		return p;
 	};
@@ -640,9 +641,16 @@ __global__ void __launch_bounds__(1024) shrink16_kernel(const Fast32Args a)
 		const Place p = place_of(grp);
 		pre_valid = p.full;
 		if (pre_valid) {
-			const uint8_t *q = p.src + (size_t)(tid >> 3) * a.pitch + (tid & 7u) * 16u;
+			const uint8_t *q = p.src + (size_t)(tid >> 3) * a.pitch + (tid & 7u) * (4u * (uint32_t)C);
 #pragma unroll
-			for (int k = 0; k < 4; ++k) pre[k] = *reinterpret_cast<const uint4 *>(q + (size_t)(8 * k) * a.pitch);
+			for (int k = 0; k < 4; ++k) {
+				if constexpr (C == 4) {
+					pre[k] = *reinterpret_cast<const uint4 *>(q + (size_t)(8 * k) * a.pitch);
+				} else {
+					const uint3 v = *reinterpret_cast<const uint3 *>(q + (size_t)(8 * k) * a.pitch);  // rows are 4-byte aligned
+					pre[k] = make_uint4(v.x, v.y, v.z, 0u);
+				}
+			}
 		}
 	};
 	const uint32_t first = group_of_ticket(__builtin_amdgcn_readfirstlane(sub));
@@ -682,26 +690,33 @@ __global__ void __launch_bounds__(1024) shrink16_kernel(const Fast32Args a)
 		// ---- stage: registers -> planar u16 pairs (as shrink32_kernel)
 		// every alpha byte is 255 iff the smallest of the 16 pixel dwords is >= 0xff000000 (alpha is the top byte): eight
 		// three-way minima instead of sixteen ANDs and a shift
-		uint32_t least;
-		{
+		uint32_t least = 0xffffffffu;
+		if constexpr (C == 4) {
 			const uint32_t m0 = min(min(pre[0].x, pre[0].y), pre[0].z), m1 = min(min(pre[0].w, pre[1].x), pre[1].y);
 			const uint32_t m2 = min(min(pre[1].z, pre[1].w), pre[2].x), m3 = min(min(pre[2].y, pre[2].z), pre[2].w);
 			const uint32_t m4 = min(min(pre[3].x, pre[3].y), pre[3].z);
 			least = min(min(min(m0, m1), m2), min(min(m3, m4), pre[3].w));
 		}
-		const bool transparent = __builtin_amdgcn_ballot_w64(least < 0xff000000u) != 0ull;
+		const bool transparent = C == 4 && __builtin_amdgcn_ballot_w64(least < 0xff000000u) != 0ull;
 #pragma unroll
 		for (int k = 0; k < 4; ++k) {
 			const uint32_t row = (tid >> 3) + 8u * (uint32_t)k, col = tid & 7u;
 			const uint4 v = pre[k];
 			uint32_t *d = s_pl + row * kRS32 + col * 2u;
+			if constexpr (C == 4) {
 #pragma unroll
-			for (uint32_t c = 0; c < 3; ++c) {
-				const uint32_t sel = c | 0x0c000c00u | ((4u + c) << 16);
-				uint2 pr;
-				pr.x = __builtin_amdgcn_perm(v.y, v.x, sel);
-				pr.y = __builtin_amdgcn_perm(v.w, v.z, sel);
-				*reinterpret_cast<uint2 *>(d + c * kPD32) = pr;
+				for (uint32_t c = 0; c < 3; ++c) {
+					const uint32_t sel = c | 0x0c000c00u | ((4u + c) << 16);
+					uint2 pr;
+					pr.x = __builtin_amdgcn_perm(v.y, v.x, sel);
+					pr.y = __builtin_amdgcn_perm(v.w, v.z, sel);
+					*reinterpret_cast<uint2 *>(d + c * kPD32) = pr;
+				}
+			} else {
+				// bytes R0 G0 B0 R1 | G1 B1 R2 G2 | B2 R3 G3 B3 (as shrink32_kernel<.., 3>)
+				*reinterpret_cast<uint2 *>(d) = make_uint2(__builtin_amdgcn_perm(v.x, v.x, 0x0c070c00u), __builtin_amdgcn_perm(v.z, v.y, 0x0c050c02u));
+				*reinterpret_cast<uint2 *>(d + kPD32) = make_uint2(__builtin_amdgcn_perm(v.y, v.x, 0x0c040c01u), __builtin_amdgcn_perm(v.z, v.y, 0x0c060c03u));
+				*reinterpret_cast<uint2 *>(d + 2 * kPD32) = make_uint2(__builtin_amdgcn_perm(v.y, v.x, 0x0c050c02u), __builtin_amdgcn_perm(v.z, v.z, 0x0c070c00u));
 			}
 		}
 		prefetch(grp_next);
@@ -803,7 +818,7 @@ __global__ void __launch_bounds__(1024) shrink16_kernel(const Fast32Args a)
 				}
 			}
 			if (!FULL && a.out_px == nullptr) continue;
-			uint32_t *dst = reinterpret_cast<uint32_t *>(a.out_px + (size_t)t * 1024u);
+			uint32_t *dst = reinterpret_cast<uint32_t *>(a.out_px + (size_t)t * (256u * (uint32_t)C));
 			const uint32_t *tile_pl = s_pl + (16u * (k >> 1)) * kRS32 + 8u * (k & 1u);  // first pixel pair of the tile
 			if (nw[k] == 16u && nh[k] == 16u) {
 				// clone (block.rs:279-281): 64 groups of 4 pixels, one per lane
@@ -812,14 +827,23 @@ __global__ void __launch_bounds__(1024) shrink16_kernel(const Fast32Args a)
 				const uint2 r = *reinterpret_cast<const uint2 *>(p), gch = *reinterpret_cast<const uint2 *>(p + kPD32);
 				const uint2 b = *reinterpret_cast<const uint2 *>(p + 2 * kPD32);
 				const uint32_t opq = 0x00ff00ffu;
-				const uint32_t rg01 = __builtin_amdgcn_perm(gch.x, r.x, 0x06020400u), ba01 = __builtin_amdgcn_perm(opq, b.x, 0x06020400u);
-				const uint32_t rg23 = __builtin_amdgcn_perm(gch.y, r.y, 0x06020400u), ba23 = __builtin_amdgcn_perm(opq, b.y, 0x06020400u);
-				uint4 o;
-				o.x = __builtin_amdgcn_perm(ba01, rg01, 0x05040100u);
-				o.y = __builtin_amdgcn_perm(ba01, rg01, 0x07060302u);
-				o.z = __builtin_amdgcn_perm(ba23, rg23, 0x05040100u);
-				o.w = __builtin_amdgcn_perm(ba23, rg23, 0x07060302u);
-				reinterpret_cast<uint4 *>(dst)[tid] = o;
+				const uint32_t rg01 = __builtin_amdgcn_perm(gch.x, r.x, 0x06020400u), rg23 = __builtin_amdgcn_perm(gch.y, r.y, 0x06020400u);
+				if constexpr (C == 4) {
+					const uint32_t ba01 = __builtin_amdgcn_perm(opq, b.x, 0x06020400u), ba23 = __builtin_amdgcn_perm(opq, b.y, 0x06020400u);
+					uint4 o;
+					o.x = __builtin_amdgcn_perm(ba01, rg01, 0x05040100u);
+					o.y = __builtin_amdgcn_perm(ba01, rg01, 0x07060302u);
+					o.z = __builtin_amdgcn_perm(ba23, rg23, 0x05040100u);
+					o.w = __builtin_amdgcn_perm(ba23, rg23, 0x07060302u);
+					reinterpret_cast<uint4 *>(dst)[tid] = o;
+				} else {
+					uint3 o;
+					o.x = __builtin_amdgcn_perm(b.x, rg01, 0x02040100u);                  // R0 G0 B0 R1
+					const uint32_t gb1 = __builtin_amdgcn_perm(b.x, rg01, 0x0c0c0603u);   // G1 B1 . .
+					o.y = __builtin_amdgcn_perm(rg23, gb1, 0x05040100u);                  // G1 B1 R2 G2
+					o.z = __builtin_amdgcn_perm(b.y, rg23, 0x06030204u);                  // B2 R3 G3 B3
+					reinterpret_cast<uint3 *>(dst)[tid] = o;
+				}
 			} else if (filt == 0) {
 				// ResizeAlg::Nearest: source index = floor((o + 0.5) * 2^m); any (nw, nh)
 				const uint32_t mx = m0[k], my = m1[k];
@@ -830,12 +854,19 @@ __global__ void __launch_bounds__(1024) shrink16_kernel(const Fast32Args a)
 					const uint32_t x = mx == 0 ? ox : (mx < 5u ? (2u * ox + 1u) << (mx - 1u) : 8u);
 					const uint32_t y = my == 0 ? oy : (my < 5u ? (2u * oy + 1u) << (my - 1u) : 8u);
 					const uint32_t idx = y * (2u * kRS32) + x;
-					dst[i] = (uint32_t)pl16[idx] | ((uint32_t)pl16[idx + 2u * kPD32] << 8) | ((uint32_t)pl16[idx + 4u * kPD32] << 16) | 0xff000000u;
+					if constexpr (C == 4) {
+						dst[i] = (uint32_t)pl16[idx] | ((uint32_t)pl16[idx + 2u * kPD32] << 8) | ((uint32_t)pl16[idx + 4u * kPD32] << 16) | 0xff000000u;
+					} else {
+						uint8_t *o3 = reinterpret_cast<uint8_t *>(dst) + 3u * i;
+						o3[0] = (uint8_t)pl16[idx];
+						o3[1] = (uint8_t)pl16[idx + 2u * kPD32];
+						o3[2] = (uint8_t)pl16[idx + 4u * kPD32];
+					}
 				}
 			} else {
 				const uint32_t lx = m0[k] < (uint32_t)kMaxLevel ? m0[k] : (uint32_t)kMaxLevel - 1;
 				const uint32_t ly = m1[k] < (uint32_t)kMaxLevel ? m1[k] : (uint32_t)kMaxLevel - 1;
-				resample_fast16_hv(s_tab, a.tabs[lx], a.tabs[ly], tile_pl, s_tmp, tid, nw[k], nh[k], dst);
+				resample_fast16_hv<C>(s_tab, a.tabs[lx], a.tabs[ly], tile_pl, s_tmp, tid, nw[k], nh[k], dst);
 			}
 		}
 		tile_sync<1>();  // the next group reuses this wave's LDS image
@@ -920,6 +951,9 @@ hipError_t launch_fast32_16(const ShrinkArgs &a, ShrinkArgs &ga, uint32_t channe
 		const bool full = a.out_px != nullptr && a.out_w != nullptr && a.out_h != nullptr;
 		void (*k)(const Fast32Args) = a.mode == 1 ? (full ? shrink16_kernel<1, true> : shrink16_kernel<1, false>)
 		                                          : (full ? shrink16_kernel<0, true> : shrink16_kernel<0, false>);
+		if (channels == 3)
+			k = a.mode == 1 ? (full ? shrink16_kernel<1, true, 3> : shrink16_kernel<1, false, 3>)
+			                : (full ? shrink16_kernel<0, true, 3> : shrink16_kernel<0, false, 3>);
 		if (lds_bytes > 64u * 1024u && (e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)) != hipSuccess) return e;
 		hipLaunchKernelGGL(k, dim3(blocks), dim3(64u * wpb), lds_bytes, stream, f);
 	} else {

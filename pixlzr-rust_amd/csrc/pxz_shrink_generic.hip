@@ -684,7 +684,7 @@ bool fast64_applicable(const ShrinkArgs &a, uint32_t channels)
 
 bool fast16_applicable(const ShrinkArgs &a, uint32_t channels)
 {
-	return channels == 4 && a.bw == 16 && a.bh == 16 && a.work != nullptr &&
+	return (channels == 4 || channels == 3) && a.bw == 16 && a.bh == 16 && a.work != nullptr &&
 	       (a.out_px == nullptr || a.filter == 0 || a.tab_dw != 0) && !(a.mode == 0 && !a.oklab_given);
 }
 
