@@ -722,6 +722,69 @@ __device__ __forceinline__ void resample_mfma32(const uint32_t *s_tab, const Axi
 	}
 }
 
+// The matrix-core form for narrow outputs, 32x32 -> nw x nh with nw in {4, 2, 1}, nh <= 16, opaque tile whose alpha
+// stays 255 (both tables say so): the three channels share ONE accumulator.  Column n of the horizontal product is
+// (channel n / nw, output column n % nw) -- the weight operand of channel c is the level's table in the columns of
+// channel c and zero elsewhere (a lane picks its own row of the table or an all-zero one), and the three products
+// accumulate: D[y][(c, ox)] = sum_c' sum_x P_c'[y][x] B_c'[x][(c, ox)].  One clamp per 16 rows instead of three, one
+// vertical product instead of three, and the columns of a fourth "channel" carry the constant 255 (bias = the clamp's
+// top) through the vertical product: the alpha byte.  Lane (n, g) ends with channel n / nw of the pixels (4g + r, n % nw)
+// and stores them as bytes of the parked pixels.  Same integers as resample_mfma32, 14 MFMAs + ~85 vector instructions
+// (the dot2 form: ~125 for a 2x1 tile; resample_mfma32: ~170).
+__device__ __forceinline__ void resample_mfma32_narrow(const uint32_t *s_tab, const AxisTab &tx, const AxisTab &ty, const uint32_t *s_pl,
+                                                       uint32_t lane, uint32_t nw, uint32_t *out)
+{
+	const uint32_t o = lane & 15u, g = lane >> 4;
+	const uint32_t lgw = nw >> 1;  // 1, 2, 4 -> 0, 1, 2
+	const uint32_t ch = o >> lgw, ox = o & (nw - 1u);
+	const uint32_t *mx = s_tab + tx.mf_off, *my = s_tab + ty.mf_off;
+	const uint32_t own = 2u * (16u * g + ox), none = 2u * (16u * g + 15u);  // (rows >= the output size hold zero weights)
+	const long ky_lo = *reinterpret_cast<const long *>(my + 2u * lane), ky_hi = *reinterpret_cast<const long *>(my + 128u + 2u * lane);
+	const uint32_t px_ = tx.precision, py = ty.precision;
+	const int32_t top_x = (int32_t)((256u << px_) - 1u), top_y = (int32_t)((256u << py) - 1u);
+	const int32_t bx = ch == 3u ? top_x : (int32_t)mx[256u + ox];
+	const v4i32 cy = *reinterpret_cast<const v4i32 *>(my + 256u + 4u * g);
+	const v4i32 zero = {0, 0, 0, 0};
+	v4i32 lo[2] = {{bx, bx, bx, bx}, {bx, bx, bx, bx}}, hi[2] = {zero, zero};
+	const uint32_t *rowp = s_pl + o * kRS32 + 2u * g;
+#pragma unroll
+	for (uint32_t c = 0; c < 3; ++c) {
+		const uint32_t sel = ch == c ? own : none;
+		const long k_lo = *reinterpret_cast<const long *>(mx + sel), k_hi = *reinterpret_cast<const long *>(mx + 128u + sel);
+#pragma unroll
+		for (uint32_t mb = 0; mb < 2; ++mb) {
+			const uint32_t *row = rowp + c * kPD32 + mb * (16u * kRS32);
+			const uint2 d0 = *reinterpret_cast<const uint2 *>(row);       // columns 4g .. 4g+3
+			const uint2 d1 = *reinterpret_cast<const uint2 *>(row + 8u);  // columns 16+4g .. 16+4g+3
+			const uint32_t a0 = __builtin_amdgcn_perm(d0.y, d0.x, 0x06040200u) ^ 0x80808080u;
+			const uint32_t a1 = __builtin_amdgcn_perm(d1.y, d1.x, 0x06040200u) ^ 0x80808080u;
+			const long av = (long)(((unsigned long long)a1 << 32) | (unsigned long long)a0);
+			lo[mb] = __builtin_amdgcn_mfma_i32_16x16x32_i8(av, k_lo, lo[mb], 0, 0, 0);
+			hi[mb] = __builtin_amdgcn_mfma_i32_16x16x32_i8(av, k_hi, hi[mb], 0, 0, 0);
+		}
+	}
+	uint32_t t[2];
+#pragma unroll
+	for (uint32_t mb = 0; mb < 2; ++mb) {
+		uint32_t packed = 0;
+		put_byte_shr<0>(packed, clamp_fixed(hi[mb][0], lo[mb][0], top_x), px_);
+		put_byte_shr<1>(packed, clamp_fixed(hi[mb][1], lo[mb][1], top_x), px_);
+		put_byte_shr<2>(packed, clamp_fixed(hi[mb][2], lo[mb][2], top_x), px_);
+		put_byte_shr<3>(packed, clamp_fixed(hi[mb][3], lo[mb][3], top_x), px_);
+		t[mb] = packed ^ 0x80808080u;
+	}
+	const long tv = (long)(((unsigned long long)t[1] << 32) | (unsigned long long)t[0]);
+	const v4i32 vlo = __builtin_amdgcn_mfma_i32_16x16x32_i8(ky_lo, tv, cy, 0, 0, 0);
+	const v4i32 vhi = __builtin_amdgcn_mfma_i32_16x16x32_i8(ky_hi, tv, zero, 0, 0, 0);
+	// rows 4g + r of column (ch, ox): byte ch of pixel (4g + r) * nw + ox.  Rows past nh land beyond the parked pixels
+	// (at most 16 rows x 4 pixels: inside the output region) and are never flushed.
+	if (o < 4u * nw) {
+		uint8_t *dst = reinterpret_cast<uint8_t *>(out) + (4u * g * nw + ox) * 4u + ch;
+#pragma unroll
+		for (uint32_t r = 0; r < 4; ++r) dst[r * nw * 4u] = (uint8_t)(clamp_fixed(vhi[r], vlo[r], top_y) >> py);
+	}
+}
+
 // Fast-path eligibility of a tile (full 32x32 RGBA, 16-byte aligned rows) and its first byte.
 template <int C = 4, class Args>
 __device__ __forceinline__ bool fast32_tile_src(const Args &a, uint32_t tile_g, const uint8_t *&src)

@@ -138,6 +138,7 @@ struct Fast32Args {
 	uint32_t tab_dw, tile_dw;
 	uint32_t chunk_lg;       // tickets deal runs of 2^chunk_lg adjacent tiles
 	uint32_t finish_here;    // shrink32_kernel: every block finishes the tiles it completed (value / lod outputs) at its end
+	uint32_t narrow;         // shrink32_kernel: 4/2/1-px-wide outputs take resample_mfma32_narrow (0: PXZ_NO_NARROW=1, the round-1 forms)
 	float factor;            //   with these, as the worklist kernel's scan over all tiles would
 	float *value, *lod0, *lod1;
 	uint32_t breaks[kMaxLevel];
@@ -180,6 +181,7 @@ struct Knobs {
 	bool no_repitch;        // PXZ_NO_REPITCH: unaligned device batches are staged pixel by pixel
 	bool no_widen;          // PXZ_NO_WIDEN: RGB batches never ride the RGBA kernels
 	bool no_native_rgb;     // PXZ_NO_NATIVE_RGB: RGB batches are widened to RGBA even where a kernel reads RGB itself
+	bool no_narrow;         // PXZ_NO_NARROW: 4/2/1-px-wide outputs of 32x32 tiles keep the round-1 resample forms
 	bool oklab_v1;          // PXZ_OKLAB_V1: round-1 detector (one chain wave, two barriers per band) for 16/32-px tiles
 	int wpb;                // PXZ_WPB: waves per block of the persistent kernels (0: default)
 	int chunk_lg;           // PXZ_CHUNK_LG: log2 of the ticket run length of shrink32_kernel (-1: default)

@@ -20,6 +20,15 @@ namespace pxz {
 // kept as loop-invariant lane masks they cost scalar registers, and a spilled one two v_readlane per use.
 // C = 3: RGB frames read and RGB slots written directly (round 2) -- 12-byte pixel quads in, the same three LDS planes,
 // no opacity test (there is no alpha), outputs packed to 3 bytes per pixel by the flush.
+// One dword of the LDS image as a load of its own (base + 16-bit immediate): left to itself the compiler pairs
+// neighbouring dwords into ds_read2_b32, whose 8-bit offsets cost a vector add per new base -- 16 of them per tile in the
+// detector, which is bound by vector instructions, not by LDS instructions.
+__device__ __forceinline__ uint32_t lds_dword(const uint32_t *p)
+{
+	typedef const volatile __attribute__((address_space(3))) uint32_t *lds_ptr;
+	return *(lds_ptr)p;
+}
+
 template <int MODE, bool FULL, int C = 4>
 __global__ void __launch_bounds__(1024) shrink32_kernel(const Fast32Args a)
 {
@@ -232,7 +241,8 @@ __global__ void __launch_bounds__(1024) shrink32_kernel(const Fast32Args a)
 			uint32_t rA[3], rB[3], tP[3], dP[3];
 #pragma unroll
 			for (int c = 0; c < 3; ++c) {
-				const uint32_t a0 = pc[c][0], a1 = pc[c][1], b0 = pc[c][kRS32], b1 = pc[c][kRS32 + 1];
+				const uint32_t a0 = lds_dword(pc[0] + c * kPD32), a1 = lds_dword(pc[0] + c * kPD32 + 1);
+				const uint32_t b0 = lds_dword(pc[0] + c * kPD32 + kRS32), b1 = lds_dword(pc[0] + c * kPD32 + kRS32 + 1);
 				rA[c] = pk_mad_u16(__builtin_amdgcn_alignbit(a1, a0, 16), two, u32(us2(a0) + us2(a1)));
 				rB[c] = pk_mad_u16(__builtin_amdgcn_alignbit(b1, b0, 16), two, u32(us2(b0) + us2(b1)));
 				tP[c] = u32(us2(a0) + us2(b0));
@@ -243,8 +253,8 @@ __global__ void __launch_bounds__(1024) shrink32_kernel(const Fast32Args a)
 				if (st < 3 || last_rows(g)) {  // the last group has 6 window rows = 3 steps
 #pragma unroll
 					for (int c = 0; c < 3; ++c) {
-						const uint32_t *pr = pc[c] + (2 + 2 * st) * (int)kRS32;
-						const uint32_t n0 = pr[0], n1 = pr[1], o0 = pr[kRS32], o1 = pr[kRS32 + 1];
+						const uint32_t *pr = pc[0] + c * kPD32 + (2 + 2 * st) * (int)kRS32;
+						const uint32_t n0 = lds_dword(pr), n1 = lds_dword(pr + 1), o0 = lds_dword(pr + kRS32), o1 = lds_dword(pr + kRS32 + 1);
 						const uint32_t rN = pk_mad_u16(__builtin_amdgcn_alignbit(n1, n0, 16), two, u32(us2(n0) + us2(n1)));
 						sum_hz = sad16(rN, rA[c], sum_hz);
 						const uint32_t tN = u32(us2(dP[c]) + us2(n0));
@@ -294,7 +304,13 @@ __global__ void __launch_bounds__(1024) shrink32_kernel(const Fast32Args a)
 			} else if (nw != 32u && nh != 32u && filt != 0) {
 				const uint32_t lx = m0 < (uint32_t)kMaxLevel ? m0 : (uint32_t)kMaxLevel - 1;
 				const uint32_t ly = m1 < (uint32_t)kMaxLevel ? m1 : (uint32_t)kMaxLevel - 1;
-				if (a.tabs[lx].mf_off != 0 && a.tabs[ly].mf_off != 0 && nw >= 4u && nh >= 4u) {
+				const bool both_mf = a.tabs[lx].mf_off != 0 && a.tabs[ly].mf_off != 0;
+				if (a.narrow && both_mf && nw <= 4u && nh <= 16u && (s_tab[a.tabs[lx].mf_off + 288u] & s_tab[a.tabs[ly].mf_off + 288u])) {
+					// narrow outputs (4, 2, 1 px wide): the three channels through one accumulator
+					resample_mfma32_narrow(s_tab, a.tabs[lx], a.tabs[ly], s_pl, tid, nw, s_tmp);
+					pend_src = s_tmp;
+					pend_kind = 1;
+				} else if (both_mf && nw >= 4u && nh >= 4u) {
 					// (2- and 1-px outputs have tables too -- shrink32a_kernel uses them -- but the dot2 form is cheaper there)
 					resample_mfma32<3>(s_tab, a.tabs[lx], a.tabs[ly], s_pl, tid, nw, nh, s_tmp);
 					pend_src = s_tmp;
@@ -907,6 +923,7 @@ hipError_t launch_fast32_16(const ShrinkArgs &a, ShrinkArgs &ga, uint32_t channe
 	f.work = a.work;
 	f.work_slot = a.work_slot;
 	f.finish_here = groups16 ? 0u : 1u;
+	f.narrow = knobs().no_narrow ? 0u : 1u;
 	f.factor = a.factor;
 	f.value = a.value;
 	f.lod0 = a.lod0;
