@@ -285,6 +285,23 @@ __device__ __forceinline__ uint32_t level_count(uint32_t key, const uint32_t *br
 	return m;
 }
 
+// LDS accesses spelled one by one (base + 16-bit immediate): left to itself the compiler pairs neighbouring accesses
+// into ds_read2 / ds_write2, whose 8-bit offsets cost a vector add per new base -- 16 of them per tile in the detector of
+// shrink32_kernel, which is bound by vector instructions, not by LDS instructions.
+typedef const volatile __attribute__((address_space(3))) uint32_t *lds_cptr;
+__device__ __forceinline__ uint32_t lds_dword(const uint32_t *p) { return *(lds_cptr)p; }
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint2 lds_load2(const uint32_t *p)
+{
+	const u32x2 v = *(const volatile __attribute__((address_space(3))) u32x2 *)p;
+	return make_uint2(v.x, v.y);
+}
+__device__ __forceinline__ void lds_store2(uint32_t *p, uint2 v)
+{
+	u32x2 w = {v.x, v.y};
+	*(volatile __attribute__((address_space(3))) u32x2 *)p = w;
+}
+
 // ---------------------------------------------------------------------------
 // resample fast path: full, opaque 32x32 RGBA tile, both passes needed.
 // Compile-time geometry (plane row stride 18 dwords -- 16 + 2 of bank skew --, plane 576
@@ -673,8 +690,8 @@ __device__ __forceinline__ void resample_mfma32(const uint32_t *s_tab, const Axi
 #pragma unroll
 		for (uint32_t mb = 0; mb < 2; ++mb) {
 			const uint32_t *row = rowp + c * kPD32 + mb * (16u * kRS32);
-			const uint2 d0 = *reinterpret_cast<const uint2 *>(row);       // columns 4g .. 4g+3
-			const uint2 d1 = *reinterpret_cast<const uint2 *>(row + 8u);  // columns 16+4g .. 16+4g+3
+			const uint2 d0 = lds_load2(row);       // columns 4g .. 4g+3
+			const uint2 d1 = lds_load2(row + 8u);  // columns 16+4g .. 16+4g+3
 			const uint32_t a0 = __builtin_amdgcn_perm(d0.y, d0.x, 0x06040200u) ^ 0x80808080u;
 			const uint32_t a1 = __builtin_amdgcn_perm(d1.y, d1.x, 0x06040200u) ^ 0x80808080u;
 			const long av = (long)(((unsigned long long)a1 << 32) | (unsigned long long)a0);
@@ -754,8 +771,8 @@ __device__ __forceinline__ void resample_mfma32_narrow(const uint32_t *s_tab, co
 #pragma unroll
 		for (uint32_t mb = 0; mb < 2; ++mb) {
 			const uint32_t *row = rowp + c * kPD32 + mb * (16u * kRS32);
-			const uint2 d0 = *reinterpret_cast<const uint2 *>(row);       // columns 4g .. 4g+3
-			const uint2 d1 = *reinterpret_cast<const uint2 *>(row + 8u);  // columns 16+4g .. 16+4g+3
+			const uint2 d0 = lds_load2(row);       // columns 4g .. 4g+3
+			const uint2 d1 = lds_load2(row + 8u);  // columns 16+4g .. 16+4g+3
 			const uint32_t a0 = __builtin_amdgcn_perm(d0.y, d0.x, 0x06040200u) ^ 0x80808080u;
 			const uint32_t a1 = __builtin_amdgcn_perm(d1.y, d1.x, 0x06040200u) ^ 0x80808080u;
 			const long av = (long)(((unsigned long long)a1 << 32) | (unsigned long long)a0);

@@ -20,15 +20,6 @@ namespace pxz {
 // kept as loop-invariant lane masks they cost scalar registers, and a spilled one two v_readlane per use.
 // C = 3: RGB frames read and RGB slots written directly (round 2) -- 12-byte pixel quads in, the same three LDS planes,
 // no opacity test (there is no alpha), outputs packed to 3 bytes per pixel by the flush.
-// One dword of the LDS image as a load of its own (base + 16-bit immediate): left to itself the compiler pairs
-// neighbouring dwords into ds_read2_b32, whose 8-bit offsets cost a vector add per new base -- 16 of them per tile in the
-// detector, which is bound by vector instructions, not by LDS instructions.
-__device__ __forceinline__ uint32_t lds_dword(const uint32_t *p)
-{
-	typedef const volatile __attribute__((address_space(3))) uint32_t *lds_ptr;
-	return *(lds_ptr)p;
-}
-
 template <int MODE, bool FULL, int C = 4>
 __global__ void __launch_bounds__(1024) shrink32_kernel(const Fast32Args a)
 {
@@ -190,13 +181,13 @@ __global__ void __launch_bounds__(1024) shrink32_kernel(const Fast32Args a)
 					uint2 pr;
 					pr.x = __builtin_amdgcn_perm(v.y, v.x, sel);
 					pr.y = __builtin_amdgcn_perm(v.w, v.z, sel);
-					*reinterpret_cast<uint2 *>(d + c * kPD32) = pr;
+					lds_store2(d + c * kPD32, pr);
 				}
 			} else {
 				// bytes R0 G0 B0 R1 | G1 B1 R2 G2 | B2 R3 G3 B3 -> the u16 pairs (c0, c1), (c2, c3) of each plane
-				*reinterpret_cast<uint2 *>(d) = make_uint2(__builtin_amdgcn_perm(v.x, v.x, 0x0c070c00u), __builtin_amdgcn_perm(v.z, v.y, 0x0c050c02u));
-				*reinterpret_cast<uint2 *>(d + kPD32) = make_uint2(__builtin_amdgcn_perm(v.y, v.x, 0x0c040c01u), __builtin_amdgcn_perm(v.z, v.y, 0x0c060c03u));
-				*reinterpret_cast<uint2 *>(d + 2 * kPD32) = make_uint2(__builtin_amdgcn_perm(v.y, v.x, 0x0c050c02u), __builtin_amdgcn_perm(v.z, v.z, 0x0c070c00u));
+				lds_store2(d, make_uint2(__builtin_amdgcn_perm(v.x, v.x, 0x0c070c00u), __builtin_amdgcn_perm(v.z, v.y, 0x0c050c02u)));
+				lds_store2(d + kPD32, make_uint2(__builtin_amdgcn_perm(v.y, v.x, 0x0c040c01u), __builtin_amdgcn_perm(v.z, v.y, 0x0c060c03u)));
+				lds_store2(d + 2 * kPD32, make_uint2(__builtin_amdgcn_perm(v.y, v.x, 0x0c050c02u), __builtin_amdgcn_perm(v.z, v.z, 0x0c070c00u)));
 			}
 		}
 		PXZ_STAMP(0);  // wait for the prefetched pixels + staging
@@ -459,7 +450,7 @@ __global__ void __launch_bounds__(1024) shrink32a_kernel(const Fast32Args a)
 				uint2 pr;
 				pr.x = __builtin_amdgcn_perm(v.y, v.x, sel);
 				pr.y = __builtin_amdgcn_perm(v.w, v.z, sel);
-				*reinterpret_cast<uint2 *>(d + c * kPD32) = pr;
+				lds_store2(d + c * kPD32, pr);
 			}
 		}
 		fast32_prefetch(a, tile_next, tid, pre, pre_valid);
@@ -726,13 +717,13 @@ __global__ void __launch_bounds__(1024) shrink16_kernel(const Fast32Args a)
 					uint2 pr;
 					pr.x = __builtin_amdgcn_perm(v.y, v.x, sel);
 					pr.y = __builtin_amdgcn_perm(v.w, v.z, sel);
-					*reinterpret_cast<uint2 *>(d + c * kPD32) = pr;
+					lds_store2(d + c * kPD32, pr);
 				}
 			} else {
 				// bytes R0 G0 B0 R1 | G1 B1 R2 G2 | B2 R3 G3 B3 (as shrink32_kernel<.., 3>)
-				*reinterpret_cast<uint2 *>(d) = make_uint2(__builtin_amdgcn_perm(v.x, v.x, 0x0c070c00u), __builtin_amdgcn_perm(v.z, v.y, 0x0c050c02u));
-				*reinterpret_cast<uint2 *>(d + kPD32) = make_uint2(__builtin_amdgcn_perm(v.y, v.x, 0x0c040c01u), __builtin_amdgcn_perm(v.z, v.y, 0x0c060c03u));
-				*reinterpret_cast<uint2 *>(d + 2 * kPD32) = make_uint2(__builtin_amdgcn_perm(v.y, v.x, 0x0c050c02u), __builtin_amdgcn_perm(v.z, v.z, 0x0c070c00u));
+				lds_store2(d, make_uint2(__builtin_amdgcn_perm(v.x, v.x, 0x0c070c00u), __builtin_amdgcn_perm(v.z, v.y, 0x0c050c02u)));
+				lds_store2(d + kPD32, make_uint2(__builtin_amdgcn_perm(v.y, v.x, 0x0c040c01u), __builtin_amdgcn_perm(v.z, v.y, 0x0c060c03u)));
+				lds_store2(d + 2 * kPD32, make_uint2(__builtin_amdgcn_perm(v.y, v.x, 0x0c050c02u), __builtin_amdgcn_perm(v.z, v.z, 0x0c070c00u)));
 			}
 		}
 		prefetch(grp_next);
