@@ -749,7 +749,7 @@ __device__ __forceinline__ void resample_mfma32(const uint32_t *s_tab, const Axi
 // and stores them as bytes of the parked pixels.  Same integers as resample_mfma32, 14 MFMAs + ~85 vector instructions
 // (the dot2 form: ~125 for a 2x1 tile; resample_mfma32: ~170).
 __device__ __forceinline__ void resample_mfma32_narrow(const uint32_t *s_tab, const AxisTab &tx, const AxisTab &ty, const uint32_t *s_pl,
-                                                       uint32_t lane, uint32_t nw, uint32_t *out)
+                                                       uint32_t lane, uint32_t nw, uint32_t nh, uint32_t *out)
 {
 	const uint32_t o = lane & 15u, g = lane >> 4;
 	const uint32_t lgw = nw >> 1;  // 1, 2, 4 -> 0, 1, 2
@@ -793,12 +793,16 @@ __device__ __forceinline__ void resample_mfma32_narrow(const uint32_t *s_tab, co
 	const long tv = (long)(((unsigned long long)t[1] << 32) | (unsigned long long)t[0]);
 	const v4i32 vlo = __builtin_amdgcn_mfma_i32_16x16x32_i8(ky_lo, tv, cy, 0, 0, 0);
 	const v4i32 vhi = __builtin_amdgcn_mfma_i32_16x16x32_i8(ky_hi, tv, zero, 0, 0, 0);
-	// rows 4g + r of column (ch, ox): byte ch of pixel (4g + r) * nw + ox.  Rows past nh land beyond the parked pixels
-	// (at most 16 rows x 4 pixels: inside the output region) and are never flushed.
-	if (o < 4u * nw) {
+	// rows 4g + r of column (ch, ox): byte ch of pixel (4g + r) * nw + ox.  nh is a power of two: a lane with 4g < nh has
+	// min(nh, 4) rows (scalar tests); rows past nh are not produced.
+	if (o < 4u * nw && 4u * g < nh) {
 		uint8_t *dst = reinterpret_cast<uint8_t *>(out) + (4u * g * nw + ox) * 4u + ch;
-#pragma unroll
-		for (uint32_t r = 0; r < 4; ++r) dst[r * nw * 4u] = (uint8_t)(clamp_fixed(vhi[r], vlo[r], top_y) >> py);
+		dst[0] = (uint8_t)(clamp_fixed(vhi[0], vlo[0], top_y) >> py);
+		if (nh > 1u) dst[nw * 4u] = (uint8_t)(clamp_fixed(vhi[1], vlo[1], top_y) >> py);
+		if (nh > 2u) {
+			dst[2u * nw * 4u] = (uint8_t)(clamp_fixed(vhi[2], vlo[2], top_y) >> py);
+			dst[3u * nw * 4u] = (uint8_t)(clamp_fixed(vhi[3], vlo[3], top_y) >> py);
+		}
 	}
 }
 

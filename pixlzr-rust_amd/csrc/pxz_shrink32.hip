@@ -263,7 +263,11 @@ __global__ void __launch_bounds__(1024) shrink32_kernel(const Fast32Args a)
 					}
 				}
 			}
-			if (q == 15u) sum_hz = sum_vr = 0;  // pair 15 starts no window (x = 30, 31)
+			{
+				uint32_t qq = q;
+				asm volatile("" : "+v"(qq));  // (a fresh compare, not a hoisted and spilled lane mask)
+				if (qq == 15u) sum_hz = sum_vr = 0;  // pair 15 starts no window (x = 30, 31)
+			}
 			sum_hz = wave_sum_sgpr(sum_hz);
 			sum_vr = wave_sum_sgpr(sum_vr);
 			m0 = level_of(sum_hz);
@@ -298,7 +302,7 @@ __global__ void __launch_bounds__(1024) shrink32_kernel(const Fast32Args a)
 				const bool both_mf = a.tabs[lx].mf_off != 0 && a.tabs[ly].mf_off != 0;
 				if (a.narrow && both_mf && nw <= 4u && nh <= 16u && (s_tab[a.tabs[lx].mf_off + 288u] & s_tab[a.tabs[ly].mf_off + 288u])) {
 					// narrow outputs (4, 2, 1 px wide): the three channels through one accumulator
-					resample_mfma32_narrow(s_tab, a.tabs[lx], a.tabs[ly], s_pl, tid, nw, s_tmp);
+					resample_mfma32_narrow(s_tab, a.tabs[lx], a.tabs[ly], s_pl, tid, nw, nh, s_tmp);
 					pend_src = s_tmp;
 					pend_kind = 1;
 				} else if (both_mf && nw >= 4u && nh >= 4u) {
