@@ -14,7 +14,11 @@ frames = h.synth_frames_device(nf, 4320, 7680, 4, 0, dist)
 mode, factor = (1, 16.0) if variant.startswith("dir") else (0, 1.0)
 if os.environ.get("FACTOR"):
     factor = float(os.environ["FACTOR"])  # with DIST=3 (noise) the factor picks ONE size class for every tile
-if variant.endswith("lod"):
+if variant == "enc":  # shrink once, then the device writer n times
+    out = h.shrink_frames_device(frames, 32, 32, 1, 4, 16.0)
+    enc = h.encode_frames_device(tuple(frames.shape), 32, 32, *out)
+    for _ in range(n - 1): h.encode_frames_device(tuple(frames.shape), 32, 32, *out, out=enc)
+elif variant.endswith("lod"):
     for _ in range(n): h.lod_frames_device(frames, 32, 32, mode, factor)
 else:
     out = h.shrink_frames_device(frames, 32, 32, mode, 4, factor)
