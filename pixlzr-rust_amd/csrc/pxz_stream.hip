@@ -472,10 +472,29 @@ __device__ __forceinline__ void splice_piece(uint8_t *dst, const uint8_t *src, u
 // splice: one wave per tile copies the pieces of its record to (frame+1)*hdr + offset[t]; the pieces of a segmented tile
 // four at a time, a quarter wave each.  (A quarter wave per TILE -- four times fewer waves -- was tried: 0.33 ms
 // against 0.25, the short records' byte copies then take three rounds of 16 lanes instead of one of 64.)
+// Records of one piece (tiles below 128 pixels: two thirds of the tiles of a typical frame, records of 30 .. 700 bytes):
+// a quarter wave per tile, four tiles per wave, tiles taken in the encoder's class order (perm) so that the four of a
+// wave are alike.  A wave per tile spent its life in three dependent memory round trips for 40 bytes.
+__global__ void __launch_bounds__(256) qoi_splice_small_kernel(const QoiArgs a)
+{
+	const uint32_t n_big = a.bins[kBinTiles + 6];  // tiles of the classes >= 7 (several pieces) come first in perm
+	const uint32_t p = n_big + (blockIdx.x * 4u + (threadIdx.x >> 6)) * 4u + ((threadIdx.x & 63u) >> 4), lane = threadIdx.x & 15u;
+	if (p >= a.n_tiles) return;
+	const uint32_t t = a.perm[p];
+	const unsigned long long off = a.chunk_totals[t / kPackChunk] + a.offsets[t];
+	const uint32_t len = a.rec_len[t];
+	if (lane == 0) a.offsets[t] = off;
+	const uint32_t frame = t / a.tiles_per_frame;
+	const unsigned long long dstoff = (unsigned long long)(frame + 1u) * a.hdr_bytes + off;
+	if (dstoff + len > a.capacity) return;
+	splice_piece(a.out + dstoff, a.scratch + (size_t)t * a.stride, len, lane, 16u);
+}
+
 __global__ void __launch_bounds__(256) qoi_splice_kernel(const QoiArgs a)
 {
-	const uint32_t t = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
-	if (t >= a.n_tiles) return;
+	const uint32_t p = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+	if (p >= a.bins[kBinTiles + 6]) return;  // (the tiles of several pieces; qoi_splice_small_kernel takes the others)
+	const uint32_t t = a.perm[p];
 	const unsigned long long off = a.chunk_totals[t / kPackChunk] + a.offsets[t];
 	if (lane == 0) a.offsets[t] = off;
 	const uint32_t frame = t / a.tiles_per_frame;
@@ -571,6 +590,7 @@ hipError_t launch_qoi(const QoiArgs &a, hipStream_t stream)
 	hipLaunchKernelGGL(pack_scan_local_kernel, dim3(a.n_chunks), dim3(256), 0, stream, p);
 	hipLaunchKernelGGL(pack_scan_chunks_kernel, dim3(1), dim3(1024), 0, stream, p);
 	hipLaunchKernelGGL(qoi_splice_kernel, dim3((a.n_tiles + 3u) / 4u), dim3(256), 0, stream, a);
+	hipLaunchKernelGGL(qoi_splice_small_kernel, dim3((a.n_tiles + 15u) / 16u), dim3(256), 0, stream, a);
 	const uint32_t frames = a.n_tiles / a.tiles_per_frame;
 	hipLaunchKernelGGL(qoi_headers_kernel, dim3((frames * a.rows + 255u) / 256u), dim3(256), 0, stream, a);
 	return hipGetLastError();
