@@ -8,7 +8,8 @@ P = load_product()
 h = P.Handle(0)
 frames = h.synth_frames_device(8, 4320, 7680, 4, 0, 0)
 for mode, factor in ((1, 16.0), (0, 1.0)):
-    vals, ow, oh, slots = h.shrink_frames_device(frames, 32, 32, mode, 4, factor)
+    bs = int(os.environ.get("BLOCK", "32"))
+    vals, ow, oh, slots = h.shrink_frames_device(frames, bs, bs, mode, 4, factor)
     w = ow.cpu().numpy().ravel().astype(int); hh = oh.cpu().numpy().ravel().astype(int)
     c = collections.Counter(zip(w.tolist(), hh.tolist()))
     n = len(w)
