@@ -109,7 +109,7 @@ def run_mode(args, handle, frames, mode_name, world, dist_mod, with_writer=False
         if with_writer:
             handle.encode_frames_device(tuple(frames.shape), bw, bh, vals, ow, oh, slots, out=enc_out)
 
-    # untimed: bring the chip to its steady clocks (~80 launches / 30 ms of load, tools/exp_ramp.py), whatever W is
+    # untimed: bring the chip to its steady clocks (~80 launches / 30 ms of load, measured in round 1), whatever W is
     t_spin = time.perf_counter()
     while (time.perf_counter() - t_spin) * 1e3 < args.spinup_ms:
         for _ in range(10):
