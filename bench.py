@@ -421,7 +421,10 @@ def main():
         del frames
         torch.cuda.empty_cache()
         note(f"strong scaling: {frames_total} frames over {world} ranks, {args.strong_steps} steps")
-        strong = run_strong(args, handle, product, frames_total, world, rank, dist)
+        try:
+            strong = run_strong(args, handle, product, frames_total, world, rank, dist)
+        except Exception as exc:  # noqa: BLE001  (the line with the headline metric is printed whatever this leg does)
+            strong = {"error": f"{type(exc).__name__}: {exc}"[:300]}
         dog.cancel()
         note("strong scaling done")
         if rank == 0:
