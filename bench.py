@@ -432,6 +432,8 @@ def main():
     if rank == 0:
         print(json.dumps(line), flush=True)
     if world > 1:
+        if frames_total and not args.no_strong and isinstance(locals().get("strong"), dict) and "error" in strong:
+            os._exit(0)  # (a rank that failed in the exchange leaves the others in a collective: no barrier to wait in)
         dist.barrier()
         dist.destroy_process_group()
 
