@@ -593,6 +593,9 @@ int timed_launch(pxz_handle *h, pxz::ShrinkArgs &a, uint32_t channels, float *va
 	a.stats = h->dev_stats;
 	if (!a.alpha_kernel && h->host_stats && *const_cast<volatile uint32_t *>(h->host_stats) >= 2048u && !pxz::knobs().no_alpha_kernel)
 		a.alpha_kernel = 1;
+	// ... and past half of the tiles the lean kernel would only read, test and list them: the four-plane kernel goes first
+	a.alpha_first = a.alpha_kernel && h->host_stats && *const_cast<volatile uint32_t *>(h->host_stats) >= a.n_tiles / 2u &&
+	                        *const_cast<volatile uint32_t *>(h->host_stats) >= 2048u && !pxz::knobs().no_alpha_first ? 1u : 0u;
 	// 32x32 fast path: which tiles are full-size, and whether every tile row of the batch is 16-byte aligned
 	a.full_cols = a.full_rows = a.ok_rows = 0;
 	const bool aligned16 = channels == 4 &&

@@ -81,6 +81,7 @@ struct ShrinkArgs {
 	uint32_t full_cols, full_rows;  // 32x32 fast path: tile (tx, ty) is eligible iff tx < full_cols && ty < full_rows
 	                                //   (full size, 16-byte aligned rows; 0/0 when the batch is not aligned)
 	uint32_t alpha_kernel;   // frames with transparency announced (pxz_params.reserved bit 0) or seen by the last launch
+	uint32_t alpha_first;    // most tiles of the last launch had transparency: the four-plane kernel takes every tile
 	uint32_t finish_scan;    // worklist kernel: 1 = finish every tile the fast kernel completed (scan of all sums); 0 = the fast
 	                         //   kernel did that itself, only the tiles of list A are left (when shrink32a_kernel took them)
 	uint32_t list_a_too;     // worklist kernel: list A (full tiles with transparency) was not taken by shrink32a_kernel
@@ -138,6 +139,7 @@ struct Fast32Args {
 	uint32_t tab_dw, tile_dw;
 	uint32_t chunk_lg;       // tickets deal runs of 2^chunk_lg adjacent tiles
 	uint32_t finish_here;    // shrink32_kernel: every block finishes the tiles it completed (value / lod outputs) at its end
+	uint32_t all_tiles;      // shrink32a_kernel: every tile of the batch (not list A): the launch that skips shrink32_kernel
 	uint32_t narrow;         // shrink32_kernel: 4/2/1-px-wide outputs take resample_mfma32_narrow (0: PXZ_NO_NARROW=1, the round-1 forms)
 	float factor;            //   with these, as the worklist kernel's scan over all tiles would
 	float *value, *lod0, *lod1;
@@ -181,6 +183,7 @@ struct Knobs {
 	bool no_repitch;        // PXZ_NO_REPITCH: unaligned device batches are staged pixel by pixel
 	bool no_widen;          // PXZ_NO_WIDEN: RGB batches never ride the RGBA kernels
 	bool no_native_rgb;     // PXZ_NO_NATIVE_RGB: RGB batches are widened to RGBA even where a kernel reads RGB itself
+	bool no_alpha_first;    // PXZ_NO_ALPHA_FIRST: transparent batches keep the two-kernel flow (shrink32_kernel lists, shrink32a_kernel takes the list)
 	bool no_narrow;         // PXZ_NO_NARROW: 4/2/1-px-wide outputs of 32x32 tiles keep the round-1 resample forms
 	bool oklab_v1;          // PXZ_OKLAB_V1: round-1 detector (one chain wave, two barriers per band) for 16/32-px tiles
 	int wpb;                // PXZ_WPB: waves per block of the persistent kernels (0: default)

@@ -420,11 +420,16 @@ __global__ void __launch_bounds__(1024) shrink32a_kernel(const Fast32Args a)
 	uint32_t *s_pl = lds + a.tab_dw + sub * a.tile_dw;  // four planes: R, G, B, A
 	uint32_t *s_batch = s_ticket + 4u + sub * kListBatch;  // this wave's pending list-B entries
 	uint32_t n_listb = 0;
-	const uint32_t count = __builtin_amdgcn_readfirstlane(a.work[kWorkA + a.work_slot]);
+	// all_tiles (round 2): every tile of the batch comes here first -- the host has seen that most tiles of the last
+	// launch had transparency, so shrink32_kernel would only read, test and list them.  An opaque tile comes out of this
+	// kernel as it does out of the other one (premultiplying by 255 and dividing by it again are identities, and a
+	// constant-255 plane convolves to the weight sums the opaque path uses).
+	const uint32_t count = a.all_tiles ? a.n_tiles : __builtin_amdgcn_readfirstlane(a.work[kWorkA + a.work_slot]);
 	const uint32_t *list = a.work + kWorkList + a.n_tiles;
+	uint32_t n_transparent = 0;  // all_tiles: what the list counter would have said (the host's statistic)
 	auto tile_of_ticket = [&](uint32_t t) -> uint32_t {
 		const unsigned long long i = (unsigned long long)blockIdx.x + (unsigned long long)t * gridDim.x;
-		return i < (unsigned long long)count ? list[(uint32_t)i] : 0xffffffffu;
+		return i < (unsigned long long)count ? (a.all_tiles ? (uint32_t)i : list[(uint32_t)i]) : 0xffffffffu;
 	};
 	auto next_ticket = [&]() -> uint32_t {
 		uint32_t t = 0;
@@ -440,9 +445,31 @@ __global__ void __launch_bounds__(1024) shrink32a_kernel(const Fast32Args a)
 		auto defer = [&]() {  // on to the generic kernel (list B); the marker in sums[] is there already (MODE 1) / not wanted (MODE 0)
 			list_push(s_batch, n_listb, tile_g, a.work + kWorkList, a.work + a.work_slot, tid);
 		};
+		if (!pre_valid) {  // (all_tiles only: a ragged-edge tile, or unaligned rows) generic kernel
+			if (tid == 0) {
+				bool keep = false;  // MODE 0: a value the block-cooperative detector left is final and stays
+				if constexpr (MODE == 0) {
+					const uint32_t t = tile_g - fastdiv(tile_g, a.div_tpf) * a.tiles_per_frame;
+					const uint32_t ty = fastdiv(t, a.div_cols), tx = t - ty * a.cols;
+					keep = oklab_value_given(a, tx, ty);
+				}
+				if (!keep) reinterpret_cast<uint2 *>(a.sums)[tile_g] = make_uint2(kDeferredKey, kDeferredKey);
+			}
+			defer();
+			fast32_prefetch(a, tile_next, tid, pre, pre_valid);
+			tile_g = tile_next;
+			continue;
+		}
 		uint32_t given_bits = 0;
 		if constexpr (MODE == 0) given_bits = a.sums[2 * tile_g];
-		// ---- stage: registers -> four planes of u16 pairs (only full, aligned tiles are ever listed)
+		if (a.all_tiles) {
+			const uint32_t m0 = min(min(pre[0].x, pre[0].y), pre[0].z), m1 = min(min(pre[0].w, pre[1].x), pre[1].y);
+			const uint32_t m2 = min(min(pre[1].z, pre[1].w), pre[2].x), m3 = min(min(pre[2].y, pre[2].z), pre[2].w);
+			const uint32_t m4 = min(min(pre[3].x, pre[3].y), pre[3].z);
+			const uint32_t least = min(min(min(m0, m1), m2), min(min(m3, m4), pre[3].w));
+			n_transparent += __builtin_amdgcn_ballot_w64(least < 0xff000000u) != 0ull ? 1u : 0u;
+		}
+		// ---- stage: registers -> four planes of u16 pairs (list mode: only full, aligned tiles are ever listed)
 #pragma unroll
 		for (int k = 0; k < 4; ++k) {
 			const uint32_t row = (tid >> 3) + 8u * (uint32_t)k, col = tid & 7u;
@@ -583,6 +610,7 @@ __global__ void __launch_bounds__(1024) shrink32a_kernel(const Fast32Args a)
 		tile_g = tile_next;
 	}
 	list_flush(s_batch, n_listb, a.work + kWorkList, a.work + a.work_slot, tid);
+	if (a.all_tiles && n_transparent != 0u && tid == 0) atomicAdd(a.work + kWorkA + a.work_slot, n_transparent);
 }
 
 // ---------------------------------------------------------------------------
@@ -928,7 +956,10 @@ hipError_t launch_fast32_16(const ShrinkArgs &a, ShrinkArgs &ga, uint32_t channe
 	// or seen before, else the worklist kernel walks it after list B
 	f.alpha_list = (!groups16 && channels == 4 && a.out_px != nullptr && (a.filter == 0 || a.tab_dw != 0)) ? 1u : 0u;
 	const bool run_alpha = f.alpha_list != 0 && a.alpha_kernel != 0;
+	// most tiles of the last launch had transparency: shrink32a_kernel takes every tile, shrink32_kernel is not launched
+	const bool alpha_first = run_alpha && a.alpha_first != 0;
 	ga.list_a_too = f.alpha_list != 0 && !run_alpha ? 1u : 0u;
+	if (alpha_first) ga.finish_scan = 1u;  // (nobody finishes tiles in passing: the worklist kernel scans)
 	f.trows = a.trows;
 	f.tab_dw = a.out_px && a.filter != 0 ? a.tab_dw : 0u;
 	// only the x-axis tables of full tiles are used (the y axis of a 32x32 tile is identical): they
@@ -959,7 +990,9 @@ hipError_t launch_fast32_16(const ShrinkArgs &a, ShrinkArgs &ga, uint32_t channe
 	f.chunk_lg = 3;
 	if (knobs().chunk_lg >= 0) f.chunk_lg = (uint32_t)knobs().chunk_lg;
 	hipError_t e = hipSuccess;  // the worklist counter of this launch was zeroed by the previous one (or at allocation)
-	if (groups16) {
+	if (alpha_first) {
+		// (nothing here: the four-plane kernel below is the first kernel of the step)
+	} else if (groups16) {
 		const bool full = a.out_px != nullptr && a.out_w != nullptr && a.out_h != nullptr;
 		void (*k)(const Fast32Args) = a.mode == 1 ? (full ? shrink16_kernel<1, true> : shrink16_kernel<1, false>)
 		                                          : (full ? shrink16_kernel<0, true> : shrink16_kernel<0, false>);
@@ -979,11 +1012,12 @@ hipError_t launch_fast32_16(const ShrinkArgs &a, ShrinkArgs &ga, uint32_t channe
 		hipLaunchKernelGGL(k, dim3(blocks), dim3(64u * wpb), lds_bytes, stream, f);
 	}
 	if ((e = hipGetLastError()) != hipSuccess) return e;
-	if (a.mid_event && (e = hipEventRecord(static_cast<hipEvent_t>(a.mid_event), stream)) != hipSuccess) return e;
+	if (!alpha_first && a.mid_event && (e = hipEventRecord(static_cast<hipEvent_t>(a.mid_event), stream)) != hipSuccess) return e;
 	ga.mid_event = nullptr;
 	if (run_alpha) {
 		// 1b) the full tiles with transparency that shrink32_kernel listed: four planes, no output region
 		Fast32Args fa = f;
+		fa.all_tiles = alpha_first ? 1u : 0u;
 		fa.tile_dw = (4u * kPD32 + 2u * kRS32 + 3u) & ~3u;
 		uint32_t wa = (kLds - fa.tab_dw * 4u - kTail) / (fa.tile_dw * 4u);
 		if (wa > 16u) wa = 16u;
@@ -998,6 +1032,7 @@ hipError_t launch_fast32_16(const ShrinkArgs &a, ShrinkArgs &ga, uint32_t channe
 			hipLaunchKernelGGL(k, dim3(n_cus), dim3(64u * wa), lds_a, stream, fa);
 		}
 		if ((e = hipGetLastError()) != hipSuccess) return e;
+		if (alpha_first && a.mid_event && (e = hipEventRecord(static_cast<hipEvent_t>(a.mid_event), stream)) != hipSuccess) return e;
 	}
 	// 2) the generic kernel walks the worklist (usually empty or a few percent of the tiles)
 	return hipSuccess;
