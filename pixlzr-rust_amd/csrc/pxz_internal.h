@@ -166,6 +166,7 @@ struct Fast64Args {
 	uint8_t *out_px;
 	uint32_t *work;
 	uint32_t work_slot;
+	uint32_t all_tiles;      // ALPHA instance: every tile of the batch (not list A): the launch that skips the opaque instance
 	const uint32_t *mf64;
 	uint32_t mf_off[kMaxLevel];      // dword offset of the level's table in mf64 (0: none; the blob starts with a pad)
 	uint32_t precision[kMaxLevel];

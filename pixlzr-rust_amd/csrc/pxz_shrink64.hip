@@ -98,11 +98,16 @@ __global__ void __launch_bounds__(256) shrink64_kernel(const Fast64Args a)
 	const uint32_t n_ctr = ALPHA ? gridDim.x : (gridDim.x < kTicketCounters ? gridDim.x : kTicketCounters);
 	const uint32_t cid = blockIdx.x % n_ctr, nb_c = (gridDim.x - cid + n_ctr - 1u) / n_ctr;
 	uint32_t *ctr = a.work + 2u + kTicketCounters * a.work_slot + cid;
-	const uint32_t n_items = ALPHA ? a.work[kWorkA + a.work_slot] : a.n_tiles;
+	// (ALPHA with all_tiles, round 2: every tile of the batch -- the launch that skips the opaque instance because most
+	// tiles of the last launch had transparency; an opaque tile comes out of the four-plane arithmetic unchanged)
+	const uint32_t n_items = (ALPHA && !a.all_tiles) ? a.work[kWorkA + a.work_slot] : a.n_tiles;
+	uint32_t n_transparent = 0;  // all_tiles: what the list counter would have said (thread 0 counts)
 	auto tile_of = [&](uint32_t k) -> uint32_t {
 		const unsigned long long t = (unsigned long long)k * n_ctr + cid;
 		if (t >= (unsigned long long)n_items) return 0xffffffffu;
-		if constexpr (ALPHA) return a.work[kWorkList + a.n_tiles + (uint32_t)t];
+		if constexpr (ALPHA) {
+			if (!a.all_tiles) return a.work[kWorkList + a.n_tiles + (uint32_t)t];
+		}
 		return (uint32_t)t;
 	};
 	uint32_t tile_g = tile_of(blockIdx.x / n_ctr), tile_next = tile_of(blockIdx.x / n_ctr + nb_c);
@@ -179,6 +184,9 @@ __global__ void __launch_bounds__(256) shrink64_kernel(const Fast64Args a)
 		if (lane == 0) s_red[8 + wave] = wave_transparent ? 1u : 0u;
 		prefetch(tile_next);  // lands while this tile is processed
 		__syncthreads();      // B1: the whole tile is staged
+		if constexpr (ALPHA) {
+			if (a.all_tiles && threadIdx.x == 0 && (s_red[8] | s_red[9] | s_red[10] | s_red[11]) != 0u) ++n_transparent;
+		}
 		if (!ALPHA && (FULL || a.out_px != nullptr) && (s_red[8] | s_red[9] | s_red[10] | s_red[11]) != 0u) {
 			// transparency: the premultiplied convolution needs the alpha plane -- list A (the ALPHA instance of this
 			// kernel, or the generic kernel when that one is not launched).  Detector-only launches do not care.
@@ -471,6 +479,9 @@ __global__ void __launch_bounds__(256) shrink64_kernel(const Fast64Args a)
 	}
 	list_flush(s_red + 16, n_listb, a.work + kWorkList, a.work + a.work_slot, threadIdx.x);
 	list_flush(s_red + 32, n_lista, a.work + kWorkList + a.n_tiles, a.work + kWorkA + a.work_slot, threadIdx.x);
+	if constexpr (ALPHA) {
+		if (a.all_tiles && threadIdx.x == 0 && n_transparent != 0u) atomicAdd(a.work + kWorkA + a.work_slot, n_transparent);
+	}
 }
 
 // 64x64 flow, first part: the four-wave kernel (and its four-plane instance); ga = the arguments of the worklist
@@ -511,8 +522,13 @@ hipError_t launch_fast64(const ShrinkArgs &a, ShrinkArgs &ga, uint32_t channels,
 	const uint32_t per_cu = kLds / lds_bytes;
 	const uint32_t resident = n_cus * per_cu;
 	const uint32_t blocks = a.n_tiles < resident ? a.n_tiles : resident;
-	hipError_t e;
-	{
+	hipError_t e = hipSuccess;
+	// full tiles with transparency are on list A: the four-plane instance takes it when transparency was
+	// announced or seen before, else the generic kernel walks it after list B.  When most tiles of the last launch had
+	// transparency the four-plane instance takes EVERY tile and the opaque instance is not launched.
+	const bool run_alpha = channels == 4 && a.out_px != nullptr && a.out_w != nullptr && a.out_h != nullptr && a.alpha_kernel != 0;
+	const bool alpha_first = run_alpha && a.alpha_first != 0;
+	if (!alpha_first) {
 		const bool full = a.out_px != nullptr && a.out_w != nullptr && a.out_h != nullptr;
 		void (*k)(const Fast64Args) = a.mode == 1 ? (full ? shrink64_kernel<1, false, true> : shrink64_kernel<1, false, false>)
 		                                          : (full ? shrink64_kernel<0, false, true> : shrink64_kernel<0, false, false>);
@@ -523,13 +539,11 @@ hipError_t launch_fast64(const ShrinkArgs &a, ShrinkArgs &ga, uint32_t channels,
 		hipLaunchKernelGGL(k, dim3(blocks), dim3(256), lds_bytes, stream, f);
 	}
 	if ((e = hipGetLastError()) != hipSuccess) return e;
-	if (a.mid_event && (e = hipEventRecord(static_cast<hipEvent_t>(a.mid_event), stream)) != hipSuccess) return e;
+	if (!alpha_first && a.mid_event && (e = hipEventRecord(static_cast<hipEvent_t>(a.mid_event), stream)) != hipSuccess) return e;
 	ga.mid_event = nullptr;
-	// full tiles with transparency are on list A: the four-plane instance takes it when transparency was
-	// announced or seen before, else the generic kernel walks it after list B
-	const bool run_alpha = channels == 4 && a.out_px != nullptr && a.out_w != nullptr && a.out_h != nullptr && a.alpha_kernel != 0;
 	ga.list_a_too = channels == 4 && a.out_px != nullptr && !run_alpha ? 1u : 0u;
 	if (run_alpha) {
+		f.all_tiles = alpha_first ? 1u : 0u;
 		const uint32_t lds_a = lds64_dwords(4) * 4u;
 		const uint32_t blocks_a = n_cus * (kLds / lds_a);
 		if (a.mode == 1) {
@@ -542,6 +556,7 @@ hipError_t launch_fast64(const ShrinkArgs &a, ShrinkArgs &ga, uint32_t channels,
 			hipLaunchKernelGGL(k, dim3(blocks_a), dim3(256), lds_a, stream, f);
 		}
 		if ((e = hipGetLastError()) != hipSuccess) return e;
+		if (alpha_first && a.mid_event && (e = hipEventRecord(static_cast<hipEvent_t>(a.mid_event), stream)) != hipSuccess) return e;
 	}
 	return hipSuccess;
 }

@@ -873,21 +873,22 @@ def test_rgb_frames_on_the_square_fast_paths(gpu, oracle, filt, mode, factors, b
             assert_same_tiles(got, exp, 3, f"rgb{bs} view x0={x0} frame {n}")
 
 
+@pytest.mark.parametrize("bs", [32, 64])
 @pytest.mark.parametrize("mode,factor", [(1, 16.0), (1, 2.0), (0, 1.0)])
-def test_mostly_transparent_batches_go_to_the_four_plane_kernel_first(product, oracle, mode, factor):
+def test_mostly_transparent_batches_go_to_the_four_plane_kernel_first(product, oracle, mode, factor, bs):
     """A handle that has seen a launch in which most full tiles had transparency sends the next launches to
-    shrink32a_kernel alone (every tile, no listing pass by shrink32_kernel): the results must not depend on that -- for
+    shrink32a_kernel / the four-plane instance of shrink64_kernel alone (every tile, no listing pass by the opaque kernel): the results must not depend on that -- for
     transparent frames, for the opaque frames that follow them (still in that mode: the statistic is one launch behind),
     with a ragged edge (those tiles go on to the generic kernel) and after the handle has swung back."""
     import torch
     h = product.Handle(0)
-    seq = [(1, 1080, 1920), (1, 1080, 1920), (0, 1080, 1920), (0, 1080, 1920), (1, 1056, 1920), (1, 1056, 1920)]
+    seq = [(1, 2160, 3840), (1, 2160, 3840), (0, 2160, 3840), (0, 2160, 3840), (1, 2112, 3840), (1, 2112, 3840)]
     for k, (dist, hh, ww) in enumerate(seq):
         frames = h.synth_frames_device(2, hh, ww, 4, first_frame=5 + k, dist=dist)
         f = frames.cpu().numpy()
-        vals, ow, oh, slots = h.shrink_frames_device(frames, 32, 32, mode, 4, factor)
+        vals, ow, oh, slots = h.shrink_frames_device(frames, bs, bs, mode, 4, factor)
         torch.cuda.synchronize()
         for n in range(2):
-            exp = oracle.shrink_image(f[n], 32, 32, mode, 4, factor, nthreads=8)
+            exp = oracle.shrink_image(f[n], bs, bs, mode, 4, factor, nthreads=8)
             got = (vals[n].cpu().numpy(), ow[n].cpu().numpy().astype(np.uint32), oh[n].cpu().numpy().astype(np.uint32), slots[n].cpu().numpy())
             assert_same_tiles(got, exp, 4, f"launch {k} (dist {dist}, {ww}x{hh}) frame {n}")
