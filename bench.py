@@ -181,60 +181,68 @@ def run_mode(args, handle, frames, mode_name, world, dist_mod, with_writer=False
 def run_strong(args, handle, product, frames_total, world, rank, dist_mod):
     """BASELINE configs[4] as stated: a FIXED batch of `frames_total` frames sharded over the ranks (contiguous ranges,
     dist.shard_frames).  Step = shrink_directionally + device writer (QOI + container: finished .pixlzr files) + gather
-    of the files to the writer rank 0.  Two sets of output buffers: the shrink + writer of step k + 1 are enqueued
-    before the gather of step k is issued on a second stream, so the exchange runs under the next step's kernels."""
+    of the files to the writer rank 0.  Three sets of output buffers (dist.run_pipelined): the kernels of step k + 1
+    are enqueued before anything of step k is looked at, the sizes of step k cross to the host while they run, and the
+    files of step k travel on a second stream; a set is only overwritten behind the event that ends its sends."""
     import torch
     pdist = product.dist
     pxz_mode, factor = MODES["shrink_directionally"]
     mine = pdist.shard_frames(frames_total, world, rank)
     n = len(mine)
     dev = torch.device("cuda", handle.device_id)
+    bw = bh = args.block
     ok, err = True, ""
     try:
         frames = handle.synth_frames_device(max(n, 1), args.height, args.width, 4, first_frame=mine.start, dist=args.dist)
-        bw = bh = args.block
         compute, comm = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
         bufs = []
         with torch.cuda.stream(compute):
-            for _ in range(2):
+            for _ in range(pdist.PIPELINE_SETS):
                 out = handle.shrink_frames_device(frames, bw, bh, pxz_mode, args.filter, factor)
                 enc = handle.encode_frames_device(tuple(frames.shape), bw, bh, *out)
-                bufs.append((out, enc, torch.cuda.Event()))
+                bufs.append((out, enc))
         torch.cuda.synchronize()
     except Exception as exc:  # noqa: BLE001
         ok, err = False, f"{type(exc).__name__}: {exc}"[:300]
     if not agree(dist_mod, world, dev, ok):
         return {"error": err or "another rank failed to set the batch up"}
-    state = {"bytes": 0, "files": 0}
+    state = {"bytes": 0, "files": 0, "last": None}
 
-    def produce(i):
-        out, enc, ev = bufs[i & 1]
-        with torch.cuda.stream(compute):
-            handle.shrink_frames_device(frames, bw, bh, pxz_mode, args.filter, factor, out=out)
-            handle.encode_frames_device(tuple(frames.shape), bw, bh, *out, out=enc)
-            ev.record(compute)
+    def produce(i):  # (run_pipelined puts it on `compute`, behind the sends that still read this buffer set)
+        out, enc = bufs[i % len(bufs)]
+        handle.shrink_frames_device(frames, bw, bh, pxz_mode, args.filter, factor, out=out)
+        handle.encode_frames_device(tuple(frames.shape), bw, bh, *out, out=enc)
 
-    def exchange(i):
-        _, (offs, buf), ev = bufs[i & 1]
-        with torch.cuda.stream(comm):
-            comm.wait_event(ev)
-            if world > 1:
-                got = pdist.gather_files(offs, buf, dst=0)
-                if got is not None:
-                    state["bytes"] = sum(int(g[1].numel()) for g in got)
-                    state["files"] = sum(int(g[0].numel()) - 1 for g in got)
-            else:  # one rank: the files are where the writer left them; the sizes still cross to the host
-                o = offs.cpu()
-                state["bytes"], state["files"] = int(o[-1]), int(o.numel()) - 1
+    def begin(i):
+        offs, buf = bufs[i % len(bufs)][1]
+        if world > 1:
+            return pdist.gather_files_begin(offs, buf)
+        host = torch.empty(offs.numel(), dtype=torch.int64, pin_memory=True)  # one rank: only the sizes cross to the host
+        host.copy_(offs, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(dev))
+        return host, ev
+
+    def finish(i, token):
+        if world > 1:
+            got = pdist.gather_files_finish(token, dst=0)
+            if got is not None:
+                state["bytes"] = sum(int(g[1].numel()) for g in got)
+                state["files"] = sum(int(g[0].numel()) - 1 for g in got)
+                state["last"] = got
+        else:
+            host, ev = token
+            ev.synchronize()
+            state["bytes"], state["files"] = int(host[-1]), int(host.numel()) - 1
 
     def loop(k):
-        pdist.run_pipelined(k, produce, exchange)  # produce(i + 1) is enqueued before exchange(i): the files travel under it
+        pdist.run_pipelined(k, produce, begin, finish, compute=compute, comm=comm)
         torch.cuda.synchronize()
 
     ok, err, ms = True, "", 0.0
     try:
         note("strong scaling: buffers ready, warm-up exchange")
-        loop(3)  # untimed: allocations, RCCL channels
+        loop(4)  # untimed: allocations, RCCL channels
         note("strong scaling: timed loop")
         if world > 1:
             dist_mod.barrier()
@@ -249,25 +257,48 @@ def run_strong(args, handle, product, frames_total, world, rank, dist_mod):
         ok, err = False, f"{type(exc).__name__}: {exc}"[:300]
     if not agree(dist_mod, world, dev, ok):
         return {"error": err or "another rank failed in the exchange"}
+    # what arrived is what one process writes: rank 0 encodes the shard of the LAST rank itself and compares the bytes of
+    # the last step (untimed)
+    checked = None
+    if world > 1 and rank == 0 and state["last"] is not None:
+        try:
+            other = pdist.shard_frames(frames_total, world, world - 1)
+            f2 = handle.synth_frames_device(len(other), args.height, args.width, 4, first_frame=other.start, dist=args.dist)
+            out2 = handle.shrink_frames_device(f2, bw, bh, pxz_mode, args.filter, factor)
+            offs2, buf2 = handle.encode_frames_device(tuple(f2.shape), bw, bh, *out2)
+            roffs, rbuf = state["last"][world - 1]
+            torch.cuda.synchronize()
+            nb = int(offs2[-1].item())
+            checked = bool(torch.equal(roffs.cpu(), offs2.cpu()) and rbuf.numel() == nb and torch.equal(rbuf, buf2[:nb]))
+            del f2, out2, offs2, buf2
+        except Exception as exc:  # noqa: BLE001
+            checked = f"{type(exc).__name__}: {exc}"[:200]
     if world > 1:
         t = torch.tensor([ms], dtype=torch.float64, device=dev)
         dist_mod.all_reduce(t, op=dist_mod.ReduceOp.MAX)
         ms = float(t[0])
     mp = frames_total * args.width * args.height / 1e6
-    return {"scaling": "strong", "frames_total": frames_total, "frames_this_rank": n, "steps": args.strong_steps,
-            "ms_per_step": ms, "value": mp / (ms * 1e-3), "unit": "MP/s",
-            "what": "shrink_directionally + device QOI/container writer + gather of the .pixlzr files to rank 0; "
-                    "the gather of step k overlaps the kernels of step k+1 (second stream, two buffer sets)",
-            "files_at_rank0": state["files"], "bytes_at_rank0": state["bytes"],
-            "backend": (dist_mod.get_backend() if world > 1 else None),
-            "rccl_ranks": (dist_mod.get_world_size() if world > 1 and dist_mod.get_backend() == "nccl" else 0)}
+    res = {"scaling": "strong", "frames_total": frames_total, "frames_this_rank": n, "steps": args.strong_steps,
+           "ms_per_step": ms, "value": mp / (ms * 1e-3), "unit": "MP/s",
+           "what": "shrink_directionally + device QOI/container writer + gather of the .pixlzr files to rank 0; "
+                   "the gather of step k overlaps the kernels of step k+1 (second stream, three buffer sets, sizes one step behind)",
+           "files_at_rank0": state["files"], "bytes_at_rank0": state["bytes"],
+           "gathered_files_equal_single_process": checked,
+           "backend": (dist_mod.get_backend() if world > 1 else None),
+           "rccl_ranks": (dist_mod.get_world_size() if world > 1 and dist_mod.get_backend() == "nccl" else 0)}
+    if checked is not None and checked is not True:
+        res["error"] = f"the files gathered from rank {world - 1} differ from a single-process encode: {checked}"
+    return res
 
 
 def cpu_baseline(args, primary, names):
     """The oracle (CPU restatement of the reference path) timed on this box's host cores on a bounded
     sample: ONE frame of the batch, every caller in `names`.  kind="port": the Rust reference itself cannot be
-    built here.  All cores: best of 5; one thread (what the reference's sequential shrink_* loops
-    use, pixlzr.rs:163-204): best of 2 for the integer detector, one run for the Oklab one (~5 s)."""
+    built here.  Best of 5 after a warm-up run, on all cores over tile rows and on ONE thread
+    (what the reference's sequential shrink_* loops use, pixlzr.rs:163-204); plus the reference's own Criterion case
+    (benches/bench-00.rs:55,79-81: base.png, 64x64 tiles, shrink_by(CatmullRom, 0.25)) on one thread, to stand beside
+    log_24-09-26.txt:6.  About 25 s of CPU work in all; the other rows of BASELINE.md section 3 (1080p, 16384^2 at
+    16/32/64) are in profiles/ (tools/cpu_baseline_table.py), not in this line."""
     from oracle import binding as oracle
     oracle.build()
     img = oracle.synth_frame(args.width, args.height, 4, 0, args.dist)
@@ -277,26 +308,40 @@ def cpu_baseline(args, primary, names):
         avail = os.cpu_count() or 1
     cores = max(1, min(avail, 16))  # the GPU box grants ~16 host cores per GPU
     mp = args.width * args.height / 1e6
+
+    def best_of(n, fn):
+        fn()  # warm-up
+        best = None
+        for _ in range(n):
+            t0 = time.perf_counter()
+            fn()
+            dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+        return best
+
     per_mode = {}
     for name in names:
         pxz_mode, factor = MODES[name]
-        best_all = best_one = None
-        for _ in range(5):
-            t0 = time.perf_counter()
-            oracle.shrink_image(img, args.block, args.block, pxz_mode, args.filter, factor, nthreads=cores)
-            dt = time.perf_counter() - t0
-            best_all = dt if best_all is None else min(best_all, dt)
-        for _ in range(2 if pxz_mode == 1 else 1):
-            t0 = time.perf_counter()
-            oracle.shrink_image(img, args.block, args.block, pxz_mode, args.filter, factor, nthreads=1)
-            dt = time.perf_counter() - t0
-            best_one = dt if best_one is None else min(best_one, dt)
-        per_mode[name] = {"value": mp / best_all, "unit": "MP/s", "cores": cores, "single_thread_value": mp / best_one}
+        best_all = best_of(5, lambda: oracle.shrink_image(img, args.block, args.block, pxz_mode, args.filter, factor, nthreads=cores))
+        best_one = best_of(5, lambda: oracle.shrink_image(img, args.block, args.block, pxz_mode, args.filter, factor, nthreads=1))
+        per_mode[name] = {"value": mp / best_all, "unit": "MP/s", "cores": cores, "single_thread_value": mp / best_one,
+                          "single_thread_runs": "best of 5 after one warm-up"}
     p = per_mode[primary]
-    return {"value": p["value"], "unit": "MP/s", "cores": cores, "kind": "port",
-            "sample": f"1 frame {args.width}x{args.height} RGBA8, {primary}, best of 5, {cores} threads over tile rows",
-            "single_thread_value": p["single_thread_value"], "modes": per_mode,
-            "reference_published": "88.4 ms / 1.746 MP = 19.8 MP/s single thread (shrink_by, 64x64), hardware unstated (log_24-09-26.txt:6)"}
+    res = {"value": p["value"], "unit": "MP/s", "cores": cores, "kind": "port",
+           "sample": f"1 frame {args.width}x{args.height} RGBA8, {primary}, best of 5, {cores} threads over tile rows",
+           "single_thread_value": p["single_thread_value"], "modes": per_mode,
+           "reference_published": "88.4 ms / 1.746 MP = 19.8 MP/s single thread (shrink_by, 64x64), hardware unstated (log_24-09-26.txt:6)"}
+    try:  # the reference's own bench case on this box's cores, one thread
+        import numpy as np
+        from PIL import Image
+        base = np.asarray(Image.open(os.path.join(ROOT, "tests", "golden", "base.png")).convert("RGBA")).copy()
+        t = best_of(5, lambda: oracle.shrink_image(base, 64, 64, 0, 2, 0.25, nthreads=1))
+        res["reference_bench_case"] = {"what": "benches/base.png 1080x1617 RGBA, 64x64 tiles, shrink_by(CatmullRom, 0.25), one thread, best of 5",
+                                       "ms": t * 1e3, "mp_per_s": base.shape[0] * base.shape[1] / 1e6 / t,
+                                       "reference_log_ms": 88.4}
+    except Exception as exc:  # noqa: BLE001
+        res["reference_bench_case"] = {"error": f"{type(exc).__name__}: {exc}"[:200]}
+    return res
 
 
 def load_traffic(mode_name):
@@ -406,18 +451,14 @@ def main():
 
     # the strong-scaling leg comes last and under a watchdog: whatever happens to the exchange, the line above is printed
     frames_total = args.frames_total or (64 if world > 1 else 0)
+    failed = False
     if frames_total and not args.no_strong:
-        import threading
-
-        def bail():
+        def on_expiry():  # a leg stuck in a collective: say what is known, then the process ends non-zero (dist.exit_on_timeout)
             if rank == 0:
                 line["strong_scaling"] = {"error": f"no result within {args.strong_timeout} s; the leg was abandoned"}
                 print(json.dumps(line), flush=True)
-            os._exit(0)
 
-        dog = threading.Timer(args.strong_timeout, bail)
-        dog.daemon = True
-        dog.start()
+        dog = product.dist.exit_on_timeout(args.strong_timeout, on_expiry, code=3)
         del frames
         torch.cuda.empty_cache()
         note(f"strong scaling: {frames_total} frames over {world} ranks, {args.strong_steps} steps")
@@ -427,13 +468,17 @@ def main():
             strong = {"error": f"{type(exc).__name__}: {exc}"[:300]}
         dog.cancel()
         note("strong scaling done")
+        failed = isinstance(strong, dict) and "error" in strong
         if rank == 0:
             line["strong_scaling"] = strong
     if rank == 0:
         print(json.dumps(line), flush=True)
+    if failed:
+        # a leg that failed ends the process non-zero, at once: a rank that failed in the exchange may have left the
+        # others inside a collective, so there is no barrier to wait in and no teardown to run
+        sys.stdout.flush()
+        os._exit(1)
     if world > 1:
-        if frames_total and not args.no_strong and isinstance(locals().get("strong"), dict) and "error" in strong:
-            os._exit(0)  # (a rank that failed in the exchange leaves the others in a collective: no barrier to wait in)
         dist.barrier()
         dist.destroy_process_group()
 

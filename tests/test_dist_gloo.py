@@ -153,22 +153,29 @@ def _worker_strong(rank, world, port, result_path, n_steps):
     product = load_product()
     from pixlzr_rust_amd import dist as pdist
     mine = pdist.shard_frames(NF, world, rank)  # the fixed batch of NF frames, contiguous shards
-    bufs = [None, None]                         # two buffer sets, as in bench.py
+    bufs = [None] * pdist.PIPELINE_SETS         # three buffer sets, as in bench.py
     got_steps = []
+    order = []
 
     def produce(i):
         # step i "shrinks" its frames with a step-dependent factor, so that a stale buffer set would be noticed
+        order.append(("produce", i))
         files = []
         for f in mine:
             img = oracle.synth_frame(W, H, 4, f, 1)
             v, ow, oh, slots = oracle.shrink_image(img, B, B, 1, 4, 4.0 + 4.0 * i)
             files.append(product.encode_container(W, H, B, B, 4, 0, v, None, ow, oh, slots))
         offs = np.concatenate([[0], np.cumsum([len(x) for x in files])]).astype(np.int64)
-        bufs[i & 1] = (torch.from_numpy(offs), torch.from_numpy(np.frombuffer(b"".join(files) + bytes(16), np.uint8).copy()))
+        bufs[i % len(bufs)] = (torch.from_numpy(offs), torch.from_numpy(np.frombuffer(b"".join(files) + bytes(16), np.uint8).copy()))
 
-    def exchange(i):
-        offs, buf = bufs[i & 1]
-        got = pdist.gather_files(offs, buf, dst=0)
+    def begin(i):
+        order.append(("begin", i))
+        offs, buf = bufs[i % len(bufs)]
+        return pdist.gather_files_begin(offs, buf)
+
+    def finish(i, token):
+        order.append(("finish", i))
+        got = pdist.gather_files_finish(token, dst=0)
         if rank == 0:
             blob = b""
             for roffs, rbuf in got:
@@ -178,7 +185,18 @@ def _worker_strong(rank, world, port, result_path, n_steps):
         else:
             assert got is None
 
-    pdist.run_pipelined(n_steps, produce, exchange)
+    pdist.run_pipelined(n_steps, produce, begin, finish)
+    # the host order the docstring promises: the kernels of step i + 1 are enqueued before anything of step i is looked
+    # at, and the files of step i move one iteration after their sizes started travelling
+    want = [("produce", 0)]
+    for i in range(n_steps):
+        if i + 1 < n_steps:
+            want.append(("produce", i + 1))
+        want.append(("begin", i))
+        if i >= 1:
+            want.append(("finish", i - 1))
+    want.append(("finish", n_steps - 1))
+    assert order == want, order
     if rank == 0:
         with open(result_path, "wb") as fh:
             for blob in got_steps:
@@ -188,12 +206,12 @@ def _worker_strong(rank, world, port, result_path, n_steps):
 
 
 def test_strong_scaling_loop_over_two_ranks(tmp_path, product, oracle):
-    """bench.py's strong-scaling leg on CPU: a fixed batch of 5 frames over 2 ranks (shards of 2 and 3), three steps
-    through run_pipelined with two buffer sets; at every step the writer rank holds all five files of THAT step, in
-    frame order, byte for byte what one process writes."""
+    """bench.py's strong-scaling leg on CPU: a fixed batch of 5 frames over 2 ranks (shards of 2 and 3), five steps
+    through run_pipelined with three buffer sets (every set is reused); at every step the writer rank holds all five
+    files of THAT step, in frame order, byte for byte what one process writes."""
     result = str(tmp_path / "strong.bin")
     port = 33500 + (os.getpid() % 2000)
-    n_steps = 3
+    n_steps = 5
     mp.spawn(_worker_strong, args=(2, port, result, n_steps), nprocs=2, join=True)
     data = open(result, "rb").read()
     pos = 0
@@ -208,3 +226,63 @@ def test_strong_scaling_loop_over_two_ranks(tmp_path, product, oracle):
             ref += oracle.encode_container(W, H, B, B, 4, 0, v, None, ow, oh, slots)
         assert blob == ref, f"step {i}"
     assert pos == len(data)
+
+
+_FAILING_RANK_SCRIPT = r"""
+import os, sys, time
+import torch, torch.distributed as dist
+sys.path.insert(0, {root!r})
+rank, world, port, fail_how = int(sys.argv[1]), 2, sys.argv[2], sys.argv[3]
+os.environ["MASTER_ADDR"] = "127.0.0.1"
+os.environ["MASTER_PORT"] = port
+dist.init_process_group("gloo", rank=rank, world_size=world)
+from tests.conftest import load_product
+product = load_product()
+from pixlzr_rust_amd import dist as pdist
+dog = pdist.exit_on_timeout(8.0, lambda: print("rank", rank, "abandons the leg", flush=True), code=3)
+bufs = [None] * pdist.PIPELINE_SETS
+def produce(i):
+    if rank == 1 and i == 2:
+        if fail_how == "raise":
+            raise RuntimeError("injected failure on rank 1")
+        time.sleep(3600)  # "hang": a rank that never arrives
+    n = 100 + i
+    bufs[i % len(bufs)] = (torch.tensor([0, n], dtype=torch.int64), torch.full((n + 8,), i, dtype=torch.uint8))
+def begin(i):
+    return pdist.gather_files_begin(*bufs[i % len(bufs)])
+def finish(i, token):
+    pdist.gather_files_finish(token, dst=0)
+failed = False
+try:
+    pdist.run_pipelined(6, produce, begin, finish)
+except Exception as exc:
+    print("rank", rank, "failed:", type(exc).__name__, flush=True)
+    failed = True
+dog.cancel()
+if failed:
+    os._exit(1)   # as bench.py: no barrier, no teardown -- the others may sit in a collective
+dist.barrier()
+dist.destroy_process_group()
+"""
+
+
+@pytest.mark.parametrize("fail_how", ["raise", "hang"])
+def test_a_failing_rank_ends_every_rank_non_zero(tmp_path, fail_how):
+    """The strong-scaling loop with a rank that fails (raises) or never arrives (hangs) in step 2: every rank comes back
+    -- the failing one at once, its peer out of the broken collective or through the watchdog (dist.exit_on_timeout)
+    -- and every exit code is non-zero.  This is what bench.py's strong-scaling leg does around the same calls."""
+    import subprocess
+    script = tmp_path / "failing_rank.py"
+    script.write_text(_FAILING_RANK_SCRIPT.format(root=ROOT))
+    port = str(35500 + (os.getpid() % 2000))
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), port, fail_how], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+             for r in range(2)]
+    codes = []
+    for p in procs:
+        try:
+            p.communicate(timeout=60)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            pytest.fail("a rank did not return")
+        codes.append(p.returncode)
+    assert all(c != 0 for c in codes), codes
