@@ -606,6 +606,11 @@ int timed_launch(pxz_handle *h, pxz::ShrinkArgs &a, uint32_t channels, float *va
 	const bool general_oklab = !square_fast && a.mode == PXZ_MODE_SHRINK_BY && a.bw % 4u == 0 && a.bw * a.bh >= 64u &&
 	                           a.bw * a.bh <= 16384u && !pxz::knobs().no_oklab_general;
 	a.ok_bands = (a.bw * a.bh + 255u) / 256u;
+	// rows of a ragged last tile row the square detectors can take: whole 256-px bands (oklab_kernel), for 64-px tiles
+	// whole 512-px super-bands (oklab2_kernel<64>: four producer waves x two rows)
+	const uint32_t ok_row_quantum = a.bw == 64u ? 8u : (a.bw != 0u && a.bw <= 256u ? 256u / a.bw : 1u);
+	// 64x64 tiles are converted by oklab2_kernel<64> (round 3), which parks nothing in HBM; PXZ_OKLAB_V1 keeps oklab_kernel<64>
+	const bool parks64 = !(a.bw == 64u && a.bh == 64u) || pxz::knobs().oklab_v1;
 	a.ok_region = 0;
 	a.ok_count = a.n_tiles;
 	a.ok_edges = 0;
@@ -615,13 +620,13 @@ int timed_launch(pxz_handle *h, pxz::ShrinkArgs &a, uint32_t channels, float *va
 	if (rgb_native) {
 		a.full_cols = a.edge_w == a.bw ? a.cols : a.cols - 1;
 		a.full_rows = a.edge_h == a.bh ? a.rows : a.rows - 1;
-		a.ok_rows = a.edge_h % (256u / a.bw) == 0 ? a.rows : a.full_rows;  // (a ragged last row of whole bands, as below)
+		a.ok_rows = a.edge_h % ok_row_quantum == 0 ? a.rows : a.full_rows;  // (a ragged last row of whole bands, as below)
 	}
 	if (aligned16 && (square_fast || general_oklab)) {
 		a.full_cols = a.edge_w == a.bw ? a.cols : a.cols - 1;
 		a.full_rows = a.edge_h == a.bh ? a.rows : a.rows - 1;
 		// the Oklab detector also takes a ragged last row of whole bands (256 pixels = 256/bw rows) of the square sizes
-		a.ok_rows = square_fast && a.edge_h % (256u / a.bw) == 0 ? a.rows : a.full_rows;
+		a.ok_rows = square_fast && a.edge_h % ok_row_quantum == 0 ? a.rows : a.full_rows;
 	}
 	const pxz::FinishArgs fin{a.sums, value, lod0, lod1, a.n_tiles, a.tiles_per_frame, a.cols, a.rows,
 	                          a.bw, a.bh, a.edge_w, a.edge_h, a.mode, a.factor};
@@ -657,7 +662,7 @@ int timed_launch(pxz_handle *h, pxz::ShrinkArgs &a, uint32_t channels, float *va
 		    {1u, a.edge_w, a.bh, a.full_rows, 1u, a.full_cols < a.cols},
 		    {2u, a.bw, a.edge_h, a.full_cols, 2u, a.full_rows < a.rows && a.ok_rows < a.rows},
 		    {3u, a.edge_w, a.edge_h, 1u, 4u, a.full_cols < a.cols && a.full_rows < a.rows}};
-		size_t scratch = a.ok_bands > 4u ? (size_t)a.n_tiles * a.ok_bands * 3328u : 0u;
+		size_t scratch = a.ok_bands > 4u && parks64 ? (size_t)a.n_tiles * a.ok_bands * 3328u : 0u;
 		for (Region &r : regions) {
 			const uint32_t wp = (r.w + 3u) & ~3u;  // rows are walked in whole quads (the padding counts as zeros)
 			r.wanted = r.wanted && r.per_frame != 0u && a.bw % 4u == 0u && wp * r.hh <= 16384u && !pxz::knobs().no_oklab_edges;
@@ -689,7 +694,7 @@ int timed_launch(pxz_handle *h, pxz::ShrinkArgs &a, uint32_t channels, float *va
 	if (a.mode == PXZ_MODE_SHRINK_BY && rgb_native && a.full_cols != 0 && a.full_rows != 0 && !pxz::knobs().no_oklab32) {
 		// RGB, 16x16 / 32x32 / 64x64: oklab2_kernel<16 | 32, 3> / oklab_kernel<64, 0, 3> for the full tiles; a ragged edge
 		// keeps its chains in the generic kernel
-		if (a.ok_bands > 4u) {  // 64x64: the converted tile is parked in HBM between the passes
+		if (a.ok_bands > 4u && parks64) {  // 64x64 with PXZ_OKLAB_V1: the converted tile is parked in HBM between the passes
 			if ((rc = ensure(h, h->okscratch, (size_t)a.n_tiles * a.ok_bands * 3328u)) != PXZ_OK) return rc;
 			a.ok_scratch = (float *)h->okscratch.ptr;
 		}

@@ -575,56 +575,111 @@ __global__ void __launch_bounds__(1024) oklab_kernel(const ShrinkArgs a)
 //   chain B at g     adds raw band s = g - 2 - NB (p2[(g - 2) % 3]); it picks the means up with a batch's first band
 //                    (published one barrier earlier) and writes the values after its last
 // ---------------------------------------------------------------------------
-constexpr uint32_t kOk2Prod = 14;                       // producer waves = tiles per batch
-constexpr uint32_t kOk2Plane = 128 + 4;                 // floats per (tile, channel) band + bank skew
-constexpr uint32_t kOk2Band = kOk2Prod * 4 * kOk2Plane; // floats per band buffer
 constexpr uint32_t kOk2Tables = 3072u + 256u + 2u * 128u + 64u; // dwords: matrix-column products, alpha, scale (doubles), means
-constexpr uint32_t kOk2LdsBytes = (kOk2Tables + 5u * kOk2Band) * 4u;
+
+// Geometry of oklab2_kernel<T>.  T = 16 | 32: one producer wave per tile (G = 1), 14 tiles per batch.
+// T = 64 (round 3): a tile's 4096 converted pixels are 48 KB, so FOUR producer waves share a tile (G = 4: wave j of the
+// group converts the 128-px bands 4k + j, k = 0..7, i.e. rows 8k + 2j, 8k + 2j + 1) and three tiles are in flight per
+// block; an interval hands the chains a "super-band" of 4 x 128 = 512 consecutive pixels per tile.  Nothing is parked
+// in HBM (oklab_kernel<64> wrote and re-read 13 bytes per pixel: 6.9 GB per 8 x 8K frames).
+template <int T>
+struct Ok2Geom {
+	static constexpr uint32_t G = T == 64 ? 4u : 1u;                  // producer waves per tile
+	static constexpr uint32_t kProd = T == 64 ? 12u : 14u;            // producer waves per block
+	static constexpr uint32_t kTiles = kProd / G;                     // tiles per batch: 14 | 3
+	static constexpr uint32_t NB = T == 64 ? 8u : T * T / 128u;       // bands per producer and tile = intervals per period: 2 | 8 | 8
+	static constexpr uint32_t kLanesPerRow = T / 2;                   // 8 | 16 | 32
+	static constexpr uint32_t kRowsPerBand = 128 / T;                 // 8 | 4 | 2
+	// floats per (tile, channel) and interval + bank skew.  G = 4: the chains read 16 consecutive floats per quad of
+	// lanes with ds_read_b128 (16 lanes per LDS cycle); a plane stride of 16 mod 64 dwords puts the four chains of
+	// every such group on four different quarters of the banks
+	static constexpr uint32_t kPlane = G * 128u + (G == 4u ? 16u : 4u);
+	static constexpr uint32_t kBand = kTiles * 4u * kPlane;           // floats per band buffer
+	static constexpr uint32_t kLdsBytes = (kOk2Tables + 5u * kBand) * 4u;
+};
+constexpr uint32_t kOk2Prod = Ok2Geom<32>::kProd;
+
+// The chain step of oklab2_kernel<64>: sum = (..((sum + e0(lane 0)) + e1(lane 0)) .. + e3(lane 3)), sixteen dependent adds
+// whose operands come from the four lanes of the quad in turn (DPP quad_perm broadcast on the first source; the running
+// sum is the plain second source, so consecutive adds forward it as usual).  One asm statement: left to the compiler
+// the sixteen DPP moves are not folded into the adds and, being independent of the sum, are hoisted and spilled.
+// ABS: add |e| (pass 2).  The operands of that variant were just written by vector instructions of the same wave: a DPP
+// read of such a register needs two wait states, which the compiler does not count for an asm statement -- s_nop 1.
+#define PXZ_QADD(Q, E, M) "v_add_f32_dpp %0, " M "%" #E M ", %0 quad_perm:[" #Q "," #Q "," #Q "," #Q "] row_mask:0xf bank_mask:0xf\n\t"
+#define PXZ_QADD4(Q, M) PXZ_QADD(Q, 1, M) PXZ_QADD(Q, 2, M) PXZ_QADD(Q, 3, M) PXZ_QADD(Q, 4, M)
+template <bool ABS>
+__device__ __forceinline__ void quad_chain_add16(float &sum, float e0, float e1, float e2, float e3)
+{
+	if constexpr (ABS)
+		asm volatile("s_nop 1\n\t" PXZ_QADD4(0, "|") PXZ_QADD4(1, "|") PXZ_QADD4(2, "|") PXZ_QADD4(3, "|") : "+v"(sum) : "v"(e0), "v"(e1), "v"(e2), "v"(e3));
+	else
+		asm volatile(PXZ_QADD4(0, "") PXZ_QADD4(1, "") PXZ_QADD4(2, "") PXZ_QADD4(3, "") : "+v"(sum) : "v"(e0), "v"(e1), "v"(e2), "v"(e3));
+}
 
 // C = 3 (round 2): RGB frames read directly -- a lane's two pixels are six bytes inside an aligned eight (rows are 4-byte
 // aligned), cut out with two funnel shifts; there is no alpha (the plane is the constant 1).
 template <int T, int C = 4>
 __global__ void __launch_bounds__(1024) oklab2_kernel(const ShrinkArgs a)
 {
-	constexpr uint32_t NB = T * T / 128;        // bands per tile: 2 | 8
-	constexpr uint32_t kLanesPerRow = T / 2;    // 8 | 16
-	constexpr uint32_t kRowsPerBand = 128 / T;  // 8 | 4
+	using Geo = Ok2Geom<T>;
+	constexpr uint32_t G = Geo::G, NB = Geo::NB, kProd = Geo::kProd, kTiles = Geo::kTiles;
+	constexpr uint32_t kLanesPerRow = Geo::kLanesPerRow, kRowsPerBand = Geo::kRowsPerBand;
+	constexpr uint32_t kPlane = Geo::kPlane, kBand = Geo::kBand;
 	static_assert(NB % 2 == 0, "the pass-1 buffers alternate with the band index");
 	// (a static array: its address is a compile-time constant, so table and buffer offsets fold into the instructions'
 	// offset fields -- with `extern __shared__` every LDS access of the loop paid a v_add of the relocated base)
-	__shared__ __attribute__((aligned(16))) uint32_t lds[kOk2LdsBytes / 4u];
+	__shared__ __attribute__((aligned(16))) uint32_t lds[Geo::kLdsBytes / 4u];
 	float4 *s_lms = reinterpret_cast<float4 *>(lds);
 	float *s_alpha = reinterpret_cast<float *>(s_lms + 768);
 	double *s_scale = reinterpret_cast<double *>(s_alpha + 256);
 	float *s_mean = reinterpret_cast<float *>(s_scale + 128);
-	float *s_p1 = s_mean + 64;                  // [2][kOk2Band]: converted values, pass 1
-	float *s_p2 = s_p1 + 2 * kOk2Band;          // [3][kOk2Band]: the same values of the batch before, pass 2
+	float *s_p1 = s_mean + 64;                  // [2][kBand]: converted values, pass 1
+	float *s_p2 = s_p1 + 2 * kBand;             // [3][kBand]: the same values of the batch before, pass 2
 	const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
 	oklab_fill_tables(s_lms, s_alpha, s_scale, threadIdx.x);
 	__syncthreads();
 
-	const uint32_t n_batches = (a.ok_count + kOk2Prod - 1) / kOk2Prod;
+	// Roles.  G = 1: waves 0..13 produce, 14 walks pass 1, 15 pass 2.  G = 4: a block's waves go to the four SIMDs in
+	// turn (waves w and w + 4 share one), and a chain wave here issues four times the adds of the G = 1 one, so it gets a
+	// SIMD with two producers beside it instead of three or four: wave 0 = pass 1, wave 1 = pass 2, waves 12 and 13
+	// have no work (they only keep the barriers), the other twelve produce: tile slot 0 = waves 2, 6, 10, 14; slot 1 = 3, 7, 11,
+	// 15; slot 2 = 4, 8, 5, 9.  (The placement is a matter of speed only.)
+	uint32_t pi;           // producer index: tile slot pi / G, part pi % G; >= kProd: not a producer
+	bool chain_a, chain_b;
+	if constexpr (G == 1u) {
+		pi = wave;
+		chain_a = wave == kProd;
+		chain_b = wave == kProd + 1u;
+	} else {
+		chain_a = wave == 0u;
+		chain_b = wave == 1u;
+		const uint32_t cls = wave & 3u, q = wave >> 2;
+		pi = cls == 2u ? q : (cls == 3u ? 4u + q : (q == 1u || q == 2u ? 8u + (cls << 1) + (q - 1u) : kProd));
+	}
+
+	const uint32_t n_batches = (a.ok_count + kTiles - 1) / kTiles;
 	const uint32_t own = n_batches > blockIdx.x ? (n_batches - blockIdx.x + gridDim.x - 1) / gridDim.x : 0u;
 	// batch q is converted in period q, re-delivered in period q + 1, and chain B adds its last band in interval 1 of
 	// period q + 2: the last period ends after two intervals
 	const uint32_t periods = own + 2u;
 	constexpr uint32_t kLastIntervals = 2u;
 
-	if (wave < kOk2Prod) {
+	if (pi < kProd) {
 		// ---------------- producers ----------------
+		const uint32_t pslot = pi / G, part = pi % G;
 		// RGBA: the lane's two pixels are 8 aligned bytes.  RGB: bytes 6l .. 6l+5 of the row (l = lane in row) lie inside the
 		// aligned 8 bytes at 6l & ~3, shifted by 0 or 2 bytes
 		const uint32_t rgb_off = (lane % kLanesPerRow) * 6u, rgb_shift = (rgb_off & 3u) * 8u;
-		const size_t lane_off = (size_t)(lane / kLanesPerRow) * a.pitch + (C == 4 ? (lane % kLanesPerRow) * 8u : (rgb_off & ~3u));
-		const size_t band_step = (size_t)kRowsPerBand * a.pitch;
+		const size_t lane_off = (size_t)(lane / kLanesPerRow + part * kRowsPerBand) * a.pitch + (C == 4 ? (lane % kLanesPerRow) * 8u : (rgb_off & ~3u));
+		const size_t band_step = (size_t)(G * kRowsPerBand) * a.pitch;  // from a producer's band k to its band k + 1
 		auto batch_src = [&](uint32_t j, uint32_t &bands) -> const uint8_t * {
 			const uint8_t *src;
 			bands = 0;
 			if (j >= own) return nullptr;
 			uint32_t unused_tile;
-			const uint32_t th = oklab_tile_src<T, C>(a, (blockIdx.x + j * gridDim.x) * kOk2Prod + wave, src, unused_tile);
+			const uint32_t th = oklab_tile_src<T, C>(a, (blockIdx.x + j * gridDim.x) * kTiles + pslot, src, unused_tile);
 			if (th == 0) return nullptr;
-			bands = th / kRowsPerBand;  // (a ragged tile is only taken when its height is a multiple of 8 rows)
+			bands = th / (G * kRowsPerBand);  // (a ragged tile is only taken when its height is a multiple of 8 rows)
 			return src + lane_off;
 		};
 		uint32_t nb0 = 0, nb1 = 0, nb_prev = 0;
@@ -640,7 +695,7 @@ __global__ void __launch_bounds__(1024) oklab2_kernel(const ShrinkArgs a)
 		};
 		request(0, src1, nb1, nullptr, 0, q[0]);
 		request(1, src1, nb1, nullptr, 0, q[1]);
-		float lab[NB][2][3];  // [band][pixel][a, b, l]: this wave's tile of the batch in conversion / re-delivery
+		float lab[NB][2][3];  // [band][pixel][a, b, l]: this wave's share of the tile in conversion / re-delivery
 		// Alpha.  An opaque band's alpha plane is the constant 1 (255 / 255): no bytes are kept and nothing is looked up.
 		// Only tiles with transparency keep their alpha bytes (two per band): al_cur for the tile in conversion, al_old for
 		// the one in re-delivery; the flags are wave-uniform.
@@ -648,18 +703,18 @@ __global__ void __launch_bounds__(1024) oklab2_kernel(const ShrinkArgs a)
 #pragma unroll
 		for (uint32_t k = 0; k < NB / 2; ++k) al_cur[k] = al_old[k] = 0xffffffffu;
 		bool cur_opaque = true, old_opaque = true, band_opaque = true;  // tile in conversion / in re-delivery / band awaiting its store
-		const uint32_t slot = (wave * 4u) * kOk2Plane + lane * 2u;
+		const uint32_t slot = (pslot * 4u) * kPlane + part * 128u + lane * 2u;
 		// one band (two pixels per lane, three planes + alpha) into a band buffer
 		float2 ones;  // (kept in a register pair: as a constant it is re-made with two moves at each of its uses)
 		asm volatile("v_mov_b32 %0, 1.0\n\tv_mov_b32 %1, 1.0" : "=v"(ones.x), "=v"(ones.y));
 		auto store_band = [&](float *d, const float (&x)[2][3], bool opaque, uint32_t ab) {
 #pragma unroll
-			for (int c = 0; c < 3; ++c) *reinterpret_cast<float2 *>(d + c * kOk2Plane) = make_float2(x[0][c], x[1][c]);
+			for (int c = 0; c < 3; ++c) *reinterpret_cast<float2 *>(d + c * kPlane) = make_float2(x[0][c], x[1][c]);
 			// (a store in each branch: a value merged after the branch makes the compiler wait for every LDS operation in flight)
 			if (opaque) {
-				*reinterpret_cast<float2 *>(d + 3 * kOk2Plane) = ones;
+				*reinterpret_cast<float2 *>(d + 3 * kPlane) = ones;
 			} else {
-				*reinterpret_cast<float2 *>(d + 3 * kOk2Plane) = make_float2(s_alpha[ab & 255u], s_alpha[(ab >> 8) & 255u]);
+				*reinterpret_cast<float2 *>(d + 3 * kPlane) = make_float2(s_alpha[ab & 255u], s_alpha[(ab >> 8) & 255u]);
 			}
 		};
 		bool have_prev = false, elig_cur = false, pending = false;  // pending: the band converted last interval awaits its store
@@ -699,7 +754,7 @@ __global__ void __launch_bounds__(1024) oklab2_kernel(const ShrinkArgs a)
 				if (p + 1u == periods && k == kLastIntervals) break;  // (block-uniform)
 				const uint32_t kp = (k + NB - 1u) % NB;  // the band converted in the interval before (k = 0: of the batch before)
 				const bool convert = st_valid;  // (= elig_cur && k < nb0)
-				if (pending) store_band(s_p1 + (k & 1u) * kOk2Band + slot, lab[kp], band_opaque, al_cur[kp >> 1] >> (16u * (kp & 1u)));
+				if (pending) store_band(s_p1 + (k & 1u) * kBand + slot, lab[kp], band_opaque, al_cur[kp >> 1] >> (16u * (kp & 1u)));
 				if (k == 0u) {
 					// the tile converted last period is the one in re-delivery now
 					old_opaque = cur_opaque;
@@ -709,7 +764,7 @@ __global__ void __launch_bounds__(1024) oklab2_kernel(const ShrinkArgs a)
 					}
 					cur_opaque = true;
 				}
-				if (have_prev && k < nb_prev) store_band(s_p2 + g3 * kOk2Band + slot, lab[k], old_opaque, al_old[k >> 1] >> (16u * (k & 1u)));
+				if (have_prev && k < nb_prev) store_band(s_p2 + g3 * kBand + slot, lab[k], old_opaque, al_old[k >> 1] >> (16u * (k & 1u)));
 				__builtin_amdgcn_sched_barrier(0);
 				pending = convert;
 				if (convert) {
@@ -735,61 +790,108 @@ __global__ void __launch_bounds__(1024) oklab2_kernel(const ShrinkArgs a)
 			}
 			have_prev = elig_cur;
 		}
-	} else {
-		// ---------------- chain waves: lane = tile * 4 + channel (a, b, l, alpha) ----------------
-		const bool second = wave == kOk2Prod + 1u;  // pass 2
-		const uint32_t ct = lane >> 2, cc = lane & 3u;
-		const bool live = ct < kOk2Prod;
-		const float *plane = (second ? s_p2 : s_p1) + (live ? (ct * 4u + cc) * kOk2Plane : 0u);
+	} else if (chain_a || chain_b) {
+		// ---------------- chain waves ----------------
+		// G = 1: lane = tile * 4 + channel (a, b, l, alpha), 56 lanes live.  G = 4: a QUAD of lanes per chain (12 chains
+		// = 3 tiles x 4 channels): a ds_read_b128 hands the quad 16 consecutive values, and the adds take them from
+		// the quad's lanes in turn through DPP -- one LDS instruction per 16 dependent adds, and every lane of a quad
+		// carries the same running sum
+		const bool second = chain_b;  // pass 2
+		const uint32_t chain = G == 1u ? lane : lane >> 2, sub = G == 1u ? 0u : lane & 3u;
+		const uint32_t ct = chain >> 2, cc = chain & 3u;
+		const bool live = ct < kTiles;
+		const float *plane = (second ? s_p2 : s_p1) + (live ? chain : chain - kTiles * 4u) * kPlane + sub * 4u;
 		float acc = 0.0f, mean = 0.0f;
 		__builtin_amdgcn_s_setprio(3);  // the serial part of every interval: first pick of its SIMD's issue slots
-		// one dependent add per element; 32 values in flight from LDS while 32 are added
-		auto walk = [&](const float *band, float sum, const bool deviation) -> float {
+		// G = 1: one dependent add per element; 32 values in flight from LDS while 32 are added
+		auto walk = [&](const float *band, float sum, const bool deviation) __attribute__((always_inline)) -> float {
 			const float4 *x = reinterpret_cast<const float4 *>(band);
-			auto add32 = [&](const float4 (&v)[8]) {
+			if constexpr (G == 1u) {
+				auto add32 = [&](const float4 (&v)[8]) __attribute__((always_inline)) {
 #pragma unroll
-				for (int q = 0; q < 8; ++q) {
-					if (deviation) {
-						// operations.rs:80-83 with `before` = |x - avg| (pixlzr.rs:160-161); the differences two per packed
-						// instruction (independent of the running sum), |.| as the add's source modifier
-						const f32x2 m2 = {mean, mean};
-						const f32x2 d0 = f32x2{v[q].x, v[q].y} - m2, d1 = f32x2{v[q].z, v[q].w} - m2;
-						sum += fabsf(d0.x);
-						sum += fabsf(d0.y);
-						sum += fabsf(d1.x);
-						sum += fabsf(d1.y);
-					} else {
-						sum += v[q].x;  // operations.rs:60-63, row-major pixel order
-						sum += v[q].y;
-						sum += v[q].z;
-						sum += v[q].w;
+					for (int q = 0; q < 8; ++q) {
+						if (deviation) {
+							// operations.rs:80-83 with `before` = |x - avg| (pixlzr.rs:160-161); the differences two per packed
+							// instruction (independent of the running sum), |.| as the add's source modifier
+							const f32x2 m2 = {mean, mean};
+							const f32x2 d0 = f32x2{v[q].x, v[q].y} - m2, d1 = f32x2{v[q].z, v[q].w} - m2;
+							sum += fabsf(d0.x);
+							sum += fabsf(d0.y);
+							sum += fabsf(d1.x);
+							sum += fabsf(d1.y);
+						} else {
+							sum += v[q].x;  // operations.rs:60-63, row-major pixel order
+							sum += v[q].y;
+							sum += v[q].z;
+							sum += v[q].w;
+						}
+					}
+				};
+				float4 va[8], vb[8];
+#pragma unroll
+				for (int q = 0; q < 8; ++q) va[q] = x[q];
+#pragma unroll
+				for (int q = 0; q < 8; ++q) vb[q] = x[8 + q];
+				__builtin_amdgcn_sched_barrier(0);
+				add32(va);
+				__builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+				for (int q = 0; q < 8; ++q) va[q] = x[16 + q];
+				__builtin_amdgcn_sched_barrier(0);
+				add32(vb);
+				__builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+				for (int q = 0; q < 8; ++q) vb[q] = x[24 + q];
+				__builtin_amdgcn_sched_barrier(0);
+				add32(va);
+				__builtin_amdgcn_sched_barrier(0);
+				add32(vb);
+			} else {
+				// 512 values per chain: 32 reads of 16 (x[4 i] is this lane's float4 of read i), four reads per register set
+				auto add64 = [&](const float4 (&v)[4]) __attribute__((always_inline)) {
+#pragma unroll
+					for (int r = 0; r < 4; ++r) {
+						if (deviation) {
+							// operations.rs:80-83: every lane takes the mean off its own four values (two packed subtractions,
+							// independent of the running sum); the chain adds |x - avg| in pixel order
+							const f32x2 m2 = {mean, mean};
+							const f32x2 d0 = f32x2{v[r].x, v[r].y} - m2, d1 = f32x2{v[r].z, v[r].w} - m2;
+							quad_chain_add16<true>(sum, d0.x, d0.y, d1.x, d1.y);
+						} else {
+							quad_chain_add16<false>(sum, v[r].x, v[r].y, v[r].z, v[r].w);  // operations.rs:60-63, row-major pixel order
+						}
+					}
+				};
+				float4 va[4], vb[4];
+#pragma unroll
+				for (int q = 0; q < 4; ++q) va[q] = x[4 * q];
+#pragma unroll
+				for (int q = 0; q < 4; ++q) vb[q] = x[4 * (4 + q)];
+#pragma unroll
+				for (int it = 0; it < 4; ++it) {
+					__builtin_amdgcn_sched_barrier(0);
+					add64(va);
+					__builtin_amdgcn_sched_barrier(0);
+					if (it < 3) {
+#pragma unroll
+						for (int q = 0; q < 4; ++q) va[q] = x[4 * (8 * it + 8 + q)];
+					}
+					__builtin_amdgcn_sched_barrier(0);
+					add64(vb);
+					__builtin_amdgcn_sched_barrier(0);
+					if (it < 3) {
+#pragma unroll
+						for (int q = 0; q < 4; ++q) vb[q] = x[4 * (8 * it + 12 + q)];
 					}
 				}
-			};
-			float4 va[8], vb[8];
-#pragma unroll
-			for (int q = 0; q < 8; ++q) va[q] = x[q];
-#pragma unroll
-			for (int q = 0; q < 8; ++q) vb[q] = x[8 + q];
-			__builtin_amdgcn_sched_barrier(0);
-			add32(va);
-			__builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-			for (int q = 0; q < 8; ++q) va[q] = x[16 + q];
-			__builtin_amdgcn_sched_barrier(0);
-			add32(vb);
-			__builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-			for (int q = 0; q < 8; ++q) vb[q] = x[24 + q];
-			__builtin_amdgcn_sched_barrier(0);
-			add32(va);
-			__builtin_amdgcn_sched_barrier(0);
-			add32(vb);
+			}
 			return sum;
 		};
 		uint32_t h0 = 0, hm1 = 0, hm2 = 0;  // height of this lane's tile in batches p, p-1, p-2 (0: not taken)
 		uint32_t g0 = 0, gm1 = 0, gm2 = 0;  // and its number in the batch of frames
 		uint32_t g3 = 0;                    // interval number mod 3
+		const int lane_ch0 = G == 1u ? (int)(lane & ~3u) : (int)(lane & ~15u);  // the lane that holds channel 0 of this lane's tile
+		constexpr int kChStep = G == 1u ? 1 : 4;                               // and the distance to the next channel's
 		for (uint32_t p = 0; p < periods; ++p) {
 			{
 				const uint8_t *unused;
@@ -797,7 +899,7 @@ __global__ void __launch_bounds__(1024) oklab2_kernel(const ShrinkArgs a)
 				hm1 = h0;
 				gm2 = gm1;
 				gm1 = g0;
-				h0 = (live && p < own) ? oklab_tile_src<T, C>(a, (blockIdx.x + p * gridDim.x) * kOk2Prod + ct, unused, g0) : 0u;
+				h0 = (live && p < own) ? oklab_tile_src<T, C>(a, (blockIdx.x + p * gridDim.x) * kTiles + ct, unused, g0) : 0u;
 			}
 #pragma unroll 1
 			for (uint32_t k = 0; k < NB; ++k) {
@@ -807,33 +909,42 @@ __global__ void __launch_bounds__(1024) oklab2_kernel(const ShrinkArgs a)
 				const uint32_t kk = same ? k - 2u : k + NB - 2u;
 				if (!second) {
 					const uint32_t h = same ? h0 : hm1;
-					const float *band = plane + ((k + 1u) & 1u) * kOk2Band;  // stored in interval g - 1
+					const float *band = plane + ((k + 1u) & 1u) * kBand;  // stored in interval g - 1
 #if !(defined(PXZ_EXP) && (PXZ_EXP == 2 || PXZ_EXP == 3))
-					if (kk * kRowsPerBand < h) acc = walk(band, acc, false);
+					if (kk * (G * kRowsPerBand) < h) acc = walk(band, acc, false);
 #endif
 					if (kk == NB - 1u) {
-						s_mean[lane] = __fdiv_rn(acc, (float)((uint32_t)T * h));  // operations.rs:65-68 (h = 0: never read)
+						s_mean[chain] = __fdiv_rn(acc, (float)((uint32_t)T * h));  // operations.rs:65-68 (h = 0: never read)
 						acc = 0.0f;
 					}
 				} else {
 					const uint32_t h = same ? hm1 : hm2;
-					const float *band = plane + (g3 == 0u ? 1u : (g3 == 1u ? 2u : 0u)) * kOk2Band;  // stored in interval g - 2
-					if (kk == 0u) mean = s_mean[lane];  // published by chain A during the interval before
+					const float *band = plane + (g3 == 0u ? 1u : (g3 == 1u ? 2u : 0u)) * kBand;  // stored in interval g - 2
+					if (kk == 0u) mean = s_mean[chain];  // published by chain A during the interval before
 #if !(defined(PXZ_EXP) && (PXZ_EXP == 2 || PXZ_EXP == 3))
-					if (kk * kRowsPerBand < h) acc = walk(band, acc, true);
+					if (kk * (G * kRowsPerBand) < h) acc = walk(band, acc, true);
 #endif
 					if (kk == NB - 1u) {
-						const float d0 = __shfl(acc, (int)(lane & ~3u) + 0, 64), d1 = __shfl(acc, (int)(lane & ~3u) + 1, 64);
-						const float d2 = __shfl(acc, (int)(lane & ~3u) + 2, 64), d3 = __shfl(acc, (int)(lane & ~3u) + 3, 64);
+						const float d0 = __shfl(acc, lane_ch0, 64), d1 = __shfl(acc, lane_ch0 + kChStep, 64);
+						const float d2 = __shfl(acc, lane_ch0 + 2 * kChStep, 64), d3 = __shfl(acc, lane_ch0 + 3 * kChStep, 64);
 						const float total = d0 + d1 + d2 + d3;  // :89
 						const float value = __fdiv_rn(total, (float)((uint32_t)T * h)) * a.factor * a.scale2;  // pixlzr.rs:162
 						const uint32_t tg = same ? gm1 : gm2;
-						if (live && cc == 0 && h != 0u)
+						if (live && cc == 0 && sub == 0u && h != 0u)
 							reinterpret_cast<uint2 *>(a.sums)[tg] = make_uint2(__float_as_uint(value), __float_as_uint(value));
 						acc = 0.0f;
 					}
 				}
 				g3 = g3 == 2u ? 0u : g3 + 1u;
+				__syncthreads();
+			}
+		}
+	} else {
+		// (G = 4: the two waves without a role keep the barriers)
+		for (uint32_t p = 0; p < periods; ++p) {
+#pragma unroll 1
+			for (uint32_t k = 0; k < NB; ++k) {
+				if (p + 1u == periods && k == kLastIntervals) break;
 				__syncthreads();
 			}
 		}
@@ -851,14 +962,15 @@ hipError_t launch_oklab(const ShrinkArgs &a, uint32_t n_cus, hipStream_t stream,
 		hipLaunchKernelGGL(kernel, dim3(blocks), dim3(1024), lds_bytes, stream, a);
 		return hipGetLastError();
 	};
-	if (a.bw == a.bh && a.ok_region == 0u && (a.bw == 16u || a.bw == 32u) && !knobs().oklab_v1) {
-		const uint32_t nb2 = (a.ok_count + kOk2Prod - 1) / kOk2Prod, blocks2 = nb2 < n_cus ? nb2 : n_cus;
+	if (a.bw == a.bh && a.ok_region == 0u && (a.bw == 16u || a.bw == 32u || a.bw == 64u) && !knobs().oklab_v1) {
+		const uint32_t per_batch = a.bw == 64u ? Ok2Geom<64>::kTiles : kOk2Prod;
+		const uint32_t nb2 = (a.ok_count + per_batch - 1) / per_batch, blocks2 = nb2 < n_cus ? nb2 : n_cus;
 		auto go2 = [&](auto kernel) -> hipError_t {
 			hipLaunchKernelGGL(kernel, dim3(blocks2), dim3(1024), 0, stream, a);
 			return hipGetLastError();
 		};
-		if (channels == 3) return a.bw == 16u ? go2(oklab2_kernel<16, 3>) : go2(oklab2_kernel<32, 3>);
-		return a.bw == 16u ? go2(oklab2_kernel<16>) : go2(oklab2_kernel<32>);
+		if (channels == 3) return a.bw == 16u ? go2(oklab2_kernel<16, 3>) : (a.bw == 32u ? go2(oklab2_kernel<32, 3>) : go2(oklab2_kernel<64, 3>));
+		return a.bw == 16u ? go2(oklab2_kernel<16>) : (a.bw == 32u ? go2(oklab2_kernel<32>) : go2(oklab2_kernel<64>));
 	}
 	if (channels == 3 && a.bw == 64u && a.bh == 64u && a.ok_region == 0u) return go(oklab_kernel<64, 0, 3>);
 	if (channels != 4) return hipErrorInvalidValue;  // (the other round-1 kernels read RGBA)
