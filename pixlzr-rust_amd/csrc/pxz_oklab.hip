@@ -57,29 +57,71 @@ constexpr uint32_t kOkBand = kOkTiles * 4 * kOkPlane;  // floats per band buffer
 // for that reason: the products make a root's last double bits depend on its neighbours, the exhaustive test then
 // samples 2^24 of 2^48 pairs, and with one partner per colour it already found a colour whose float flipped.)
 struct Cbrt6State {
-	double xmd[6];  // frexpf mantissas
-	double sc[6];   // 2^(xe/3) * third[xe % 3] (0 for x = 0)
+	float x[6];  // the six inputs (l, m, s of two pixels): everything else is derived in cbrt6_tail
 };
-// first part: mantissa and scale factor of each input (bit fields, one LDS read each)
-__device__ __forceinline__ void cbrt6_head(const float (&x)[6], const double *scale, Cbrt6State &st)
+// first part: nothing but the hand-over (round 3: mantissas and scale factors used to be extracted here, 24 registers that
+// then lived across the interval's barrier; as six floats the state leaves room for the shared reciprocal below)
+__device__ __forceinline__ void cbrt6_head(const float (&x)[6], Cbrt6State &st)
 {
 #pragma unroll
-	for (int i = 0; i < 6; ++i) {
-		const uint32_t bits = __float_as_uint(x[i]);
-		uint32_t xmb;  // frexpf mantissa, [0.5, 1): one v_and_or_b32 (the compiler splits it in two)
-		asm("v_and_or_b32 %0, %1, %2, 0.5" : "=v"(xmb) : "v"(bits), "s"(0x007fffffu));
-		st.sc[i] = *reinterpret_cast<const double *>(reinterpret_cast<const char *>(scale) + ((bits >> 20) & 0x7f8u));
-		st.xmd[i] = (double)__uint_as_float(xmb);
+	for (int i = 0; i < 6; ++i) st.x[i] = x[i];
+}
+// mantissa and scale factor of one input (bit fields, one LDS read whose result is not needed before the root's last step)
+__device__ __forceinline__ void cbrt_split(float x, const double *scale, double &xmd, double &sc)
+{
+	const uint32_t bits = __float_as_uint(x);
+	uint32_t xmb;  // frexpf mantissa, [0.5, 1): one v_and_or_b32 (the compiler splits it in two)
+	asm("v_and_or_b32 %0, %1, %2, 0.5" : "=v"(xmb) : "v"(bits), "s"(0x007fffffu));
+	sc = *reinterpret_cast<const double *>(reinterpret_cast<const char *>(scale) + ((bits >> 20) & 0x7f8u));
+	xmd = (double)__uint_as_float(xmb);
+}
+// second part: mantissas, seed, Halley step, scaling
+#if !defined(PXZ_CBRT_OWN_RCP)
+// ONE reciprocal for the three roots of a pixel (l, m, s: indices j, j + 2, j + 4): 1 / (d0 d1 d2), then each root's own
+// reciprocal as that times the other two denominators -- six multiplications instead of two v_rcp_f64 (16 issue cycles
+// each) and two Newton steps.  The three roots of a pixel are functions of the same colour, so the conversion stays a pure
+// function of one colour and the 2^24-colour test still covers it completely (it passes; PXZ_CBRT_OWN_RCP builds the
+// round-2 form with a reciprocal per root).
+__device__ __forceinline__ void cbrt6_tail(const Cbrt6State &st, const double *scale, float (&y)[6])
+{
+	float x[6];
+#pragma unroll
+	for (int i = 0; i < 6; ++i) x[i] = st.x[i];
+	// one pixel after the other (its three roots side by side): both at once want 8 registers more than the kernels have
+#pragma unroll
+	for (int j = 0; j < 2; ++j) {
+		double den[3], num[3], sc[3];
+#pragma unroll
+		for (int k = 0; k < 3; ++k) {
+			double xmd;
+			cbrt_split(x[j + 2 * k], scale, xmd, sc[k]);
+			const float u = (float)__builtin_fma(__builtin_fma(-0.191502161678719066, xmd, 0.697570460207922770), xmd, 0.492659620528969547);
+			const float t2 = u * u * u;  // two f32 roundings, as glibc's float t2 = u * u * u
+			const double ud = (double)u, t2d = (double)t2;
+			den[k] = __builtin_fma(2.0, t2d, xmd);
+			num[k] = ud * __builtin_fma(2.0, xmd, t2d);
+		}
+		const double p01 = den[0] * den[1], d012 = p01 * den[2];
+		double r = __builtin_amdgcn_rcp(d012);
+		r = __builtin_fma(r, __builtin_fma(-d012, r, 1.0), r);
+		const double r2 = r * p01, t = r * den[2], r1 = t * den[0], r0 = t * den[1];
+		y[j] = (float)(num[0] * r0 * sc[0]);  // (u * N / D) * factor, glibc's order
+		y[j + 2] = (float)(num[1] * r1 * sc[1]);
+		y[j + 4] = (float)(num[2] * r2 * sc[2]);
+		// (an anchor: the second pixel's inputs pass through a statement that needs the first pixel's results)
+		if (j == 0) asm volatile("" : "+v"(y[0]), "+v"(y[2]), "+v"(y[4]), "+v"(x[1]), "+v"(x[3]), "+v"(x[5]));
 	}
 }
-// second part: seed, Halley step, scaling
-__device__ __forceinline__ void cbrt6_tail(const Cbrt6State &st, float (&y)[6])
+#else
+__device__ __forceinline__ void cbrt6_tail(const Cbrt6State &st, const double *scale, float (&y)[6])
 {
-	double den[6], num[6];
+	double xmd[6], sc[6], den[6], num[6];
+#pragma unroll
+	for (int i = 0; i < 6; ++i) cbrt_split(st.x[i], scale, xmd[i], sc[i]);
 	f32x2 u[3];
 #pragma unroll
 	for (int i = 0; i < 6; ++i) {
-		const float ui = (float)__builtin_fma(__builtin_fma(-0.191502161678719066, st.xmd[i], 0.697570460207922770), st.xmd[i], 0.492659620528969547);
+		const float ui = (float)__builtin_fma(__builtin_fma(-0.191502161678719066, xmd[i], 0.697570460207922770), xmd[i], 0.492659620528969547);
 		if (i & 1) u[i >> 1].y = ui; else u[i >> 1].x = ui;
 	}
 #pragma unroll
@@ -89,17 +131,18 @@ __device__ __forceinline__ void cbrt6_tail(const Cbrt6State &st, float (&y)[6])
 		for (int h = 0; h < 2; ++h) {
 			const int i = 2 * k + h;
 			const double ud = (double)(h ? u[k].y : u[k].x), t2d = (double)(h ? t2.y : t2.x);
-			den[i] = __builtin_fma(2.0, t2d, st.xmd[i]);
-			num[i] = ud * __builtin_fma(2.0, st.xmd[i], t2d);
+			den[i] = __builtin_fma(2.0, t2d, xmd[i]);
+			num[i] = ud * __builtin_fma(2.0, xmd[i], t2d);
 		}
 	}
 #pragma unroll
 	for (int i = 0; i < 6; ++i) {
 		double r = __builtin_amdgcn_rcp(den[i]);
 		r = __builtin_fma(r, __builtin_fma(-den[i], r, 1.0), r);
-		y[i] = (float)(num[i] * r * st.sc[i]);  // (u * N / D) * factor, glibc's order
+		y[i] = (float)(num[i] * r * sc[i]);  // (u * N / D) * factor, glibc's order
 	}
 }
+#endif
 
 // byte BYTE of v, times 16: the byte offset of a 256-entry float4 table row, in one SDWA shift
 template <int BYTE>
@@ -132,7 +175,7 @@ __device__ __forceinline__ f32x2 pk_add_f32_asm(f32x2 a, f32x2 b)
 // the three products of channel c's linear value: the same single-rounded f32 multiplications, done once per
 // block), which leaves its six additions; the second matrix runs two pixels per packed-f32 instruction (same IEEE
 // results per component).  out[k] = {a, b, l} of pixel k, the order the reference sums them in.
-__device__ __forceinline__ void oklab_pair_head(uint32_t v0, uint32_t v1, const float4 *s_lms, const double *s_scale, Cbrt6State &st)
+__device__ __forceinline__ void oklab_pair_head(uint32_t v0, uint32_t v1, const float4 *s_lms, Cbrt6State &st)
 {
 	const float4 r0 = row_at(s_lms, byte_times16<0>(v0)), g0 = row_at(s_lms + 256, byte_times16<1>(v0)), b0 = row_at(s_lms + 512, byte_times16<2>(v0));
 	const float4 r1 = row_at(s_lms, byte_times16<0>(v1)), g1 = row_at(s_lms + 256, byte_times16<1>(v1)), b1 = row_at(s_lms + 512, byte_times16<2>(v1));
@@ -148,12 +191,12 @@ __device__ __forceinline__ void oklab_pair_head(uint32_t v0, uint32_t v1, const 
 	// l, m, s are zero only for black (every coefficient is positive, the table is zero at 0 only); their cube roots
 	// are then +0 (entry 0 of the scale table) and so are L = (+0 + +0) - +0, a and b
 	const float x[6] = {lm0.x, lm1.x, lm0.y, lm1.y, s0, s1};
-	cbrt6_head(x, s_scale, st);
+	cbrt6_head(x, st);
 }
-__device__ __forceinline__ void oklab_pair_tail(const Cbrt6State &st, float (&out0)[3], float (&out1)[3])
+__device__ __forceinline__ void oklab_pair_tail(const Cbrt6State &st, const double *s_scale, float (&out0)[3], float (&out1)[3])
 {
 	float c[6];
-	cbrt6_tail(st, c);
+	cbrt6_tail(st, s_scale, c);
 	const f32x2 l_ = {c[0], c[1]}, m_ = {c[2], c[3]}, s_ = {c[4], c[5]};
 	const f32x2 L = 0.2104542553f * l_ + 0.7936177850f * m_ - 0.0040720468f * s_;
 	const f32x2 A = 1.9779984951f * l_ - 2.4285922050f * m_ + 0.4505937099f * s_;
@@ -166,8 +209,8 @@ __device__ __forceinline__ void oklab_pair(uint32_t v0, uint32_t v1, const float
                                            float (&out0)[3], float (&out1)[3])
 {
 	Cbrt6State st;
-	oklab_pair_head(v0, v1, s_lms, s_scale, st);
-	oklab_pair_tail(st, out0, out1);
+	oklab_pair_head(v0, v1, s_lms, st);
+	oklab_pair_tail(st, s_scale, out0, out1);
 }
 
 // The conversion tables of the Oklab kernels in LDS: the products of the sRGB u8 -> linear values with the columns of
@@ -731,13 +774,13 @@ __global__ void __launch_bounds__(1024) oklab2_kernel(const ShrinkArgs a)
 			st_valid = valid;
 			if (valid) {
 				if constexpr (C == 4) {
-					oklab_pair_head(px.x, px.y, s_lms, s_scale, st);
+					oklab_pair_head(px.x, px.y, s_lms, st);
 					st_opaque = __all((px.x & px.y) >= 0xff000000u);
 					st_ab = (px.x >> 24) | ((px.y >> 24) << 8);
 				} else {
 					const uint32_t w0 = __builtin_amdgcn_alignbit(px.y, px.x, rgb_shift);  // R0 G0 B0 R1
 					const uint32_t w1 = px.y >> rgb_shift;                                  // G1 B1 . .
-					oklab_pair_head(w0, __builtin_amdgcn_alignbit(w1, w0, 24), s_lms, s_scale, st);  // (byte 3 of either is not looked at)
+					oklab_pair_head(w0, __builtin_amdgcn_alignbit(w1, w0, 24), s_lms, st);  // (byte 3 of either is not looked at)
 					st_opaque = true;
 				}
 			}
@@ -769,9 +812,9 @@ __global__ void __launch_bounds__(1024) oklab2_kernel(const ShrinkArgs a)
 				pending = convert;
 				if (convert) {
 #if defined(PXZ_EXP) && (PXZ_EXP == 1 || PXZ_EXP == 3)
-					for (int c = 0; c < 3; ++c) { lab[k][0][c] = (float)st.sc[c]; lab[k][1][c] = (float)st.xmd[c]; }
+					for (int c = 0; c < 3; ++c) { lab[k][0][c] = st.x[c]; lab[k][1][c] = st.x[3 + c]; }
 #else
-					oklab_pair_tail(st, lab[k][0], lab[k][1]);
+					oklab_pair_tail(st, s_scale, lab[k][0], lab[k][1]);
 #endif
 					band_opaque = st_opaque;
 					if (!st_opaque) {

@@ -43,6 +43,10 @@ PROBE(k_add_f32_ind, "v_add_f32 %8, %9, %10\n v_add_f32 %11, %12, %13\n v_add_f3
 PROBE(k_add_f32_dep, "v_add_f32 %8, %8, %9\n v_add_f32 %8, %8, %10\n v_add_f32 %8, %8, %11\n v_add_f32 %8, %8, %12\n", )
 PROBE(k_add_f32_dep_abs, "v_add_f32 %8, %8, |%9|\n v_add_f32 %8, %8, |%10|\n v_add_f32 %8, %8, |%11|\n v_add_f32 %8, %8, |%12|\n", )
 PROBE(k_add_f32_dep2, "v_add_f32 %8, %8, %9\n v_add_f32 %10, %10, %11\n v_add_f32 %8, %8, %12\n v_add_f32 %10, %10, %13\n", )
+PROBE(k_add_f32_dpp_dep, "v_add_f32_dpp %8, %9, %8 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf\n v_add_f32_dpp %8, %10, %8 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf\n v_add_f32_dpp %8, %11, %8 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf\n v_add_f32_dpp %8, %12, %8 quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf\n", )
+PROBE(k_add_f32_dpp_dep_abs, "v_add_f32_dpp %8, |%9|, %8 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf\n v_add_f32_dpp %8, |%10|, %8 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf\n v_add_f32_dpp %8, |%11|, %8 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf\n v_add_f32_dpp %8, |%12|, %8 quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf\n", )
+PROBE(k_add_f32_dpp_ind, "v_add_f32_dpp %8, %9, %10 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf\n v_add_f32_dpp %11, %12, %13 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf\n v_add_f32_dpp %14, %15, %9 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf\n v_add_f32_dpp %10, %12, %13 quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf\n", )
+PROBE(k_add_f32_dep_two_chains, "v_add_f32 %8, %8, %9\n v_add_f32 %10, %10, %11\n v_add_f32 %8, %8, %12\n v_add_f32 %10, %10, %13\n", )
 PROBE(k_fma_f32_dep, "v_fma_f32 %8, %8, %9, %10\n v_fma_f32 %8, %8, %9, %10\n v_fma_f32 %8, %8, %9, %10\n v_fma_f32 %8, %8, %9, %10\n", )
 PROBE(k_mul_f32_ind, "v_mul_f32 %8, %9, %10\n v_mul_f32 %11, %12, %13\n v_mul_f32 %14, %15, %9\n v_mul_f32 %10, %12, %13\n", )
 PROBE(k_ldexp_f64, "v_ldexp_f64 %0, %1, %16\n v_ldexp_f64 %2, %3, %17\n v_ldexp_f64 %4, %5, %18\n v_ldexp_f64 %6, %7, %19\n", )
@@ -123,7 +127,7 @@ int main()
 {
 	const int N = 256 * 64 * 4;
 #define R(k) run(#k, k, N); run(#k, k, N, 8);
-	R(k_add_f32_ind) R(k_add_f32_dep) R(k_add_f32_dep_abs) R(k_add_f32_dep2) R(k_fma_f32_dep) R(k_mul_f32_ind)
+	R(k_add_f32_dpp_dep) R(k_add_f32_dpp_dep_abs) R(k_add_f32_dpp_ind) R(k_add_f32_dep_two_chains) R(k_add_f32_ind) R(k_add_f32_dep) R(k_add_f32_dep_abs) R(k_add_f32_dep2) R(k_fma_f32_dep) R(k_mul_f32_ind)
 	R(k_fma_f64_ind) R(k_fma_f64_dep) R(k_mul_f64_ind) R(k_add_f64_ind) R(k_rcp_f64_ind) R(k_rcp_f64_dep) R(k_rcp_f32_ind)
 	R(k_cvt_f64_f32) R(k_cvt_f32_f64) R(k_cvt_dep_chain) R(k_frexp_mant) R(k_frexp_exp) R(k_pk_mul_f32) R(k_pk_fma_f32) R(k_ldexp_f64)
 	R(k_and_or) R(k_cndmask) R(k_sdwa_shift) R(k_mixed_f64_f32)
