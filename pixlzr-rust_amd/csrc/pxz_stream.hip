@@ -184,10 +184,13 @@ __global__ void __launch_bounds__(256) qoi_bin_scatter_kernel(const QoiArgs a)
 	if (t < a.n_tiles) a.perm[s_base[cls] + local] = t;
 }
 
+typedef __attribute__((address_space(1))) unsigned long long *global_qword_ptr;
 struct ByteSink {
 	unsigned long long acc;
 	uint32_t cnt;        // bytes in acc (0..7)
-	unsigned long long *out;
+	// (a pointer the compiler knows to be global: through a generic one the stores are flat_store, which also count as LDS
+	// operations -- every wait for an index read then waited for the stores in flight as well)
+	global_qword_ptr out;
 	// n <= 8 bytes at once, first byte in the low bits of v (bits above 8n must be zero)
 	__device__ __forceinline__ void append(unsigned long long v, uint32_t n)
 	{
@@ -354,7 +357,7 @@ __global__ void __launch_bounds__(64) qoi_tiles_kernel(const QoiArgs a)
 	// ---- the segment's ops
 	uint8_t *rec = a.scratch + (size_t)t * a.stride;
 	uint8_t *piece = seg ? rec + qoi_piece0_bytes(seg_px, C) + (size_t)(seg - 1u) * qoi_piece_bytes(seg_px, C) : rec;
-	ByteSink s{0ull, 0u, reinterpret_cast<unsigned long long *>(seg ? piece + 8 : piece)};
+	ByteSink s{0ull, 0u, (global_qword_ptr)(seg ? piece + 8 : piece)};
 	if (seg == 0u) {
 		// encode_block: magic, value, length placeholder (mod.rs:172-178,195), then the qoi header minus its 4-byte magic
 		// (mod.rs:191): width, height BE, channels, colourspace 0 -- 23 bytes
@@ -366,72 +369,97 @@ __global__ void __launch_bounds__(64) qoi_tiles_kernel(const QoiArgs a)
 	}
 	uint32_t prev = first_prev, run = run_in, last_slot = qoi_hash(first_prev);
 	bool seen_op = seen_in;
-	// (the next four pixels are requested before the current four are encoded -- a lane's pixel loop is one dependent
-	// chain, and a memory round trip every four pixels was most of its time)
-	uint32_t ahead[4] = {0, 0, 0, 0};
-	if (len) qoi_load4<C>(src, start, aligned, slot_px, ahead);
-	for (uint32_t base = start; base < end; base += 4u) {
-		uint32_t px4[4] = {ahead[0], ahead[1], ahead[2], ahead[3]};
-		if (base + 4u < end) qoi_load4<C>(src, base + 4u, aligned, slot_px, ahead);
+	// One pixel (px = pixel pi of the tile):
+	auto step = [&](const uint32_t px, const uint32_t pi) __attribute__((always_inline)) {
+		// One pixel, without branches: the lanes of a wave sit in different ops at every pixel, and a wave that
+		// takes every branch in turn spends its time in the ones its lanes did not want.  Every candidate op is
+		// worked out, selects pick the bytes (a pending run byte first), one append writes them.
+		const bool same = px == prev;
+		// (a) the pixel repeats: count it; the run is written at 62 or at the end of the tile
+		const uint32_t run_if_same = run + 1u;
+		const bool flush_same = run_if_same == 62u || pi + 1u == n;
+		// (b) it differs: a pending run first -- as INDEX of the repeated pixel when it is a run of ONE and any op was
+		// written before (the crate's quirk), else as RUN
+		const uint32_t pre_byte = (run == 1u && seen_op) ? last_slot : (0xc0u | (run - 1u));
+		const uint32_t pre_len = run ? 1u : 0u;
+		const uint32_t slot = qoi_hash(px);
+		const bool hit = index[slot] == px;
+		index[same ? 64u : slot] = px;  // (a hit rewrites the same value; slot 64 takes the writes of repeats)
+		const uint32_t dr = ((px & 255u) - (prev & 255u)) & 255u;
+		const uint32_t dg = (((px >> 8) & 255u) - ((prev >> 8) & 255u)) & 255u;
+		const uint32_t db = (((px >> 16) & 255u) - ((prev >> 16) & 255u)) & 255u;
+		const bool alpha_moves = C == 4 && (px >> 24) != (prev >> 24);
+		const bool diff_ok = ((dr + 2u) & 255u) < 4u && ((dg + 2u) & 255u) < 4u && ((db + 2u) & 255u) < 4u;
+		const bool luma_ok = ((dg + 32u) & 255u) < 64u && ((dr - dg + 8u) & 255u) < 16u && ((db - dg + 8u) & 255u) < 16u;
+		const unsigned long long rgb = (unsigned long long)(px & 0x00ffffffu);
+		unsigned long long op = 0xfeull | (rgb << 8);  // QOI_OP_RGB
+		uint32_t op_len = 4u;
+		if (luma_ok) {
+			op = (0x80u | ((dg + 32u) & 63u)) | (((((dr - dg + 8u) & 15u) << 4) | ((db - dg + 8u) & 15u)) << 8);  // QOI_OP_LUMA
+			op_len = 2u;
+		}
+		if (diff_ok) {
+			op = 0x40u | (((dr + 2u) & 3u) << 4) | (((dg + 2u) & 3u) << 2) | ((db + 2u) & 3u);  // QOI_OP_DIFF
+			op_len = 1u;
+		}
+		if (alpha_moves) {
+			op = 0xffull | ((unsigned long long)px << 8);  // QOI_OP_RGBA
+			op_len = 5u;
+		}
+		if (hit) {
+			op = slot;  // QOI_OP_INDEX
+			op_len = 1u;
+		}
+		unsigned long long bytes = pre_len ? ((unsigned long long)pre_byte | (op << 8)) : op;
+		uint32_t n_bytes = pre_len + op_len;
+		if (same) {
+			bytes = flush_same ? (0xc0u | (run_if_same - 1u)) : 0u;
+			n_bytes = flush_same ? 1u : 0u;
+		}
+		s.append(bytes, n_bytes);
+		run = same ? (flush_same ? 0u : run_if_same) : 0u;
+		seen_op = seen_op || !same;
+		last_slot = same ? last_slot : slot;
+		prev = px;  // (unchanged when the pixel repeats)
+	};
+	// Sixteen pixels per round, the next sixteen requested before the current ones are encoded -- a lane's pixel loop is one
+	// dependent chain, and loads and stores share one in-order counter: waiting for a load also waits for every store issued
+	// before it, so the loop waits once per sixteen pixels instead of once per four.  The last pixels of a segment (fewer
+	// than sixteen) go four at a time.
+	constexpr int kGroup = 16;
+	uint32_t base = start;
+	if (base + (uint32_t)kGroup <= end) {
+		uint32_t ahead[kGroup];
+		auto load_group = [&](uint32_t from, uint32_t (&dst)[kGroup]) __attribute__((always_inline)) {
+#pragma unroll
+			for (int q = 0; q < kGroup / 4; ++q) {
+				uint32_t t4[4];
+				qoi_load4<C>(src, from + 4u * (uint32_t)q, aligned, slot_px, t4);
+#pragma unroll
+				for (int j = 0; j < 4; ++j) dst[4 * q + j] = t4[j];
+			}
+		};
+		load_group(base, ahead);
+		for (; base + (uint32_t)kGroup <= end; base += (uint32_t)kGroup) {
+			uint32_t cur[kGroup];
+#pragma unroll
+			for (int j = 0; j < kGroup; ++j) cur[j] = ahead[j];
+			if (base + 2u * (uint32_t)kGroup <= end) load_group(base + (uint32_t)kGroup, ahead);
+#pragma unroll
+			for (int j = 0; j < kGroup; ++j) step(cur[j], base + (uint32_t)j);
+		}
+	}
+	for (; base < end; base += 4u) {
+		uint32_t px4[4];
+		qoi_load4<C>(src, base, aligned, slot_px, px4);
 #pragma unroll
 		for (int j = 0; j < 4; ++j) {
-			const uint32_t pi = base + (uint32_t)j;
-			if (pi >= end) break;
-			// One pixel, without branches: the lanes of a wave sit in different ops at every pixel, and a wave that
-			// takes every branch in turn spends its time in the ones its lanes did not want.  Every candidate op is
-			// worked out, selects pick the bytes (a pending run byte first), one append writes them.
-			const uint32_t px = px4[j];
-			const bool same = px == prev;
-			// (a) the pixel repeats: count it; the run is written at 62 or at the end of the tile
-			const uint32_t run_if_same = run + 1u;
-			const bool flush_same = run_if_same == 62u || pi + 1u == n;
-			// (b) it differs: a pending run first -- as INDEX of the repeated pixel when it is a run of ONE and any op was
-			// written before (the crate's quirk), else as RUN
-			const uint32_t pre_byte = (run == 1u && seen_op) ? last_slot : (0xc0u | (run - 1u));
-			const uint32_t pre_len = run ? 1u : 0u;
-			const uint32_t slot = qoi_hash(px);
-			const bool hit = index[slot] == px;
-			index[same ? 64u : slot] = px;  // (a hit rewrites the same value; slot 64 takes the writes of repeats)
-			const uint32_t dr = ((px & 255u) - (prev & 255u)) & 255u;
-			const uint32_t dg = (((px >> 8) & 255u) - ((prev >> 8) & 255u)) & 255u;
-			const uint32_t db = (((px >> 16) & 255u) - ((prev >> 16) & 255u)) & 255u;
-			const bool alpha_moves = C == 4 && (px >> 24) != (prev >> 24);
-			const bool diff_ok = ((dr + 2u) & 255u) < 4u && ((dg + 2u) & 255u) < 4u && ((db + 2u) & 255u) < 4u;
-			const bool luma_ok = ((dg + 32u) & 255u) < 64u && ((dr - dg + 8u) & 255u) < 16u && ((db - dg + 8u) & 255u) < 16u;
-			const unsigned long long rgb = (unsigned long long)(px & 0x00ffffffu);
-			unsigned long long op = 0xfeull | (rgb << 8);  // QOI_OP_RGB
-			uint32_t op_len = 4u;
-			if (luma_ok) {
-				op = (0x80u | ((dg + 32u) & 63u)) | (((((dr - dg + 8u) & 15u) << 4) | ((db - dg + 8u) & 15u)) << 8);  // QOI_OP_LUMA
-				op_len = 2u;
-			}
-			if (diff_ok) {
-				op = 0x40u | (((dr + 2u) & 3u) << 4) | (((dg + 2u) & 3u) << 2) | ((db + 2u) & 3u);  // QOI_OP_DIFF
-				op_len = 1u;
-			}
-			if (alpha_moves) {
-				op = 0xffull | ((unsigned long long)px << 8);  // QOI_OP_RGBA
-				op_len = 5u;
-			}
-			if (hit) {
-				op = slot;  // QOI_OP_INDEX
-				op_len = 1u;
-			}
-			unsigned long long bytes = pre_len ? ((unsigned long long)pre_byte | (op << 8)) : op;
-			uint32_t n_bytes = pre_len + op_len;
-			if (same) {
-				bytes = flush_same ? (0xc0u | (run_if_same - 1u)) : 0u;
-				n_bytes = flush_same ? 1u : 0u;
-			}
-			s.append(bytes, n_bytes);
-			run = same ? (flush_same ? 0u : run_if_same) : 0u;
-			seen_op = seen_op || !same;
-			last_slot = same ? last_slot : slot;
-			prev = px;  // (unchanged when the pixel repeats)
+			if (base + (uint32_t)j >= end) break;
+			step(px4[j], base + (uint32_t)j);
 		}
 	}
 	if (len && end == n) s.append(0x0100000000000000ull, 8);  // QOI end marker: seven zero bytes and a one
-	uint32_t bytes_here = (uint32_t)(reinterpret_cast<uint8_t *>(s.out) - (seg ? piece + 8 : piece)) + s.cnt;
+	uint32_t bytes_here = (uint32_t)((const uint8_t *)s.out - (seg ? piece + 8 : piece)) + s.cnt;
 	if (s.cnt) *s.out = s.acc;  // partial tail (the piece leaves room)
 	if (seg) *reinterpret_cast<uint32_t *>(piece) = bytes_here;
 	// the record's length: every piece of the tile (a butterfly over the tile's lanes; all of them are here)
