@@ -295,25 +295,51 @@ __global__ void __launch_bounds__(64) qoi_tiles_kernel(const QoiArgs a)
 	bool all_same = true;
 	if (G > 1u) {
 		uint32_t prev = first_prev;
-		for (uint32_t base = start; base < end; base += 4u) {
+		auto dry = [&](const uint32_t px) __attribute__((always_inline)) {
+			if (px != prev) {
+				const uint32_t slot = qoi_hash(px);
+				index[slot] = px;
+				const uint32_t bit = 1u << (slot & 31u);
+				wr_lo |= slot < 32u ? bit : 0u;
+				wr_hi |= slot < 32u ? 0u : bit;
+				trail = 0;
+				all_same = false;
+			} else {
+				++trail;
+			}
+			prev = px;
+		};
+		// (sixteen pixels per round with the next sixteen on their way, as in the real pass below: four at a time without
+		// prefetch this loop was one memory round trip per four pixels)
+		uint32_t base = start;
+		if (base + 16u <= end) {
+			uint32_t ahead[16];
+			auto load16 = [&](uint32_t from) __attribute__((always_inline)) {
+#pragma unroll
+				for (int q = 0; q < 4; ++q) {
+					uint32_t t4[4];
+					qoi_load4<C>(src, from + 4u * (uint32_t)q, aligned, slot_px, t4);
+#pragma unroll
+					for (int j = 0; j < 4; ++j) ahead[4 * q + j] = t4[j];
+				}
+			};
+			load16(base);
+			for (; base + 16u <= end; base += 16u) {
+				uint32_t cur[16];
+#pragma unroll
+				for (int j = 0; j < 16; ++j) cur[j] = ahead[j];
+				if (base + 32u <= end) load16(base + 16u);
+#pragma unroll
+				for (int j = 0; j < 16; ++j) dry(cur[j]);
+			}
+		}
+		for (; base < end; base += 4u) {
 			uint32_t px4[4];
 			qoi_load4<C>(src, base, aligned, slot_px, px4);
 #pragma unroll
 			for (int j = 0; j < 4; ++j) {
 				if (base + (uint32_t)j >= end) break;
-				const uint32_t px = px4[j];
-				if (px != prev) {
-					const uint32_t slot = qoi_hash(px);
-					index[slot] = px;
-					const uint32_t bit = 1u << (slot & 31u);
-					wr_lo |= slot < 32u ? bit : 0u;
-					wr_hi |= slot < 32u ? 0u : bit;
-					trail = 0;
-					all_same = false;
-				} else {
-					++trail;
-				}
-				prev = px;
+				dry(px4[j]);
 			}
 		}
 	}
@@ -370,7 +396,7 @@ __global__ void __launch_bounds__(64) qoi_tiles_kernel(const QoiArgs a)
 	uint32_t prev = first_prev, run = run_in, last_slot = qoi_hash(first_prev);
 	bool seen_op = seen_in;
 	// One pixel (px = pixel pi of the tile):
-	auto step = [&](const uint32_t px, const uint32_t pi) __attribute__((always_inline)) {
+	auto step = [&](const uint32_t px, const uint32_t pi, const uint32_t slot, const bool hit) __attribute__((always_inline)) {
 		// One pixel, without branches: the lanes of a wave sit in different ops at every pixel, and a wave that
 		// takes every branch in turn spends its time in the ones its lanes did not want.  Every candidate op is
 		// worked out, selects pick the bytes (a pending run byte first), one append writes them.
@@ -382,9 +408,6 @@ __global__ void __launch_bounds__(64) qoi_tiles_kernel(const QoiArgs a)
 		// written before (the crate's quirk), else as RUN
 		const uint32_t pre_byte = (run == 1u && seen_op) ? last_slot : (0xc0u | (run - 1u));
 		const uint32_t pre_len = run ? 1u : 0u;
-		const uint32_t slot = qoi_hash(px);
-		const bool hit = index[slot] == px;
-		index[same ? 64u : slot] = px;  // (a hit rewrites the same value; slot 64 takes the writes of repeats)
 		const uint32_t dr = ((px & 255u) - (prev & 255u)) & 255u;
 		const uint32_t dg = (((px >> 8) & 255u) - ((prev >> 8) & 255u)) & 255u;
 		const uint32_t db = (((px >> 16) & 255u) - ((prev >> 16) & 255u)) & 255u;
@@ -445,8 +468,19 @@ __global__ void __launch_bounds__(64) qoi_tiles_kernel(const QoiArgs a)
 #pragma unroll
 			for (int j = 0; j < kGroup; ++j) cur[j] = ahead[j];
 			if (base + 2u * (uint32_t)kGroup <= end) load_group(base + (uint32_t)kGroup, ahead);
+			// the index traffic of the whole round first: LDS works a wave's instructions off in order, so every look-up
+			// sees the table as the pixels before it left it, and the sixteen round trips overlap instead of standing one
+			// in front of every pixel (a hit rewrites the same value; slot 64 takes the writes of repeats)
+			uint32_t slot16[kGroup], was16[kGroup];
 #pragma unroll
-			for (int j = 0; j < kGroup; ++j) step(cur[j], base + (uint32_t)j);
+			for (int j = 0; j < kGroup; ++j) {
+				slot16[j] = qoi_hash(cur[j]);
+				was16[j] = lds_dword(index + slot16[j]);
+				const bool rep = cur[j] == (j ? cur[j - 1] : prev);
+				*(volatile __attribute__((address_space(3))) uint32_t *)(index + (rep ? 64u : slot16[j])) = cur[j];
+			}
+#pragma unroll
+			for (int j = 0; j < kGroup; ++j) step(cur[j], base + (uint32_t)j, slot16[j], was16[j] == cur[j]);
 		}
 	}
 	for (; base < end; base += 4u) {
@@ -455,7 +489,10 @@ __global__ void __launch_bounds__(64) qoi_tiles_kernel(const QoiArgs a)
 #pragma unroll
 		for (int j = 0; j < 4; ++j) {
 			if (base + (uint32_t)j >= end) break;
-			step(px4[j], base + (uint32_t)j);
+			const uint32_t slot = qoi_hash(px4[j]);
+			const bool hit = index[slot] == px4[j];
+			index[px4[j] == prev ? 64u : slot] = px4[j];
+			step(px4[j], base + (uint32_t)j, slot, hit);
 		}
 	}
 	if (len && end == n) s.append(0x0100000000000000ull, 8);  // QOI end marker: seven zero bytes and a one
