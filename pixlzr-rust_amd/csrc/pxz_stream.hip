@@ -555,45 +555,75 @@ __global__ void __launch_bounds__(256) qoi_splice_small_kernel(const QoiArgs a)
 	splice_piece(a.out + dstoff, a.scratch + (size_t)t * a.stride, len, lane, 16u);
 }
 
+// The records of several pieces (tiles of 128 pixels and more; they come first in perm): a wave per record, the waves of a
+// fixed grid walking the records with a stride.  Round 3: what a record needs before its first byte moves is four dependent
+// round trips (perm -> offsets / lengths / size of the tile -> the lengths of its pieces -> the pieces), and a wave that did
+// them one record at a time spent 92 % of its life waiting (one wave per tile of the batch, most of them leaving at once:
+// 0.18 ms for 182 MB).  Now the three look-ups of the records to come are in flight while the current one is copied.
 __global__ void __launch_bounds__(256) qoi_splice_kernel(const QoiArgs a)
 {
-	const uint32_t p = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
-	if (p >= a.bins[kBinTiles + 6]) return;  // (the tiles of several pieces; qoi_splice_small_kernel takes the others)
-	const uint32_t t = a.perm[p];
-	const unsigned long long off = a.chunk_totals[t / kPackChunk] + a.offsets[t];
-	if (lane == 0) a.offsets[t] = off;
-	const uint32_t frame = t / a.tiles_per_frame;
-	const unsigned long long dstoff = (unsigned long long)(frame + 1u) * a.hdr_bytes + off;
-	const uint32_t len = a.rec_len[t];
-	if (dstoff + len > a.capacity) return;
-	const uint8_t *rec = a.scratch + (size_t)t * a.stride;  // 8-byte aligned (records sit at a stride of whole qwords)
-	uint8_t *dst = a.out + dstoff;
-	const uint32_t n = a.w[t] * a.h[t];
-	const uint32_t G = qoi_class_segments(31u - (uint32_t)__builtin_clz(n | 1u));
-	if (G == 1u) {
-		splice_piece(dst, rec, len, lane, 64u);
-		return;
-	}
-	const uint32_t seg_px = qoi_segment_pixels(n, G), p0 = qoi_piece0_bytes(seg_px, a.channels), pn = qoi_piece_bytes(seg_px, a.channels);
-	// lane j holds the length of piece j (G <= 64; piece 0 is what the others leave of the record) and, after the scan,
-	// where it starts; quarter waves then copy pieces side by side
-	uint32_t mine = (lane >= 1u && lane < G) ? *reinterpret_cast<const uint32_t *>(rec + p0 + (size_t)(lane - 1u) * pn) : 0u;
-	if (mine > pn - 8u) mine = 0u;  // (cannot happen)
-	uint32_t others = mine;
-	for (uint32_t d = 1; d < 64u; d <<= 1) others += __shfl_xor(others, (int)d, 64);
-	if (others > len || len - others > p0) return;  // (cannot happen: the pieces add up to the record)
-	if (lane == 0u) mine = len - others;
-	uint32_t startpos = mine;  // inclusive scan, then minus own = exclusive
-	for (uint32_t d = 1; d < 64u; d <<= 1) {
-		const uint32_t up = __shfl_up(startpos, d, 64);
-		if (lane >= d) startpos += up;
-	}
-	startpos -= mine;
-	const uint32_t quarter = lane >> 4, ql = lane & 15u;
-	for (uint32_t j0 = 0; j0 < G; j0 += 4u) {
-		const uint32_t j = j0 + quarter;
-		const uint32_t lj = __shfl(mine, (int)(j & 63u), 64), pj = __shfl(startpos, (int)(j & 63u), 64);
-		if (j < G && lj) splice_piece(dst + pj, j ? rec + p0 + (size_t)(j - 1u) * pn + 8u : rec, lj, ql, 16u);
+	const uint32_t lane = threadIdx.x & 63u;
+	const uint32_t n_big = a.bins[kBinTiles + 6];  // (qoi_splice_small_kernel takes the other tiles)
+	const uint32_t stride = gridDim.x * 4u;
+	uint32_t p1 = blockIdx.x * 4u + (threadIdx.x >> 6);
+	// stage 2: tile known; stage 3: its offset, length and size known; stage 4: the lengths of its pieces known
+	bool v2 = false, v3 = false, v4 = false;
+	uint32_t t2 = 0, t3 = 0, t4 = 0, len3 = 0, len4 = 0, n3 = 0, n4 = 0, mine4 = 0;
+	unsigned long long off3 = 0, off4 = 0;
+	for (;;) {
+		// ---- the look-ups of the records to come (issued first: they travel while the copy below runs)
+		const bool v1 = p1 < n_big;
+		uint32_t t1 = 0;
+		if (v1) t1 = a.perm[p1];
+		unsigned long long off2 = 0;
+		uint32_t len2 = 0, n2 = 0;
+		if (v2) {
+			off2 = a.chunk_totals[t2 / kPackChunk] + a.offsets[t2];
+			len2 = a.rec_len[t2];
+			n2 = a.w[t2] * a.h[t2];
+		}
+		uint32_t mine3 = 0;
+		if (v3) {
+			const uint32_t G = qoi_class_segments(31u - (uint32_t)__builtin_clz(n3 | 1u));
+			const uint32_t seg_px = qoi_segment_pixels(n3, G), p0 = qoi_piece0_bytes(seg_px, a.channels), pn = qoi_piece_bytes(seg_px, a.channels);
+			// lane j holds the length of piece j (G <= 64; piece 0 is what the others leave of the record)
+			if (lane >= 1u && lane < G) mine3 = *reinterpret_cast<const uint32_t *>(a.scratch + (size_t)t3 * a.stride + p0 + (size_t)(lane - 1u) * pn);
+		}
+		// ---- the record whose pieces are known: scan of their lengths, then quarter waves copy pieces side by side
+		if (v4) {
+			const uint32_t frame = t4 / a.tiles_per_frame;
+			const unsigned long long dstoff = (unsigned long long)(frame + 1u) * a.hdr_bytes + off4;
+			if (lane == 0) a.offsets[t4] = off4;
+			const uint32_t G = qoi_class_segments(31u - (uint32_t)__builtin_clz(n4 | 1u));
+			const uint32_t seg_px = qoi_segment_pixels(n4, G), p0 = qoi_piece0_bytes(seg_px, a.channels), pn = qoi_piece_bytes(seg_px, a.channels);
+			const uint8_t *rec = a.scratch + (size_t)t4 * a.stride;  // 8-byte aligned (records sit at a stride of whole qwords)
+			uint8_t *dst = a.out + dstoff;
+			uint32_t mine = mine4 > pn - 8u ? 0u : mine4;  // (cannot happen)
+			uint32_t others = mine;
+			for (uint32_t d = 1; d < 64u; d <<= 1) others += __shfl_xor(others, (int)d, 64);
+			const bool fine = dstoff + len4 <= a.capacity && others <= len4 && len4 - others <= p0;  // (the pieces add up to the record)
+			if (fine) {
+				if (lane == 0u) mine = len4 - others;
+				uint32_t startpos = mine;  // inclusive scan, then minus own = exclusive
+				for (uint32_t d = 1; d < 64u; d <<= 1) {
+					const uint32_t up = __shfl_up(startpos, d, 64);
+					if (lane >= d) startpos += up;
+				}
+				startpos -= mine;
+				const uint32_t quarter = lane >> 4, ql = lane & 15u;
+				for (uint32_t j0 = 0; j0 < G; j0 += 4u) {
+					const uint32_t j = j0 + quarter;
+					const uint32_t lj = __shfl(mine, (int)(j & 63u), 64), pj = __shfl(startpos, (int)(j & 63u), 64);
+					if (j < G && lj) splice_piece(dst + pj, j ? rec + p0 + (size_t)(j - 1u) * pn + 8u : rec, lj, ql, 16u);
+				}
+			}
+		}
+		if (!(v1 || v2 || v3)) break;
+		// ---- everyone moves on by one stage
+		v4 = v3; t4 = t3; off4 = off3; len4 = len3; n4 = n3; mine4 = mine3;
+		v3 = v2; t3 = t2; off3 = off2; len3 = len2; n3 = n2;
+		v2 = v1; t2 = t1;
+		p1 += stride;
 	}
 }
 
@@ -654,7 +684,11 @@ hipError_t launch_qoi(const QoiArgs &a, hipStream_t stream)
 	p.n_chunks = a.n_chunks;
 	hipLaunchKernelGGL(pack_scan_local_kernel, dim3(a.n_chunks), dim3(256), 0, stream, p);
 	hipLaunchKernelGGL(pack_scan_chunks_kernel, dim3(1), dim3(1024), 0, stream, p);
-	hipLaunchKernelGGL(qoi_splice_kernel, dim3((a.n_tiles + 3u) / 4u), dim3(256), 0, stream, a);
+	{
+		// a fixed grid of waves that walk the multi-piece records with a stride (their number is only known on the device)
+		const uint32_t need = (a.n_tiles + 3u) / 4u, cap = 2048u;
+		hipLaunchKernelGGL(qoi_splice_kernel, dim3(need < cap ? need : cap), dim3(256), 0, stream, a);
+	}
 	hipLaunchKernelGGL(qoi_splice_small_kernel, dim3((a.n_tiles + 15u) / 16u), dim3(256), 0, stream, a);
 	const uint32_t frames = a.n_tiles / a.tiles_per_frame;
 	hipLaunchKernelGGL(qoi_headers_kernel, dim3((frames * a.rows + 255u) / 256u), dim3(256), 0, stream, a);
