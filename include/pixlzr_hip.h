@@ -49,7 +49,7 @@ typedef enum pxz_status {
 /* FilterType, repr(u8): src/data_types/mod.rs:10-30 */
 typedef enum pxz_filter {
 	PXZ_FILTER_NEAREST = 0,
-	PXZ_FILTER_TRIANGLE = 1,    /* down-scales with fir Hamming (mod.rs:298-300) */
+	PXZ_FILTER_TRIANGLE = 1,    /* down-scales with fir Hamming (data_types/mod.rs:93-95) */
 	PXZ_FILTER_CATMULLROM = 2,
 	PXZ_FILTER_GAUSSIAN = 3,
 	PXZ_FILTER_LANCZOS3 = 4
@@ -231,13 +231,16 @@ int pxz_process_frames_device(pxz_handle *h, const pxz_frames *frames, const pxz
  * block_w x block_h grid get_block_variance (|x - avg|, identity); a tile with (value >= |threshold|) ^ (threshold >= 0)
  * is pixelised as process() does it (reduce_image_section((v, v)) with params->filter, resized back with
  * filter_upscale); any other tile is handed to the same function with both block sizes halved (|threshold| from
- * there on, so only the outermost level can be inverted) until a block size reaches min(min_block_*, 4), where the
- * tile keeps its pixels.  tree::process(image, n, k) is block_w = block_h = n, min 4 x 4, PXZ_FILTER_LANCZOS3 down,
- * PXZ_FILTER_NEAREST up, threshold k.  Output RGBA8 (RGB input gains alpha 255; also in the degenerate case of a
- * block size at or below the minimum, where the reference returns the image unchanged in its own colour type).
- * One detector + shrink + expand pass per level over that level's regular grid; this needs block sizes that halve
- * evenly down to the last level (64, 48, 40, ...: PXZ_ERR_UNSUPPORTED otherwise), and tiles that fit the kernels' LDS
- * residency (about 128 x 96).  params->mode and factor are ignored.  Asynchronous on the handle's stream. */
+ * there on, so only the outermost level can be inverted) until a block size is no larger than max(min_block_*, 4)
+ * (tree.rs:32-36), where the tile keeps its pixels.  tree::process(image, n, k) is block_w = block_h = n, min 4 x 4,
+ * PXZ_FILTER_LANCZOS3 down, PXZ_FILTER_NEAREST up, threshold k.  Output RGBA8 (RGB input gains alpha 255; also in the
+ * degenerate case of a block size at or below the minimum, where the reference returns the image unchanged in its own
+ * colour type).  Any block geometry up to 128 x 128 (what src/bin/tree.rs:6 calls it with): blocks of at most 64 px that
+ * halve evenly down to the last level run one detector + shrink + expand pass per level over that level's regular
+ * grid; everything else -- 128-px blocks, halvings that go odd (50 -> 25 -> 12 + 12 + 1: every tile is cut from its own
+ * corner, tree.rs:70-79) -- goes level by level over lists of rectangles, one block of threads per open tile, with one
+ * 4-byte read-back per level (so that form is asynchronous only from its last level on).  Blocks above 128 px:
+ * PXZ_ERR_UNSUPPORTED.  params->mode and factor are ignored. */
 int pxz_tree_process_frames_device(pxz_handle *h, const pxz_frames *frames, const pxz_params *params,
                                    uint32_t filter_upscale, float threshold, uint32_t min_block_w, uint32_t min_block_h,
                                    const uint8_t *d_pixels, uint8_t *d_out_rgba, uint32_t out_pitch_bytes,

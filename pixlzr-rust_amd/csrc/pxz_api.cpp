@@ -13,6 +13,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <set>
 #include <string>
 #include <tuple>
 #include <vector>
@@ -25,6 +26,7 @@ namespace pxz {
 hipError_t launch_shrink(const ShrinkArgs &a, uint32_t channels, uint32_t n_cus, hipStream_t stream);
 hipError_t launch_synth(const SynthArgs &s, hipStream_t stream);
 hipError_t launch_tree_decide(const TreeArgs &a, hipStream_t stream);
+hipError_t launch_tree_rects(const TreeRectArgs &a, hipStream_t stream);
 hipError_t launch_oklab_pixels(const uint32_t *px, uint32_t n, float *out, uint32_t n_cus, hipStream_t stream);
 hipError_t launch_finish(const FinishArgs &f, hipStream_t stream);
 bool fast32_applicable(const ShrinkArgs &a, uint32_t channels);
@@ -70,6 +72,15 @@ struct DeviceBuffer {
 	size_t cap = 0;
 };
 
+// tree::process on rectangle lists: every axis table (down with the one filter, back up with the other) of every tile
+// size the recursion can reach from one (frame, block, minimum) geometry
+struct TreeTables {
+	pxz::TreeAxisEntry *d_dir = nullptr;
+	int32_t *d_starts = nullptr, *d_sizes = nullptr;
+	int16_t *d_coeffs = nullptr;
+	uint32_t n_dir = 0;
+};
+
 }  // namespace
 
 constexpr uint32_t kMaxImageSide = 1u << 24;  // see pxz_grid
@@ -89,6 +100,8 @@ struct pxz_handle {
 	static constexpr int kRing = 3;  // buffer sets of the pipelined host boundary (pxz_shrink_images*)
 	DeviceBuffer ring_in[kRing], ring_val[kRing], ring_ow[kRing], ring_oh[kRing], ring_out[kRing], ring_pk[kRing], ring_pkoff[kRing];
 	std::map<std::tuple<uint32_t, uint32_t, uint32_t, uint32_t, uint32_t>, ExpandTables> expand_tables;
+	std::map<std::tuple<uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t>, TreeTables> tree_tables;
+	DeviceBuffer tree_rects[2], tree_count;
 	uint32_t *host_stats = nullptr;  // pinned, device-visible: [0] = tiles with transparency the last finished 32x32 launch saw
 	uint32_t *dev_stats = nullptr;   //   (its device-side address); read without synchronisation, steers only the kernel choice
 	bool work_ready = false;   // both worklist counters are zero / consistent with work_slot
@@ -835,7 +848,13 @@ void pxz_destroy(pxz_handle *h)
 		(void)hipFree(kv.second.d_sizes);
 		(void)hipFree(kv.second.d_coeffs);
 	}
-	for (DeviceBuffer *b : {&h->in, &h->val, &h->ow, &h->oh, &h->out, &h->sums, &h->chunks, &h->work, &h->qscratch, &h->qmeta, &h->status, &h->dmeta, &h->okscratch, &h->rgba, &h->slots4, &h->pk, &h->pkoff, &h->tree})
+	for (auto &kv : h->tree_tables) {
+		(void)hipFree(kv.second.d_dir);
+		(void)hipFree(kv.second.d_starts);
+		(void)hipFree(kv.second.d_sizes);
+		(void)hipFree(kv.second.d_coeffs);
+	}
+	for (DeviceBuffer *b : {&h->in, &h->val, &h->ow, &h->oh, &h->out, &h->sums, &h->chunks, &h->work, &h->qscratch, &h->qmeta, &h->status, &h->dmeta, &h->okscratch, &h->rgba, &h->slots4, &h->pk, &h->pkoff, &h->tree, &h->tree_rects[0], &h->tree_rects[1], &h->tree_count})
 		if (b->ptr) (void)hipFree(b->ptr);
 	for (int i = 0; i < pxz_handle::kRing; ++i)
 		for (DeviceBuffer *b : {&h->ring_in[i], &h->ring_val[i], &h->ring_ow[i], &h->ring_oh[i], &h->ring_out[i], &h->ring_pk[i], &h->ring_pkoff[i]})
@@ -1113,6 +1132,160 @@ int pxz_process_frames_device(pxz_handle *h, const pxz_frames *frames, const pxz
 	                     (const uint8_t *)h->out.ptr, d_out_rgba);
 }
 
+namespace {
+// tree::process for any block geometry (round 3): the levels of the recursion as lists of rectangles, one launch of
+// pxz::tree_rect_kernel per level (pxz_tree.hip).  The host only learns how many tiles went on to the next level -- one
+// 4-byte read-back per level.
+int tree_process_rects(pxz_handle *h, const pxz_frames *frames, const pxz_params &p, uint32_t filter_upscale, float threshold,
+                       uint32_t mbw, uint32_t mbh, const std::vector<std::pair<uint32_t, uint32_t>> &levels, const uint8_t *d_pixels,
+                       uint8_t *d_out_rgba, uint32_t out_pitch_bytes, uint64_t src_stride, uint64_t dst_stride)
+{
+	constexpr uint32_t kMaxSide = 128;  // pxz_tree.hip: kTreeMaxSide
+	if (levels[0].first > kMaxSide || levels[0].second > kMaxSide)
+		return fail(h, PXZ_ERR_UNSUPPORTED, "tree::process on the device takes blocks up to %ux%u (got %ux%u)", kMaxSide, kMaxSide,
+		            levels[0].first, levels[0].second);
+	// ---- every tile size of every level, per axis (split.rs:18-19 applied level after level to the sizes of the level before)
+	auto split = [](uint32_t s, uint32_t b, std::set<uint32_t> &out) {
+		const uint32_t c = (s + b - 1) / b;
+		if (c > 1) out.insert(b);
+		out.insert(s - (c - 1) * b);
+	};
+	std::set<uint32_t> all[2];
+	{
+		std::set<uint32_t> cur[2];
+		split(frames->width, levels[0].first, cur[0]);
+		split(frames->height, levels[0].second, cur[1]);
+		for (size_t l = 0;; ++l) {
+			for (int ax = 0; ax < 2; ++ax) all[ax].insert(cur[ax].begin(), cur[ax].end());
+			if (l + 1 >= levels.size()) break;
+			std::set<uint32_t> next[2];
+			for (uint32_t v : cur[0]) split(v, levels[l + 1].first, next[0]);
+			for (uint32_t v : cur[1]) split(v, levels[l + 1].second, next[1]);
+			cur[0].swap(next[0]);
+			cur[1].swap(next[1]);
+		}
+	}
+	int rc;
+	const auto key = std::make_tuple(frames->width, frames->height, levels[0].first, levels[0].second, mbw, mbh, p.filter, filter_upscale);
+	auto it = h->tree_tables.find(key);
+	if (it == h->tree_tables.end()) {
+		std::set<std::tuple<uint32_t, uint32_t, uint32_t>> pairs;  // (in, out, up)
+		for (int ax = 0; ax < 2; ++ax)
+			for (uint32_t sz : all[ax])
+				for (uint32_t m = 1; m <= 32; ++m) {
+					const uint32_t o = reduced(sz, m);
+					if (o == sz) continue;
+					pairs.insert(std::make_tuple(sz, o, 0u));
+					pairs.insert(std::make_tuple(o, sz, 1u));
+				}
+		std::vector<pxz::TreeAxisEntry> dir;
+		std::vector<int32_t> starts, sizes;
+		std::vector<int16_t> coeffs;
+		for (const auto &pr : pairs) {
+			const uint32_t in = std::get<0>(pr), out = std::get<1>(pr), up = std::get<2>(pr);
+			pxz::AxisWindows win;
+			if (!pxz::build_axis(in, out, up ? filter_upscale : p.filter, &win, up != 0)) return fail(h, PXZ_ERR_INVALID_ARG, "unknown filter");
+			pxz::TreeAxisEntry e{};
+			e.in = (uint16_t)in;
+			e.out = (uint16_t)out;
+			e.up = (uint16_t)up;
+			e.window = (uint16_t)win.window;
+			e.precision = (uint32_t)win.precision;
+			e.starts_off = (uint32_t)starts.size();
+			e.coeff_off = (uint32_t)coeffs.size();
+			for (uint32_t o = 0; o < out; ++o) {
+				starts.push_back(win.starts[o]);
+				sizes.push_back(win.sizes.empty() ? 0 : win.sizes[o]);
+			}
+			coeffs.insert(coeffs.end(), win.coeffs.begin(), win.coeffs.end());
+			dir.push_back(e);
+		}
+		if (dir.empty()) dir.push_back(pxz::TreeAxisEntry{});
+		if (starts.empty()) { starts.push_back(0); sizes.push_back(0); }
+		if (coeffs.empty()) coeffs.push_back(0);
+		TreeTables tt;
+		tt.n_dir = (uint32_t)dir.size();
+		PXZ_HIP(h, hipMalloc((void **)&tt.d_dir, dir.size() * sizeof(pxz::TreeAxisEntry)));
+		PXZ_HIP(h, hipMalloc((void **)&tt.d_starts, starts.size() * 4));
+		PXZ_HIP(h, hipMalloc((void **)&tt.d_sizes, sizes.size() * 4));
+		PXZ_HIP(h, hipMalloc((void **)&tt.d_coeffs, coeffs.size() * 2));
+		PXZ_HIP(h, hipMemcpy(tt.d_dir, dir.data(), dir.size() * sizeof(pxz::TreeAxisEntry), hipMemcpyHostToDevice));
+		PXZ_HIP(h, hipMemcpy(tt.d_starts, starts.data(), starts.size() * 4, hipMemcpyHostToDevice));
+		PXZ_HIP(h, hipMemcpy(tt.d_sizes, sizes.data(), sizes.size() * 4, hipMemcpyHostToDevice));
+		PXZ_HIP(h, hipMemcpy(tt.d_coeffs, coeffs.data(), coeffs.size() * 2, hipMemcpyHostToDevice));
+		it = h->tree_tables.emplace(key, tt).first;
+	}
+	const TreeTables &tt = it->second;
+	// ---- level 0: the frame's own grid (split.rs:37-61)
+	uint32_t cols, rows;
+	pxz_grid(frames->width, frames->height, levels[0].first, levels[0].second, &cols, &rows);
+	if ((uint64_t)cols * rows * frames->n_frames > 0x0fffffffull) return fail(h, PXZ_ERR_UNSUPPORTED, "too many tiles");
+	uint32_t n = cols * rows * frames->n_frames;
+	{
+		std::vector<pxz::TreeRect> r0(n);
+		size_t i = 0;
+		for (uint32_t f = 0; f < frames->n_frames; ++f)
+			for (uint32_t ty = 0; ty < rows; ++ty)
+				for (uint32_t tx = 0; tx < cols; ++tx, ++i) {
+					r0[i].x = tx * levels[0].first;
+					r0[i].y = ty * levels[0].second;
+					r0[i].w = (uint16_t)std::min(levels[0].first, frames->width - r0[i].x);
+					r0[i].h = (uint16_t)std::min(levels[0].second, frames->height - r0[i].y);
+					r0[i].frame = f;
+				}
+		if ((rc = ensure(h, h->tree_rects[0], (size_t)n * sizeof(pxz::TreeRect))) != PXZ_OK) return rc;
+		PXZ_HIP(h, hipMemcpyAsync(h->tree_rects[0].ptr, r0.data(), (size_t)n * sizeof(pxz::TreeRect), hipMemcpyHostToDevice, h->stream));
+		PXZ_HIP(h, hipStreamSynchronize(h->stream));  // (r0 leaves scope)
+	}
+	if ((rc = ensure(h, h->tree_count, 64)) != PXZ_OK) return rc;
+	pxz::TreeRectArgs a{};
+	a.src = d_pixels;
+	a.dst = d_out_rgba;
+	a.src_frame_stride = src_stride;
+	a.dst_frame_stride = dst_stride;
+	a.src_pitch = frames->pitch_bytes;
+	a.dst_pitch = out_pitch_bytes;
+	a.channels = frames->channels;
+	a.filter_down = p.filter;
+	a.filter_up = filter_upscale;
+	a.dir = tt.d_dir;
+	a.n_dir = tt.n_dir;
+	a.starts = tt.d_starts;
+	a.sizes = tt.d_sizes;
+	a.coeffs = tt.d_coeffs;
+	std::memcpy(a.thresholds, h->thresholds, sizeof a.thresholds);
+	for (size_t l = 0; l < levels.size() && n != 0; ++l) {
+		const bool leaf_next = l + 1 == levels.size();
+		const uint32_t nbw = levels[l].first >> 1, nbh = levels[l].second >> 1;
+		// every tile of this level may go on: (ceil(bw / (bw >> 1)))^2 children each at most
+		const uint64_t per_tile = leaf_next ? 0 : (uint64_t)((levels[l].first + nbw - 1) / nbw) * ((levels[l].second + nbh - 1) / nbh);
+		const uint64_t cap = per_tile * n;
+		if (cap > 0x7fffffffull) return fail(h, PXZ_ERR_UNSUPPORTED, "too many tiles");
+		DeviceBuffer &cur = h->tree_rects[l & 1], &nxt = h->tree_rects[(l + 1) & 1];
+		if (!leaf_next && (rc = ensure(h, nxt, (size_t)cap * sizeof(pxz::TreeRect))) != PXZ_OK) return rc;
+		PXZ_HIP(h, hipMemsetAsync(h->tree_count.ptr, 0, 4, h->stream));
+		a.rects = (const pxz::TreeRect *)cur.ptr;
+		a.n_rects = n;
+		a.threshold = std::fabs(threshold);
+		a.positive = (l == 0 ? threshold >= 0.0f : true) ? 1u : 0u;  // tree.rs:37-38: the recursion passes |threshold| on
+		a.next_bw = nbw;
+		a.next_bh = nbh;
+		a.next_is_leaf = leaf_next ? 1u : 0u;
+		a.next_rects = leaf_next ? nullptr : (pxz::TreeRect *)nxt.ptr;
+		a.next_count = (uint32_t *)h->tree_count.ptr;
+		a.next_capacity = (uint32_t)cap;
+		PXZ_HIP(h, pxz::launch_tree_rects(a, h->stream));
+		if (leaf_next) break;
+		uint32_t count = 0;
+		PXZ_HIP(h, hipMemcpyAsync(&count, h->tree_count.ptr, 4, hipMemcpyDeviceToHost, h->stream));
+		PXZ_HIP(h, hipStreamSynchronize(h->stream));
+		if (count > cap) return fail(h, PXZ_ERR_HIP, "tree::process: %u tiles for a list of %llu", count, (unsigned long long)cap);
+		n = count;
+	}
+	return PXZ_OK;
+}
+}  // namespace
+
 int pxz_tree_process_frames_device(pxz_handle *h, const pxz_frames *frames, const pxz_params *params, uint32_t filter_upscale,
                                    float threshold, uint32_t min_block_w, uint32_t min_block_h, const uint8_t *d_pixels,
                                    uint8_t *d_out_rgba, uint32_t out_pitch_bytes, uint64_t out_frame_stride_bytes)
@@ -1133,14 +1306,19 @@ int pxz_tree_process_frames_device(pxz_handle *h, const pxz_frames *frames, cons
 	const uint32_t mbw = min_block_w > 4u ? min_block_w : 4u, mbh = min_block_h > 4u ? min_block_h : 4u;
 	std::vector<std::pair<uint32_t, uint32_t>> levels;
 	for (uint32_t bw = p.block_w, bh = p.block_h; bw > mbw && bh > mbh; bw >>= 1, bh >>= 1) levels.emplace_back(bw, bh);
-	// A level's tiles are the children of the level before: they form that level's regular grid over the frame as long as
-	// a block is exactly two of the next (the recursion splits every tile from its own corner).
-	for (size_t l = 0; l + 1 < levels.size(); ++l)
-		if ((levels[l].first & 1u) || (levels[l].second & 1u))
-			return fail(h, PXZ_ERR_UNSUPPORTED, "tree::process on the device needs block sizes that halve evenly down to the minimum (%ux%u does not)",
-			            levels[l].first, levels[l].second);
 	const uint64_t src_stride = frames->n_frames > 1 ? frames->frame_stride_bytes : (uint64_t)frames->pitch_bytes * frames->height;
 	const uint64_t dst_stride = frames->n_frames > 1 ? out_frame_stride_bytes : (uint64_t)out_pitch_bytes * frames->height;
+	// A level's tiles are the children of the level before: they form that level's regular grid over the frame as long as
+	// a block is exactly two of the next (the recursion splits every tile from its own corner), and the per-level passes
+	// below need tiles that fit the fused kernel's LDS image.  Anything else -- 50 -> 25 -> 12, the 128-px blocks of
+	// src/bin/tree.rs:6 -- goes level by level over lists of rectangles (round 3).
+	bool regular = !pxz::knobs().tree_rects;
+	for (size_t l = 0; l + 1 < levels.size(); ++l)
+		if ((levels[l].first & 1u) || (levels[l].second & 1u)) regular = false;
+	if (!levels.empty() && (levels[0].first > 64u || levels[0].second > 64u)) regular = false;
+	if (!regular && !levels.empty())
+		return tree_process_rects(h, frames, p, filter_upscale, threshold, mbw, mbh, levels, d_pixels, d_out_rgba, out_pitch_bytes,
+		                          src_stride, dst_stride);
 	pxz::TreeArgs t{};
 	t.src = d_pixels;
 	t.dst = d_out_rgba;

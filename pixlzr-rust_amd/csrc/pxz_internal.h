@@ -186,7 +186,8 @@ struct Knobs {
 	bool no_native_rgb;     // PXZ_NO_NATIVE_RGB: RGB batches are widened to RGBA even where a kernel reads RGB itself
 	bool no_alpha_first;    // PXZ_NO_ALPHA_FIRST: transparent batches keep the two-kernel flow (shrink32_kernel lists, shrink32a_kernel takes the list)
 	bool no_narrow;         // PXZ_NO_NARROW: 4/2/1-px-wide outputs of 32x32 tiles keep the round-1 resample forms
-	bool oklab_v1;          // PXZ_OKLAB_V1: round-1 detector (one chain wave, two barriers per band) for 16/32-px tiles
+	bool oklab_v1;          // PXZ_OKLAB_V1: round-1 detector (one chain wave, two barriers per band; 64-px tiles parked in HBM)
+	bool tree_rects;        // PXZ_TREE_RECTS: tree::process always goes over rectangle lists (pxz_tree.hip), also where the per-level grids apply
 	int wpb;                // PXZ_WPB: waves per block of the persistent kernels (0: default)
 	int chunk_lg;           // PXZ_CHUNK_LG: log2 of the ticket run length of shrink32_kernel (-1: default)
 };
@@ -306,6 +307,44 @@ struct TreeArgs {
 	float threshold;              // |threshold|
 	uint32_t positive;            // tree.rs:37: threshold >= 0 (deeper levels: always)
 	uint32_t last;                // no further level: a tile that fails the test keeps its pixels (tree.rs:34-36)
+};
+
+// tree::process on rectangle lists (pxz_tree.hip): the tiles of one level of the recursion, wherever they lie
+struct TreeRect {
+	uint32_t x, y;      // origin in the frame
+	uint16_t w, h;
+	uint32_t frame;
+};
+// one axis table of the rectangle kernel: windows of `out` samples over `in` samples; up = 1: the table of the way back
+// (PixlzrBlock::resize with the upscale flag set, block.rs:301-306)
+struct TreeAxisEntry {
+	uint16_t in, out;
+	uint16_t up, window;
+	uint32_t precision;
+	uint32_t starts_off;   // into starts[] / sizes[] (Nearest: starts[] is the source index, no sizes / coefficients)
+	uint32_t coeff_off;    // into coeffs[]: out * window weights
+};
+struct TreeRectArgs {
+	const uint8_t *src;
+	uint8_t *dst;                  // RGBA frames
+	uint64_t src_frame_stride, dst_frame_stride;
+	uint32_t src_pitch, dst_pitch, channels;
+	const TreeRect *rects;
+	uint32_t n_rects;
+	float threshold;               // |threshold|
+	uint32_t positive;             // tree.rs:37 (deeper levels: always)
+	uint32_t next_bw, next_bh;     // block of the next level (tree.rs:73)
+	uint32_t next_is_leaf;         // ... which is not above the minimum: a tile that goes on keeps its pixels (tree.rs:34-36)
+	TreeRect *next_rects;
+	uint32_t *next_count;
+	uint32_t next_capacity;
+	uint32_t filter_down, filter_up;
+	const TreeAxisEntry *dir;
+	uint32_t n_dir;
+	const int32_t *starts;
+	const int32_t *sizes;
+	const int16_t *coeffs;
+	float thresholds[kNumThresholds];
 };
 
 struct SynthArgs {

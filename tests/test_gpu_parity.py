@@ -817,9 +817,33 @@ def test_tree_process_edge_cases(gpu, product, oracle):
     out = gpu.tree_process_frames_device(frames, 64, 64, 0.02, 16, 16).cpu().numpy()[0]
     assert (out == oracle.tree_process_image(f, 64, 64, 0.02, 16, 16)).all()
     with pytest.raises(product.PxzError) as e:
-        gpu.tree_process_frames_device(frames, 50, 50, 0.05)  # 50 -> 25 -> 12: 25 does not halve evenly
+        gpu.tree_process_frames_device(frames, 160, 160, 0.05)  # blocks above 128 px are refused
     assert e.value.code == -5
-    oracle.tree_process_image(f, 50, 50, 0.05)  # (the oracle takes any geometry)
+
+
+@pytest.mark.parametrize("c,dist", [(4, 0), (4, 1), (3, 0)])
+@pytest.mark.parametrize("bw,bh,down,up", [(128, 128, 4, 0), (50, 50, 4, 0), (50, 50, 2, 4), (100, 36, 1, 2), (128, 96, 3, 3), (37, 61, 4, 1)])
+def test_tree_process_on_any_geometry(gpu, oracle, c, dist, bw, bh, down, up):
+    """tree::process where the per-level grids do not exist (round 3, pxz_tree.hip): the 128-px blocks src/bin/tree.rs:6
+    calls it with, and blocks whose halvings go odd (50 -> 25 -> 12 + 12 + 1: every tile is cut from its own corner,
+    tree.rs:70-79), ragged frames, every filter pair, RGBA opaque / transparent and RGB -- against the oracle's recursion,
+    pixel for pixel."""
+    frames = gpu.synth_frames_device(2, 300, 428, c, first_frame=23, dist=dist)
+    f = frames.cpu().numpy()
+    mixtures = 0
+    for thr in (0.0, 0.012, 0.04, 0.15, 50.0, -0.04):
+        out = gpu.tree_process_frames_device(frames, bw, bh, thr, 4, 4, down, up).cpu().numpy()
+        for n in range(2):
+            exp = oracle.tree_process_image(f[n], bw, bh, thr, 4, 4, down, up)
+            bad = (out[n] != exp).any(axis=2)
+            assert not bad.any(), f"{bw}x{bh} thr {thr} frame {n}: {int(bad.sum())} pixels differ, first at {np.argwhere(bad)[0]}"
+            src = np.concatenate([f[n], np.full(f[n].shape[:2] + (1,), 255, np.uint8)], axis=2) if c == 3 else f[n]
+            mixtures += int(bool((exp != src).any()) and bool((exp == src).all(axis=2).any()))
+    assert mixtures  # some threshold gave a real mixture of pixelised tiles and tiles that kept their pixels
+    # a larger minimum ends the recursion earlier
+    out = gpu.tree_process_frames_device(frames, bw, bh, 0.03, 20, 9, down, up).cpu().numpy()
+    for n in range(2):
+        assert (out[n] == oracle.tree_process_image(f[n], bw, bh, 0.03, 20, 9, down, up)).all()
 
 
 @pytest.mark.parametrize("c,mode,factor,bs", [(4, 1, 8.0, 32), (3, 0, 0.5, 64), (4, 0, 1.0, 16)])
