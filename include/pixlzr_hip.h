@@ -135,12 +135,21 @@ int pxz_shrink_image_packed(pxz_handle *h, const uint8_t *pixels, uint32_t width
                             float *block_value, uint32_t *out_w, uint32_t *out_h, uint64_t *packed_len);
 int pxz_fetch_packed(pxz_handle *h, uint8_t *dst, uint64_t capacity);
 
+/* Releases every scratch buffer the handle has grown (inputs, tile slots, worklists, the rings of the pipelined list
+ * calls, the writer's scratch ...) after finishing what is queued on its stream; tables stay.  The next call allocates
+ * what it needs again.  Nothing in the reference corresponds to it (its Vecs are freed when a Pixlzr is dropped). */
+int pxz_trim(pxz_handle *h);
+
 /* pxz_shrink_image / pxz_shrink_image_packed over a LIST of equally sized host images (a folder of frames, what
  * src/bin/whole-folder.rs:69-117 loops over): outputs as for the single-image calls, one set of caller-allocated arrays
  * per image (out_pixels may be NULL, or hold NULLs, for detector + dimensions only; packed[k] needs packed_capacity
  * bytes -- width*height*channels always suffices -- and packed_len[k] receives the stream's length).  The images go
  * through a three-stage pipeline on the device -- upload of image k+1, kernels of image k, download of image k-1 at the
- * same time -- so that a list costs about one PCIe direction per image rather than the sum of both.  Synchronous. */
+ * same time -- so that a list costs about one PCIe direction per image rather than the sum of both.  Synchronous.
+ * On an error the arrays of the images that were finished before it are complete, those of later images are untouched
+ * or partly written, and packed_len[k] is written for every image that was downloaded even when the call then returns
+ * PXZ_ERR_BUFFER_TOO_SMALL (it names the capacity that would have sufficed).  The three sets of device buffers of
+ * the pipeline stay with the handle for the next list (about 1.2 GB for 8K RGBA): pxz_trim releases them. */
 int pxz_shrink_images(pxz_handle *h, const uint8_t *const *pixels, uint32_t n_images, uint32_t width, uint32_t height,
                       uint32_t channels, uint32_t pitch_bytes, uint32_t block_w, uint32_t block_h, uint32_t mode,
                       uint32_t filter, float factor, float *const *block_value, uint32_t *const *out_w,

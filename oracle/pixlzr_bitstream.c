@@ -152,12 +152,19 @@ static int qoi_decode_body(const uint8_t *body, size_t len, uint32_t *w, uint32_
 				px[1] = *p++;
 				px[2] = *p++;
 			} else if (b1 == QOI_OP_RGBA) {
-				if (*c == 3)
-					return -4; /* the crate's 3-channel decoder has no arm for 0xff: malformed */
-				px[0] = *p++;
-				px[1] = *p++;
-				px[2] = *p++;
-				px[3] = *p++;
+				if (*c == 3) {
+					/* qoi 0.4.1 decode_impl_slice<3, RGBA = false> [from memory: the crate's source is not in this environment]: the
+					 * RGBA arm is guarded by the channel count, so 0xff falls into the catch-all arm, which fails only with
+					 * fewer than 8 bytes left (never in front of the end marker) and otherwise consumes nothing: the
+					 * unchanged pixel is stored in the index and written, and the same byte is met again by every pixel
+					 * that follows -- the rest of the tile repeats the last pixel, the decode succeeds. */
+					p--;
+				} else {
+					px[0] = *p++;
+					px[1] = *p++;
+					px[2] = *p++;
+					px[3] = *p++;
+				}
 			} else if ((b1 & 0xc0) == QOI_OP_INDEX) {
 				memcpy(px, index[b1], 4);
 			} else if ((b1 & 0xc0) == QOI_OP_DIFF) {

@@ -19,7 +19,7 @@ EXPORTED_SYMBOLS = [
     "pxz_synchronize", "pxz_grid", "pxz_shrink_image", "pxz_shrink_image_packed", "pxz_fetch_packed", "pxz_shrink_images", "pxz_shrink_images_packed", "pxz_shrink_frames_device", "pxz_lod_frames_device", "pxz_oklab_pixels_device",
     "pxz_pack_tiles_device", "pxz_encode_frames_device", "pxz_encode_container", "pxz_qoi_encode", "pxz_qoi_bound", "pxz_synth_frames_device", "pxz_axis_table",
     "pxz_enable_timing", "pxz_last_kernel_ms", "pxz_last_first_kernel_ms",
-    "pxz_debug_read_work", "pxz_expand_frames_device", "pxz_expand_image", "pxz_decode_frames_device", "pxz_decode_file", "pxz_decode_status", "pxz_process_frames_device", "pxz_tree_process_frames_device",
+    "pxz_debug_read_work", "pxz_expand_frames_device", "pxz_expand_image", "pxz_decode_frames_device", "pxz_decode_file", "pxz_decode_status", "pxz_process_frames_device", "pxz_tree_process_frames_device", "pxz_trim",
 ]
 
 STATUS = {0: "PXZ_OK", -1: "PXZ_ERR_INVALID_ARG", -2: "PXZ_ERR_NO_DEVICE", -3: "PXZ_ERR_HIP",
@@ -91,6 +91,8 @@ def load_library():
     L.pxz_set_stream.argtypes = [vp, vp]
     L.pxz_synchronize.restype = C.c_int
     L.pxz_synchronize.argtypes = [vp]
+    L.pxz_trim.restype = C.c_int
+    L.pxz_trim.argtypes = [vp]
     L.pxz_grid.restype = C.c_int
     L.pxz_grid.argtypes = [u32] * 4 + [C.POINTER(u32)] * 2
     L.pxz_shrink_image.restype = C.c_int
@@ -234,6 +236,10 @@ class Handle:
     def use_torch_stream(self):
         import torch
         self.set_stream(torch.cuda.current_stream(self.device_id).cuda_stream)
+
+    def trim(self):
+        """pxz_trim: the handle's scratch buffers go back to the device (the next call grows them again)"""
+        self._check(self._L.pxz_trim(self._h))
 
     def synchronize(self):
         self._check(self._L.pxz_synchronize(self._h))

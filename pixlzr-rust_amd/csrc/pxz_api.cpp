@@ -14,6 +14,7 @@
 #include <cstring>
 #include <map>
 #include <set>
+#include <system_error>
 #include <string>
 #include <tuple>
 #include <vector>
@@ -873,6 +874,26 @@ void pxz_destroy(pxz_handle *h)
 
 const char *pxz_last_error(const pxz_handle *h) { return h ? h->error.c_str() : "null handle"; }
 
+int pxz_trim(pxz_handle *h)
+{
+	if (!h) return PXZ_ERR_INVALID_ARG;
+	PXZ_HIP(h, hipSetDevice(h->device));
+	PXZ_HIP(h, hipStreamSynchronize(h->stream));
+	auto drop = [](DeviceBuffer &b) {
+		if (b.ptr) (void)hipFree(b.ptr);
+		b.ptr = nullptr;
+		b.cap = 0;
+	};
+	for (DeviceBuffer *b : {&h->in, &h->val, &h->ow, &h->oh, &h->out, &h->sums, &h->chunks, &h->work, &h->qscratch, &h->qmeta, &h->status, &h->dmeta, &h->okscratch, &h->rgba, &h->slots4, &h->pk, &h->pkoff, &h->tree, &h->tree_rects[0], &h->tree_rects[1], &h->tree_count})
+		drop(*b);
+	for (int i = 0; i < pxz_handle::kRing; ++i)
+		for (DeviceBuffer *b : {&h->ring_in[i], &h->ring_val[i], &h->ring_ow[i], &h->ring_oh[i], &h->ring_out[i], &h->ring_pk[i], &h->ring_pkoff[i]})
+			drop(*b);
+	h->packed_len = 0;
+	h->work_ready = false;  // (the worklist counters went with their buffer)
+	return PXZ_OK;
+}
+
 int pxz_set_stream(pxz_handle *h, void *hip_stream)
 {
 	if (!h) return PXZ_ERR_INVALID_ARG;
@@ -1301,6 +1322,9 @@ int pxz_tree_process_frames_device(pxz_handle *h, const pxz_frames *frames, cons
 	int rc = check_frames(h, frames, &p);
 	if (rc != PXZ_OK) return rc;
 	if ((uint64_t)out_pitch_bytes < (uint64_t)frames->width * 4u) return fail(h, PXZ_ERR_INVALID_ARG, "output pitch smaller than a row");
+	// (the kernels store whole RGBA pixels)
+	if ((reinterpret_cast<uintptr_t>(d_out_rgba) & 3u) != 0 || (out_pitch_bytes & 3u) != 0 || (frames->n_frames > 1 && (out_frame_stride_bytes & 3u) != 0))
+		return fail(h, PXZ_ERR_INVALID_ARG, "the RGBA output must be 4-byte aligned (pointer, pitch and frame stride)");
 	PXZ_HIP(h, hipSetDevice(h->device));
 	// the levels of the recursion (tree.rs:32-36): block sizes halve while both stay above the minimum (at least 4)
 	const uint32_t mbw = min_block_w > 4u ? min_block_w : 4u, mbh = min_block_h > 4u ? min_block_h : 4u;
@@ -1328,8 +1352,16 @@ int pxz_tree_process_frames_device(pxz_handle *h, const pxz_frames *frames, cons
 	t.dst_pitch = out_pitch_bytes;
 	t.channels = frames->channels;
 	if (levels.empty()) {
-		// tree.rs:34-36: the image comes back as it is (as RGBA here).  One "level" of whole-image tiles, none pixelised.
-		levels.emplace_back(frames->width, frames->height);
+		// tree.rs:34-36: the image comes back as it is (as RGBA here): a plain 2-D copy / widening of the frames
+		if (frames->channels == 4) {
+			for (uint32_t f = 0; f < frames->n_frames; ++f)
+				PXZ_HIP(h, hipMemcpy2DAsync(d_out_rgba + (size_t)f * dst_stride, out_pitch_bytes, d_pixels + (size_t)f * src_stride, frames->pitch_bytes,
+				                            (size_t)frames->width * 4u, frames->height, hipMemcpyDeviceToDevice, h->stream));
+		} else {
+			pxz::WidenArgs wa{d_pixels, d_out_rgba, src_stride, dst_stride, frames->pitch_bytes, out_pitch_bytes, frames->width, frames->height, frames->n_frames};
+			PXZ_HIP(h, pxz::launch_widen(wa, h->stream));
+		}
+		return PXZ_OK;
 	}
 	uint32_t prev_cols = 0, prev_tpf = 0;
 	size_t max_tiles = 0;
@@ -1674,7 +1706,7 @@ static int shrink_images_impl(pxz_handle *h, const uint8_t *const *pixels, uint3
 	bool stop = false;
 	const int device = h->device;
 
-	std::thread uploader([&] {
+	auto upload_fn = [&] {
 		(void)hipSetDevice(device);
 		for (uint32_t k = 0; k < n_images; ++k) {
 			{
@@ -1696,8 +1728,8 @@ static int shrink_images_impl(pxz_handle *h, const uint8_t *const *pixels, uint3
 			cv.notify_all();
 			if (stop) return;
 		}
-	});
-	std::thread downloader([&] {
+	};
+	auto download_fn = [&] {
 		(void)hipSetDevice(device);
 		for (uint32_t k = 0; k < n_images; ++k) {
 			{
@@ -1730,7 +1762,23 @@ static int shrink_images_impl(pxz_handle *h, const uint8_t *const *pixels, uint3
 			cv.notify_all();
 			if (stop) return;
 		}
-	});
+	};
+	// (a thread that cannot be started must not take the process down: nothing may be thrown across the C boundary)
+	std::thread uploader, downloader;
+	try {
+		uploader = std::thread(upload_fn);
+		downloader = std::thread(download_fn);
+	} catch (const std::system_error &) {
+		{
+			std::lock_guard<std::mutex> lk(m);
+			stop = true;
+		}
+		cv.notify_all();
+		if (uploader.joinable()) uploader.join();
+		(void)hipStreamDestroy(up);
+		(void)hipStreamDestroy(down);
+		return fail(h, PXZ_ERR_HIP, "could not start the copy threads of the pipelined boundary");
+	}
 	// this thread: the kernels, on the handle's stream
 	rc = PXZ_OK;
 	for (uint32_t k = 0; k < n_images && rc == PXZ_OK; ++k) {

@@ -925,8 +925,8 @@ __global__ void __launch_bounds__(64 * kQoiWaves) qoi_decode_kernel(const Decode
 			new_run = 0u;
 		}
 		if (b1 == 0xffu) {  // QOI_OP_RGBA
-			cand = next4;
-			used = 5u;
+			cand = C == 4 ? next4 : px;
+			used = C == 4 ? 5u : 0u;  // (3 channels: see below)
 			new_run = 0u;
 		}
 		px = take ? cand : px;
@@ -934,10 +934,13 @@ __global__ void __launch_bounds__(64 * kQoiWaves) qoi_decode_kernel(const Decode
 		// The qoi crate stores the pixel in the index after RGB / RGBA / DIFF / LUMA ops only: its RUN and INDEX arms go
 		// on to the next op before the store (an INDEX op's pixel is in its slot already; a RUN's is too, except when the
 		// stream OPENS with a run of the implicit opaque black, which is never stored -- the encoder's run-of-one quirk
-		// has the same root).  A 3-channel stream has no RGBA op: the crate's decoder for 3 channels does not match 0xff,
-		// which ends in its error arm -- the record is flagged as malformed.
+		// has the same root).  A 3-channel stream has no RGBA op: the crate's 3-channel decoder does not match 0xff (its
+		// RGBA arm is guarded by the channel count) and falls into its catch-all arm, which fails only when fewer than
+		// eight bytes are left -- never in front of the end marker -- and otherwise consumes NOTHING, stores the unchanged
+		// pixel in the index and writes it: the same byte is met again by every pixel that follows, so the rest of the tile
+		// repeats the last pixel and the decode succeeds [qoi 0.4.1 decode_impl_slice, from memory: the crate's source is
+		// not in this environment; round 2 flagged such a record as malformed].
 		const bool is_run_op = tag == 0xc0u && b1 < 0xfeu;
-		if (C == 3 && take && b1 == 0xffu) starved = true;
 		index[(take && !is_run_op) ? qoi_hash(px) : 64u][lane] = px;
 		const uint32_t step = take ? used : 0u;
 		left = left > step ? left - step : 0u;

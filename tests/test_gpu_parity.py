@@ -752,7 +752,8 @@ def _one_tile_file(w, h, c, ops):
 def test_decoder_on_streams_the_crate_encoder_never_writes(gpu, oracle):
     """The qoi 0.4.1 decoder stores a pixel in its index after RGB / RGBA / DIFF / LUMA ops only: a stream that OPENS
     with a run of the implicit opaque black and later names that slot with an INDEX op gets the zero pixel there, not
-    opaque black.  And a 3-channel stream has no RGBA op: 0xff is malformed.  Oracle and device decoder agree."""
+    opaque black.  And a 3-channel stream has no RGBA op: at 0xff the crate's decoder stops consuming and repeats its pixel.
+    Oracle and device decoder agree."""
     import torch
     # RUN of 3 (opaque black x3), INDEX 53 (= hash of opaque black: (255 * 11) % 64) -> zero pixel, then RGB
     ops = [0xc0 | 2, 53, 0xfe, 10, 20, 30, 0xc0 | 0]
@@ -769,15 +770,18 @@ def test_decoder_on_streams_the_crate_encoder_never_writes(gpu, oracle):
         torch.cuda.synchronize()
         assert gpu.decode_status() == 0
         assert (slots.cpu().numpy()[0, 0, : 6 * c].reshape(6, c) == exp).all()
-    # an RGBA op in a 3-channel stream: flagged, the tile gets size 0x0
-    raw = _one_tile_file(2, 1, 3, [0xff, 1, 2, 3, 4, 0xc0])
-    with pytest.raises(Exception):
-        oracle.decode_container(raw)
+    # an RGBA op byte in a 3-channel stream: the crate's 3-channel decoder has no arm for it, consumes nothing and repeats
+    # the pixel it holds for the rest of the tile (qoi 0.4.1's catch-all arm, restated from memory): RGB (9, 8, 7), then 0xff
+    raw = _one_tile_file(3, 2, 3, [0xfe, 9, 8, 7, 0xff, 1, 2, 3, 4, 0xc0])
+    d = oracle.decode_container(raw)
+    exp = d["slots"][0][: 6 * 3].reshape(6, 3)
+    assert (exp == np.array([9, 8, 7], np.uint8)).all()
     files = torch.frombuffer(bytearray(raw), dtype=torch.uint8).cuda()
     offs = torch.tensor([0, len(raw)], dtype=torch.int64).cuda()
-    vals, ow, oh, slots = gpu.decode_frames_device(files, offs, (1, 1, 2, 3), 2, 1)
+    vals, ow, oh, slots = gpu.decode_frames_device(files, offs, (1, 2, 3, 3), 3, 2)
     torch.cuda.synchronize()
-    assert gpu.decode_status() == 2 and int(ow[0, 0]) == 0 and int(oh[0, 0]) == 0
+    assert gpu.decode_status() == 0 and int(ow[0, 0]) == 3 and int(oh[0, 0]) == 2
+    assert (slots.cpu().numpy()[0, 0, : 6 * 3].reshape(6, 3) == exp).all()
 
 
 # ---- legacy quad-tree filter: tree::process / tree::process_custom --------------------------------
@@ -844,6 +848,21 @@ def test_tree_process_on_any_geometry(gpu, oracle, c, dist, bw, bh, down, up):
     out = gpu.tree_process_frames_device(frames, bw, bh, 0.03, 20, 9, down, up).cpu().numpy()
     for n in range(2):
         assert (out[n] == oracle.tree_process_image(f[n], bw, bh, 0.03, 20, 9, down, up)).all()
+
+
+def test_trim_releases_and_the_handle_goes_on(gpu, oracle):
+    """pxz_trim between calls: the scratch buffers (and the rings of the list calls) are given back, results do not change."""
+    imgs = [oracle.synth_frame(256, 160, 4, 70 + k, 0) for k in range(4)]
+    before = gpu.shrink_images(imgs, 32, 32, 1, 4, 8.0)
+    gpu.trim()
+    after = gpu.shrink_images(imgs, 32, 32, 1, 4, 8.0)
+    for k, img in enumerate(imgs):
+        exp = oracle.shrink_image(img, 32, 32, 1, 4, 8.0)
+        assert_same_tiles(before[k], exp, 4, f"before trim, image {k}")
+        assert_same_tiles(after[k], exp, 4, f"after trim, image {k}")
+    gpu.trim()
+    got = gpu.shrink_image(imgs[0], 32, 32, 0, 4, 1.0)
+    assert_same_tiles(got, oracle.shrink_image(imgs[0], 32, 32, 0, 4, 1.0), 4, "after trim")
 
 
 @pytest.mark.parametrize("c,mode,factor,bs", [(4, 1, 8.0, 32), (3, 0, 0.5, 64), (4, 0, 1.0, 16)])
