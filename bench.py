@@ -39,7 +39,7 @@ ENCODE_MODE = "shrink_directionally+encode_to_vec"
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--event-stride", type=int, default=8,
-                    help="runs of >= 64 steps: every n-th timed step is bracketed by HIP events (shorter runs: every step)")
+                    help="runs of >= 64 steps: every n-th timed step is bracketed by HIP events (16..63 steps: every fourth, shorter runs: every step)")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=500)
     ap.add_argument("--warmup", type=int, default=100,
@@ -122,7 +122,8 @@ def run_mode(args, handle, frames, mode_name, world, dist_mod, with_writer=False
     if world > 1:
         dist_mod.barrier()
     torch.cuda.synchronize()
-    stride = 1 if steps < 64 else max(1, args.event_stride)
+    # (three event records cost a step ~2 % of its wall clock: also short runs carry them on every fourth step only)
+    stride = 1 if steps < 16 else (4 if steps < 64 else max(1, args.event_stride))
     handle.enable_timing(True, every=stride)  # which steps of the timed region carry the events (~2 us each)
     t0 = time.perf_counter()
     for _ in range(steps):
@@ -345,13 +346,69 @@ def cpu_baseline(args, primary, names):
 
 
 def load_traffic(mode_name):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes of this same command, if present."""
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (tools/pmc_traffic.sh: one flow per pass, every kernel of
+    the library counted), if present."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
         with open(path) as f:
             return json.load(f).get(mode_name)
     except Exception:
         return None
+
+
+def load_flow_traffic(flow):
+    """the same file's per-flow record (dir32, by32, by64, dir64, by16, dir16, enc32): bytes per step and per kernel"""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            rec = json.load(f)["flows"][flow]
+        return {"hbm_bytes_per_step": rec["hbm_bytes_per_step"], "traffic_over_algorithmic": rec["traffic_over_algorithmic"],
+                "kernels": {k: v["hbm_bytes_per_step"] for k, v in rec["kernels"].items()}}
+    except Exception:
+        return None
+
+
+def load_sq(kernel_prefix):
+    """vector-ALU figures of a kernel from the committed SQ counter passes (profiles/sq_summary.json, tools/sq_summary.py)"""
+    try:
+        with open(os.path.join(ROOT, "profiles", "sq_summary.json")) as f:
+            for name, rec in json.load(f)["kernels"].items():
+                if name.startswith(kernel_prefix):
+                    return dict(rec, kernel=name)
+    except Exception:
+        pass
+    return None
+
+
+def mode_roofline(name, r):
+    """roofline object of a mode other than the headline: the step's algorithmic bytes over the time of ALL its kernels (by
+    events), the counter bytes of the committed PMC passes beside them, and -- where the dominant kernel is not bound by
+    bytes at all -- what it is bound by"""
+    if name == ENCODE_MODE:
+        ach = r["achieved_gbps"]
+        out = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS,
+               "traffic": load_traffic(ENCODE_MODE), "algorithmic_bytes_per_launch": r["algo_bytes_per_launch"],
+               "time_ms": r["ms_per_step"], "time_is": "wall clock of the step (shrink + writer)",
+               "kernels": "shrink32_kernel<1> + qoi_bin_* + qoi_tiles_kernel<4> + pack_scan_* + qoi_splice_* + qoi_headers_kernel",
+               "writer_traffic": load_flow_traffic("enc32"),
+               "what_bounds_it": "qoi_tiles_kernel: a lane per segment of 64..128 pixels, ~100 vector instructions per pixel at 9 waves per CU "
+                                 "(its 16 KB index table per wave fills LDS); its 8-byte piece stores reach HBM as partial sectors (see writer_traffic)",
+               "sq": load_sq("qoi_tiles_kernel")}
+        return out
+    ach = r["achieved_gbps_all_kernels"]
+    out = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS,
+           "traffic": load_traffic(name), "algorithmic_bytes_per_launch": r["algo_bytes_per_launch"],
+           "time_ms": r["step_kernels_ms"], "time_is": "all kernels of the step, HIP events",
+           "dominant_kernel_ms": r["dominant_kernel_ms"]}
+    if name == "shrink_by":
+        out["kernels"] = "oklab2_kernel<32> (dominant) + shrink32_kernel<0> + worklist kernel"
+        out["flow_traffic"] = load_flow_traffic("by32")
+        out["what_bounds_it"] = ("vector-instruction issue, not bytes: the detector reproduces glibc's cbrtf bit for bit (three per pixel, f64 path) "
+                                 "and replays the reference's sequential f32 sums; sq.valu_busy is the share of SIMD cycles with a vector "
+                                 "instruction executing")
+        out["sq"] = load_sq("oklab2_kernel<32")
+    return out
+
+
 
 
 def main():
@@ -407,7 +464,8 @@ def main():
                     handle.shrink_frames_device(frames, bs, bs, pxz_mode, args.filter, factor, out=out)
                 ms = handle.last_kernel_ms()
                 handle.enable_timing(False)
-                others[f"{bs}x{bs} {name}"] = {"kernel_ms": ms, "mp_per_s": nf * args.width * args.height / 1e6 / (ms * 1e-3)}
+                others[f"{bs}x{bs} {name}"] = {"kernel_ms": ms, "mp_per_s": nf * args.width * args.height / 1e6 / (ms * 1e-3),
+                                               "traffic": load_flow_traffic(("dir" if pxz_mode == 1 else "by") + str(bs))}
                 del out
 
     line = None
@@ -443,6 +501,9 @@ def main():
                                    if primary == "shrink_directionally" else "pxz::oklab2_kernel<32> + pxz::shrink32_kernel<0, true>"},
             "modes": {k: {kk: v[kk] for kk in keep if kk in v} for k, v in results.items()},
         }
+        for k, v in results.items():
+            if k != primary:
+                line["modes"][k]["roofline"] = mode_roofline(k, v)
         if others:
             line["other_tile_sizes"] = others
         if world == 1 and not args.no_cpu_baseline:
