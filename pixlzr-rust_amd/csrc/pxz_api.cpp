@@ -605,6 +605,7 @@ int timed_launch(pxz_handle *h, pxz::ShrinkArgs &a, uint32_t channels, float *va
 	// (one dword in pinned memory, written by the worklist kernel).  Past ~2000 tiles shrink32a_kernel pays for
 	// its launch.  Either way the results are the same; only the kernel that produces them differs.
 	a.stats = h->dev_stats;
+	a.expect_listed = h->host_stats ? const_cast<volatile uint32_t *>(h->host_stats)[1] : 0xffffffffu;
 	if (!a.alpha_kernel && h->host_stats && *const_cast<volatile uint32_t *>(h->host_stats) >= 2048u && !pxz::knobs().no_alpha_kernel)
 		a.alpha_kernel = 1;
 	// ... and past half of the tiles the lean kernel would only read, test and list them: the four-plane kernel goes first
@@ -820,6 +821,7 @@ int pxz_create(int device_id, pxz_handle **out)
 	void *hs = nullptr, *ds = nullptr;
 	if (hipHostMalloc(&hs, 64, hipHostMallocMapped) == hipSuccess) {
 		std::memset(hs, 0, 64);
+		static_cast<uint32_t *>(hs)[1] = 0xffffffffu;  // listed tiles of the last launch: unknown
 		if (hipHostGetDevicePointer(&ds, hs, 0) == hipSuccess) {
 			h->host_stats = static_cast<uint32_t *>(hs);
 			h->dev_stats = static_cast<uint32_t *>(ds);

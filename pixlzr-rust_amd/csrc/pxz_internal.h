@@ -86,7 +86,8 @@ struct ShrinkArgs {
 	                         //   kernel did that itself, only the tiles of list A are left (when shrink32a_kernel took them)
 	uint32_t list_a_too;     // worklist kernel: list A (full tiles with transparency) was not taken by shrink32a_kernel
 	void *mid_event;         // host side only: hipEvent_t to record behind the first kernel of the step, or null
-	uint32_t *stats;         // pinned host dword (device address) <- number of list-A tiles of this launch; may be null
+	uint32_t *stats;         // pinned host dwords (device address) <- [0] list-A tiles, [1] all listed tiles of this launch; may be null
+	uint32_t expect_listed;  // what [1] said after the last finished launch (0xffffffff: unknown): sizes the worklist kernel's grid, nothing else
 	uint32_t *work;          // worklist: [work_slot] = count, [2..] = tile ids (null: all tiles).  The two
 	uint32_t work_slot;      //   counters alternate between launches; a launch zeroes the other one
 	float *value;            // worklist mode only: the kernel finishes its tiles itself (finish_tile) and,

@@ -560,7 +560,10 @@ __global__ void __launch_bounds__(NW == 1 ? 768 : 64 * NW) shrink_kernel(const S
 				if (threadIdx.x == 0) {
 					a.work[a.work_slot ^ 1u] = 0u;
 					a.work[kWorkA + (a.work_slot ^ 1u)] = 0u;
-					if (a.stats) *a.stats = count_a;  // steers the next launches' kernel choice (pxz_api.cpp)
+					if (a.stats) {  // steers the next launches' kernel choice and the size of this kernel's grid (pxz_api.cpp)
+						a.stats[0] = count_a;
+						a.stats[1] = count_b + count_a;
+					}
 				}
 				if (threadIdx.x < kTicketCounters) a.work[2u + kTicketCounters * (a.work_slot ^ 1u) + threadIdx.x] = 0u;
 			}
@@ -590,7 +593,10 @@ __global__ void __launch_bounds__(NW == 1 ? 768 : 64 * NW) shrink_kernel(const S
 				if (threadIdx.x == 0) {
 					a.work[a.work_slot ^ 1u] = 0u;
 					a.work[kWorkA + (a.work_slot ^ 1u)] = 0u;
-					if (a.stats) *a.stats = count_a;
+					if (a.stats) {
+						a.stats[0] = count_a;
+						a.stats[1] = count_b + count_a;
+					}
 				}
 				if (threadIdx.x < kTicketCounters) a.work[2u + kTicketCounters * (a.work_slot ^ 1u) + threadIdx.x] = 0u;
 			}
@@ -664,7 +670,16 @@ LaunchGeom plan_launch(const ShrinkArgs &a, uint32_t channels, uint32_t n_cus)
 		g.lds_bytes = wpb * tile_bytes + 16u;
 		const uint32_t per_cu = kLds / g.lds_bytes > 0 ? kLds / g.lds_bytes : 1u;
 		uint32_t resident = n_cus * (per_cu > 2u ? 2u : per_cu);
-		const uint32_t need = (a.n_tiles + wpb - 1u) / wpb;
+		uint32_t need = (a.n_tiles + wpb - 1u) / wpb;
+		// Behind shrink32_kernel (which finishes its own tiles) this kernel only walks the lists, and on most batches they are
+		// empty: 512 blocks of 12 waves and 110 KB of LDS then take 6 us to start and leave.  The grid follows what the last
+		// finished launch of the handle listed (twice that, at least 8 blocks); any grid walks any list, so only this
+		// kernel's duration depends on it.
+		if (a.work && !a.finish_scan && a.expect_listed != 0xffffffffu) {
+			const uint32_t expect = a.expect_listed < a.n_tiles ? a.expect_listed : a.n_tiles;
+			const uint32_t few = (2u * expect + wpb - 1u) / wpb + 8u;
+			if (few < need) need = few;
+		}
 		g.blocks = need < resident ? need : resident;
 	} else {
 		g.threads = 64u * nw;
