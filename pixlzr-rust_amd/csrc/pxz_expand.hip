@@ -188,7 +188,23 @@ __global__ void __launch_bounds__(256) expand_kernel(const ExpandArgs a)
 						}
 						tile_sync<1>();
 					}
-					if (need_v) {
+					// A stored tile of ONE row (40 % of the tiles of a typical frame are 2x1): every window of the way up is that
+					// row with the single weight 2^precision, and clip8((2^(p-1) + v 2^p) >> p) = v -- the vertical pass is the
+					// identity, row for row.  The horizontal result is un-premultiplied once and written to every row.
+					const bool one_row = need_v && th == 1u && (s_wy[0] >> 16) == 1u && (s_wy[1] & 0xffffu) == (1u << tab_y.precision) &&
+					                     tab_y.precision < 15u;
+					if (one_row) {
+						const uint32_t *cur = need_h ? s_tmp : s_src;
+						for (uint32_t i = lane; i < q4 * fh; i += 64u) {
+							const uint32_t oy = small_div(i, q4), q = i - oy * q4;
+							uint4 v = *reinterpret_cast<const uint4 *>(cur + 4u * q);
+							const uint32_t alpha_and = (v.x & v.y & v.z & v.w) >> 24;
+							if (__builtin_amdgcn_ballot_w64(alpha_and != 255u) != 0ull) {
+								v.x = unpremultiply(v.x); v.y = unpremultiply(v.y); v.z = unpremultiply(v.z); v.w = unpremultiply(v.w);
+							}
+							put4(q, oy, v);
+						}
+					} else if (need_v) {
 						// vertical pass: item = (4 adjacent columns, oy); rows are fw wide (fw == tw when only this pass runs)
 						const uint32_t *cur = need_h ? s_tmp : s_src;
 						const int prec = tab_y.precision;
