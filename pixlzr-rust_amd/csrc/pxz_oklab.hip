@@ -451,13 +451,19 @@ constexpr uint32_t kOk2Prod = Ok2Geom<32>::kProd;
 // read of such a register needs two wait states, which the compiler does not count for an asm statement -- s_nop 1.
 #define PXZ_QADD(Q, E, M) "v_add_f32_dpp %0, " M "%" #E M ", %0 quad_perm:[" #Q "," #Q "," #Q "," #Q "] row_mask:0xf bank_mask:0xf\n\t"
 #define PXZ_QADD4(Q, M) PXZ_QADD(Q, 1, M) PXZ_QADD(Q, 2, M) PXZ_QADD(Q, 3, M) PXZ_QADD(Q, 4, M)
+// (the quad's first lane is the chain: its own four values come in as plain adds -- 2 cycles of the SIMD each instead of the
+// 4.3 of a DPP add, profiles/r03_issue_probe.txt -- and only the other twelve through the broadcast; the other three lanes
+// add THEIR own values first and hold nothing anyone reads.  The four plain adds also are the wait states a DPP read needs
+// behind the vector instructions that have just written e0..e3.)
 template <bool ABS>
 __device__ __forceinline__ void quad_chain_add16(float &sum, float e0, float e1, float e2, float e3)
 {
 	if constexpr (ABS)
-		asm volatile("s_nop 1\n\t" PXZ_QADD4(0, "|") PXZ_QADD4(1, "|") PXZ_QADD4(2, "|") PXZ_QADD4(3, "|") : "+v"(sum) : "v"(e0), "v"(e1), "v"(e2), "v"(e3));
+		asm volatile("v_add_f32_e64 %0, |%1|, %0\n\tv_add_f32_e64 %0, |%2|, %0\n\tv_add_f32_e64 %0, |%3|, %0\n\tv_add_f32_e64 %0, |%4|, %0\n\t"
+		             PXZ_QADD4(1, "|") PXZ_QADD4(2, "|") PXZ_QADD4(3, "|") : "+v"(sum) : "v"(e0), "v"(e1), "v"(e2), "v"(e3));
 	else
-		asm volatile(PXZ_QADD4(0, "") PXZ_QADD4(1, "") PXZ_QADD4(2, "") PXZ_QADD4(3, "") : "+v"(sum) : "v"(e0), "v"(e1), "v"(e2), "v"(e3));
+		asm volatile("v_add_f32_e32 %0, %1, %0\n\tv_add_f32_e32 %0, %2, %0\n\tv_add_f32_e32 %0, %3, %0\n\tv_add_f32_e32 %0, %4, %0\n\t"
+		             PXZ_QADD4(1, "") PXZ_QADD4(2, "") PXZ_QADD4(3, "") : "+v"(sum) : "v"(e0), "v"(e1), "v"(e2), "v"(e3));
 }
 
 // C = 3 (round 2): RGB frames read directly -- a lane's two pixels are six bytes inside an aligned eight (rows are 4-byte
@@ -758,7 +764,7 @@ __global__ void __launch_bounds__(1024) oklab2_kernel(const ShrinkArgs a)
 					if (kk * (G * kRowsPerBand) < h) acc = walk(band, acc, false);
 #endif
 					if (kk == NB - 1u) {
-						s_mean[chain] = __fdiv_rn(acc, (float)((uint32_t)T * h));  // operations.rs:65-68 (h = 0: never read)
+						if (sub == 0u) s_mean[chain] = __fdiv_rn(acc, (float)((uint32_t)T * h));  // operations.rs:65-68 (h = 0: never read)
 						acc = 0.0f;
 					}
 				} else {
