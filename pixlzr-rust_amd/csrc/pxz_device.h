@@ -236,6 +236,10 @@ __device__ __forceinline__ uint32_t sad16(uint32_t a, uint32_t b, uint32_t acc)
 {
 	return __builtin_amdgcn_sad_u16(a, b, acc);
 }
+// a + b on both u16 halves where the low halves cannot carry (sums of a few 8-bit samples): ONE plain 32-bit add.  Written
+// as a packed add (v_pk_add_u16) it is a VOP3P instruction, and those -- like every three-source integer form, SDWA and DPP
+// -- occupy the SIMD for 4.3 cycles against the 2 of a VOP2 add (profiles/r03_issue_probe.txt).
+__device__ __forceinline__ uint32_t add2x16(uint32_t a, uint32_t b) { return a + b; }
 // horizontal 1-2-1 smoothing of the pixel pairs D0=(x,x+1), D1=(x+2,x+3): (x+2(x+1)+(x+2), (x+1)+2(x+2)+(x+3))
 __device__ __forceinline__ uint32_t smooth121(uint32_t d0, uint32_t d1)
 {

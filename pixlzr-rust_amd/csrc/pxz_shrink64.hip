@@ -214,9 +214,9 @@ __global__ void __launch_bounds__(256) shrink64_kernel(const Fast64Args a)
 #pragma unroll
 			for (int c = 0; c < 3; ++c) {
 				const uint32_t a0 = pc[c][0], a1 = pc[c][1], b0 = pc[c][kRS64], b1 = pc[c][kRS64 + 1];
-				rA[c] = pk_mad_u16(__builtin_amdgcn_alignbit(a1, a0, 16), two, u32(us2(a0) + us2(a1)));
-				rB[c] = pk_mad_u16(__builtin_amdgcn_alignbit(b1, b0, 16), two, u32(us2(b0) + us2(b1)));
-				tP[c] = u32(us2(a0) + us2(b0));
+				rA[c] = pk_mad_u16(__builtin_amdgcn_alignbit(a1, a0, 16), two, add2x16(a0, a1));
+				rB[c] = pk_mad_u16(__builtin_amdgcn_alignbit(b1, b0, 16), two, add2x16(b0, b1));
+				tP[c] = add2x16(a0, b0);
 				dP[c] = b0;
 			}
 #pragma unroll
@@ -226,15 +226,15 @@ __global__ void __launch_bounds__(256) shrink64_kernel(const Fast64Args a)
 					for (int c = 0; c < 3; ++c) {
 						const uint32_t *pr = pc[c] + (2 + 2 * st) * (int)kRS64;
 						const uint32_t n0 = pr[0], n1 = pr[1], o0 = pr[kRS64], o1 = pr[kRS64 + 1];
-						const uint32_t rN = pk_mad_u16(__builtin_amdgcn_alignbit(n1, n0, 16), two, u32(us2(n0) + us2(n1)));
+						const uint32_t rN = pk_mad_u16(__builtin_amdgcn_alignbit(n1, n0, 16), two, add2x16(n0, n1));
 						sum_hz = sad16(rN, rA[c], sum_hz);
-						const uint32_t tN = u32(us2(dP[c]) + us2(n0));
-						const uint32_t c0 = u32(us2(tP[c]) + us2(tN));
+						const uint32_t tN = add2x16(dP[c], n0);
+						const uint32_t c0 = add2x16(tP[c], tN);
 						sum_vr = sad16(dpp_mov<0x130>(c0), c0, sum_vr);  // wave_shl:1 = the pair to the right
-						const uint32_t rO = pk_mad_u16(__builtin_amdgcn_alignbit(o1, o0, 16), two, u32(us2(o0) + us2(o1)));
+						const uint32_t rO = pk_mad_u16(__builtin_amdgcn_alignbit(o1, o0, 16), two, add2x16(o0, o1));
 						sum_hz = sad16(rO, rB[c], sum_hz);
-						const uint32_t tO = u32(us2(n0) + us2(o0));
-						const uint32_t e0 = u32(us2(tN) + us2(tO));
+						const uint32_t tO = add2x16(n0, o0);
+						const uint32_t e0 = add2x16(tN, tO);
 						sum_vr = sad16(dpp_mov<0x130>(e0), e0, sum_vr);
 						rA[c] = rN;
 						rB[c] = rO;

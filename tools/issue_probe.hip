@@ -47,6 +47,24 @@ PROBE(k_add_f32_dpp_dep, "v_add_f32_dpp %8, %9, %8 quad_perm:[0,0,0,0] row_mask:
 PROBE(k_add_f32_dpp_dep_abs, "v_add_f32_dpp %8, |%9|, %8 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf\n v_add_f32_dpp %8, |%10|, %8 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf\n v_add_f32_dpp %8, |%11|, %8 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf\n v_add_f32_dpp %8, |%12|, %8 quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf\n", )
 PROBE(k_add_f32_dpp_ind, "v_add_f32_dpp %8, %9, %10 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf\n v_add_f32_dpp %11, %12, %13 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf\n v_add_f32_dpp %14, %15, %9 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf\n v_add_f32_dpp %10, %12, %13 quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf\n", )
 PROBE(k_add_f32_dep_two_chains, "v_add_f32 %8, %8, %9\n v_add_f32 %10, %10, %11\n v_add_f32 %8, %8, %12\n v_add_f32 %10, %10, %13\n", )
+// integer forms the directional detector and the resample are made of (%16-%19 ints)
+PROBE(k_perm_b32, "v_perm_b32 %16, %17, %18, %19\n v_perm_b32 %17, %18, %19, %16\n v_perm_b32 %18, %19, %16, %17\n v_perm_b32 %19, %16, %17, %18\n", )
+PROBE(k_sad_u16, "v_sad_u16 %16, %17, %18, %16\n v_sad_u16 %19, %17, %18, %19\n v_sad_u16 %16, %18, %17, %16\n v_sad_u16 %19, %18, %17, %19\n", )
+PROBE(k_mad_u32_u24, "v_mad_u32_u24 %16, %17, %18, %19\n v_mad_u32_u24 %17, %18, %19, %16\n v_mad_u32_u24 %18, %19, %16, %17\n v_mad_u32_u24 %19, %16, %17, %18\n", )
+PROBE(k_pk_add_u16, "v_pk_add_u16 %16, %17, %18\n v_pk_add_u16 %17, %18, %19\n v_pk_add_u16 %18, %19, %16\n v_pk_add_u16 %19, %16, %17\n", )
+PROBE(k_dot2_i32_i16, "v_dot2_i32_i16 %16, %17, %18, %16\n v_dot2_i32_i16 %19, %17, %18, %19\n v_dot2_i32_i16 %16, %18, %17, %16\n v_dot2_i32_i16 %19, %18, %17, %19\n", )
+PROBE(k_add_u32, "v_add_u32 %16, %17, %18\n v_add_u32 %17, %18, %19\n v_add_u32 %18, %19, %16\n v_add_u32 %19, %16, %17\n", )
+PROBE(k_add3_u32, "v_add3_u32 %16, %17, %18, %19\n v_add3_u32 %17, %18, %19, %16\n v_add3_u32 %18, %19, %16, %17\n v_add3_u32 %19, %16, %17, %18\n", )
+PROBE(k_lshl_add_u32, "v_lshl_add_u32 %16, %17, 2, %19\n v_lshl_add_u32 %17, %18, 2, %16\n v_lshl_add_u32 %18, %19, 2, %17\n v_lshl_add_u32 %19, %16, 2, %18\n", )
+PROBE(k_bfe_u32, "v_bfe_u32 %16, %17, 8, 8\n v_bfe_u32 %17, %18, 8, 8\n v_bfe_u32 %18, %19, 8, 8\n v_bfe_u32 %19, %16, 8, 8\n", )
+PROBE(k_med3_i32, "v_med3_i32 %16, %17, 0, %19\n v_med3_i32 %17, %18, 0, %16\n v_med3_i32 %18, %19, 0, %17\n v_med3_i32 %19, %16, 0, %18\n", )
+PROBE(k_alignbit, "v_alignbit_b32 %16, %17, %18, 8\n v_alignbit_b32 %17, %18, %19, 8\n v_alignbit_b32 %18, %19, %16, 8\n v_alignbit_b32 %19, %16, %17, 8\n", )
+PROBE(k_and_b32, "v_and_b32 %16, %17, %18\n v_and_b32 %17, %18, %19\n v_and_b32 %18, %19, %16\n v_and_b32 %19, %16, %17\n", )
+PROBE(k_lshrrev_b32, "v_lshrrev_b32 %16, 8, %18\n v_lshrrev_b32 %17, 8, %19\n v_lshrrev_b32 %18, 8, %16\n v_lshrrev_b32 %19, 8, %17\n", )
+PROBE(k_lshlrev_b64, "v_lshlrev_b64 %0, 8, %1\n v_lshlrev_b64 %2, 8, %3\n v_lshlrev_b64 %4, 8, %5\n v_lshlrev_b64 %6, 8, %7\n", )
+PROBE(k_dot4_u32_u8, "v_dot4_u32_u8 %16, %17, %18, %16\n v_dot4_u32_u8 %19, %17, %18, %19\n v_dot4_u32_u8 %16, %18, %17, %16\n v_dot4_u32_u8 %19, %18, %17, %19\n", )
+PROBE(k_cmp_cndmask_vcc, "v_cmp_lt_u32 vcc, %16, %17\n v_cndmask_b32 %18, %19, %16, vcc\n v_cmp_lt_u32 vcc, %17, %18\n v_cndmask_b32 %19, %16, %17, vcc\n", )
+PROBE(k_cmp_e64_cndmask_e64, "v_cmp_lt_u32_e64 s[20:21], %16, %17\n v_cndmask_b32_e64 %18, %19, %16, s[20:21]\n v_cmp_lt_u32_e64 s[22:23], %17, %18\n v_cndmask_b32_e64 %19, %16, %17, s[22:23]\n", )
 PROBE(k_fma_f32_dep, "v_fma_f32 %8, %8, %9, %10\n v_fma_f32 %8, %8, %9, %10\n v_fma_f32 %8, %8, %9, %10\n v_fma_f32 %8, %8, %9, %10\n", )
 PROBE(k_mul_f32_ind, "v_mul_f32 %8, %9, %10\n v_mul_f32 %11, %12, %13\n v_mul_f32 %14, %15, %9\n v_mul_f32 %10, %12, %13\n", )
 PROBE(k_ldexp_f64, "v_ldexp_f64 %0, %1, %16\n v_ldexp_f64 %2, %3, %17\n v_ldexp_f64 %4, %5, %18\n v_ldexp_f64 %6, %7, %19\n", )
@@ -127,7 +145,7 @@ int main()
 {
 	const int N = 256 * 64 * 4;
 #define R(k) run(#k, k, N); run(#k, k, N, 8);
-	R(k_add_f32_dpp_dep) R(k_add_f32_dpp_dep_abs) R(k_add_f32_dpp_ind) R(k_add_f32_dep_two_chains) R(k_add_f32_ind) R(k_add_f32_dep) R(k_add_f32_dep_abs) R(k_add_f32_dep2) R(k_fma_f32_dep) R(k_mul_f32_ind)
+	R(k_perm_b32) R(k_sad_u16) R(k_mad_u32_u24) R(k_pk_add_u16) R(k_dot2_i32_i16) R(k_add_u32) R(k_add3_u32) R(k_lshl_add_u32) R(k_bfe_u32) R(k_med3_i32) R(k_alignbit) R(k_and_b32) R(k_lshrrev_b32) R(k_lshlrev_b64) R(k_dot4_u32_u8) R(k_cmp_cndmask_vcc) R(k_cmp_e64_cndmask_e64) R(k_add_f32_dpp_dep) R(k_add_f32_dpp_dep_abs) R(k_add_f32_dpp_ind) R(k_add_f32_dep_two_chains) R(k_add_f32_ind) R(k_add_f32_dep) R(k_add_f32_dep_abs) R(k_add_f32_dep2) R(k_fma_f32_dep) R(k_mul_f32_ind)
 	R(k_fma_f64_ind) R(k_fma_f64_dep) R(k_mul_f64_ind) R(k_add_f64_ind) R(k_rcp_f64_ind) R(k_rcp_f64_dep) R(k_rcp_f32_ind)
 	R(k_cvt_f64_f32) R(k_cvt_f32_f64) R(k_cvt_dep_chain) R(k_frexp_mant) R(k_frexp_exp) R(k_pk_mul_f32) R(k_pk_fma_f32) R(k_ldexp_f64)
 	R(k_and_or) R(k_cndmask) R(k_sdwa_shift) R(k_mixed_f64_f32)
