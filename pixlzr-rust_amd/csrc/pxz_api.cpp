@@ -66,6 +66,7 @@ struct ExpandTables {
 	uint16_t *d_starts = nullptr, *d_sizes = nullptr;
 	int16_t *d_coeffs = nullptr;
 	uint32_t dir_stride = 0;
+	uint32_t *d_xmf = nullptr;  // 32x32 tiles, convolutions: matrix-core operand tables (pxz_internal.h: kXmfDw)
 };
 
 struct DeviceBuffer {
@@ -392,6 +393,47 @@ int get_expand_tables(pxz_handle *h, uint32_t bw, uint32_t bh, uint32_t edge_w, 
 	if (coeffs.empty()) coeffs.push_back(0);
 	ExpandTables et;
 	et.dir_stride = stride;
+	// 32x32 tiles: the up-scales 1, 2, 4, 8, 16 -> 32 as matrix-core operands (layout: pxz_internal.h)
+	if (bw == 32 && bh == 32 && filter != 0) {
+		std::vector<uint32_t> xmf((size_t)pxz::kXmfLevels * pxz::kXmfDw, 0u);
+		bool fits = true;
+		for (uint32_t li = 0; li < pxz::kXmfLevels; ++li) {
+			const uint32_t in = 1u << li;
+			pxz::AxisWindows win;
+			if (!pxz::build_axis(in, 32, filter, &win, true)) return fail(h, PXZ_ERR_INVALID_ARG, "unknown filter %u", filter);
+			uint32_t *mf = xmf.data() + (size_t)li * pxz::kXmfDw;
+			const int32_t half = 1 << (win.precision - 1);
+			bool copies = in == 1 && win.precision < 15;
+			for (uint32_t o = 0; o < 32; ++o) {
+				int32_t k[16] = {0};
+				int32_t total = 0;
+				for (uint32_t i = 0; i < (uint32_t)win.sizes[o]; ++i) {
+					k[(uint32_t)win.starts[o] + i] = win.coeffs[(size_t)o * win.window + i];
+					total += k[(uint32_t)win.starts[o] + i];
+				}
+				if (win.sizes[o] != 1 || k[0] != (1 << win.precision)) copies = false;
+				for (uint32_t kg = 0; kg < 2; ++kg) {
+					for (uint32_t j = 0; j < 8; ++j) {
+						const int32_t v = k[pxz::xmf_src(kg, j)];
+						const int32_t lo = ((v + 128) & 255) - 128, hi = (v - lo) / 256;
+						if (hi < -128 || hi > 127) fits = false;
+						const uint32_t lane = kg * 32 + o, dw = 2 * lane + j / 4, sh = 8 * (j & 3);
+						mf[dw] |= (uint32_t)(uint8_t)lo << sh;
+						mf[128 + dw] |= (uint32_t)(uint8_t)hi << sh;
+					}
+				}
+				mf[256 + o] = (uint32_t)(128 * total + half);
+			}
+			for (uint32_t g = 0; g < 2; ++g)
+				for (uint32_t reg = 0; reg < 16; ++reg) mf[288 + 16 * g + reg] = mf[256 + pxz::xmf_row(g, reg)];
+			mf[320] = (uint32_t)win.precision;
+			mf[321] = copies ? 1u : 0u;
+		}
+		if (fits) {
+			PXZ_HIP(h, hipMalloc((void **)&et.d_xmf, xmf.size() * sizeof(uint32_t)));
+			PXZ_HIP(h, hipMemcpy(et.d_xmf, xmf.data(), xmf.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+		}
+	}
 	PXZ_HIP(h, hipMalloc((void **)&et.d_dir, dir.size() * sizeof(pxz::ExpandTab)));
 	PXZ_HIP(h, hipMalloc((void **)&et.d_starts, starts.size() * sizeof(uint16_t)));
 	PXZ_HIP(h, hipMalloc((void **)&et.d_sizes, sizes.size() * sizeof(uint16_t)));
@@ -850,6 +892,7 @@ void pxz_destroy(pxz_handle *h)
 		(void)hipFree(kv.second.d_starts);
 		(void)hipFree(kv.second.d_sizes);
 		(void)hipFree(kv.second.d_coeffs);
+		(void)hipFree(kv.second.d_xmf);
 	}
 	for (auto &kv : h->tree_tables) {
 		(void)hipFree(kv.second.d_dir);
@@ -1107,6 +1150,8 @@ static int expand_launch(pxz_handle *h, const pxz_frames *frames, uint32_t slot_
 	a.starts = et->d_starts;
 	a.sizes = et->d_sizes;
 	a.coeffs = et->d_coeffs;
+	a.fast32 = pxz::knobs().no_expand_fast32 ? 0u : 1u;
+	a.xmf = a.fast32 ? et->d_xmf : nullptr;
 	a.tile_dw = (2u * bw * bh + 5u * (bw + bh) + 3u) & ~3u;
 	if ((rc = ensure(h, h->status, 4)) != PXZ_OK) return rc;
 	a.status = (uint32_t *)h->status.ptr;

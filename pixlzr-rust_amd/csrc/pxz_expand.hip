@@ -6,6 +6,160 @@
 
 namespace pxz {
 
+typedef int v16i32 __attribute__((ext_vector_type(16)));
+
+// ---------------------------------------------------------------------------
+// The convolutions of a full 32x32 RGBA tile stored as tw x th, both in {1, 2, 4, 8, 16}, on the matrix cores
+// (v_mfma_i32_32x32x16_i8; same integers as the vector form in expand_kernel, which follows block.rs:273-334):
+//   horizontal  T[(c, y)][ox] = clip8(sum_x P_c[y][x] Kx[x][ox])   A = pixel bytes of the channel planes, rows (channel, y):
+//               all four channels in ONE product when th <= 8, two products of two channels at 16;  B = weights
+//   vertical    O_c[oy][ox]   = clip8(sum_y Ky[oy][y] T_c[y][ox])   A = weights, B = T_c
+// T never leaves the registers: the accumulator of the horizontal product holds, for column ox = lane & 31, the rows
+// xmf_row(g, reg) -- bytes y = 4g + j (and 8 + 4g + j) of a channel, which IS a B operand whose k slots stand for the
+// rows xmf_src(g, j); the weight tables are stored with their k slots in that order (pxz_internal.h) and the pixel operand of
+// the horizontal product reads its source columns in that order too, so one table per stored size serves both passes.
+// Weights are 16-bit: two products (low bytes, high bytes) per block, pixels as signed bytes (p - 128, the bias
+// carries 128 * weight sum + the rounding half), recombined and clamped by clamp_fixed.
+// Output: lane (ox, g) ends with the 16 pixels of column ox in the rows xmf_row(g, reg): 16 dword stores whose 32 lanes
+// of a half-wave cover 128 contiguous bytes of a frame row.  A stored height of 1 whose table says "copied" skips the
+// vertical product (40 % of the tiles of a typical frame are 2x1): the row goes through LDS and is written 32 times.
+// s_wave: the wave's LDS (planes: 1 KB; the row: 128 B behind them).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void expand_tile_mfma(const ExpandArgs &a, const uint32_t *s_xmf, uint32_t *s_wave, uint32_t lane,
+                                                 uint32_t tw, uint32_t th, const uint8_t *src, uint32_t first_px, uint8_t *dst)
+{
+	const uint32_t n = lane & 31u, g = lane >> 5;
+	const uint32_t lw = 31u - (uint32_t)__builtin_clz(tw), lh = 31u - (uint32_t)__builtin_clz(th);
+	const uint32_t *mx = s_xmf + lw * kXmfDw, *my = s_xmf + lh * kXmfDw;
+	const bool fold = th <= 8u;
+	const uint32_t plane = fold ? 128u : 256u;  // bytes per channel plane: rows of 16 bytes
+	uint8_t *s_pl = reinterpret_cast<uint8_t *>(s_wave);
+	// ---- stored pixels -> premultiplied channel planes [c][y][16]
+	const uint32_t npx = tw * th;
+	for (uint32_t i = lane; i < npx; i += 64u) {
+		uint32_t px = i == lane ? first_px : reinterpret_cast<const uint32_t *>(src)[i];
+		if (__builtin_amdgcn_ballot_w64((px >> 24) != 255u) != 0ull) px = premultiply(px);  // fir: U8x4 is alpha-premultiplied before a convolution
+		uint8_t *d = s_pl + (i >> lw) * 16u + (i & (tw - 1u));
+		d[0] = (uint8_t)px;
+		d[plane] = (uint8_t)(px >> 8);
+		d[2u * plane] = (uint8_t)(px >> 16);
+		d[3u * plane] = (uint8_t)(px >> 24);
+	}
+	tile_sync<1>();
+	// ---- horizontal product(s)
+	const uint32_t px_ = __builtin_amdgcn_readfirstlane(mx[320]), py = __builtin_amdgcn_readfirstlane(my[320]);
+	const int32_t top_x = (int32_t)((256u << px_) - 1u), top_y = (int32_t)((256u << py) - 1u);
+	const long kx_lo = *reinterpret_cast<const long *>(mx + 2u * lane), kx_hi = *reinterpret_cast<const long *>(mx + 128u + 2u * lane);
+	const int32_t bx = (int32_t)mx[256u + n];
+	v16i32 cx, zero;
+#pragma unroll
+	for (int r = 0; r < 16; ++r) { cx[r] = bx; zero[r] = 0; }
+	uint32_t t0[4] = {0, 0, 0, 0}, t1[4] = {0, 0, 0, 0};  // per channel: rows 4g + j | rows 8 + 4g + j of column n, as bytes
+	auto product = [&](uint32_t blk, auto place) __attribute__((always_inline)) {
+		const uint32_t *row = reinterpret_cast<const uint32_t *>(s_pl + (32u * blk + n) * 16u + 4u * g);
+		const uint32_t a0 = row[0] ^ 0x80808080u, a1 = row[2] ^ 0x80808080u;  // columns 4g + j | 8 + 4g + j of row (channel, y) = n
+		const long av = (long)(((unsigned long long)a1 << 32) | (unsigned long long)a0);
+		const v16i32 lo = __builtin_amdgcn_mfma_i32_32x32x16_i8(av, kx_lo, cx, 0, 0, 0);
+		const v16i32 hi = __builtin_amdgcn_mfma_i32_32x32x16_i8(av, kx_hi, zero, 0, 0, 0);
+#pragma unroll
+		for (int r = 0; r < 16; ++r) place(r, clamp_fixed(hi[r], lo[r], top_x));
+	};
+	auto put_byte = [&](uint32_t &d, uint32_t j, uint32_t v, uint32_t sh) __attribute__((always_inline)) {
+		if (j == 0) put_byte_shr<0>(d, v, sh);
+		else if (j == 1) put_byte_shr<1>(d, v, sh);
+		else if (j == 2) put_byte_shr<2>(d, v, sh);
+		else put_byte_shr<3>(d, v, sh);
+	};
+	if (fold) {
+		product(0, [&](int r, uint32_t v) __attribute__((always_inline)) { put_byte(t0[r >> 2], (uint32_t)r & 3u, v, px_); });  // reg = 4 c + j
+	} else {
+#pragma unroll
+		for (uint32_t blk = 0; blk < 2; ++blk)  // reg = 8 (c & 1) + 4 (second group of rows) + j
+			product(blk, [&](int r, uint32_t v) __attribute__((always_inline)) {
+				put_byte(((r >> 2) & 1) ? t1[2u * blk + ((uint32_t)r >> 3)] : t0[2u * blk + ((uint32_t)r >> 3)], (uint32_t)r & 3u, v, px_);
+			});
+	}
+	uint32_t *s_row = s_wave + 256u;  // behind the planes
+	if (th == 1u && __builtin_amdgcn_readfirstlane(my[321]) != 0u) {
+		// ---- one stored row, copied by every window of the way up: un-premultiply it once, write it 32 times
+		if (g == 0u) {
+			uint32_t px = (t0[0] & 255u) | ((t0[1] & 255u) << 8) | ((t0[2] & 255u) << 16) | (t0[3] << 24);
+			s_row[n] = unpremultiply(px);
+		}
+		tile_sync<1>();
+		typedef uint32_t u32q __attribute__((ext_vector_type(4)));
+		const uint4 v = *reinterpret_cast<const uint4 *>(s_row + 4u * (lane & 7u));
+		const u32q w = {v.x, v.y, v.z, v.w};
+#pragma unroll
+		for (uint32_t k = 0; k < 4; ++k)
+			__builtin_nontemporal_store(w, reinterpret_cast<u32q *>(dst + (size_t)(8u * k + (lane >> 3)) * a.pitch + 16u * (lane & 7u)));
+		return;
+	}
+	// ---- vertical products, channel by channel
+	const long ky_lo = *reinterpret_cast<const long *>(my + 2u * lane), ky_hi = *reinterpret_cast<const long *>(my + 128u + 2u * lane);
+	v16i32 cy;
+	{
+		const uint4 *bp = reinterpret_cast<const uint4 *>(my + 288u + 16u * g);
+#pragma unroll
+		for (int q = 0; q < 4; ++q) {
+			const uint4 b = bp[q];
+			cy[4 * q] = (int)b.x; cy[4 * q + 1] = (int)b.y; cy[4 * q + 2] = (int)b.z; cy[4 * q + 3] = (int)b.w;
+		}
+	}
+	uint32_t pix[16];
+#pragma unroll
+	for (int r = 0; r < 16; ++r) pix[r] = 0;
+#pragma unroll
+	for (uint32_t c = 0; c < 4; ++c) {
+		const long tv = (long)(((unsigned long long)(t1[c] ^ 0x80808080u) << 32) | (unsigned long long)(t0[c] ^ 0x80808080u));
+		const v16i32 lo = __builtin_amdgcn_mfma_i32_32x32x16_i8(ky_lo, tv, cy, 0, 0, 0);
+		const v16i32 hi = __builtin_amdgcn_mfma_i32_32x32x16_i8(ky_hi, tv, zero, 0, 0, 0);
+#pragma unroll
+		for (int r = 0; r < 16; ++r) put_byte(pix[r], c, clamp_fixed(hi[r], lo[r], top_y), py);
+	}
+	// un-premultiplying is the identity at alpha 255: skipped when no lane of the wave holds anything else
+	uint32_t alpha_and = 0xffffffffu;
+#pragma unroll
+	for (int r = 0; r < 16; ++r) alpha_and &= pix[r];
+	if (__builtin_amdgcn_ballot_w64((alpha_and >> 24) != 255u) != 0ull) {
+#pragma unroll
+		for (int r = 0; r < 16; ++r) pix[r] = unpremultiply(pix[r]);
+	}
+	const uint32_t lane_off = 4u * g * a.pitch + 4u * n;
+#pragma unroll
+	for (uint32_t r = 0; r < 16; ++r)
+		__builtin_nontemporal_store(pix[r], reinterpret_cast<uint32_t *>(dst + (size_t)xmf_row(0, r) * a.pitch + lane_off));
+}
+
+// ResizeAlg::Nearest of a full 32x32 RGBA tile stored as tw x th, both powers of two: the source index
+// floor((o + 0.5) * tw / 32) is o >> (5 - log2 tw), so no table is needed; a lane writes 4 adjacent pixels of 4 rows.
+__device__ __forceinline__ void expand_tile_nearest_pow2(const ExpandArgs &a, uint32_t *s_src, uint32_t lane, uint32_t tw, uint32_t th,
+                                                         const uint8_t *src, uint32_t first_px, uint8_t *dst)
+{
+	const uint32_t lw = 31u - (uint32_t)__builtin_clz(tw), sx = 5u - lw, sy = 5u - (31u - (uint32_t)__builtin_clz(th));
+	const uint32_t npx = tw * th;
+	for (uint32_t i = lane; i < npx; i += 64u) s_src[i] = i == lane ? first_px : reinterpret_cast<const uint32_t *>(src)[i];
+	tile_sync<1>();
+	typedef uint32_t u32q __attribute__((ext_vector_type(4)));
+	const uint32_t q = lane & 7u;
+#pragma unroll
+	for (uint32_t k = 0; k < 4; ++k) {
+		const uint32_t oy = 8u * k + (lane >> 3);
+		const uint32_t *row = s_src + ((oy >> sy) << lw);
+		u32q w;
+		if (sx >= 2u) {
+			const uint32_t v = row[q >> (sx - 2u)];
+			w = u32q{v, v, v, v};
+		} else if (sx == 1u) {
+			const uint2 v = *reinterpret_cast<const uint2 *>(row + 2u * q);
+			w = u32q{v.x, v.x, v.y, v.y};
+		} else {
+			const uint4 v = *reinterpret_cast<const uint4 *>(row + 4u * q);
+			w = u32q{v.x, v.y, v.z, v.w};
+		}
+		__builtin_nontemporal_store(w, reinterpret_cast<u32q *>(dst + (size_t)oy * a.pitch + 16u * q));
+	}
+}
 
 // ---------------------------------------------------------------------------
 // Decode side: Pixlzr::expand (reference pixlzr.rs:77-122) + to_image
@@ -16,15 +170,22 @@ namespace pxz {
 // one dword per pixel (premultiplied) and the horizontal pass's result [y][ox].  First version: scalar
 // multiply-adds straight from the global tables; correctness and coalesced frame writes first.
 // ---------------------------------------------------------------------------
-template <int C>
-__global__ void __launch_bounds__(256) expand_kernel(const ExpandArgs a)
+// F32 (RGBA tiles of 32x32 in RGBA frames): blocks of up to 16 waves that share the matrix-core tables; full tiles stored
+// at power-of-two sizes take expand_tile_mfma / expand_tile_nearest_pow2, everything else the general forms below.
+template <int C, bool F32 = false>
+__global__ void __launch_bounds__(F32 ? 1024 : 256) expand_kernel(const ExpandArgs a)
 {
 	extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
 	const uint32_t wpb = blockDim.x / 64u, sub = threadIdx.x / 64u, lane = threadIdx.x % 64u;
-	uint32_t *s_ticket = lds + wpb * a.tile_dw;
+	// the matrix-core tables of the block (32x32 tiles, convolutions), then the waves' tile images
+	const uint32_t xmf_dw = F32 && a.xmf ? kXmfLevels * kXmfDw : 0u;
+	for (uint32_t i = threadIdx.x; i < xmf_dw / 4u; i += blockDim.x)
+		reinterpret_cast<uint4 *>(lds)[i] = reinterpret_cast<const uint4 *>(a.xmf)[i];
+	const uint32_t *s_xmf = lds;
+	uint32_t *s_ticket = lds + xmf_dw + wpb * a.tile_dw;
 	if (threadIdx.x == 0) *s_ticket = wpb;
 	__syncthreads();
-	uint32_t *s_src = lds + sub * a.tile_dw;
+	uint32_t *s_src = lds + xmf_dw + sub * a.tile_dw;
 	uint32_t *s_tmp = s_src + a.bw * a.bh;
 	// A tile's stored size and its first 64 pixels (all of them for most tiles) are requested one tile ahead: the
 	// size -> pixels -> windows chain of dependent memory round trips was most of a tile's time.
@@ -68,6 +229,13 @@ __global__ void __launch_bounds__(256) expand_kernel(const ExpandArgs a)
 		};
 		if (tw == 0 || th == 0 || tw > fw || th > fh) {
 			if (lane == 0 && !(a.quiet_empty && tw == 0 && th == 0)) atomicOr(a.status, 1u);
+		} else if (F32 && fw == 32u && fh == 32u && (tw & (tw - 1u)) == 0u && (th & (th - 1u)) == 0u &&
+		           (a.filter == 0 ? tw * th < 1024u : (xmf_dw != 0u && tw <= 16u && th <= 16u))) {
+			if constexpr (F32) {
+				const uint8_t *src = a.slots + (size_t)t * a.slot_bytes;
+				if (a.filter == 0) expand_tile_nearest_pow2(a, s_src, lane, tw, th, src, first_px, dst);
+				else expand_tile_mfma(a, s_xmf, s_src, lane, tw, th, src, first_px, dst);
+			}
 		} else {
 			// ---- stored pixels -> one dword per pixel
 			const uint8_t *src = a.slots + (size_t)t * a.slot_bytes;
@@ -331,17 +499,25 @@ hipError_t launch_expand(const ExpandArgs &a, uint32_t n_cus, hipStream_t stream
 {
 	constexpr uint32_t kLds = 160u * 1024u;
 	const uint32_t tile_bytes = a.tile_dw * 4u;
-	uint32_t wpb = (kLds - 16u) / tile_bytes;
-	if (wpb > 4u) wpb = 4u;
+	const bool f32 = a.fast32 && a.channels == 4 && a.out_channels == 4 && a.bw == 32 && a.bh == 32 && (a.filter == 0 || a.xmf);
+	const uint32_t xmf_bytes = f32 && a.xmf ? kXmfLevels * kXmfDw * 4u : 0u;
+	// 32x32 RGBA tiles: one block of up to 16 waves per CU (they share the matrix-core tables); else blocks of up to 4 waves
+	uint32_t wpb = (kLds - 16u - xmf_bytes) / tile_bytes;
+	const uint32_t wpb_max = f32 ? 16u : 4u;
+	if (wpb > wpb_max) wpb = wpb_max;
 	if (wpb < 1u) return hipErrorInvalidValue;
-	const uint32_t lds_bytes = wpb * tile_bytes + 16u;
+	const uint32_t lds_bytes = xmf_bytes + wpb * tile_bytes + 16u;
 	uint32_t per_cu = kLds / lds_bytes;
 	if (per_cu > 4u) per_cu = 4u;
 	if (per_cu < 1u) per_cu = 1u;
 	const uint32_t need = (a.n_tiles + wpb - 1u) / wpb, resident = n_cus * per_cu;
 	const uint32_t blocks = need < resident ? need : resident;
 	hipError_t e;
-	if (a.channels == 4) {
+	if (f32) {
+		auto k = expand_kernel<4, true>;
+		if (lds_bytes > 64u * 1024u && (e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)) != hipSuccess) return e;
+		hipLaunchKernelGGL(k, dim3(blocks), dim3(64u * wpb), lds_bytes, stream, a);
+	} else if (a.channels == 4) {
 		auto k = expand_kernel<4>;
 		if (lds_bytes > 64u * 1024u && (e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)) != hipSuccess) return e;
 		hipLaunchKernelGGL(k, dim3(blocks), dim3(64u * wpb), lds_bytes, stream, a);

@@ -188,6 +188,7 @@ struct Knobs {
 	bool no_alpha_first;    // PXZ_NO_ALPHA_FIRST: transparent batches keep the two-kernel flow (shrink32_kernel lists, shrink32a_kernel takes the list)
 	bool no_narrow;         // PXZ_NO_NARROW: 4/2/1-px-wide outputs of 32x32 tiles keep the round-1 resample forms
 	bool oklab_v1;          // PXZ_OKLAB_V1: round-1 detector (one chain wave, two barriers per band; 64-px tiles parked in HBM)
+	bool no_expand_fast32;    // PXZ_NO_EXPAND_FAST32: expand_kernel keeps its general forms for 32x32 RGBA tiles (no matrix-core convolutions, no shift-indexed Nearest)
 	bool tree_rects;        // PXZ_TREE_RECTS: tree::process always goes over rectangle lists (pxz_tree.hip), also where the per-level grids apply
 	int wpb;                // PXZ_WPB: waves per block of the persistent kernels (0: default)
 	int chunk_lg;           // PXZ_CHUNK_LG: log2 of the ticket run length of shrink32_kernel (-1: default)
@@ -245,6 +246,16 @@ struct ExpandTab {
 	uint16_t precision;
 };
 
+// expand_kernel's matrix-core tables (32x32 tiles, the convolutions): one block of kXmfDw dwords per stored size 2^li,
+// li = 0 .. kXmfLevels-1 (1, 2, 4, 8, 16 px -> 32 px; one table serves both axes).  Operand of v_mfma_i32_32x32x16_i8
+// for output sample o = lane & 31 and k group kg = lane >> 5: k slot j stands for source sample xmf_src(kg, j).
+//   [0, 128)    low bytes of the weights, lane l at dwords 2l, 2l+1      [128, 256)  high bytes (weight = 256 hi + lo, lo signed)
+//   [256, 288)  bias per output sample (128 * weight sum + half)           [288, 320)  the same in accumulator order [g][reg]
+//   [320]       precision        [321]  1: a one-sample source is copied (every window is the weight 2^precision alone)
+constexpr uint32_t kXmfLevels = 5, kXmfDw = 324;
+constexpr uint32_t xmf_src(uint32_t kg, uint32_t j) { return j < 4u ? 4u * kg + j : 8u + 4u * kg + (j - 4u); }
+constexpr uint32_t xmf_row(uint32_t g, uint32_t reg) { return (reg & 3u) + 8u * (reg >> 2) + 4u * g; }  // accumulator reg -> row
+
 struct ExpandArgs {
 	const uint32_t *tile_w, *tile_h;  // per tile: stored size
 	const uint8_t *slots;             // per tile slot_bytes, tile_w*tile_h*channels valid, tightly packed
@@ -260,6 +271,8 @@ struct ExpandArgs {
 	const uint16_t *starts, *sizes;
 	const int16_t *coeffs;
 	uint32_t tile_dw;                 // LDS dwords per wave: source pixels + horizontal-pass result
+	const uint32_t *xmf;              // kXmfLevels * kXmfDw dwords, or null (other tile sizes, Nearest, weights beyond 16 bits)
+	uint32_t fast32;                  // 0: the general forms only (PXZ_NO_EXPAND_FAST32)
 	uint32_t *status;                 // set to 1 when a tile's stored size is 0 or exceeds its full size
 	uint32_t quiet_empty;             // 1: tiles of stored size 0 x 0 are simply not written (tree::process: not this level's)
 };

@@ -210,6 +210,7 @@ const Knobs &knobs()
 		v.no_alpha_first = on("PXZ_NO_ALPHA_FIRST");
 		v.oklab_v1 = on("PXZ_OKLAB_V1");
 		v.tree_rects = on("PXZ_TREE_RECTS");
+		v.no_expand_fast32 = on("PXZ_NO_EXPAND_FAST32");
 		const char *e = getenv("PXZ_WPB");
 		v.wpb = e ? atoi(e) : 0;
 		e = getenv("PXZ_CHUNK_LG");

@@ -21,6 +21,8 @@ KNOBS = [
     ("PXZ_OKLAB_V1", "test_shrink_1080p_rgba_32 or test_shrink_by_blocks_16_and_64"),
     # (the per-level grids and the rectangle lists are two implementations of the same recursion: where both apply, both run)
     ("PXZ_TREE_RECTS", "test_tree_process_matches_oracle or test_tree_process_edge_cases"),
+    # (expand_kernel's general forms for 32x32 RGBA tiles, which the matrix-core / shift-indexed forms replace by default)
+    ("PXZ_NO_EXPAND_FAST32", "test_expand_matches_oracle or test_expand_of_power_of_two_tiles or test_process_matches_oracle"),
     ("PXZ_NO_ALPHA_FIRST", "test_mostly_transparent_batches_go_to_the_four_plane_kernel_first or test_transparent_tiles_through_the_alpha_kernel"),
     ("PXZ_NO_ALPHA_KERNEL", "test_transparent_tiles_through_the_alpha_kernel or test_transparent_64x64_tiles_through_the_alpha_instance"),
 ]

@@ -443,6 +443,36 @@ def test_expand_matches_oracle(gpu, oracle, c, filt):
         assert not bad.any(), f"c{c} f{filt} {bw}x{bh} k{factor}: {int(bad.sum())} pixels differ"
 
 
+@pytest.mark.parametrize("filt", [0, 1, 2, 3, 4])
+def test_expand_of_power_of_two_tiles(gpu, oracle, filt):
+    """32x32 RGBA tiles stored at every combination of 1, 2, 4, 8, 16, 32 (also the ones no shrink produces from a level
+    pair, and a few odd sizes between them): the matrix-core convolutions and the shift-indexed Nearest of expand_kernel
+    against the oracle's PixlzrBlock::resize (block.rs:273-334).  Random pixels; a third of the tiles opaque, a third
+    with random alpha, a third with alpha in {0, 255} (premultiplied convolution, fir's U8x4 default)."""
+    rng = np.random.default_rng(40 + filt)
+    sizes = [1, 2, 4, 8, 16, 32]
+    pairs = [(a, b) for a in sizes for b in sizes] * 3 + [(3, 8), (8, 5), (31, 16), (16, 17), (12, 12)]
+    cols, rows = 9, (len(pairs) + 8) // 9
+    n = cols * rows
+    tw = np.ones(n, np.uint32); th = np.ones(n, np.uint32)
+    slots = np.zeros((n, 32 * 32 * 4), np.uint8)
+    for t in range(n):
+        w, h = pairs[t % len(pairs)]
+        tw[t], th[t] = w, h
+        px = rng.integers(0, 256, (h * w, 4), dtype=np.uint8)
+        kind = t % 3
+        if kind == 0: px[:, 3] = 255
+        elif kind == 2: px[:, 3] = rng.choice(np.array([0, 255], np.uint8), h * w)
+        if t % 7 == 0: px[:, :3] = rng.choice(np.array([0, 255], np.uint8), (h * w, 3))  # extremes: the clamps
+        slots[t, : h * w * 4] = px.ravel()
+    exp = oracle.expand_image(cols * 32, rows * 32, 32, 32, 4, filt, tw, th, slots)
+    got = gpu.expand_image(cols * 32, rows * 32, 4, 32, 32, filt, tw, th, slots)
+    bad = (got != exp).any(axis=2)
+    if bad.any():
+        t_bad = sorted({int((y // 32) * cols + x // 32) for y, x in zip(*np.nonzero(bad))})
+        raise AssertionError(f"filter {filt}: {int(bad.sum())} pixels differ, tiles {[(t, int(tw[t]), int(th[t])) for t in t_bad[:8]]}")
+
+
 def test_expand_frames_device_round_trip_properties(gpu, oracle):
     """Device-resident batch: shrink -> expand.  Tiles kept at full size come back unchanged; the batch equals
     the per-frame oracle; an invalid stored size is flagged and leaves the tile untouched."""

@@ -2,7 +2,7 @@
 the flow's algorithmic bytes per step beside the counters (source once + shrunk pixels + 12 B per tile; the
 writer: valid slot bytes + value/w/h read, file bytes written).
 
-  python3 tools/pmc_run.py <variant>       variant = dir | by | enc | dirlod | bylod     (dir_full = dir, kept for old scripts)
+  python3 tools/pmc_run.py <variant>       variant = dir | by | enc | exp | dirlod | bylod     (dir_full = dir, kept for old scripts)
   env: BLOCK (tile side, 32), NF (frames, 8), N (steps, 3), DIST (0 opaque .. 3 noise), FACTOR, FILTER (4), OUTJSON
 """
 import json, os, sys
@@ -31,6 +31,12 @@ if variant == "enc":  # shrink once, then the device writer n times
     valid = int((ow.long() * oh.long()).sum().item()) * 4
     info.update(step_kernels="qoi_,pack_", setup_kernels="shrink,oklab",
                 algo_bytes=valid + 12 * ow.numel() + int(enc[0][-1].item()), file_bytes=int(enc[0][-1].item()))
+elif variant == "exp":  # shrink once (directional, factor 16, Lanczos3), then expand n times with FILTER
+    vals, ow, oh, slots = h.shrink_frames_device(frames, bs, bs, 1, 4, 16.0)
+    out = h.expand_frames_device(tuple(frames.shape), bs, bs, flt, ow, oh, slots)
+    for _ in range(n - 1): h.expand_frames_device(tuple(frames.shape), bs, bs, flt, ow, oh, slots, out=out)
+    info.update(step_kernels="expand_", setup_kernels="shrink,oklab",
+                algo_bytes=int((ow.long() * oh.long()).sum().item()) * 4 + 8 * ow.numel() + frames.numel())
 elif variant.endswith("lod"):
     for _ in range(n): h.lod_frames_device(frames, bs, bs, mode, factor)
     info.update(step_kernels="", algo_bytes=frames.numel() + 8 * (frames.shape[0] * ((4320 + bs - 1) // bs) * ((7680 + bs - 1) // bs)))
