@@ -39,7 +39,7 @@ hipError_t launch_widen(const WidenArgs &a, hipStream_t stream);
 hipError_t launch_narrow(const NarrowArgs &a, hipStream_t stream);
 hipError_t launch_pack(const PackArgs &a, hipStream_t stream);
 hipError_t launch_oklab(const ShrinkArgs &a, uint32_t n_cus, hipStream_t stream, uint32_t channels = 4);
-hipError_t launch_qoi(const QoiArgs &a, hipStream_t stream);
+hipError_t launch_qoi(const QoiArgs &a, bool bins_clean, hipStream_t stream);
 uint32_t waves_per_tile(uint32_t bw, uint32_t bh);
 }  // namespace pxz
 
@@ -107,6 +107,7 @@ struct pxz_handle {
 	uint32_t *host_stats = nullptr;  // pinned, device-visible: [0] = tiles with transparency the last finished 32x32 launch saw
 	uint32_t *dev_stats = nullptr;   //   (its device-side address); read without synchronisation, steers only the kernel choice
 	bool work_ready = false;   // both worklist counters are zero / consistent with work_slot
+	const uint32_t *qbins_clean = nullptr;  // the writer's binning counters at this address were left zeroed by the last launch_qoi
 	uint32_t work_slot = 0;    // the counter the next 32x32 launch uses
 	bool timing = false;
 	uint32_t timing_stride = 1, timing_count = 0;  // every stride-th step is bracketed by events
@@ -936,6 +937,7 @@ int pxz_trim(pxz_handle *h)
 			drop(*b);
 	h->packed_len = 0;
 	h->work_ready = false;  // (the worklist counters went with their buffer)
+	h->qbins_clean = nullptr;
 	return PXZ_OK;
 }
 
@@ -1993,7 +1995,11 @@ int pxz_encode_frames_device(pxz_handle *h, const pxz_frames *frames, const pxz_
 	a.bw = params->block_w;
 	a.bh = params->block_h;
 	a.filter_byte = filter_byte;
-	PXZ_HIP(h, pxz::launch_qoi(a, h->stream));
+	// (a launch leaves the binning counters zeroed for the next one on the same buffer)
+	const bool bins_clean = h->qbins_clean == a.bins;
+	h->qbins_clean = nullptr;
+	PXZ_HIP(h, pxz::launch_qoi(a, bins_clean, h->stream));
+	h->qbins_clean = a.bins;
 	return PXZ_OK;
 }
 

@@ -235,6 +235,7 @@ struct QoiArgs {
 	uint32_t n_tiles, n_chunks, tiles_per_frame, cols, rows;
 	uint32_t channels, slot_bytes, stride, hdr_bytes;
 	uint32_t width, height, bw, bh, filter_byte;
+	uint32_t splice_big_blocks, splice_small_blocks;  // (set by launch_qoi) the roles of qoi_splice_kernel's blocks
 };
 
 // Decode side (expand_kernel): one table per (axis, size class, source size) of an up-scale to the full

@@ -129,7 +129,7 @@ hipError_t launch_pack(const PackArgs &a, hipStream_t stream)
 // pieces 1.. = {u32 length, pad} + ops of the segment, at fixed distances; the last one ends with 0x00*7 0x01.
 // Then: scan of the record lengths, splice of the pieces into the final files, header + per-row length table.
 // ---------------------------------------------------------------------------
-constexpr uint32_t kBinCounts = 0, kBinCursor = 32, kBinUnits = 64, kBinTiles = 96, kBinTotal = 128;  // u32 offsets in bins[]
+constexpr uint32_t kBinCounts = 0, kBinCursor = 32, kBinUnits = 64, kBinTiles = 96, kBinTotal = 128, kBinArrive = 129;  // u32 offsets in bins[]
 
 __device__ __host__ __forceinline__ uint32_t qoi_class_segments(uint32_t cls) { return cls <= 6u ? 1u : (cls >= 12u ? 64u : 1u << (cls - 6u)); }
 // pixels per segment (a multiple of 4: the RGBA loads stay 16-byte aligned, the RGB ones dword aligned)
@@ -138,50 +138,77 @@ __device__ __forceinline__ uint32_t qoi_segment_pixels(uint32_t n, uint32_t g) {
 __device__ __host__ __forceinline__ uint32_t qoi_piece0_bytes(uint32_t seg_px, uint32_t c) { return (23u + seg_px * (c + 1u) + 8u + 8u + 7u) & ~7u; }
 __device__ __host__ __forceinline__ uint32_t qoi_piece_bytes(uint32_t seg_px, uint32_t c) { return (8u + seg_px * (c + 1u) + 8u + 8u + 7u) & ~7u; }
 
+// Binning (counting sort by class, largest first): two launches of ceil(n / 4096) blocks, 16 tiles per thread.
+//   qoi_bin_count_kernel    per-block histogram in LDS, one global atomic per non-empty class and block; the block that
+//                           arrives last turns the counts into the classes' places in the permutation of tiles and in the
+//                           run of segments ("units": a class starts a fresh wave) -- round 3: this was a launch of one thread
+//   qoi_bin_scatter_kernel  the block reserves one range per class (one global atomic each), threads take slots inside it
+// (Round 2 ran one tile per thread: a thousand blocks whose atomics queued on a handful of addresses, 13 us each for 2 MB of
+// sizes.)  bins[kBinCounts ..] must be zero at the start: launch_qoi's last kernel leaves them so.
+constexpr uint32_t kBinChunk = 4096;  // tiles per block: 256 threads x 16
+__device__ __forceinline__ uint32_t qoi_tile_class(const QoiArgs &a, uint32_t t) { return 31u - (uint32_t)__builtin_clz((a.w[t] * a.h[t]) | 1u); }
+
 __global__ void __launch_bounds__(256) qoi_bin_count_kernel(const QoiArgs a)
 {
-	// per-block histogram in LDS, then one global atomic per non-empty class and block
 	__shared__ uint32_t s_hist[32];
+	__shared__ uint32_t s_last;
 	if (threadIdx.x < 32) s_hist[threadIdx.x] = 0;
 	__syncthreads();
-	const uint32_t t = blockIdx.x * 256u + threadIdx.x;
-	if (t < a.n_tiles) atomicAdd(&s_hist[31u - (uint32_t)__builtin_clz((a.w[t] * a.h[t]) | 1u)], 1u);
-	__syncthreads();
-	if (threadIdx.x < 32 && s_hist[threadIdx.x]) atomicAdd(&a.bins[kBinCounts + threadIdx.x], s_hist[threadIdx.x]);
-}
-
-__global__ void qoi_bin_scan_kernel(const QoiArgs a)
-{
-	// largest tiles first (they set the tail): where each class starts in the permutation of tiles, and in the run of
-	// segments ("units", a class starts a fresh wave)
-	uint32_t tiles = 0, units = 0;
-	for (int c = 31; c >= 0; --c) {
-		const uint32_t n = a.bins[kBinCounts + c];
-		a.bins[kBinCursor + c] = tiles;
-		a.bins[kBinTiles + c] = tiles;
-		a.bins[kBinUnits + c] = units;
-		tiles += n;
-		units += (n * qoi_class_segments((uint32_t)c) + 63u) & ~63u;
+#pragma unroll 4
+	for (uint32_t i = 0; i < kBinChunk / 256u; ++i) {
+		const uint32_t t = blockIdx.x * kBinChunk + i * 256u + threadIdx.x;
+		if (t < a.n_tiles) atomicAdd(&s_hist[qoi_tile_class(a, t)], 1u);
 	}
-	a.bins[kBinTotal] = units;
+	__syncthreads();
+	if (threadIdx.x < 32) {
+		if (s_hist[threadIdx.x]) atomicAdd(&a.bins[kBinCounts + threadIdx.x], s_hist[threadIdx.x]);
+		__threadfence();  // the counts before the arrival
+	}
+	__syncthreads();
+	if (threadIdx.x == 0) s_last = atomicAdd(&a.bins[kBinArrive], 1u) == gridDim.x - 1u ? 1u : 0u;
+	__syncthreads();
+	if (!s_last) return;
+	// the last block: every count is in (device-scope atomics, read as such)
+	if (threadIdx.x < 32) s_hist[threadIdx.x] = __hip_atomic_load(&a.bins[kBinCounts + threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		uint32_t tiles = 0, units = 0;
+		for (int c = 31; c >= 0; --c) {
+			const uint32_t n = s_hist[c];
+			a.bins[kBinCursor + c] = tiles;
+			a.bins[kBinTiles + c] = tiles;
+			a.bins[kBinUnits + c] = units;
+			tiles += n;
+			units += (n * qoi_class_segments((uint32_t)c) + 63u) & ~63u;
+		}
+		a.bins[kBinTotal] = units;
+		a.bins[kBinArrive] = 0u;  // for the next launch
+	}
 }
 
 __global__ void __launch_bounds__(256) qoi_bin_scatter_kernel(const QoiArgs a)
 {
-	// the block reserves one range per class (one global atomic each), threads take slots inside it
 	__shared__ uint32_t s_hist[32], s_base[32];
 	if (threadIdx.x < 32) s_hist[threadIdx.x] = 0;
 	__syncthreads();
-	const uint32_t t = blockIdx.x * 256u + threadIdx.x;
-	uint32_t cls = 0, local = 0;
-	if (t < a.n_tiles) {
-		cls = 31u - (uint32_t)__builtin_clz((a.w[t] * a.h[t]) | 1u);
-		local = atomicAdd(&s_hist[cls], 1u);
+	uint32_t where[kBinChunk / 256u];  // class | place inside the block's share of the class << 5
+#pragma unroll
+	for (uint32_t i = 0; i < kBinChunk / 256u; ++i) {
+		const uint32_t t = blockIdx.x * kBinChunk + i * 256u + threadIdx.x;
+		where[i] = 0;
+		if (t < a.n_tiles) {
+			const uint32_t cls = qoi_tile_class(a, t);
+			where[i] = cls | (atomicAdd(&s_hist[cls], 1u) << 5);
+		}
 	}
 	__syncthreads();
 	if (threadIdx.x < 32 && s_hist[threadIdx.x]) s_base[threadIdx.x] = atomicAdd(&a.bins[kBinCursor + threadIdx.x], s_hist[threadIdx.x]);
 	__syncthreads();
-	if (t < a.n_tiles) a.perm[s_base[cls] + local] = t;
+#pragma unroll
+	for (uint32_t i = 0; i < kBinChunk / 256u; ++i) {
+		const uint32_t t = blockIdx.x * kBinChunk + i * 256u + threadIdx.x;
+		if (t < a.n_tiles) a.perm[s_base[where[i] & 31u] + (where[i] >> 5)] = t;
+	}
 }
 
 typedef __attribute__((address_space(1))) unsigned long long *global_qword_ptr;
@@ -513,8 +540,11 @@ __global__ void __launch_bounds__(64) qoi_tiles_kernel(const QoiArgs a)
 }
 
 // bytes [0, len) from src (8-byte aligned) to dst (any alignment), by `width` lanes (lane = 0 .. width-1): whole aligned
-// dwords of the destination, each from two aligned dwords of the source; the bytes before the first and after the last
-// one (shared with the neighbouring pieces' dwords) one by one
+// dwords of the destination, four per lane and round (16-byte loads and stores at dword alignment; each destination dword
+// from two aligned dwords of the source), then the dwords that are left one per lane; the bytes before the first and after
+// the last one (shared with the neighbouring pieces' dwords) one by one.  (Round 2 moved one dword per lane and round: a
+// 500-byte piece was eight dependent load -> store rounds of a quarter wave, and the splice 0.19 ms for 182 MB.)
+typedef uint32_t u32q_a4 __attribute__((ext_vector_type(4), aligned(4)));
 __device__ __forceinline__ void splice_piece(uint8_t *dst, const uint8_t *src, uint32_t len, uint32_t lane, uint32_t width)
 {
 	const uint32_t head = (uint32_t)((4u - (uint32_t)(reinterpret_cast<uintptr_t>(dst) & 3u)) & 3u);
@@ -526,9 +556,22 @@ __device__ __forceinline__ void splice_piece(uint8_t *dst, const uint8_t *src, u
 	const uint32_t n_dw = (len - head) / 4u, tail = head + 4u * n_dw;
 	const uint32_t *s32 = reinterpret_cast<const uint32_t *>(src);
 	uint32_t *d32 = reinterpret_cast<uint32_t *>(dst + head);
-	const uint32_t sh = head & 3u;  // source byte offset of destination dword j is head + 4j
-	for (uint32_t j = lane; j < n_dw; j += width) {
-		const uint32_t lo = s32[j + (head >> 2)], hi = sh ? s32[j + (head >> 2) + 1u] : 0u;  // (the piece leaves room behind it)
+	const uint32_t sh = head;  // source byte offset of destination dword j is head + 4j
+	const uint32_t n_q = n_dw >> 2;
+	for (uint32_t q = lane; q < n_q; q += width) {
+		const u32q_a4 v = *reinterpret_cast<const u32q_a4 *>(s32 + 4u * q);
+		u32q_a4 o = v;
+		if (sh) {
+			const uint32_t e = s32[4u * q + 4u];  // (the piece leaves room behind it)
+			o.x = __builtin_amdgcn_alignbyte(v.y, v.x, sh);
+			o.y = __builtin_amdgcn_alignbyte(v.z, v.y, sh);
+			o.z = __builtin_amdgcn_alignbyte(v.w, v.z, sh);
+			o.w = __builtin_amdgcn_alignbyte(e, v.w, sh);
+		}
+		*reinterpret_cast<u32q_a4 *>(d32 + 4u * q) = o;
+	}
+	for (uint32_t j = 4u * n_q + lane; j < n_dw; j += width) {
+		const uint32_t lo = s32[j], hi = sh ? s32[j + 1u] : 0u;
 		d32[j] = sh ? __builtin_amdgcn_alignbyte(hi, lo, sh) : lo;
 	}
 	if (lane < len - tail) dst[tail + lane] = src[tail + lane];
@@ -540,15 +583,14 @@ __device__ __forceinline__ void splice_piece(uint8_t *dst, const uint8_t *src, u
 // Records of one piece (tiles below 128 pixels: two thirds of the tiles of a typical frame, records of 30 .. 700 bytes):
 // a quarter wave per tile, four tiles per wave, tiles taken in the encoder's class order (perm) so that the four of a
 // wave are alike.  A wave per tile spent its life in three dependent memory round trips for 40 bytes.
-__global__ void __launch_bounds__(256) qoi_splice_small_kernel(const QoiArgs a)
+__device__ __forceinline__ void qoi_splice_small(const QoiArgs &a, uint32_t block)
 {
 	const uint32_t n_big = a.bins[kBinTiles + 6];  // tiles of the classes >= 7 (several pieces) come first in perm
-	const uint32_t p = n_big + (blockIdx.x * 4u + (threadIdx.x >> 6)) * 4u + ((threadIdx.x & 63u) >> 4), lane = threadIdx.x & 15u;
+	const uint32_t p = n_big + (block * 4u + (threadIdx.x >> 6)) * 4u + ((threadIdx.x & 63u) >> 4), lane = threadIdx.x & 15u;
 	if (p >= a.n_tiles) return;
 	const uint32_t t = a.perm[p];
 	const unsigned long long off = a.chunk_totals[t / kPackChunk] + a.offsets[t];
 	const uint32_t len = a.rec_len[t];
-	if (lane == 0) a.offsets[t] = off;
 	const uint32_t frame = t / a.tiles_per_frame;
 	const unsigned long long dstoff = (unsigned long long)(frame + 1u) * a.hdr_bytes + off;
 	if (dstoff + len > a.capacity) return;
@@ -560,12 +602,12 @@ __global__ void __launch_bounds__(256) qoi_splice_small_kernel(const QoiArgs a)
 // round trips (perm -> offsets / lengths / size of the tile -> the lengths of its pieces -> the pieces), and a wave that did
 // them one record at a time spent 92 % of its life waiting (one wave per tile of the batch, most of them leaving at once:
 // 0.18 ms for 182 MB).  Now the three look-ups of the records to come are in flight while the current one is copied.
-__global__ void __launch_bounds__(256) qoi_splice_kernel(const QoiArgs a)
+__device__ __forceinline__ void qoi_splice_big(const QoiArgs &a, uint32_t block, uint32_t n_blocks)
 {
 	const uint32_t lane = threadIdx.x & 63u;
-	const uint32_t n_big = a.bins[kBinTiles + 6];  // (qoi_splice_small_kernel takes the other tiles)
-	const uint32_t stride = gridDim.x * 4u;
-	uint32_t p1 = blockIdx.x * 4u + (threadIdx.x >> 6);
+	const uint32_t n_big = a.bins[kBinTiles + 6];  // (qoi_splice_small takes the other tiles)
+	const uint32_t stride = n_blocks * 4u;
+	uint32_t p1 = block * 4u + (threadIdx.x >> 6);
 	// stage 2: tile known; stage 3: its offset, length and size known; stage 4: the lengths of its pieces known
 	bool v2 = false, v3 = false, v4 = false;
 	uint32_t t2 = 0, t3 = 0, t4 = 0, len3 = 0, len4 = 0, n3 = 0, n4 = 0, mine4 = 0;
@@ -593,7 +635,6 @@ __global__ void __launch_bounds__(256) qoi_splice_kernel(const QoiArgs a)
 		if (v4) {
 			const uint32_t frame = t4 / a.tiles_per_frame;
 			const unsigned long long dstoff = (unsigned long long)(frame + 1u) * a.hdr_bytes + off4;
-			if (lane == 0) a.offsets[t4] = off4;
 			const uint32_t G = qoi_class_segments(31u - (uint32_t)__builtin_clz(n4 | 1u));
 			const uint32_t seg_px = qoi_segment_pixels(n4, G), p0 = qoi_piece0_bytes(seg_px, a.channels), pn = qoi_piece_bytes(seg_px, a.channels);
 			const uint8_t *rec = a.scratch + (size_t)t4 * a.stride;  // 8-byte aligned (records sit at a stride of whole qwords)
@@ -628,17 +669,22 @@ __global__ void __launch_bounds__(256) qoi_splice_kernel(const QoiArgs a)
 }
 
 // file header + line-length table (mod.rs:50-57,77-82): one thread per (frame, tile row)
-__global__ void __launch_bounds__(256) qoi_headers_kernel(const QoiArgs a)
+__device__ __forceinline__ void qoi_headers(const QoiArgs &a, uint32_t block)
 {
-	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+	// (the binning counters of the next launch: nobody reads them after qoi_tiles_kernel)
+	if (block == 0 && threadIdx.x < 32) a.bins[kBinCounts + threadIdx.x] = 0u;
+	const uint32_t i = block * 256u + threadIdx.x;
 	const uint32_t frames = a.n_tiles / a.tiles_per_frame;
 	if (i >= frames * a.rows) return;
 	const uint32_t f = i / a.rows, r = i - f * a.rows;
 	const uint32_t t0 = f * a.tiles_per_frame + r * a.cols;
-	// offsets[] already hold global record offsets (splice ran first); a row's length is a difference
-	const unsigned long long lo = a.offsets[t0];
-	const unsigned long long hi = (t0 + a.cols == a.n_tiles) ? a.offsets[a.n_tiles] : a.offsets[t0 + a.cols];
-	const unsigned long long file0 = (unsigned long long)f * a.hdr_bytes + a.offsets[f * a.tiles_per_frame];
+	// record offsets: the chunk's start + the place inside the chunk (the two scans); a row's length is a difference
+	auto record_offset = [&](uint32_t t) -> unsigned long long {
+		return t == a.n_tiles ? a.offsets[a.n_tiles] : a.chunk_totals[t / kPackChunk] + a.offsets[t];
+	};
+	const unsigned long long lo = record_offset(t0);
+	const unsigned long long hi = record_offset(t0 + a.cols);
+	const unsigned long long file0 = (unsigned long long)f * a.hdr_bytes + record_offset(f * a.tiles_per_frame);
 	if (file0 + a.hdr_bytes > a.capacity) return;
 	uint8_t *hd = a.out + file0;
 	const uint32_t len = (uint32_t)(hi - lo);
@@ -659,13 +705,24 @@ __global__ void __launch_bounds__(256) qoi_headers_kernel(const QoiArgs a)
 	}
 }
 
-hipError_t launch_qoi(const QoiArgs &a, hipStream_t stream)
+// One launch for what follows the scan of the record lengths: the blocks that walk the multi-piece records come first (they
+// run for the whole launch), the blocks of the one-piece records and of the headers fill in beside and behind them (round 2:
+// three launches, each with its own ramp and tail).
+__global__ void __launch_bounds__(256) qoi_splice_kernel(const QoiArgs a)
 {
-	hipError_t e = hipMemsetAsync(a.bins, 0, 160 * sizeof(uint32_t), stream);
-	if (e != hipSuccess) return e;
-	const uint32_t tb = (a.n_tiles + 255u) / 256u;
+	if (blockIdx.x < a.splice_big_blocks) qoi_splice_big(a, blockIdx.x, a.splice_big_blocks);
+	else if (blockIdx.x < a.splice_big_blocks + a.splice_small_blocks) qoi_splice_small(a, blockIdx.x - a.splice_big_blocks);
+	else qoi_headers(a, blockIdx.x - a.splice_big_blocks - a.splice_small_blocks);
+}
+
+hipError_t launch_qoi(const QoiArgs &args, bool bins_clean, hipStream_t stream)
+{
+	QoiArgs a = args;
+	hipError_t e;
+	// (the counters are left zeroed by the previous launch on the same buffer: bins_clean)
+	if (!bins_clean && (e = hipMemsetAsync(a.bins, 0, 160 * sizeof(uint32_t), stream)) != hipSuccess) return e;
+	const uint32_t tb = (a.n_tiles + kBinChunk - 1u) / kBinChunk;
 	hipLaunchKernelGGL(qoi_bin_count_kernel, dim3(tb), dim3(256), 0, stream, a);
-	hipLaunchKernelGGL(qoi_bin_scan_kernel, dim3(1), dim3(1), 0, stream, a);
 	hipLaunchKernelGGL(qoi_bin_scatter_kernel, dim3(tb), dim3(256), 0, stream, a);
 	// one wave per 64 segments; the number of segments is only known on the device, so the grid covers the worst case
 	// (every tile in the class of a full slot, every class padded to a whole wave) and the surplus waves leave at once
@@ -684,14 +741,15 @@ hipError_t launch_qoi(const QoiArgs &a, hipStream_t stream)
 	p.n_chunks = a.n_chunks;
 	hipLaunchKernelGGL(pack_scan_local_kernel, dim3(a.n_chunks), dim3(256), 0, stream, p);
 	hipLaunchKernelGGL(pack_scan_chunks_kernel, dim3(1), dim3(1024), 0, stream, p);
-	{
-		// a fixed grid of waves that walk the multi-piece records with a stride (their number is only known on the device)
-		const uint32_t need = (a.n_tiles + 3u) / 4u, cap = 2048u;
-		hipLaunchKernelGGL(qoi_splice_kernel, dim3(need < cap ? need : cap), dim3(256), 0, stream, a);
-	}
-	hipLaunchKernelGGL(qoi_splice_small_kernel, dim3((a.n_tiles + 15u) / 16u), dim3(256), 0, stream, a);
+	// a fixed grid of waves that walk the multi-piece records with a stride (their number is only known on the device), the
+	// one-piece records 16 to a block, a thread per (frame, tile row) for the headers
+	const uint32_t need = (a.n_tiles + 3u) / 4u, cap = 2048u;
 	const uint32_t frames = a.n_tiles / a.tiles_per_frame;
-	hipLaunchKernelGGL(qoi_headers_kernel, dim3((frames * a.rows + 255u) / 256u), dim3(256), 0, stream, a);
+	a.splice_big_blocks = need < cap ? need : cap;
+	a.splice_small_blocks = (a.n_tiles + 15u) / 16u;
+	const unsigned long long grid = (unsigned long long)a.splice_big_blocks + a.splice_small_blocks + (frames * a.rows + 255u) / 256u;
+	if (grid > 0x7fffffffull) return hipErrorInvalidValue;
+	hipLaunchKernelGGL(qoi_splice_kernel, dim3((uint32_t)grid), dim3(256), 0, stream, a);
 	return hipGetLastError();
 }
 
@@ -987,7 +1045,7 @@ hipError_t launch_decode(const DecodeArgs &a, hipStream_t stream)
 	hipError_t e = hipMemsetAsync(a.bins, 0, 160 * sizeof(uint32_t), stream);
 	if (e != hipSuccess) return e;
 	hipLaunchKernelGGL(pixlzr_index_kernel, dim3((a.n_frames * a.rows + 3u) / 4u), dim3(256), 0, stream, a);
-	const uint32_t tb = (a.n_tiles + 255u) / 256u;
+	const uint32_t tb = (a.n_tiles + kBinChunk - 1u) / kBinChunk;
 	QoiArgs q{};  // the encoder's binning by pixel count, on the sizes the index kernel has just read
 	q.w = a.tile_w;
 	q.h = a.tile_h;
@@ -995,7 +1053,6 @@ hipError_t launch_decode(const DecodeArgs &a, hipStream_t stream)
 	q.bins = a.bins;
 	q.perm = a.perm;
 	hipLaunchKernelGGL(qoi_bin_count_kernel, dim3(tb), dim3(256), 0, stream, q);
-	hipLaunchKernelGGL(qoi_bin_scan_kernel, dim3(1), dim3(1), 0, stream, q);
 	hipLaunchKernelGGL(qoi_bin_scatter_kernel, dim3(tb), dim3(256), 0, stream, q);
 	const uint32_t qb = (a.n_tiles + 64u * kQoiWaves - 1u) / (64u * kQoiWaves);
 	if (a.channels == 4) hipLaunchKernelGGL(qoi_decode_kernel<4>, dim3(qb), dim3(64u * kQoiWaves), 0, stream, a);
