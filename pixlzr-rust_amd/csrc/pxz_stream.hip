@@ -539,42 +539,25 @@ __global__ void __launch_bounds__(64) qoi_tiles_kernel(const QoiArgs a)
 	}
 }
 
-// bytes [0, len) from src (8-byte aligned) to dst (any alignment), by `width` lanes (lane = 0 .. width-1): whole aligned
-// dwords of the destination, four per lane and round (16-byte loads and stores at dword alignment; each destination dword
-// from two aligned dwords of the source), then the dwords that are left one per lane; the bytes before the first and after
-// the last one (shared with the neighbouring pieces' dwords) one by one.  (Round 2 moved one dword per lane and round: a
-// 500-byte piece was eight dependent load -> store rounds of a quarter wave, and the splice 0.19 ms for 182 MB.)
-typedef uint32_t u32q_a4 __attribute__((ext_vector_type(4), aligned(4)));
+// bytes [0, len) from src to dst (any alignment), by `width` lanes (lane = 0 .. width-1): 16 bytes per lane and round with
+// byte-aligned vector loads and stores (gfx950 runs in unaligned access mode: the memory pipeline splits what straddles),
+// the last move placed so that it ends with the piece.  Round 2 kept the destination's dwords whole -- bytes before the first one, each
+// dword funnel-shifted from two of the source, bytes after the last one: 13 vector memory instructions for a piece of 344
+// bytes against 4 now, and the splice is bound by their number (loads alone 0.08 ms, stores alone 0.07 ms, lookups alone
+// 0.007 ms of its 0.16 ms).
+typedef uint32_t u32q_a1 __attribute__((ext_vector_type(4), aligned(1)));
 __device__ __forceinline__ void splice_piece(uint8_t *dst, const uint8_t *src, uint32_t len, uint32_t lane, uint32_t width)
 {
-	const uint32_t head = (uint32_t)((4u - (uint32_t)(reinterpret_cast<uintptr_t>(dst) & 3u)) & 3u);
-	if (len < 8u + head) {
-		for (uint32_t i = lane; i < len; i += width) dst[i] = src[i];
+	if (len < 16u) {
+		if (lane < len) dst[lane] = src[lane];
 		return;
 	}
-	if (lane < head) dst[lane] = src[lane];
-	const uint32_t n_dw = (len - head) / 4u, tail = head + 4u * n_dw;
-	const uint32_t *s32 = reinterpret_cast<const uint32_t *>(src);
-	uint32_t *d32 = reinterpret_cast<uint32_t *>(dst + head);
-	const uint32_t sh = head;  // source byte offset of destination dword j is head + 4j
-	const uint32_t n_q = n_dw >> 2;
+	// ceil(len / 16) moves of 16 bytes; the last one ends with the piece (it overlaps the one before it)
+	const uint32_t n_q = (len + 15u) >> 4, last = len - 16u;
 	for (uint32_t q = lane; q < n_q; q += width) {
-		const u32q_a4 v = *reinterpret_cast<const u32q_a4 *>(s32 + 4u * q);
-		u32q_a4 o = v;
-		if (sh) {
-			const uint32_t e = s32[4u * q + 4u];  // (the piece leaves room behind it)
-			o.x = __builtin_amdgcn_alignbyte(v.y, v.x, sh);
-			o.y = __builtin_amdgcn_alignbyte(v.z, v.y, sh);
-			o.z = __builtin_amdgcn_alignbyte(v.w, v.z, sh);
-			o.w = __builtin_amdgcn_alignbyte(e, v.w, sh);
-		}
-		*reinterpret_cast<u32q_a4 *>(d32 + 4u * q) = o;
+		const uint32_t at = 16u * q < last ? 16u * q : last;
+		*reinterpret_cast<u32q_a1 *>(dst + at) = *reinterpret_cast<const u32q_a1 *>(src + at);
 	}
-	for (uint32_t j = 4u * n_q + lane; j < n_dw; j += width) {
-		const uint32_t lo = s32[j], hi = sh ? s32[j + 1u] : 0u;
-		d32[j] = sh ? __builtin_amdgcn_alignbyte(hi, lo, sh) : lo;
-	}
-	if (lane < len - tail) dst[tail + lane] = src[tail + lane];
 }
 
 // splice: one wave per tile copies the pieces of its record to (frame+1)*hdr + offset[t]; the pieces of a segmented tile
