@@ -468,6 +468,30 @@ def main():
                                                "traffic": load_flow_traffic(("dir" if pxz_mode == 1 else "by") + str(bs))}
                 del out
 
+    # not the metric either: the way back (Pixlzr::expand + to_image) of what shrink_directionally left, per filter
+    decode_side = {}
+    if world == 1 and not args.no_other_sizes and args.block == 32:
+        _, ow, oh, slots = handle.shrink_frames_device(frames, args.block, args.block, 1, args.filter, MODES["shrink_directionally"][1])
+        stored = int((ow.long() * oh.long()).sum().item()) * 4
+        for label, filt in (("expand Nearest", 0), ("expand Lanczos3", 4)):
+            back = handle.expand_frames_device(tuple(frames.shape), args.block, args.block, filt, ow, oh, slots)
+            for _ in range(20):
+                handle.expand_frames_device(tuple(frames.shape), args.block, args.block, filt, ow, oh, slots, out=back)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(40):
+                handle.expand_frames_device(tuple(frames.shape), args.block, args.block, filt, ow, oh, slots, out=back)
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / 40.0
+            algo = stored + 8 * ow.numel() + back.numel()  # stored pixels + sizes read, frames written
+            decode_side[label] = {"ms_per_step": ms, "algo_bytes_per_launch": algo, "achieved_gbps": algo / (ms * 1e-3) / 1e9,
+                                  "frac_of_hbm_peak": algo / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "time_is": "40 launches between two events on the launch stream"}
+            if filt == args.filter:
+                decode_side[label]["traffic"] = load_flow_traffic("exp32")
+            del back
+        del ow, oh, slots
+
     line = None
     if rank == 0:
         r = results[primary]
@@ -506,6 +530,8 @@ def main():
                 line["modes"][k]["roofline"] = mode_roofline(k, v)
         if others:
             line["other_tile_sizes"] = others
+        if decode_side:
+            line["decode_side"] = decode_side
         if world == 1 and not args.no_cpu_baseline:
             note("cpu baseline")
             line["cpu_baseline"] = cpu_baseline(args, primary, names)
