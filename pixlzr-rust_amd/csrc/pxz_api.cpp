@@ -40,6 +40,8 @@ hipError_t launch_narrow(const NarrowArgs &a, hipStream_t stream);
 hipError_t launch_pack(const PackArgs &a, hipStream_t stream);
 hipError_t launch_oklab(const ShrinkArgs &a, uint32_t n_cus, hipStream_t stream, uint32_t channels = 4);
 hipError_t launch_qoi(const QoiArgs &a, bool bins_clean, hipStream_t stream);
+size_t qoi_scratch_bytes(uint32_t n_tiles, uint32_t slot_px, uint32_t channels);
+uint32_t qoi_bins_dwords();
 uint32_t waves_per_tile(uint32_t bw, uint32_t bh);
 }  // namespace pxz
 
@@ -1519,7 +1521,7 @@ int pxz_decode_frames_device(pxz_handle *h, const pxz_frames *frames, const pxz_
 	a.slot_bytes = p.block_w * p.block_h * f.channels;
 	a.edge_w = f.width - (cols - 1) * p.block_w;
 	a.edge_h = f.height - (rows - 1) * p.block_h;
-	if ((rc = ensure(h, h->dmeta, (size_t)a.n_tiles * 16u + 640u)) != PXZ_OK) return rc;  // rec_off, rec_len, perm, 160 bin counters
+	if ((rc = ensure(h, h->dmeta, (size_t)a.n_tiles * 16u + 4u * pxz::qoi_bins_dwords())) != PXZ_OK) return rc;  // rec_off, rec_len, perm, the bin counters
 	a.rec_off = (unsigned long long *)h->dmeta.ptr;
 	a.rec_len = (uint32_t *)((uint8_t *)h->dmeta.ptr + (size_t)a.n_tiles * 8u);
 	a.perm = a.rec_len + a.n_tiles;
@@ -1951,18 +1953,16 @@ int pxz_encode_frames_device(pxz_handle *h, const pxz_frames *frames, const pxz_
 	const uint32_t n_tiles = (uint32_t)tiles64, c = frames->channels;
 	const uint32_t slot = params->block_w * params->block_h * c;
 	if ((slot & 15u) != 0 && c == 4) return fail(h, PXZ_ERR_UNSUPPORTED, "RGBA slots must be 16-byte multiples");
-	// record = pieces of the tile's segments (pxz_stream.hip): 13 + 10 + at most (channels+1) bytes per pixel + 8, plus per
-	// segment (64..128 pixels; at most 64 of them) a length header, the slack of the 8-byte appends and up to three
-	// pixels of rounding
+	// a record: 13 + 10 + at most (channels + 1) bytes per pixel + the 8-byte end marker; a chunk of the record scan holds 4096 of them
 	const uint32_t px = params->block_w * params->block_h;
-	const uint32_t max_seg = px < 128u ? 1u : (px / 64u < 64u ? px / 64u : 64u);
-	const uint32_t stride = (px * (c + 1u) + max_seg * (4u * (c + 1u) + 31u) + 16u + 7u) & ~7u;
+	const uint32_t stride = 23u + px * (c + 1u) + 8u;
 	const uint32_t n_chunks = (n_tiles + 4095u) / 4096u;
 	if ((uint64_t)stride * 4096ull > 0xffffffffull) return fail(h, PXZ_ERR_UNSUPPORTED, "tile too large for the chunked scan");
 	int rc;
-	if ((rc = ensure(h, h->qscratch, (size_t)n_tiles * stride)) != PXZ_OK) return rc;
-	// perm | rec_len | bins(160) as u32, then offsets (n+1) and chunk totals as u64
-	const size_t meta_u32 = (size_t)n_tiles * 2 + 160;
+	// the encoder's units (pxz_stream.hip)
+	if ((rc = ensure(h, h->qscratch, pxz::qoi_scratch_bytes(n_tiles, px, c))) != PXZ_OK) return rc;
+	// perm | rec_len | bins as u32, then offsets (n+1) and chunk totals as u64
+	const size_t meta_u32 = (size_t)n_tiles * 2 + pxz::qoi_bins_dwords();
 	const size_t meta_bytes = ((meta_u32 * 4 + 7) & ~(size_t)7) + ((size_t)n_tiles + 1 + n_chunks) * 8;
 	if ((rc = ensure(h, h->qmeta, meta_bytes)) != PXZ_OK) return rc;
 	uint32_t *m32 = (uint32_t *)h->qmeta.ptr;
@@ -1988,7 +1988,6 @@ int pxz_encode_frames_device(pxz_handle *h, const pxz_frames *frames, const pxz_
 	a.rows = rows;
 	a.channels = c;
 	a.slot_bytes = slot;
-	a.stride = stride;
 	a.hdr_bytes = 26u + rows * 4u;
 	a.width = frames->width;
 	a.height = frames->height;

@@ -225,7 +225,7 @@ struct QoiArgs {
 	const float *value;
 	uint32_t *perm;               // tiles ordered by pixel count (largest first)
 	uint32_t *bins;               // 64: histogram + cursors
-	uint8_t *scratch;             // per-tile records, `stride` bytes apart
+	uint8_t *scratch;             // the encoder's units (pxz_stream.hip: qoi_class_rows), classes in descending order
 	uint32_t *rec_len;
 	unsigned long long *offsets;  // n_tiles + 1
 	unsigned long long *chunk_totals;
@@ -233,9 +233,9 @@ struct QoiArgs {
 	unsigned long long *file_offsets;  // n_frames + 1
 	unsigned long long capacity;
 	uint32_t n_tiles, n_chunks, tiles_per_frame, cols, rows;
-	uint32_t channels, slot_bytes, stride, hdr_bytes;
+	uint32_t channels, slot_bytes, hdr_bytes;
 	uint32_t width, height, bw, bh, filter_byte;
-	uint32_t splice_big_blocks, splice_small_blocks;  // (set by launch_qoi) the roles of qoi_splice_kernel's blocks
+	uint32_t splice_unit_blocks;  // (set by launch_qoi) the blocks of qoi_splice_kernel below this one take units, the others headers
 };
 
 // Decode side (expand_kernel): one table per (axis, size class, source size) of an up-scale to the full

@@ -130,13 +130,29 @@ hipError_t launch_pack(const PackArgs &a, hipStream_t stream)
 // Then: scan of the record lengths, splice of the pieces into the final files, header + per-row length table.
 // ---------------------------------------------------------------------------
 constexpr uint32_t kBinCounts = 0, kBinCursor = 32, kBinUnits = 64, kBinTiles = 96, kBinTotal = 128, kBinArrive = 129;  // u32 offsets in bins[]
+constexpr uint32_t kBinBase = 130;   // 32 x u64 (as dword pairs): where the units of a class start in the scratch (encode side)
+constexpr uint32_t kBinN = 194;      // 32: tiles per class, for the kernels behind the binning (kBinCounts are the accumulators: the scan zeroes them again)
+constexpr uint32_t kBinDwords = 256;  // what a caller allocates (and zeroes once) for bins[]
 
 __device__ __host__ __forceinline__ uint32_t qoi_class_segments(uint32_t cls) { return cls <= 6u ? 1u : (cls >= 12u ? 64u : 1u << (cls - 6u)); }
 // pixels per segment (a multiple of 4: the RGBA loads stay 16-byte aligned, the RGB ones dword aligned)
-__device__ __forceinline__ uint32_t qoi_segment_pixels(uint32_t n, uint32_t g) { return ((n + g - 1u) / g + 3u) & ~3u; }
+__device__ __host__ __forceinline__ uint32_t qoi_segment_pixels(uint32_t n, uint32_t g) { return ((n + g - 1u) / g + 3u) & ~3u; }
 // scratch record: bytes of piece 0 (header + segment 0) and of every further piece (8-byte length header + segment)
 __device__ __host__ __forceinline__ uint32_t qoi_piece0_bytes(uint32_t seg_px, uint32_t c) { return (23u + seg_px * (c + 1u) + 8u + 8u + 7u) & ~7u; }
 __device__ __host__ __forceinline__ uint32_t qoi_piece_bytes(uint32_t seg_px, uint32_t c) { return (8u + seg_px * (c + 1u) + 8u + 8u + 7u) & ~7u; }
+// Scratch of the encoder (round 3): a UNIT is the 64 segments one wave encodes side by side, stored as rows of 512 bytes --
+// qword k of lane l at (64 k + l) * 8.  Row 0 holds the 64 lengths, the rows behind it the segments' bytes, as many as the longest
+// piece of a tile of the class can need (a record header and the largest segment).  The units of a class lie back to back, the
+// classes in descending order (bins[kBinBase ..]).  What the lanes of a wave store together is then one run of 512 bytes, and what
+// the splice reads is whole rows -- with the lanes' pieces each in a place of its own every store touched 64 cache lines, which
+// was 0.07 ms of the encoder's 0.27.
+__device__ __host__ __forceinline__ uint32_t qoi_class_rows(uint32_t c, uint32_t slot_px, uint32_t channels)
+{
+	const uint32_t g = qoi_class_segments(c);
+	uint32_t n_max = c >= 31u ? slot_px : (2u << c) - 1u;  // the class holds 2^c .. 2^(c+1) - 1 pixels
+	if (n_max > slot_px) n_max = slot_px;
+	return 1u + qoi_piece0_bytes(qoi_segment_pixels(n_max ? n_max : 1u, g), channels) / 8u;
+}
 
 // Binning (counting sort by class, largest first): two launches of ceil(n / 4096) blocks, 16 tiles per thread.
 //   qoi_bin_count_kernel    per-block histogram in LDS, one global atomic per non-empty class and block; the block that
@@ -144,7 +160,7 @@ __device__ __host__ __forceinline__ uint32_t qoi_piece_bytes(uint32_t seg_px, ui
 //                           run of segments ("units": a class starts a fresh wave) -- round 3: this was a launch of one thread
 //   qoi_bin_scatter_kernel  the block reserves one range per class (one global atomic each), threads take slots inside it
 // (Round 2 ran one tile per thread: a thousand blocks whose atomics queued on a handful of addresses, 13 us each for 2 MB of
-// sizes.)  bins[kBinCounts ..] must be zero at the start: launch_qoi's last kernel leaves them so.
+// sizes.)  bins[kBinCounts ..] must be zero at the start: the scan leaves them so (the kernels behind it read the copy at kBinN).
 constexpr uint32_t kBinChunk = 4096;  // tiles per block: 256 threads x 16
 __device__ __forceinline__ uint32_t qoi_tile_class(const QoiArgs &a, uint32_t t) { return 31u - (uint32_t)__builtin_clz((a.w[t] * a.h[t]) | 1u); }
 
@@ -171,15 +187,28 @@ __global__ void __launch_bounds__(256) qoi_bin_count_kernel(const QoiArgs a)
 	// the last block: every count is in (device-scope atomics, read as such)
 	if (threadIdx.x < 32) s_hist[threadIdx.x] = __hip_atomic_load(&a.bins[kBinCounts + threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 	__syncthreads();
+	// (the bytes of a class's units, a lane per class: the serial walk below only adds them up)
+	__shared__ unsigned long long s_bytes[32];
+	if (threadIdx.x < 32) {
+		const uint32_t c = threadIdx.x, n_units = (s_hist[c] * qoi_class_segments(c) + 63u) / 64u;
+		s_bytes[c] = a.slot_bytes ? (unsigned long long)n_units * 512ull * qoi_class_rows(c, a.slot_bytes / a.channels, a.channels) : 0ull;
+	}
+	__syncthreads();
 	if (threadIdx.x == 0) {
 		uint32_t tiles = 0, units = 0;
+		unsigned long long base = 0;
 		for (int c = 31; c >= 0; --c) {
 			const uint32_t n = s_hist[c];
+			a.bins[kBinN + c] = n;
+			a.bins[kBinCounts + c] = 0u;  // (every block has added its share: ready for the next launch)
 			a.bins[kBinCursor + c] = tiles;
 			a.bins[kBinTiles + c] = tiles;
 			a.bins[kBinUnits + c] = units;
+			a.bins[kBinBase + 2 * c] = (uint32_t)base;  // (the encoder: where the class's units start in its scratch)
+			a.bins[kBinBase + 2 * c + 1] = (uint32_t)(base >> 32);
 			tiles += n;
 			units += (n * qoi_class_segments((uint32_t)c) + 63u) & ~63u;
+			base += s_bytes[c];
 		}
 		a.bins[kBinTotal] = units;
 		a.bins[kBinArrive] = 0u;  // for the next launch
@@ -212,19 +241,23 @@ __global__ void __launch_bounds__(256) qoi_bin_scatter_kernel(const QoiArgs a)
 }
 
 typedef __attribute__((address_space(1))) unsigned long long *global_qword_ptr;
+typedef uint32_t u32q_a1 __attribute__((ext_vector_type(4), aligned(1)));
 struct ByteSink {
 	unsigned long long acc;
 	uint32_t cnt;        // bytes in acc (0..7)
+	uint32_t rows;       // qwords written
 	// (a pointer the compiler knows to be global: through a generic one the stores are flat_store, which also count as LDS
 	// operations -- every wait for an index read then waited for the stores in flight as well)
-	global_qword_ptr out;
+	global_qword_ptr out;  // this lane's qword of the unit's next row (rows are 64 qwords)
 	// n <= 8 bytes at once, first byte in the low bits of v (bits above 8n must be zero)
 	__device__ __forceinline__ void append(unsigned long long v, uint32_t n)
 	{
 		acc |= v << (8u * cnt);
 		const uint32_t total = cnt + n;
 		if (total >= 8u) {
-			*out++ = acc;
+			*out = acc;
+			out += 64;
+			++rows;
 			acc = cnt ? v >> (64u - 8u * cnt) : 0ull;  // the bytes that did not fit
 			cnt = total - 8u;
 		} else {
@@ -232,6 +265,34 @@ struct ByteSink {
 		}
 	}
 };
+
+// which tile and which of its segments lane `lane` of the wave at unit0 has: the class whose run of units holds unit0 (classes in
+// descending order, runs padded to whole waves; lane c looks at class c: one round trip to the counters instead of a walk), then
+// the tile by its rank in the class.  The same in the encoder and in the splice.
+struct QoiLane {
+	uint32_t cls, G, rank, seg, t;
+	bool live;
+	uint8_t *unit;  // the wave's unit in the scratch
+};
+__device__ __forceinline__ QoiLane qoi_lane(const QoiArgs &a, uint32_t unit0, uint32_t lane)
+{
+	QoiLane q;
+	{
+		const uint32_t c = lane & 31u;
+		const uint32_t ub = a.bins[kBinUnits + c], nu = (a.bins[kBinN + c] * qoi_class_segments(c) + 63u) & ~63u;
+		const unsigned long long mine = __ballot(lane < 32u && unit0 >= ub && unit0 < ub + nu);
+		q.cls = (uint32_t)__builtin_ctzll(mine | (1ull << 63));
+	}
+	q.G = qoi_class_segments(q.cls);  // lanes per tile (a power of two)
+	const uint32_t first = a.bins[kBinUnits + q.cls], rel = unit0 - first + lane;
+	q.rank = rel / q.G;
+	q.seg = rel & (q.G - 1u);
+	q.live = q.rank < a.bins[kBinN + q.cls];
+	q.t = q.live ? a.perm[a.bins[kBinTiles + q.cls] + q.rank] : 0u;
+	const unsigned long long base = (unsigned long long)a.bins[kBinBase + 2u * q.cls] | ((unsigned long long)a.bins[kBinBase + 2u * q.cls + 1u] << 32);
+	q.unit = a.scratch + base + (size_t)((unit0 - first) / 64u) * (512u * qoi_class_rows(q.cls, a.slot_bytes / a.channels, a.channels));
+	return q;
+}
 
 __device__ __forceinline__ uint32_t qoi_hash(uint32_t px)
 {
@@ -290,20 +351,9 @@ __global__ void __launch_bounds__(64) qoi_tiles_kernel(const QoiArgs a)
 	const uint32_t lane = threadIdx.x;
 	const uint32_t unit0 = blockIdx.x * 64u;
 	if (unit0 >= a.bins[kBinTotal]) return;  // (the grid covers the worst case: every tile in the largest class)
-	// this wave's class: the one whose run of units holds unit0 (classes in descending order, runs padded to whole waves)
-	// (lane c looks at class c: one round trip to the counters instead of a walk)
-	uint32_t cls = 0;
-	{
-		const uint32_t c = lane & 31u;
-		const uint32_t ub = a.bins[kBinUnits + c], nu = (a.bins[kBinCounts + c] * qoi_class_segments(c) + 63u) & ~63u;
-		const unsigned long long mine = __ballot(lane < 32u && unit0 >= ub && unit0 < ub + nu);
-		cls = (uint32_t)__builtin_ctzll(mine | (1ull << 63));
-	}
-	const uint32_t G = qoi_class_segments(cls);  // lanes per tile (a power of two)
-	const uint32_t rel = unit0 - a.bins[kBinUnits + cls] + lane;
-	const uint32_t rank = rel / G, seg = rel & (G - 1u);
-	const bool live = rank < a.bins[kBinCounts + cls];
-	const uint32_t t = live ? a.perm[a.bins[kBinTiles + cls] + rank] : 0u;
+	const QoiLane ql_ = qoi_lane(a, unit0, lane);
+	const uint32_t G = ql_.G, seg = ql_.seg, t = ql_.t;
+	const bool live = ql_.live;
 	const uint32_t w = live ? a.w[t] : 0u, h = live ? a.h[t] : 0u, n = w * h;
 	const uint32_t seg_px = qoi_segment_pixels(n ? n : 1u, G);  // (the same value the splice kernel derives from n)
 	const uint32_t start = seg * seg_px, end = start + seg_px < n ? start + seg_px : n;
@@ -405,12 +455,15 @@ __global__ void __launch_bounds__(64) qoi_tiles_kernel(const QoiArgs a)
 		const unsigned long long before = (ops >> first_lane) & ((1ull << seg) - 1ull);
 		seen_in = before != 0ull;
 	}
-	if (!live) return;
+	// row 0 of the unit: the 64 lengths (lanes without a segment: 0)
+	uint32_t *my_len = reinterpret_cast<uint32_t *>(ql_.unit) + 2u * lane;
+	if (!live) {
+		*my_len = 0u;
+		return;
+	}
 
-	// ---- the segment's ops
-	uint8_t *rec = a.scratch + (size_t)t * a.stride;
-	uint8_t *piece = seg ? rec + qoi_piece0_bytes(seg_px, C) + (size_t)(seg - 1u) * qoi_piece_bytes(seg_px, C) : rec;
-	ByteSink s{0ull, 0u, (global_qword_ptr)(seg ? piece + 8 : piece)};
+	// ---- the segment's ops, into this lane's qwords of the unit's rows 1, 2, ...
+	ByteSink s{0ull, 0u, 0u, (global_qword_ptr)ql_.unit + 64 + lane};
 	if (seg == 0u) {
 		// encode_block: magic, value, length placeholder (mod.rs:172-178,195), then the qoi header minus its 4-byte magic
 		// (mod.rs:191): width, height BE, channels, colourspace 0 -- 23 bytes
@@ -523,140 +576,124 @@ __global__ void __launch_bounds__(64) qoi_tiles_kernel(const QoiArgs a)
 		}
 	}
 	if (len && end == n) s.append(0x0100000000000000ull, 8);  // QOI end marker: seven zero bytes and a one
-	uint32_t bytes_here = (uint32_t)((const uint8_t *)s.out - (seg ? piece + 8 : piece)) + s.cnt;
-	if (s.cnt) *s.out = s.acc;  // partial tail (the piece leaves room)
-	if (seg) *reinterpret_cast<uint32_t *>(piece) = bytes_here;
+	const uint32_t bytes_here = 8u * s.rows + s.cnt;
+	if (s.cnt) *s.out = s.acc;  // partial tail (the unit has a row for it)
+	*my_len = bytes_here;
 	// the record's length: every piece of the tile (a butterfly over the tile's lanes; all of them are here)
 	uint32_t total = bytes_here;
 	for (uint32_t d = 1; d < G; d <<= 1) total += __shfl_xor(total, (int)d, 64);
 	if (seg == 0u) {
-		const uint32_t qlen = total - 13u;  // mod.rs:193-195
-		rec[9] = (uint8_t)(qlen >> 24);
-		rec[10] = (uint8_t)(qlen >> 16);
-		rec[11] = (uint8_t)(qlen >> 8);
-		rec[12] = (uint8_t)qlen;
+		// mod.rs:193-195: the record's length field, bytes 9..12 = bytes 1..4 of this lane's qword in row 2 (stored above, same lane)
+		typedef uint32_t u32_a1 __attribute__((aligned(1)));
+		*reinterpret_cast<u32_a1 *>(ql_.unit + (size_t)(2u * 64u + lane) * 8u + 1u) = __builtin_bswap32(total - 13u);
 		a.rec_len[t] = total;
 	}
 }
 
-// bytes [0, len) from src to dst (any alignment), by `width` lanes (lane = 0 .. width-1): 16 bytes per lane and round with
-// byte-aligned vector loads and stores (gfx950 runs in unaligned access mode: the memory pipeline splits what straddles),
-// the last move placed so that it ends with the piece.  Round 2 kept the destination's dwords whole -- bytes before the first one, each
-// dword funnel-shifted from two of the source, bytes after the last one: 13 vector memory instructions for a piece of 344
-// bytes against 4 now, and the splice is bound by their number (loads alone 0.08 ms, stores alone 0.07 ms, lookups alone
-// 0.007 ms of its 0.16 ms).
-typedef uint32_t u32q_a1 __attribute__((ext_vector_type(4), aligned(1)));
-__device__ __forceinline__ void splice_piece(uint8_t *dst, const uint8_t *src, uint32_t len, uint32_t lane, uint32_t width)
+// ---------------------------------------------------------------------------
+// splice: the units of the encoder, one wave each, into the files behind the record scan.  Lane l stands for the same segment as
+// in qoi_tiles_kernel (qoi_lane): row 0 gives it its piece's length, a scan over the tile's lanes the piece's place in the
+// record, the two scans of the record lengths the record's place in the file.  The rows then come through LDS -- whole rows of
+// 512 bytes from the scratch, 16 bytes per lane (two neighbouring pieces' qwords), into an image [piece][row] -- LPP rows at a
+// time, and LPP lanes per piece write the bytes out with byte-aligned 16-byte moves (gfx950 runs in unaligned access mode: hipcc
+// emits global_store_dwordx4 ... offset:3 for an align-1 vector), the bytes that are left of a piece one per lane.
+// LPP = 16: segments of tiles of 128 pixels and more (up to 680 bytes a piece, 32 rows at a time); LPP = 4: units whose longest
+// piece is at most 64 bytes (the records of the smallest tiles, 40 % of a typical frame: 16 of them per store).
+// History: round 2 kept records as pieces per tile and moved them dword-wise (13 memory instructions per 344-byte piece, 0.19 ms);
+// what bounds a splice is the NUMBER of its vector memory instructions (loads alone 0.08 ms, stores alone 0.07, look-ups 0.007).
+// ---------------------------------------------------------------------------
+template <int LPP>
+__device__ __forceinline__ void qoi_splice_rows(const uint8_t *unit, uint32_t *s_img32, uint32_t lane, uint32_t bytes, uint8_t *my_dst, uint32_t k_unit)
 {
-	if (len < 16u) {
-		if (lane < len) dst[lane] = src[lane];
-		return;
+	constexpr uint32_t kRows = 2u * LPP;        // rows per round: LPP lanes x 16 bytes of every piece
+	constexpr uint32_t kSlot = kQoiRow * 4u;    // image of a piece: 260 bytes apart (bank skew)
+	constexpr uint32_t kPer = 64u / LPP;        // pieces per store
+	uint8_t *s_img = reinterpret_cast<uint8_t *>(s_img32);
+	const uint32_t sub = lane / LPP, ql = lane % LPP;
+	// step st: piece kPer st + sub -- its length and where it goes, fetched once
+	const uint32_t dlo_mine = (uint32_t)reinterpret_cast<uintptr_t>(my_dst), dhi_mine = (uint32_t)(reinterpret_cast<uintptr_t>(my_dst) >> 32);
+	uint32_t pb[LPP];
+	uint8_t *pdst[LPP];
+#pragma unroll
+	for (uint32_t st = 0; st < (uint32_t)LPP; ++st) {
+		const int p = (int)(kPer * st + sub);
+		pb[st] = __shfl(bytes, p, 64);
+		const uint32_t dlo = __shfl(dlo_mine, p, 64), dhi = __shfl(dhi_mine, p, 64);
+		pdst[st] = reinterpret_cast<uint8_t *>(((uintptr_t)dhi << 32) | dlo);
 	}
-	// ceil(len / 16) moves of 16 bytes; the last one ends with the piece (it overlaps the one before it)
-	const uint32_t n_q = (len + 15u) >> 4, last = len - 16u;
-	for (uint32_t q = lane; q < n_q; q += width) {
-		const uint32_t at = 16u * q < last ? 16u * q : last;
-		*reinterpret_cast<u32q_a1 *>(dst + at) = *reinterpret_cast<const u32q_a1 *>(src + at);
-	}
-}
-
-// splice: one wave per tile copies the pieces of its record to (frame+1)*hdr + offset[t]; the pieces of a segmented tile
-// four at a time, a quarter wave each.  (A quarter wave per TILE -- four times fewer waves -- was tried: 0.33 ms
-// against 0.25, the short records' byte copies then take three rounds of 16 lanes instead of one of 64.)
-// Records of one piece (tiles below 128 pixels: two thirds of the tiles of a typical frame, records of 30 .. 700 bytes):
-// a quarter wave per tile, four tiles per wave, tiles taken in the encoder's class order (perm) so that the four of a
-// wave are alike.  A wave per tile spent its life in three dependent memory round trips for 40 bytes.
-__device__ __forceinline__ void qoi_splice_small(const QoiArgs &a, uint32_t block)
-{
-	const uint32_t n_big = a.bins[kBinTiles + 6];  // tiles of the classes >= 7 (several pieces) come first in perm
-	const uint32_t p = n_big + (block * 4u + (threadIdx.x >> 6)) * 4u + ((threadIdx.x & 63u) >> 4), lane = threadIdx.x & 15u;
-	if (p >= a.n_tiles) return;
-	const uint32_t t = a.perm[p];
-	const unsigned long long off = a.chunk_totals[t / kPackChunk] + a.offsets[t];
-	const uint32_t len = a.rec_len[t];
-	const uint32_t frame = t / a.tiles_per_frame;
-	const unsigned long long dstoff = (unsigned long long)(frame + 1u) * a.hdr_bytes + off;
-	if (dstoff + len > a.capacity) return;
-	splice_piece(a.out + dstoff, a.scratch + (size_t)t * a.stride, len, lane, 16u);
-}
-
-// The records of several pieces (tiles of 128 pixels and more; they come first in perm): a wave per record, the waves of a
-// fixed grid walking the records with a stride.  Round 3: what a record needs before its first byte moves is four dependent
-// round trips (perm -> offsets / lengths / size of the tile -> the lengths of its pieces -> the pieces), and a wave that did
-// them one record at a time spent 92 % of its life waiting (one wave per tile of the batch, most of them leaving at once:
-// 0.18 ms for 182 MB).  Now the three look-ups of the records to come are in flight while the current one is copied.
-__device__ __forceinline__ void qoi_splice_big(const QoiArgs &a, uint32_t block, uint32_t n_blocks)
-{
-	const uint32_t lane = threadIdx.x & 63u;
-	const uint32_t n_big = a.bins[kBinTiles + 6];  // (qoi_splice_small takes the other tiles)
-	const uint32_t stride = n_blocks * 4u;
-	uint32_t p1 = block * 4u + (threadIdx.x >> 6);
-	// stage 2: tile known; stage 3: its offset, length and size known; stage 4: the lengths of its pieces known
-	bool v2 = false, v3 = false, v4 = false;
-	uint32_t t2 = 0, t3 = 0, t4 = 0, len3 = 0, len4 = 0, n3 = 0, n4 = 0, mine4 = 0;
-	unsigned long long off3 = 0, off4 = 0;
-	for (;;) {
-		// ---- the look-ups of the records to come (issued first: they travel while the copy below runs)
-		const bool v1 = p1 < n_big;
-		uint32_t t1 = 0;
-		if (v1) t1 = a.perm[p1];
-		unsigned long long off2 = 0;
-		uint32_t len2 = 0, n2 = 0;
-		if (v2) {
-			off2 = a.chunk_totals[t2 / kPackChunk] + a.offsets[t2];
-			len2 = a.rec_len[t2];
-			n2 = a.w[t2] * a.h[t2];
+	for (uint32_t k0 = 0; k0 < k_unit; k0 += kRows) {
+		const uint32_t rows = k_unit - k0 < kRows ? k_unit - k0 : kRows;
+		tile_sync<1>();  // (the moves of the round before are done with the image)
+		// rows k0 .. k0 + rows (data rows: the unit's row 1 + ...): lane l takes the qwords of pieces 2 (l & 31), + 1 of row 2 j + (l >> 5);
+		// every load is issued before the first one is used (rows past the end repeat row k0: nothing is conditional)
+		uint4 v[LPP];
+#pragma unroll
+		for (uint32_t j = 0; j < (uint32_t)LPP; ++j) {
+			const uint32_t r = 2u * j + (lane >> 5), row = r < rows ? k0 + r : k0;
+			v[j] = *reinterpret_cast<const uint4 *>(unit + ((size_t)(1u + row) * 64u + 2u * (lane & 31u)) * 8u);
 		}
-		uint32_t mine3 = 0;
-		if (v3) {
-			const uint32_t G = qoi_class_segments(31u - (uint32_t)__builtin_clz(n3 | 1u));
-			const uint32_t seg_px = qoi_segment_pixels(n3, G), p0 = qoi_piece0_bytes(seg_px, a.channels), pn = qoi_piece_bytes(seg_px, a.channels);
-			// lane j holds the length of piece j (G <= 64; piece 0 is what the others leave of the record)
-			if (lane >= 1u && lane < G) mine3 = *reinterpret_cast<const uint32_t *>(a.scratch + (size_t)t3 * a.stride + p0 + (size_t)(lane - 1u) * pn);
-		}
-		// ---- the record whose pieces are known: scan of their lengths, then quarter waves copy pieces side by side
-		if (v4) {
-			const uint32_t frame = t4 / a.tiles_per_frame;
-			const unsigned long long dstoff = (unsigned long long)(frame + 1u) * a.hdr_bytes + off4;
-			const uint32_t G = qoi_class_segments(31u - (uint32_t)__builtin_clz(n4 | 1u));
-			const uint32_t seg_px = qoi_segment_pixels(n4, G), p0 = qoi_piece0_bytes(seg_px, a.channels), pn = qoi_piece_bytes(seg_px, a.channels);
-			const uint8_t *rec = a.scratch + (size_t)t4 * a.stride;  // 8-byte aligned (records sit at a stride of whole qwords)
-			uint8_t *dst = a.out + dstoff;
-			uint32_t mine = mine4 > pn - 8u ? 0u : mine4;  // (cannot happen)
-			uint32_t others = mine;
-			for (uint32_t d = 1; d < 64u; d <<= 1) others += __shfl_xor(others, (int)d, 64);
-			const bool fine = dstoff + len4 <= a.capacity && others <= len4 && len4 - others <= p0;  // (the pieces add up to the record)
-			if (fine) {
-				if (lane == 0u) mine = len4 - others;
-				uint32_t startpos = mine;  // inclusive scan, then minus own = exclusive
-				for (uint32_t d = 1; d < 64u; d <<= 1) {
-					const uint32_t up = __shfl_up(startpos, d, 64);
-					if (lane >= d) startpos += up;
-				}
-				startpos -= mine;
-				const uint32_t quarter = lane >> 4, ql = lane & 15u;
-				for (uint32_t j0 = 0; j0 < G; j0 += 4u) {
-					const uint32_t j = j0 + quarter;
-					const uint32_t lj = __shfl(mine, (int)(j & 63u), 64), pj = __shfl(startpos, (int)(j & 63u), 64);
-					if (j < G && lj) splice_piece(dst + pj, j ? rec + p0 + (size_t)(j - 1u) * pn + 8u : rec, lj, ql, 16u);
-				}
+#pragma unroll
+		for (uint32_t j = 0; j < (uint32_t)LPP; ++j) {
+			const uint32_t r = 2u * j + (lane >> 5);
+			if (r < rows) {
+				uint32_t *d0 = reinterpret_cast<uint32_t *>(s_img + (2u * (lane & 31u)) * kSlot + r * 8u);
+				uint32_t *d1 = reinterpret_cast<uint32_t *>(s_img + (2u * (lane & 31u) + 1u) * kSlot + r * 8u);
+				d0[0] = v[j].x; d0[1] = v[j].y;
+				d1[0] = v[j].z; d1[1] = v[j].w;
 			}
 		}
-		if (!(v1 || v2 || v3)) break;
-		// ---- everyone moves on by one stage
-		v4 = v3; t4 = t3; off4 = off3; len4 = len3; n4 = n3; mine4 = mine3;
-		v3 = v2; t3 = t2; off3 = off2; len3 = len2; n3 = n2;
-		v2 = v1; t2 = t1;
-		p1 += stride;
+		tile_sync<1>();
+		// piece p's bytes [8 k0, min(bytes, 8 (k0 + rows))): one 16-byte move per lane, then the bytes that are left, one per lane
+		const uint32_t lo = 8u * k0, top = 8u * (k0 + rows);
+#pragma unroll
+		for (uint32_t st = 0; st < (uint32_t)LPP; ++st) {
+			const uint32_t hi = pb[st] < top ? pb[st] : top;
+			const uint32_t span = hi > lo ? hi - lo : 0u, n_q = span >> 4;
+			const uint8_t *img = s_img + (kPer * st + sub) * kSlot;
+			uint8_t *dst = pdst[st] + lo;
+			if (ql < n_q) {
+				const uint32_t *w = reinterpret_cast<const uint32_t *>(img + 16u * ql);
+				const u32q_a1 o = {w[0], w[1], w[2], w[3]};
+				*reinterpret_cast<u32q_a1 *>(dst + 16u * ql) = o;
+			}
+#pragma unroll
+			for (uint32_t b = ql; b < 15u; b += (uint32_t)LPP)  // (one round at LPP = 16, up to four at LPP = 4)
+				if (b < (span & 15u)) dst[16u * n_q + b] = img[16u * n_q + b];
+		}
 	}
+}
+
+__device__ __forceinline__ void qoi_splice_unit(const QoiArgs &a, uint32_t unit0, uint32_t *s_img32)
+{
+	const uint32_t lane = threadIdx.x;
+	const QoiLane q = qoi_lane(a, unit0, lane);
+	const uint32_t bytes0 = reinterpret_cast<const uint32_t *>(q.unit)[2u * lane];  // row 0 (lanes without a segment: 0)
+	uint32_t bytes = bytes0;
+	// the piece's place in its record (a scan over the tile's lanes) and the record's length
+	uint32_t total = bytes, incl = bytes;
+	for (uint32_t d = 1; d < q.G; d <<= 1) {
+		total += __shfl_xor(total, (int)d, 64);
+		const uint32_t up = __shfl_up(incl, d, 64);
+		if (q.seg >= d) incl += up;
+	}
+	const unsigned long long off = q.live ? a.chunk_totals[q.t / kPackChunk] + a.offsets[q.t] : 0ull;
+	const unsigned long long dstoff = (unsigned long long)(q.t / a.tiles_per_frame + 1u) * a.hdr_bytes + off;
+	if (!q.live || dstoff + total > a.capacity) bytes = 0u;  // (a record that does not fit is left out whole: total is the same on its lanes)
+	uint8_t *my_dst = a.out + dstoff + (incl - bytes0);
+	uint32_t k_unit = (bytes + 7u) >> 3;
+	for (uint32_t d = 1; d < 64u; d <<= 1) {
+		const uint32_t o = __shfl_xor(k_unit, (int)d, 64);
+		k_unit = o > k_unit ? o : k_unit;
+	}
+	k_unit = __builtin_amdgcn_readfirstlane(k_unit);
+	if (k_unit <= 8u) qoi_splice_rows<4>(q.unit, s_img32, lane, bytes, my_dst, k_unit);
+	else qoi_splice_rows<16>(q.unit, s_img32, lane, bytes, my_dst, k_unit);
 }
 
 // file header + line-length table (mod.rs:50-57,77-82): one thread per (frame, tile row)
 __device__ __forceinline__ void qoi_headers(const QoiArgs &a, uint32_t block)
 {
-	// (the binning counters of the next launch: nobody reads them after qoi_tiles_kernel)
-	if (block == 0 && threadIdx.x < 32) a.bins[kBinCounts + threadIdx.x] = 0u;
-	const uint32_t i = block * 256u + threadIdx.x;
+	const uint32_t i = block * 64u + threadIdx.x;
 	const uint32_t frames = a.n_tiles / a.tiles_per_frame;
 	if (i >= frames * a.rows) return;
 	const uint32_t f = i / a.rows, r = i - f * a.rows;
@@ -688,22 +725,40 @@ __device__ __forceinline__ void qoi_headers(const QoiArgs &a, uint32_t block)
 	}
 }
 
-// One launch for what follows the scan of the record lengths: the blocks that walk the multi-piece records come first (they
-// run for the whole launch), the blocks of the one-piece records and of the headers fill in beside and behind them (round 2:
-// three launches, each with its own ramp and tail).
-__global__ void __launch_bounds__(256) qoi_splice_kernel(const QoiArgs a)
+// One launch for what follows the scan of the record lengths: a wave per unit (the grid covers the worst case, as
+// qoi_tiles_kernel's does; the surplus waves leave at once), then the blocks of the headers.
+__global__ void __launch_bounds__(64) qoi_splice_kernel(const QoiArgs a)
 {
-	if (blockIdx.x < a.splice_big_blocks) qoi_splice_big(a, blockIdx.x, a.splice_big_blocks);
-	else if (blockIdx.x < a.splice_big_blocks + a.splice_small_blocks) qoi_splice_small(a, blockIdx.x - a.splice_big_blocks);
-	else qoi_headers(a, blockIdx.x - a.splice_big_blocks - a.splice_small_blocks);
+	__shared__ uint32_t s_img[64 * kQoiRow];
+	if (blockIdx.x < a.splice_unit_blocks) {
+		if (blockIdx.x * 64u < a.bins[kBinTotal]) qoi_splice_unit(a, blockIdx.x * 64u, s_img);
+	} else {
+		qoi_headers(a, blockIdx.x - a.splice_unit_blocks);
+	}
 }
+
+// bytes of scratch the encoder can need for n_tiles slots of slot_px pixels: every tile in the class that costs most, plus
+// every class's run rounded up to a whole unit
+size_t qoi_scratch_bytes(uint32_t n_tiles, uint32_t slot_px, uint32_t channels)
+{
+	const uint32_t top = 31u - (uint32_t)__builtin_clz(slot_px | 1u);
+	size_t per_tile = 0, pad = 0;
+	for (uint32_t c = 0; c <= top; ++c) {
+		const size_t lane_bytes = 8u * (size_t)qoi_class_rows(c, slot_px, channels);
+		const size_t t = lane_bytes * qoi_class_segments(c);
+		per_tile = t > per_tile ? t : per_tile;
+		pad += 64u * lane_bytes;
+	}
+	return (size_t)n_tiles * per_tile + pad;
+}
+uint32_t qoi_bins_dwords() { return kBinDwords; }
 
 hipError_t launch_qoi(const QoiArgs &args, bool bins_clean, hipStream_t stream)
 {
 	QoiArgs a = args;
 	hipError_t e;
 	// (the counters are left zeroed by the previous launch on the same buffer: bins_clean)
-	if (!bins_clean && (e = hipMemsetAsync(a.bins, 0, 160 * sizeof(uint32_t), stream)) != hipSuccess) return e;
+	if (!bins_clean && (e = hipMemsetAsync(a.bins, 0, kBinDwords * sizeof(uint32_t), stream)) != hipSuccess) return e;
 	const uint32_t tb = (a.n_tiles + kBinChunk - 1u) / kBinChunk;
 	hipLaunchKernelGGL(qoi_bin_count_kernel, dim3(tb), dim3(256), 0, stream, a);
 	hipLaunchKernelGGL(qoi_bin_scatter_kernel, dim3(tb), dim3(256), 0, stream, a);
@@ -724,15 +779,12 @@ hipError_t launch_qoi(const QoiArgs &args, bool bins_clean, hipStream_t stream)
 	p.n_chunks = a.n_chunks;
 	hipLaunchKernelGGL(pack_scan_local_kernel, dim3(a.n_chunks), dim3(256), 0, stream, p);
 	hipLaunchKernelGGL(pack_scan_chunks_kernel, dim3(1), dim3(1024), 0, stream, p);
-	// a fixed grid of waves that walk the multi-piece records with a stride (their number is only known on the device), the
-	// one-piece records 16 to a block, a thread per (frame, tile row) for the headers
-	const uint32_t need = (a.n_tiles + 3u) / 4u, cap = 2048u;
+	// a wave per unit (worst case, as above), a thread per (frame, tile row) for the headers
 	const uint32_t frames = a.n_tiles / a.tiles_per_frame;
-	a.splice_big_blocks = need < cap ? need : cap;
-	a.splice_small_blocks = (a.n_tiles + 15u) / 16u;
-	const unsigned long long grid = (unsigned long long)a.splice_big_blocks + a.splice_small_blocks + (frames * a.rows + 255u) / 256u;
+	a.splice_unit_blocks = qb;
+	const unsigned long long grid = (unsigned long long)qb + (frames * a.rows + 63u) / 64u;
 	if (grid > 0x7fffffffull) return hipErrorInvalidValue;
-	hipLaunchKernelGGL(qoi_splice_kernel, dim3((uint32_t)grid), dim3(256), 0, stream, a);
+	hipLaunchKernelGGL(qoi_splice_kernel, dim3((uint32_t)grid), dim3(64), 0, stream, a);
 	return hipGetLastError();
 }
 
@@ -1025,7 +1077,7 @@ __global__ void __launch_bounds__(64 * kQoiWaves) qoi_decode_kernel(const Decode
 
 hipError_t launch_decode(const DecodeArgs &a, hipStream_t stream)
 {
-	hipError_t e = hipMemsetAsync(a.bins, 0, 160 * sizeof(uint32_t), stream);
+	hipError_t e = hipMemsetAsync(a.bins, 0, kBinDwords * sizeof(uint32_t), stream);
 	if (e != hipSuccess) return e;
 	hipLaunchKernelGGL(pixlzr_index_kernel, dim3((a.n_frames * a.rows + 3u) / 4u), dim3(256), 0, stream, a);
 	const uint32_t tb = (a.n_tiles + kBinChunk - 1u) / kBinChunk;
