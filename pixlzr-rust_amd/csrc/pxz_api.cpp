@@ -39,7 +39,7 @@ hipError_t launch_widen(const WidenArgs &a, hipStream_t stream);
 hipError_t launch_narrow(const NarrowArgs &a, hipStream_t stream);
 hipError_t launch_pack(const PackArgs &a, hipStream_t stream);
 hipError_t launch_oklab(const ShrinkArgs &a, uint32_t n_cus, hipStream_t stream, uint32_t channels = 4);
-hipError_t launch_qoi(const QoiArgs &a, bool bins_clean, hipStream_t stream);
+hipError_t launch_qoi(const QoiArgs &a, bool bins_clean, uint32_t n_cus, hipStream_t stream);
 size_t qoi_scratch_bytes(uint32_t n_tiles, uint32_t slot_px, uint32_t channels);
 uint32_t qoi_bins_dwords();
 uint32_t waves_per_tile(uint32_t bw, uint32_t bh);
@@ -1997,7 +1997,7 @@ int pxz_encode_frames_device(pxz_handle *h, const pxz_frames *frames, const pxz_
 	// (a launch leaves the binning counters zeroed for the next one on the same buffer)
 	const bool bins_clean = h->qbins_clean == a.bins;
 	h->qbins_clean = nullptr;
-	PXZ_HIP(h, pxz::launch_qoi(a, bins_clean, h->stream));
+	PXZ_HIP(h, pxz::launch_qoi(a, bins_clean, h->n_cus, h->stream));
 	h->qbins_clean = a.bins;
 	return PXZ_OK;
 }

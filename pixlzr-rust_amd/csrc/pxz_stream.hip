@@ -663,31 +663,88 @@ __device__ __forceinline__ void qoi_splice_rows(const uint8_t *unit, uint32_t *s
 	}
 }
 
-__device__ __forceinline__ void qoi_splice_unit(const QoiArgs &a, uint32_t unit0, uint32_t *s_img32)
+// The units a wave takes (a fixed grid of waves, each walking the units with a stride): what a unit needs before its first
+// row moves is a chain of dependent round trips -- the tile of every lane (perm), its record's place (the two scans), the
+// lengths (row 0) -- so the chain of the unit after next and of the next one are in flight while the current one is copied
+// (a wave per unit spent most of its 15 us in that chain).  The classes' counters are read once per wave: lane c keeps class c.
+struct SpliceClasses {
+	uint32_t first_unit, n_units64, n_tiles, first_tile, base_lo, base_hi;  // of class lane & 31
+};
+struct SpliceUnit {
+	bool valid;
+	uint32_t cls, G, seg, t, bytes0;
+	bool live;
+	const uint8_t *unit;
+	unsigned long long off;
+};
+__device__ __forceinline__ void splice_locate(const QoiArgs &a, const SpliceClasses &k, uint32_t unit0, uint32_t total_units, uint32_t lane, SpliceUnit &u)
+{
+	u.valid = unit0 < total_units;
+	u.live = false;
+	u.t = 0u;
+	u.bytes0 = 0u;
+	u.unit = a.scratch;
+	u.cls = 0u; u.G = 1u; u.seg = 0u;
+	if (!u.valid) return;
+	const unsigned long long mine = __ballot(lane < 32u && unit0 >= k.first_unit && unit0 < k.first_unit + k.n_units64);
+	u.cls = (uint32_t)__builtin_ctzll(mine | (1ull << 63));
+	u.G = qoi_class_segments(u.cls);
+	const uint32_t first = (uint32_t)__builtin_amdgcn_readlane((int)k.first_unit, (int)u.cls), rel = unit0 - first + lane;
+	const uint32_t rank = rel / u.G;
+	u.seg = rel & (u.G - 1u);
+	u.live = rank < (uint32_t)__builtin_amdgcn_readlane((int)k.n_tiles, (int)u.cls);
+	const unsigned long long base = (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)k.base_lo, (int)u.cls) |
+	                                ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)k.base_hi, (int)u.cls) << 32);
+	u.unit = a.scratch + base + (size_t)((unit0 - first) / 64u) * (512u * qoi_class_rows(u.cls, a.slot_bytes / a.channels, a.channels));
+	if (u.live) u.t = a.perm[(uint32_t)__builtin_amdgcn_readlane((int)k.first_tile, (int)u.cls) + rank];
+	u.bytes0 = reinterpret_cast<const uint32_t *>(u.unit)[2u * lane];  // row 0 (lanes without a segment: 0)
+}
+
+__device__ __forceinline__ void qoi_splice_units(const QoiArgs &a, uint32_t wave, uint32_t n_waves, uint32_t *s_img32)
 {
 	const uint32_t lane = threadIdx.x;
-	const QoiLane q = qoi_lane(a, unit0, lane);
-	const uint32_t bytes0 = reinterpret_cast<const uint32_t *>(q.unit)[2u * lane];  // row 0 (lanes without a segment: 0)
-	uint32_t bytes = bytes0;
-	// the piece's place in its record (a scan over the tile's lanes) and the record's length
-	uint32_t total = bytes, incl = bytes;
-	for (uint32_t d = 1; d < q.G; d <<= 1) {
-		total += __shfl_xor(total, (int)d, 64);
-		const uint32_t up = __shfl_up(incl, d, 64);
-		if (q.seg >= d) incl += up;
+	const uint32_t total_units = a.bins[kBinTotal];
+	SpliceClasses k;
+	{
+		const uint32_t c = lane & 31u;
+		k.first_unit = a.bins[kBinUnits + c];
+		k.n_tiles = a.bins[kBinN + c];
+		k.n_units64 = (k.n_tiles * qoi_class_segments(c) + 63u) & ~63u;
+		k.first_tile = a.bins[kBinTiles + c];
+		k.base_lo = a.bins[kBinBase + 2u * c];
+		k.base_hi = a.bins[kBinBase + 2u * c + 1u];
 	}
-	const unsigned long long off = q.live ? a.chunk_totals[q.t / kPackChunk] + a.offsets[q.t] : 0ull;
-	const unsigned long long dstoff = (unsigned long long)(q.t / a.tiles_per_frame + 1u) * a.hdr_bytes + off;
-	if (!q.live || dstoff + total > a.capacity) bytes = 0u;  // (a record that does not fit is left out whole: total is the same on its lanes)
-	uint8_t *my_dst = a.out + dstoff + (incl - bytes0);
-	uint32_t k_unit = (bytes + 7u) >> 3;
-	for (uint32_t d = 1; d < 64u; d <<= 1) {
-		const uint32_t o = __shfl_xor(k_unit, (int)d, 64);
-		k_unit = o > k_unit ? o : k_unit;
+	const uint32_t stride = n_waves * 64u;
+	SpliceUnit u0, u1, u2;  // current (place known), next (tile known), the one after (being located)
+	splice_locate(a, k, wave * 64u, total_units, lane, u0);
+	u0.off = u0.live ? a.chunk_totals[u0.t / kPackChunk] + a.offsets[u0.t] : 0ull;
+	splice_locate(a, k, wave * 64u + stride, total_units, lane, u1);
+	for (uint32_t unit0 = wave * 64u; u0.valid; unit0 += stride) {
+		// ---- the look-ups of the units to come (issued first: they travel while the copy below runs)
+		splice_locate(a, k, unit0 + 2u * stride, total_units, lane, u2);
+		u1.off = u1.live ? a.chunk_totals[u1.t / kPackChunk] + a.offsets[u1.t] : 0ull;
+		// ---- the current unit: the piece's place in its record (a scan over the tile's lanes) and the record's length
+		uint32_t bytes = u0.bytes0;
+		uint32_t total = bytes, incl = bytes;
+		for (uint32_t d = 1; d < u0.G; d <<= 1) {
+			total += __shfl_xor(total, (int)d, 64);
+			const uint32_t up = __shfl_up(incl, d, 64);
+			if (u0.seg >= d) incl += up;
+		}
+		const unsigned long long dstoff = (unsigned long long)(u0.t / a.tiles_per_frame + 1u) * a.hdr_bytes + u0.off;
+		if (!u0.live || dstoff + total > a.capacity) bytes = 0u;  // (a record that does not fit is left out whole: total is the same on its lanes)
+		uint8_t *my_dst = a.out + dstoff + (incl - u0.bytes0);
+		uint32_t k_unit = (bytes + 7u) >> 3;
+		for (uint32_t d = 1; d < 64u; d <<= 1) {
+			const uint32_t o = __shfl_xor(k_unit, (int)d, 64);
+			k_unit = o > k_unit ? o : k_unit;
+		}
+		k_unit = __builtin_amdgcn_readfirstlane(k_unit);
+		if (k_unit <= 8u) qoi_splice_rows<4>(u0.unit, s_img32, lane, bytes, my_dst, k_unit);
+		else qoi_splice_rows<16>(u0.unit, s_img32, lane, bytes, my_dst, k_unit);
+		u0 = u1;
+		u1 = u2;
 	}
-	k_unit = __builtin_amdgcn_readfirstlane(k_unit);
-	if (k_unit <= 8u) qoi_splice_rows<4>(q.unit, s_img32, lane, bytes, my_dst, k_unit);
-	else qoi_splice_rows<16>(q.unit, s_img32, lane, bytes, my_dst, k_unit);
 }
 
 // file header + line-length table (mod.rs:50-57,77-82): one thread per (frame, tile row)
@@ -725,13 +782,12 @@ __device__ __forceinline__ void qoi_headers(const QoiArgs &a, uint32_t block)
 	}
 }
 
-// One launch for what follows the scan of the record lengths: a wave per unit (the grid covers the worst case, as
-// qoi_tiles_kernel's does; the surplus waves leave at once), then the blocks of the headers.
+// One launch for what follows the scan of the record lengths: the waves that walk the units, then the blocks of the headers.
 __global__ void __launch_bounds__(64) qoi_splice_kernel(const QoiArgs a)
 {
 	__shared__ uint32_t s_img[64 * kQoiRow];
 	if (blockIdx.x < a.splice_unit_blocks) {
-		if (blockIdx.x * 64u < a.bins[kBinTotal]) qoi_splice_unit(a, blockIdx.x * 64u, s_img);
+		qoi_splice_units(a, blockIdx.x, a.splice_unit_blocks, s_img);
 	} else {
 		qoi_headers(a, blockIdx.x - a.splice_unit_blocks);
 	}
@@ -753,7 +809,7 @@ size_t qoi_scratch_bytes(uint32_t n_tiles, uint32_t slot_px, uint32_t channels)
 }
 uint32_t qoi_bins_dwords() { return kBinDwords; }
 
-hipError_t launch_qoi(const QoiArgs &args, bool bins_clean, hipStream_t stream)
+hipError_t launch_qoi(const QoiArgs &args, bool bins_clean, uint32_t n_cus, hipStream_t stream)
 {
 	QoiArgs a = args;
 	hipError_t e;
@@ -779,10 +835,12 @@ hipError_t launch_qoi(const QoiArgs &args, bool bins_clean, hipStream_t stream)
 	p.n_chunks = a.n_chunks;
 	hipLaunchKernelGGL(pack_scan_local_kernel, dim3(a.n_chunks), dim3(256), 0, stream, p);
 	hipLaunchKernelGGL(pack_scan_chunks_kernel, dim3(1), dim3(1024), 0, stream, p);
-	// a wave per unit (worst case, as above), a thread per (frame, tile row) for the headers
+	// the waves that walk the units (as many as fit the chip: eight per CU -- or fewer, if even the worst case has fewer units),
+	// a thread per (frame, tile row) for the headers
 	const uint32_t frames = a.n_tiles / a.tiles_per_frame;
-	a.splice_unit_blocks = qb;
-	const unsigned long long grid = (unsigned long long)qb + (frames * a.rows + 63u) / 64u;
+	const uint32_t per_cu = 8u;  // (its registers allow two waves per SIMD; 6 per CU: +2 %, 4: +20 %)
+	a.splice_unit_blocks = qb < n_cus * per_cu ? qb : n_cus * per_cu;
+	const unsigned long long grid = (unsigned long long)a.splice_unit_blocks + (frames * a.rows + 63u) / 64u;
 	if (grid > 0x7fffffffull) return hipErrorInvalidValue;
 	hipLaunchKernelGGL(qoi_splice_kernel, dim3((uint32_t)grid), dim3(64), 0, stream, a);
 	return hipGetLastError();
