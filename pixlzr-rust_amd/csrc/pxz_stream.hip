@@ -125,9 +125,10 @@ hipError_t launch_pack(const PackArgs &a, hipStream_t stream)
 // A pending run is written by the segment in which it ends, the end marker by the segment holding the last pixel.
 // Tiles are binned by class (counting sort, largest first) so that a wave holds segments of one class; the lanes' tables
 // live in LDS as table[lane][slot] (stride 65: conflict-free for the per-slot walk, random for the pixel loops).
-// Record of a tile in scratch: piece 0 = "block" | f32 BE value | u32 BE len | w,h BE | channels | 0 | ops of segment 0,
-// pieces 1.. = {u32 length, pad} + ops of the segment, at fixed distances; the last one ends with 0x00*7 0x01.
-// Then: scan of the record lengths, splice of the pieces into the final files, header + per-row length table.
+// What a segment writes (its PIECE of the tile's record): segment 0 starts with "block" | f32 BE value | u32 BE len | w,h BE |
+// channels | 0, every segment has its ops, the last one ends with 0x00*7 0x01.  The pieces go into the wave's unit of the
+// scratch (qoi_class_rows below).  Then: scan of the record lengths, splice of the units into the final files (every piece behind
+// the one before it), header + per-row length table.
 // ---------------------------------------------------------------------------
 constexpr uint32_t kBinCounts = 0, kBinCursor = 32, kBinUnits = 64, kBinTiles = 96, kBinTotal = 128, kBinArrive = 129;  // u32 offsets in bins[]
 constexpr uint32_t kBinBase = 130;   // 32 x u64 (as dword pairs): where the units of a class start in the scratch (encode side)
