@@ -188,31 +188,36 @@ __global__ void __launch_bounds__(256) qoi_bin_count_kernel(const QoiArgs a)
 	// the last block: every count is in (device-scope atomics, read as such)
 	if (threadIdx.x < 32) s_hist[threadIdx.x] = __hip_atomic_load(&a.bins[kBinCounts + threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 	__syncthreads();
-	// (the bytes of a class's units, a lane per class: the serial walk below only adds them up)
+	// a lane per class: what lies in front of it (the larger classes) in the permutation of tiles, in the run of units and --
+	// the encoder -- in the scratch
+	__shared__ uint32_t s_units[32];
 	__shared__ unsigned long long s_bytes[32];
 	if (threadIdx.x < 32) {
-		const uint32_t c = threadIdx.x, n_units = (s_hist[c] * qoi_class_segments(c) + 63u) / 64u;
-		s_bytes[c] = a.slot_bytes ? (unsigned long long)n_units * 512ull * qoi_class_rows(c, a.slot_bytes / a.channels, a.channels) : 0ull;
+		const uint32_t c = threadIdx.x, units = (s_hist[c] * qoi_class_segments(c) + 63u) & ~63u;
+		s_units[c] = units;
+		s_bytes[c] = a.slot_bytes ? (unsigned long long)(units / 64u) * 512ull * qoi_class_rows(c, a.slot_bytes / a.channels, a.channels) : 0ull;
 	}
 	__syncthreads();
-	if (threadIdx.x == 0) {
+	if (threadIdx.x < 32) {
+		const uint32_t c = threadIdx.x;
 		uint32_t tiles = 0, units = 0;
 		unsigned long long base = 0;
-		for (int c = 31; c >= 0; --c) {
-			const uint32_t n = s_hist[c];
-			a.bins[kBinN + c] = n;
-			a.bins[kBinCounts + c] = 0u;  // (every block has added its share: ready for the next launch)
-			a.bins[kBinCursor + c] = tiles;
-			a.bins[kBinTiles + c] = tiles;
-			a.bins[kBinUnits + c] = units;
-			a.bins[kBinBase + 2 * c] = (uint32_t)base;  // (the encoder: where the class's units start in its scratch)
-			a.bins[kBinBase + 2 * c + 1] = (uint32_t)(base >> 32);
-			tiles += n;
-			units += (n * qoi_class_segments((uint32_t)c) + 63u) & ~63u;
-			base += s_bytes[c];
+		for (uint32_t o = c + 1u; o < 32u; ++o) {
+			tiles += s_hist[o];
+			units += s_units[o];
+			base += s_bytes[o];
 		}
-		a.bins[kBinTotal] = units;
-		a.bins[kBinArrive] = 0u;  // for the next launch
+		a.bins[kBinN + c] = s_hist[c];
+		a.bins[kBinCounts + c] = 0u;  // (every block has added its share: ready for the next launch)
+		a.bins[kBinCursor + c] = tiles;
+		a.bins[kBinTiles + c] = tiles;
+		a.bins[kBinUnits + c] = units;
+		a.bins[kBinBase + 2u * c] = (uint32_t)base;
+		a.bins[kBinBase + 2u * c + 1u] = (uint32_t)(base >> 32);
+		if (c == 0u) {
+			a.bins[kBinTotal] = units + s_units[0];
+			a.bins[kBinArrive] = 0u;  // for the next launch
+		}
 	}
 }
 
