@@ -417,6 +417,52 @@ def test_device_bitstream_equals_oracle_writer(gpu, oracle, c, mode, factor):
         assert data[offs[f]:offs[f + 1]] == ref, f"frame {f}"
 
 
+@pytest.mark.parametrize("c,bw,bh", [(4, 128, 128), (3, 128, 128), (4, 96, 40), (4, 20, 12), (3, 64, 64)])
+def test_device_writer_on_tiles_of_every_class(gpu, oracle, c, bw, bh):
+    """The writer's units (one wave = 64 segments of one class; rows of 512 bytes in the scratch; the splice that walks them):
+    tiles of every size from 1x1 up to the slot -- 128x128 slots reach the classes whose segments are longer than 128 pixels --
+    with content that makes short and long pieces (constant, few colours, noise, alpha flicker), stored sizes at random.
+    GPU QOI + container == the oracle's writer (encoding/mod.rs:40-89, 168-200 with the qoi crate's encoder), byte for byte."""
+    import torch
+    rng = np.random.default_rng(1000 * c + bw + bh)
+    cols, rows = 7, 5
+    n = cols * rows
+    tw = np.zeros((2, n), np.uint32); th = np.zeros((2, n), np.uint32)
+    slots = np.zeros((2, n, bw * bh * c), np.uint8)
+    vals = rng.random((2, n)).astype(np.float32)
+    for f in range(2):
+        for t in range(n):
+            w = int(rng.choice([1, 2, 3, bw // 4, bw // 2, bw - 1, bw, int(rng.integers(1, bw + 1))]))
+            h = int(rng.choice([1, 2, bh // 4 or 1, bh // 2, bh, int(rng.integers(1, bh + 1))]))
+            w, h = max(w, 1), max(h, 1)
+            kind = int(rng.integers(0, 4))
+            if kind == 0:
+                px = np.tile(rng.integers(0, 256, c, dtype=np.uint8), (w * h, 1))
+            elif kind == 1:
+                pal = rng.integers(0, 256, (4, c), dtype=np.uint8)
+                px = pal[np.repeat(rng.integers(0, 4, w * h), rng.integers(1, 40, w * h))[: w * h]]
+            elif kind == 2:
+                px = rng.integers(0, 256, (w * h, c), dtype=np.uint8)
+            else:
+                px = (np.cumsum(rng.integers(-2, 3, (w * h, c)), axis=0) + 128).astype(np.uint8)
+                if c == 4: px[:, 3] = rng.choice(np.array([0, 255], np.uint8), w * h)
+            tw[f, t], th[f, t] = w, h
+            slots[f, t, : w * h * c] = px.reshape(-1)
+    W, H = cols * bw, rows * bh
+    offs, buf = gpu.encode_frames_device((2, H, W, c), bw, bh, torch.from_numpy(vals).cuda(), torch.from_numpy(tw.astype(np.int32)).cuda(),
+                                         torch.from_numpy(th.astype(np.int32)).cuda(), torch.from_numpy(slots).cuda())
+    torch.cuda.synchronize()
+    offs = offs.cpu().numpy()
+    data = buf[: offs[-1]].cpu().numpy().tobytes()
+    for f in range(2):
+        ref = oracle.encode_container(W, H, bw, bh, c, 0, vals[f], None, tw[f], th[f], slots[f])
+        got = data[offs[f]:offs[f + 1]]
+        assert len(got) == len(ref), f"frame {f}: {len(got)} bytes, oracle {len(ref)}"
+        if got != ref:
+            i = next(k for k in range(len(ref)) if got[k] != ref[k])
+            raise AssertionError(f"frame {f}: first difference at byte {i} of {len(ref)}")
+
+
 # ---- decode side (SURVEY §8 f2): Pixlzr::expand + to_image --------------------------------------------------
 
 def test_expand_reproduces_big_ruscher_pix_png(gpu, oracle, golden_dir):
