@@ -870,11 +870,11 @@ __device__ __forceinline__ uint32_t be32(const uint8_t *p)
 // record's position): it runs on bytes staged in LDS, chunk by chunk, so a step costs an LDS round trip instead of
 // an HBM one.  Per chunk: all lanes load it (coalesced), lane 0 walks up to 64 records ahead using only the
 // length fields, then the lanes check and publish those records in parallel.
-constexpr uint32_t kIdxChunk = 8192;   // bytes of a row held in LDS at a time (per wave)
+constexpr uint32_t kIdxChunk = 8192;   // bytes of a row held in LDS at a time (per wave; 16384: no faster)
 constexpr uint32_t kIdxHeader = 23;    // "block" + value + length + QOI header minus its magic, up to the channel byte
 __global__ void __launch_bounds__(256) pixlzr_index_kernel(const DecodeArgs a)
 {
-	__shared__ __attribute__((aligned(16))) uint32_t s_chunk[4][kIdxChunk / 4u + 4u];
+	__shared__ __attribute__((aligned(16))) uint32_t s_chunk[4][kIdxChunk / 4u + 8u];
 	__shared__ uint32_t s_pos[4][64];  // positions (relative to the chunk's first byte) of the records of a batch
 	const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
 	const uint32_t i = blockIdx.x * 4u + wave;
@@ -923,21 +923,35 @@ __global__ void __launch_bounds__(256) pixlzr_index_kernel(const DecodeArgs a)
 	const uint8_t *cb = reinterpret_cast<const uint8_t *>(s_chunk[wave]);
 	uint32_t c = 0;
 	while (c < a.cols) {
-		// ---- stage file bytes [p, p + kIdxChunk) of the row (whole aligned dwords of the buffer, then the tail bytes)
+		// ---- stage file bytes [p, p + kIdxChunk) of the row: whole aligned 16-byte granules of the buffer, every load of the
+		// chunk issued before the first one is written to LDS (round 2 staged dwords, one load -> store round per 256 bytes: a
+		// wave walks a row of ~170 KB alone, and the kernel was 0.33 ms of chained round trips)
 		const unsigned long long want = row_end - p < (unsigned long long)kIdxChunk ? row_end - p : (unsigned long long)kIdxChunk;
 		const uintptr_t g = reinterpret_cast<uintptr_t>(file + p);
-		const uint32_t skew = (uint32_t)(g & 3u);  // the chunk starts at the aligned dword below p
-		const uint32_t dwords = (skew + (uint32_t)want + 3u) / 4u;
+		const uint32_t skew = (uint32_t)(g & 15u);  // the chunk starts at the aligned granule below p
+		const uint32_t granules = (skew + (uint32_t)want + 15u) / 16u;  // <= kIdxChunk / 16 + 1
 		const uintptr_t buf_end = reinterpret_cast<uintptr_t>(a.files) + a.file_offsets[a.n_frames];
-		for (uint32_t d = lane; d < dwords; d += 64u) {
-			const uintptr_t ga = (g - skew) + 4ull * d;
-			uint32_t v = 0;
-			if (ga + 4u <= buf_end) {
-				v = *reinterpret_cast<const uint32_t *>(ga);
-			} else {
-				for (uint32_t k = 0; k < 4u && ga + k < buf_end; ++k) v |= (uint32_t) * reinterpret_cast<const uint8_t *>(ga + k) << (8u * k);
+		constexpr uint32_t kRounds = (kIdxChunk / 16u + 1u + 63u) / 64u;
+		uint4 gv[kRounds];
+#pragma unroll
+		for (uint32_t k = 0; k < kRounds; ++k) {
+			const uint32_t d = lane + 64u * k;
+			const uintptr_t ga = (g - skew) + 16ull * d;
+			gv[k] = make_uint4(0, 0, 0, 0);
+			if (d < granules) {
+				if (ga + 16u <= buf_end) {
+					gv[k] = *reinterpret_cast<const uint4 *>(ga);
+				} else {  // (the last granule of the buffer: byte by byte)
+					uint32_t w4[4] = {0, 0, 0, 0};
+					for (uint32_t b = 0; b < 16u && ga + b < buf_end; ++b) w4[b >> 2] |= (uint32_t) * reinterpret_cast<const uint8_t *>(ga + b) << (8u * (b & 3u));
+					gv[k] = make_uint4(w4[0], w4[1], w4[2], w4[3]);
+				}
 			}
-			s_chunk[wave][d] = v;
+		}
+#pragma unroll
+		for (uint32_t k = 0; k < kRounds; ++k) {
+			const uint32_t d = lane + 64u * k;
+			if (d < granules) reinterpret_cast<uint4 *>(s_chunk[wave])[d] = gv[k];
 		}
 		tile_sync<1>();
 		const uint32_t have = (uint32_t)want;  // valid bytes behind cb + skew

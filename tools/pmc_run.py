@@ -2,7 +2,7 @@
 the flow's algorithmic bytes per step beside the counters (source once + shrunk pixels + 12 B per tile; the
 writer: valid slot bytes + value/w/h read, file bytes written).
 
-  python3 tools/pmc_run.py <variant>       variant = dir | by | enc | exp | dirlod | bylod     (dir_full = dir, kept for old scripts)
+  python3 tools/pmc_run.py <variant>       variant = dir | by | enc | dec | exp | dirlod | bylod     (dir_full = dir, kept for old scripts)
   env: BLOCK (tile side, 32), NF (frames, 8), N (steps, 3), DIST (0 opaque .. 3 noise), FACTOR, FILTER (4), OUTJSON
 """
 import json, os, sys
@@ -31,6 +31,12 @@ if variant == "enc":  # shrink once, then the device writer n times
     valid = int((ow.long() * oh.long()).sum().item()) * 4
     info.update(step_kernels="qoi_,pack_", setup_kernels="shrink,oklab",
                 algo_bytes=valid + 12 * ow.numel() + int(enc[0][-1].item()), file_bytes=int(enc[0][-1].item()))
+elif variant == "dec":  # shrink + write once, then the device reader n times
+    out = h.shrink_frames_device(frames, bs, bs, 1, flt, 16.0)
+    offs, buf = h.encode_frames_device(tuple(frames.shape), bs, bs, *out)
+    for _ in range(n): d = h.decode_frames_device(buf, offs, tuple(frames.shape), bs, bs)
+    info.update(step_kernels="pixlzr_index,qoi_decode,qoi_bin", setup_kernels="shrink,oklab,qoi_tiles,qoi_splice,pack_",
+                algo_bytes=int(offs[-1].item()) + int((out[1].long() * out[2].long()).sum().item()) * 4 + 12 * out[1].numel())
 elif variant == "exp":  # shrink once (directional, factor 16, Lanczos3), then expand n times with FILTER
     vals, ow, oh, slots = h.shrink_frames_device(frames, bs, bs, 1, 4, 16.0)
     out = h.expand_frames_device(tuple(frames.shape), bs, bs, flt, ow, oh, slots)
