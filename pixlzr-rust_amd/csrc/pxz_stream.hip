@@ -1054,10 +1054,14 @@ __global__ void __launch_bounds__(64 * kQoiWaves) qoi_decode_kernel(const Decode
 	// op: every op's result is worked out and selects keep the right one.
 	const unsigned long long first_byte = a.rec_off[t];
 	const unsigned long long *wp = reinterpret_cast<const unsigned long long *>(a.files + (first_byte & ~7ull));
-	const unsigned long long *w_end = reinterpret_cast<const unsigned long long *>(a.files + ((first_byte + len + 7ull) & ~7ull));
-	unsigned long long w0 = *wp++;                          // (len > 0: the first window holds op bytes)
-	unsigned long long w1 = wp < w_end ? *wp : 0ull;
-	unsigned long long w2 = wp + 1 < w_end ? wp[1] : 0ull;  // one more ahead: its round trip overlaps a window's worth of ops
+	// (windows are requested without a condition -- a load whose result is chosen against a constant is copied into the
+	// window's register the moment it is issued, and that copy waits for it: round 2's `wp < w_end ? *wp : 0` stalled for a
+	// whole memory round trip at every window, which was the kernel's 0.69 ms -- but never past the last window of the files)
+	const unsigned long long *w_last = reinterpret_cast<const unsigned long long *>(a.files + ((a.file_offsets[a.n_frames] - 1ull) & ~7ull));
+	auto window = [&](const unsigned long long *p) __attribute__((always_inline)) { return *(p < w_last ? p : w_last); };
+	unsigned long long w0 = *wp++;  // (len > 0: the first window holds op bytes)
+	unsigned long long w1 = window(wp);
+	unsigned long long w2 = window(wp + 1);  // one more ahead: its round trip overlaps a window's worth of ops
 	uint32_t pos = (uint32_t)(first_byte & 7ull);           // byte position of the next op inside w0 (0..7)
 	uint32_t left = len;                                    // op bytes not yet consumed
 	const uint32_t n = a.tile_w[t] * a.tile_h[t];
@@ -1065,7 +1069,8 @@ __global__ void __launch_bounds__(64 * kQoiWaves) qoi_decode_kernel(const Decode
 	uint32_t px = 0xff000000u, run = 0;
 	bool starved = false;
 	uint4 hold = make_uint4(0, 0, 0, 0);
-	for (uint32_t i = 0; i < n; ++i) {
+	// one pixel: the next op (or the run in progress) -> px
+	auto next_pixel = [&]() __attribute__((always_inline)) {
 		// the (up to) 8 bytes at the stream position
 		const unsigned long long at = pos ? (w0 >> (8u * pos)) | (w1 << (64u - 8u * pos)) : w0;
 		const uint32_t b1 = (uint32_t)at & 255u, b2 = (uint32_t)(at >> 8) & 255u;
@@ -1118,22 +1123,39 @@ __global__ void __launch_bounds__(64 * kQoiWaves) qoi_decode_kernel(const Decode
 		pos += step;
 		if (pos >= 8u) {  // the window is used up: move on, request the one after next
 			pos -= 8u;
-			w0 = w1;
-			w1 = w2;
 			wp += 1;
-			w2 = wp + 1 < w_end ? wp[1] : 0ull;
+			// (the moves spelled out, in front of the request and into registers of their own: the window that was w2 is dead
+			// behind them, so the request can be loaded straight into ITS register -- else it goes through a temporary, and
+			// the copy out of the temporary waits for the load on the spot)
+			uint32_t a_lo, a_hi, b_lo, b_hi;
+			asm volatile("v_mov_b32 %0, %4\n\tv_mov_b32 %1, %5\n\tv_mov_b32 %2, %6\n\tv_mov_b32 %3, %7"
+			             : "=&v"(a_lo), "=&v"(a_hi), "=&v"(b_lo), "=&v"(b_hi)
+			             : "v"((uint32_t)w1), "v"((uint32_t)(w1 >> 32)), "v"((uint32_t)w2), "v"((uint32_t)(w2 >> 32))
+			             : "memory");
+			w0 = (unsigned long long)a_lo | ((unsigned long long)a_hi << 32);
+			w1 = (unsigned long long)b_lo | ((unsigned long long)b_hi << 32);
+			w2 = window(wp + 1);
 		}
-		if constexpr (C == 4) {
-			// four pixels per 16-byte store (slots are 16-byte aligned: bw*bh*4 bytes each)
-			const uint32_t k = i & 3u;
-			if (k == 0) hold.x = px;
-			else if (k == 1) hold.y = px;
-			else if (k == 2) hold.z = px;
-			else {
-				hold.w = px;
-				reinterpret_cast<uint4 *>(dst)[i >> 2] = hold;
-			}
-		} else {
+	};
+	if constexpr (C == 4) {
+		// four pixels per 16-byte store (slots are 16-byte aligned: bw*bh*4 bytes each), the loop unrolled by those four: a
+		// lane's pixel loop is one dependent chain, and every instruction on it counts (the kernel lasts as long as its longest
+		// lanes; the per-pixel tests of which quarter of the store a pixel is were scalar instructions on that chain)
+		uint32_t i = 0;
+		for (; i + 4u <= n; i += 4u) {
+			next_pixel(); hold.x = px;
+			next_pixel(); hold.y = px;
+			next_pixel(); hold.z = px;
+			next_pixel(); hold.w = px;
+			reinterpret_cast<uint4 *>(dst)[i >> 2] = hold;
+		}
+		hold = make_uint4(0, 0, 0, 0);
+		if (i < n) { next_pixel(); hold.x = px; }
+		if (i + 1u < n) { next_pixel(); hold.y = px; }
+		if (i + 2u < n) { next_pixel(); hold.z = px; }
+	} else {
+		for (uint32_t i = 0; i < n; ++i) {
+			next_pixel();
 			dst[3 * i] = (uint8_t)px;
 			dst[3 * i + 1] = (uint8_t)(px >> 8);
 			dst[3 * i + 2] = (uint8_t)(px >> 16);
