@@ -656,11 +656,14 @@ __device__ __forceinline__ void qoi_splice_rows(const uint8_t *unit, uint32_t *s
 			const uint32_t hi = pb[st] < top ? pb[st] : top;
 			const uint32_t span = hi > lo ? hi - lo : 0u, n_q = span >> 4;
 			const uint8_t *img = s_img + (kPer * st + sub) * kSlot;
-			uint8_t *dst = pdst[st] + lo;
+			// (a pointer put together from two shuffled dwords has lost its address space: said again, or the stores are flat_store)
+			typedef __attribute__((address_space(1))) uint8_t *global_byte_ptr;
+			typedef __attribute__((address_space(1))) u32q_a1 *global_u32q_a1_ptr;
+			global_byte_ptr dst = (global_byte_ptr)(pdst[st] + lo);
 			if (ql < n_q) {
 				const uint32_t *w = reinterpret_cast<const uint32_t *>(img + 16u * ql);
 				const u32q_a1 o = {w[0], w[1], w[2], w[3]};
-				*reinterpret_cast<u32q_a1 *>(dst + 16u * ql) = o;
+				*(global_u32q_a1_ptr)(dst + 16u * ql) = o;
 			}
 #pragma unroll
 			for (uint32_t b = ql; b < 15u; b += (uint32_t)LPP)  // (one round at LPP = 16, up to four at LPP = 4)
@@ -681,7 +684,7 @@ struct SpliceUnit {
 	uint32_t cls, G, seg, t, bytes0;
 	bool live;
 	const uint8_t *unit;
-	unsigned long long off;
+	unsigned long long off_chunk, off_tile;  // the record's place: the two scans (kept apart: adding them here would wait for them here)
 };
 __device__ __forceinline__ void splice_locate(const QoiArgs &a, const SpliceClasses &k, uint32_t unit0, uint32_t total_units, uint32_t lane, SpliceUnit &u)
 {
@@ -723,12 +726,14 @@ __device__ __forceinline__ void qoi_splice_units(const QoiArgs &a, uint32_t wave
 	const uint32_t stride = n_waves * 64u;
 	SpliceUnit u0, u1, u2;  // current (place known), next (tile known), the one after (being located)
 	splice_locate(a, k, wave * 64u, total_units, lane, u0);
-	u0.off = u0.live ? a.chunk_totals[u0.t / kPackChunk] + a.offsets[u0.t] : 0ull;
+	u0.off_chunk = a.chunk_totals[u0.t / kPackChunk];  // (lanes without a segment: tile 0's, unused)
+	u0.off_tile = a.offsets[u0.t];
 	splice_locate(a, k, wave * 64u + stride, total_units, lane, u1);
 	for (uint32_t unit0 = wave * 64u; u0.valid; unit0 += stride) {
 		// ---- the look-ups of the units to come (issued first: they travel while the copy below runs)
 		splice_locate(a, k, unit0 + 2u * stride, total_units, lane, u2);
-		u1.off = u1.live ? a.chunk_totals[u1.t / kPackChunk] + a.offsets[u1.t] : 0ull;
+		u1.off_chunk = a.chunk_totals[u1.t / kPackChunk];
+		u1.off_tile = a.offsets[u1.t];
 		// ---- the current unit: the piece's place in its record (a scan over the tile's lanes) and the record's length
 		uint32_t bytes = u0.bytes0;
 		uint32_t total = bytes, incl = bytes;
@@ -737,7 +742,7 @@ __device__ __forceinline__ void qoi_splice_units(const QoiArgs &a, uint32_t wave
 			const uint32_t up = __shfl_up(incl, d, 64);
 			if (u0.seg >= d) incl += up;
 		}
-		const unsigned long long dstoff = (unsigned long long)(u0.t / a.tiles_per_frame + 1u) * a.hdr_bytes + u0.off;
+		const unsigned long long dstoff = (unsigned long long)(u0.t / a.tiles_per_frame + 1u) * a.hdr_bytes + u0.off_chunk + u0.off_tile;
 		if (!u0.live || dstoff + total > a.capacity) bytes = 0u;  // (a record that does not fit is left out whole: total is the same on its lanes)
 		uint8_t *my_dst = a.out + dstoff + (incl - u0.bytes0);
 		uint32_t k_unit = (bytes + 7u) >> 3;
@@ -865,6 +870,17 @@ __device__ __forceinline__ uint32_t be32(const uint8_t *p)
 {
 	return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | (uint32_t)p[3];
 }
+// the same on pointers that say where they point (through generic ones every access is a flat_load: the index kernel had 150)
+typedef const __attribute__((address_space(3))) uint8_t *lds_byte_cptr;
+typedef const __attribute__((address_space(1))) uint8_t *global_byte_cptr;
+__device__ __forceinline__ uint32_t be32(lds_byte_cptr p)
+{
+	return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | (uint32_t)p[3];
+}
+__device__ __forceinline__ uint32_t be32(global_byte_cptr p)
+{
+	return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | (uint32_t)p[3];
+}
 
 // One wave per (file, tile row).  The walk over a row's records is a dependent chain (each length gives the next
 // record's position): it runs on bytes staged in LDS, chunk by chunk, so a step costs an LDS round trip instead of
@@ -881,7 +897,7 @@ __global__ void __launch_bounds__(256) pixlzr_index_kernel(const DecodeArgs a)
 	if (i >= a.n_frames * a.rows) return;
 	const uint32_t f = i / a.rows, r = i - f * a.rows;
 	const unsigned long long f0 = a.file_offsets[f], f1 = a.file_offsets[f + 1];
-	const uint8_t *file = a.files + f0;
+	global_byte_cptr file = (global_byte_cptr)(a.files + f0);
 	const unsigned long long flen = f1 - f0;
 	const unsigned long long hdr = 26ull + 4ull * a.rows;
 	const uint32_t t_row = f * a.tiles_per_frame + r * a.cols;
@@ -920,7 +936,7 @@ __global__ void __launch_bounds__(256) pixlzr_index_kernel(const DecodeArgs a)
 	}
 	unsigned long long p = hdr + before;
 	const unsigned long long row_end = p + be32(file + 26 + 4 * r);
-	const uint8_t *cb = reinterpret_cast<const uint8_t *>(s_chunk[wave]);
+	lds_byte_cptr cb = (lds_byte_cptr) reinterpret_cast<const uint8_t *>(s_chunk[wave]);
 	uint32_t c = 0;
 	while (c < a.cols) {
 		// ---- stage file bytes [p, p + kIdxChunk) of the row: whole aligned 16-byte granules of the buffer, every load of the
@@ -940,10 +956,12 @@ __global__ void __launch_bounds__(256) pixlzr_index_kernel(const DecodeArgs a)
 			gv[k] = make_uint4(0, 0, 0, 0);
 			if (d < granules) {
 				if (ga + 16u <= buf_end) {
-					gv[k] = *reinterpret_cast<const uint4 *>(ga);
+					typedef uint32_t u32q __attribute__((ext_vector_type(4)));
+					const u32q q4 = *(const __attribute__((address_space(1))) u32q *)ga;
+					gv[k] = make_uint4(q4.x, q4.y, q4.z, q4.w);
 				} else {  // (the last granule of the buffer: byte by byte)
 					uint32_t w4[4] = {0, 0, 0, 0};
-					for (uint32_t b = 0; b < 16u && ga + b < buf_end; ++b) w4[b >> 2] |= (uint32_t) * reinterpret_cast<const uint8_t *>(ga + b) << (8u * (b & 3u));
+					for (uint32_t b = 0; b < 16u && ga + b < buf_end; ++b) w4[b >> 2] |= (uint32_t) * (global_byte_cptr)(ga + b) << (8u * (b & 3u));
 					gv[k] = make_uint4(w4[0], w4[1], w4[2], w4[3]);
 				}
 			}
@@ -990,7 +1008,7 @@ __global__ void __launch_bounds__(256) pixlzr_index_kernel(const DecodeArgs a)
 			const uint32_t fw = (cc == a.cols - 1) ? a.edge_w : a.bw, fh = (r == a.rows - 1) ? a.edge_h : a.bh;
 			good = p + o + 13ull + 10ull + 8ull <= row_end;
 			if (good) {
-				const uint8_t *rec = cb + skew + o;
+				lds_byte_cptr rec = cb + skew + o;
 				good = rec[0] == 'b' && rec[1] == 'l' && rec[2] == 'o' && rec[3] == 'c' && rec[4] == 'k';
 				const uint32_t qlen = be32(rec + 9);
 				good = good && qlen >= 18u && p + o + 13ull + qlen <= row_end;
