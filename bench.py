@@ -490,7 +490,22 @@ def main():
             if filt == args.filter:
                 decode_side[label]["traffic"] = load_flow_traffic("exp32")
             del back
-        del ow, oh, slots
+        # ... and the reader in front of it (decode_from_vec: index of the records + the QOI decoder) on the files the writer makes
+        vals2, ow2, oh2, slots2 = handle.shrink_frames_device(frames, args.block, args.block, 1, args.filter, MODES["shrink_directionally"][1])
+        offs, buf = handle.encode_frames_device(tuple(frames.shape), args.block, args.block, vals2, ow2, oh2, slots2)
+        dec = handle.decode_frames_device(buf, offs, tuple(frames.shape), args.block, args.block)
+        for _ in range(5):
+            handle.decode_frames_device(buf, offs, tuple(frames.shape), args.block, args.block, out=dec)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            handle.decode_frames_device(buf, offs, tuple(frames.shape), args.block, args.block, out=dec)
+        e1.record()
+        torch.cuda.synchronize()
+        decode_side["decode (reader)"] = {"ms_per_step": e0.elapsed_time(e1) / 20.0, "file_bytes": int(offs[-1].item()),
+                                          "time_is": "20 launches between two events on the launch stream",
+                                          "what_bounds_it": "the QOI decoder's longest lanes: 1024 dependent pixel steps of a 32x32 tile (DESIGN 6c)"}
+        del ow, oh, slots, vals2, ow2, oh2, slots2, offs, buf, dec
 
     line = None
     if rank == 0:
