@@ -24,7 +24,8 @@ namespace pxz {
 constexpr uint32_t kRS64 = 36, kPD64 = 36 * 64;  // plane row stride (32 + 4 dwords: bank skew, rows stay 16-byte aligned), plane size
 constexpr uint32_t kTS64 = 20;                   // dwords per column of the horizontal pass: 16 (64 bytes of y) + 4 of bank skew
 constexpr uint32_t kRed64 = 48;                  // partial sums, flags, ticket, two worklist batches
-constexpr uint32_t lds64_dwords(uint32_t nch) { return nch * kPD64 + nch * 32u * kTS64 + kRed64; }  // planes + [channel][ox < 32][kTS64] + s_red
+constexpr uint32_t kTail64 = 72, kTailLevels = 8;  // per level: bias[32], weight sums[32], "opaque stays opaque" + pad; levels 0..7 (7 = every level whose output is 1 px)
+constexpr uint32_t lds64_dwords(uint32_t nch) { return nch * kPD64 + nch * 32u * kTS64 + kRed64 + kTailLevels * kTail64; }  // planes + [channel][ox < 32][kTS64] + s_red + tails
 
 template <int C = 4, class Args>
 __device__ __forceinline__ bool fast64_tile_src(const Args &a, uint32_t tile_g, const uint8_t *&src)
@@ -62,6 +63,15 @@ __global__ void __launch_bounds__(256) shrink64_kernel(const Fast64Args a)
 	uint32_t *s_pl = lds;                       // NCH planes of u16 pairs
 	uint32_t *s_t = lds + NCH * kPD64;          // horizontal-pass results
 	uint32_t *s_red = s_t + NCH * 32u * kTS64;  // [0..7] partial sums, [8..11] alpha, [13] ticket, [16..31] list-B batch, [32..47] list-A batch
+	// The small ends of the operand tables (biases, weight sums, flags), copied once per block (round 3): read from global memory
+	// where they are used, each was a dependent L2 round trip between a tile's level decision and its last store -- with one
+	// tile per block in flight.  (The whole tables in LDS, 16 KB, cost a block per CU and bought nothing.)
+	uint32_t *s_tail = s_red + kRed64;
+	for (uint32_t i = threadIdx.x; i < kTailLevels * kTail64; i += blockDim.x) {
+		const uint32_t lv = i / kTail64, k = i - lv * kTail64;
+		const uint32_t out = (64u >> lv) ? (64u >> lv) : 1u, nblk = out > 16u ? 2u : 1u;
+		s_tail[i] = a.mf_off[lv] ? a.mf64[a.mf_off[lv] + nblk * 512u + k] : 0u;
+	}
 	const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
 	const uint32_t brk_lane = lane < (uint32_t)kMaxLevel ? a.breaks[lane] : (a.breaks_asc ? 0xffffffffu : 0u);
 	auto level_of = [&](uint32_t key) -> uint32_t {
@@ -335,7 +345,9 @@ __global__ void __launch_bounds__(256) shrink64_kernel(const Fast64Args a)
 		const bool need_h = nw != 64u, need_v = nh != 64u;
 		const uint32_t *mx = a.mf64 + a.mf_off[need_h ? lx : ly], *my = a.mf64 + a.mf_off[need_v ? ly : lx];
 		const uint32_t nbx = nw > 16u ? 2u : 1u, nby = nh > 16u ? 2u : 1u;  // (of the axes that are resampled)
-		const uint32_t *mx_tail = mx + nbx * 512u, *my_tail = my + nby * 512u;  // bias[32], ksum[32], flag
+		const uint32_t tlx = need_h ? lx : ly, tly = need_v ? ly : lx;
+		const uint32_t *mx_tail = s_tail + kTail64 * (tlx < kTailLevels ? tlx : kTailLevels - 1u);  // bias[32], ksum[32], flag
+		const uint32_t *my_tail = s_tail + kTail64 * (tly < kTailLevels ? tly : kTailLevels - 1u);
 		const uint32_t px_ = a.precision[need_h ? lx : ly], py = a.precision[need_v ? ly : lx];
 		const int32_t top_x = (int32_t)((256u << px_) - 1u), top_y = (int32_t)((256u << py) - 1u);
 		const uint32_t o = lane & 15u, g = lane >> 4;
