@@ -14,8 +14,9 @@ BLOCK=32 bash $R/tools/sq_counters.sh ${TAG}_by32 by > /dev/null 2>&1
 BLOCK=64 bash $R/tools/sq_counters.sh ${TAG}_by64 by > /dev/null 2>&1
 bash $R/tools/sq_counters.sh ${TAG}_enc enc > /dev/null 2>&1
 FILTER=4 bash $R/tools/sq_counters.sh ${TAG}_exp exp > /dev/null 2>&1
+bash $R/tools/sq_counters.sh ${TAG}_dec dec > /dev/null 2>&1
 cd $R
-python3 tools/sq_summary.py $OUT/${TAG}_dir32_sq.txt $OUT/${TAG}_by32_sq.txt $OUT/${TAG}_by64_sq.txt $OUT/${TAG}_enc_sq.txt $OUT/${TAG}_exp_sq.txt > $OUT/${TAG}_sq_summary.json
+python3 tools/sq_summary.py $OUT/${TAG}_dir32_sq.txt $OUT/${TAG}_by32_sq.txt $OUT/${TAG}_by64_sq.txt $OUT/${TAG}_enc_sq.txt $OUT/${TAG}_exp_sq.txt $OUT/${TAG}_dec_sq.txt > $OUT/${TAG}_sq_summary.json
 echo "sq done"
 python3 bench.py > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
 echo "bench done"
