@@ -7,5 +7,5 @@ for d in sys.argv[1:]:
             k = row["Kernel_Name"][:48]
             acc[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
         for k, cs in acc.items():
-            if not any(s in k for s in ("shrink", "oklab", "qoi", "expand", "tree", "pack")): continue
+            if not any(s in k for s in ("shrink", "oklab", "qoi", "expand", "tree", "pack", "pixlzr")): continue
             print(d.split("/")[-1], k, {c: round(sum(v) / len(v)) for c, v in cs.items()}, "n=%d" % len(next(iter(cs.values()))))
