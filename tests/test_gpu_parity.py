@@ -575,6 +575,53 @@ def test_decode_frames_device_reference_files(gpu, oracle, golden_dir):
             assert (img.cpu().numpy()[0] == ref).all()
 
 
+@pytest.mark.parametrize("shift", [1, 5, 11])
+def test_reader_on_files_at_any_address(gpu, oracle, golden_dir, shift):
+    """The reader takes its files where they are: a buffer that starts `shift` bytes into an allocation (the index kernel
+    stages aligned 16-byte granules around it, the decoder's windows are aligned 8-byte words) and whose last byte is the
+    last byte of the tensor (the window requests stop at the last window of the files)."""
+    import torch
+    raw = open(os.path.join(golden_dir, "base.pixlzr"), "rb").read()
+    d = oracle.decode_container(raw)
+    whole = torch.zeros(shift + len(raw), dtype=torch.uint8, device="cuda")
+    whole[shift:] = torch.frombuffer(bytearray(raw), dtype=torch.uint8).cuda()
+    files = whole[shift:]
+    offs = torch.tensor([0, len(raw)], dtype=torch.int64).cuda()
+    vals, ow, oh, slots = gpu.decode_frames_device(files, offs, (1, d["height"], d["width"], 4), d["bw"], d["bh"])
+    torch.cuda.synchronize()
+    assert gpu.decode_status() == 0
+    assert (ow.cpu().numpy()[0] == d["tw"]).all() and (oh.cpu().numpy()[0] == d["th"]).all()
+    assert (vals.cpu().numpy()[0].view(np.uint32) == d["values"].view(np.uint32)).all()
+    got, exp = slots.cpu().numpy()[0], d["slots"]
+    valid = d["tw"].astype(np.int64) * d["th"] * 4
+    idx = np.arange(got.shape[1])[None, :] < valid[:, None]
+    assert not ((got != exp[:, : got.shape[1]]) & idx).any()
+
+
+def test_writer_with_too_little_room(gpu, oracle):
+    """pxz_encode_frames_device with a buffer shorter than the files: what fits is written where it belongs (records are
+    left out whole, nothing is written past the capacity), the offsets still say how long the files are."""
+    import torch
+    frames = gpu.synth_frames_device(2, 160, 224, 4, first_frame=3, dist=0)
+    out = gpu.shrink_frames_device(frames, 32, 32, 1, 4, 4.0)
+    offs, buf = gpu.encode_frames_device(tuple(frames.shape), 32, 32, *out)
+    torch.cuda.synchronize()
+    total = int(offs[-1].item())
+    full = buf[:total].cpu().numpy()
+    cap = total // 2
+    small = torch.full((cap + 4096,), 0xA5, dtype=torch.uint8, device="cuda")
+    offs2 = torch.zeros_like(offs)
+    gpu.encode_frames_device(tuple(frames.shape), 32, 32, *out, out=(offs2, small[:cap]))
+    torch.cuda.synchronize()
+    assert (offs2.cpu().numpy() == offs.cpu().numpy()).all()
+    got = small.cpu().numpy()
+    assert (got[cap:] == 0xA5).all(), "bytes behind the capacity were written"
+    written = got[:cap] != 0xA5
+    # (a byte that was written is the byte the full files have there; bytes of value 0xA5 cannot be told apart and are skipped)
+    assert (got[:cap][written] == full[:cap][written]).all()
+    assert written.mean() > 0.5
+
+
 @pytest.mark.parametrize("c", [4, 3])
 def test_encode_decode_round_trip_on_device(gpu, oracle, c):
     """shrink -> device writer -> device decoder gives back exactly the tiles that went in (values as bits,
