@@ -1065,21 +1065,23 @@ __global__ void __launch_bounds__(64 * kQoiWaves) qoi_decode_kernel(const Decode
 		a.tile_h[t] = 0;
 		return;
 	}
-	// The op bytes come through two aligned 64-bit windows (the current one and the next, already on its way): the five
-	// bytes an op can have are cut out at the stream position with one funnel shift.  Windows are only requested while
-	// op bytes remain beyond them -- what lies past the last op is the record's own end marker (zeros where an op could
-	// still reach), so zeros stand in for it and no load leaves the file.  As in the encoder there are no branches per
-	// op: every op's result is worked out and selects keep the right one.
+	// The op bytes come through aligned 64-bit windows: five of them in registers (w0 .. w4: 40 bytes from the window the next op
+	// starts in), the (up to) five bytes an op can have cut out of w0 | w1 at the stream position with one funnel shift.  A used-up
+	// window is shifted out on the spot -- moves of data that is there -- and the buffer is filled up again once per FOUR pixels
+	// (which use 20 bytes at most): the three windows that may be missing then are requested at the start of the four and taken
+	// at their end, one wait per four pixels with four pixels' time for the loads to arrive.
+	// Rounds 2 and 3 (first half) requested a window whenever one was used up: every lane of a wave does that at its own pixels,
+	// so the wave did it at nearly every pixel, and a request is waited for when its register is next moved -- in a wave whose
+	// lanes take turns, at the very next pixel: one memory round trip per pixel step, 1024 of them in a row for a 32x32 tile
+	// (0.69 ms; 0.52 once the request no longer went through a temporary that was copied, and waited for, on the spot).
+	// Windows are requested without a condition but never past the last one of the files (what lies behind a record's ops is its
+	// own end marker).  As in the encoder there are no branches per op: every op's result is worked out and selects keep the right one.
 	const unsigned long long first_byte = a.rec_off[t];
-	const unsigned long long *wp = reinterpret_cast<const unsigned long long *>(a.files + (first_byte & ~7ull));
-	// (windows are requested without a condition -- a load whose result is chosen against a constant is copied into the
-	// window's register the moment it is issued, and that copy waits for it: round 2's `wp < w_end ? *wp : 0` stalled for a
-	// whole memory round trip at every window, which was the kernel's 0.69 ms -- but never past the last window of the files)
+	const unsigned long long *wp = reinterpret_cast<const unsigned long long *>(a.files + (first_byte & ~7ull));  // where w0 is from
 	const unsigned long long *w_last = reinterpret_cast<const unsigned long long *>(a.files + ((a.file_offsets[a.n_frames] - 1ull) & ~7ull));
 	auto window = [&](const unsigned long long *p) __attribute__((always_inline)) { return *(p < w_last ? p : w_last); };
-	unsigned long long w0 = *wp++;  // (len > 0: the first window holds op bytes)
-	unsigned long long w1 = window(wp);
-	unsigned long long w2 = window(wp + 1);  // one more ahead: its round trip overlaps a window's worth of ops
+	unsigned long long w0 = window(wp), w1 = window(wp + 1), w2 = window(wp + 2), w3 = window(wp + 3), w4 = window(wp + 4);
+	uint32_t used_up = 0;  // windows shifted out since the buffer was last filled (0..3)
 	uint32_t pos = (uint32_t)(first_byte & 7ull);           // byte position of the next op inside w0 (0..7)
 	uint32_t left = len;                                    // op bytes not yet consumed
 	const uint32_t n = a.tile_w[t] * a.tile_h[t];
@@ -1139,21 +1141,29 @@ __global__ void __launch_bounds__(64 * kQoiWaves) qoi_decode_kernel(const Decode
 		const uint32_t step = take ? used : 0u;
 		left = left > step ? left - step : 0u;
 		pos += step;
-		if (pos >= 8u) {  // the window is used up: move on, request the one after next
+		if (pos >= 8u) {  // the window is used up: the others move down (w4 is refilled with its neighbours, below)
 			pos -= 8u;
-			wp += 1;
-			// (the moves spelled out, in front of the request and into registers of their own: the window that was w2 is dead
-			// behind them, so the request can be loaded straight into ITS register -- else it goes through a temporary, and
-			// the copy out of the temporary waits for the load on the spot)
-			uint32_t a_lo, a_hi, b_lo, b_hi;
-			asm volatile("v_mov_b32 %0, %4\n\tv_mov_b32 %1, %5\n\tv_mov_b32 %2, %6\n\tv_mov_b32 %3, %7"
-			             : "=&v"(a_lo), "=&v"(a_hi), "=&v"(b_lo), "=&v"(b_hi)
-			             : "v"((uint32_t)w1), "v"((uint32_t)(w1 >> 32)), "v"((uint32_t)w2), "v"((uint32_t)(w2 >> 32))
-			             : "memory");
-			w0 = (unsigned long long)a_lo | ((unsigned long long)a_hi << 32);
-			w1 = (unsigned long long)b_lo | ((unsigned long long)b_hi << 32);
-			w2 = window(wp + 1);
+			w0 = w1;
+			w1 = w2;
+			w2 = w3;
+			w3 = w4;
+			++used_up;
 		}
+	};
+	// four pixels with the refill around them
+	unsigned long long l0 = 0, l1 = 0, l2 = 0;
+	auto request = [&]() __attribute__((always_inline)) {
+		l0 = window(wp + 5);
+		l1 = window(wp + 6);
+		l2 = window(wp + 7);
+	};
+	auto refill = [&]() __attribute__((always_inline)) {
+		// used_up = 1: w4 <- l0;  2: w3, w4 <- l0, l1;  3: w2, w3, w4 <- l0, l1, l2
+		w2 = used_up == 3u ? l0 : w2;
+		w3 = used_up == 3u ? l1 : (used_up == 2u ? l0 : w3);
+		w4 = used_up == 3u ? l2 : (used_up == 2u ? l1 : (used_up == 1u ? l0 : w4));
+		wp += used_up;
+		used_up = 0u;
 	};
 	if constexpr (C == 4) {
 		// four pixels per 16-byte store (slots are 16-byte aligned: bw*bh*4 bytes each), the loop unrolled by those four: a
@@ -1161,10 +1171,12 @@ __global__ void __launch_bounds__(64 * kQoiWaves) qoi_decode_kernel(const Decode
 		// lanes; the per-pixel tests of which quarter of the store a pixel is were scalar instructions on that chain)
 		uint32_t i = 0;
 		for (; i + 4u <= n; i += 4u) {
+			request();
 			next_pixel(); hold.x = px;
 			next_pixel(); hold.y = px;
 			next_pixel(); hold.z = px;
 			next_pixel(); hold.w = px;
+			refill();
 			reinterpret_cast<uint4 *>(dst)[i >> 2] = hold;
 		}
 		hold = make_uint4(0, 0, 0, 0);
@@ -1172,7 +1184,19 @@ __global__ void __launch_bounds__(64 * kQoiWaves) qoi_decode_kernel(const Decode
 		if (i + 1u < n) { next_pixel(); hold.y = px; }
 		if (i + 2u < n) { next_pixel(); hold.z = px; }
 	} else {
-		for (uint32_t i = 0; i < n; ++i) {
+		uint32_t i = 0;
+		for (; i + 4u <= n; i += 4u) {
+			request();
+#pragma unroll
+			for (uint32_t k = 0; k < 4; ++k) {
+				next_pixel();
+				dst[3 * (i + k)] = (uint8_t)px;
+				dst[3 * (i + k) + 1] = (uint8_t)(px >> 8);
+				dst[3 * (i + k) + 2] = (uint8_t)(px >> 16);
+			}
+			refill();
+		}
+		for (; i < n; ++i) {
 			next_pixel();
 			dst[3 * i] = (uint8_t)px;
 			dst[3 * i + 1] = (uint8_t)(px >> 8);
