@@ -1065,11 +1065,11 @@ __global__ void __launch_bounds__(64 * kQoiWaves) qoi_decode_kernel(const Decode
 		a.tile_h[t] = 0;
 		return;
 	}
-	// The op bytes come through aligned 64-bit windows: five of them in registers (w0 .. w4: 40 bytes from the window the next op
-	// starts in), the (up to) five bytes an op can have cut out of w0 | w1 at the stream position with one funnel shift.  A used-up
-	// window is shifted out on the spot -- moves of data that is there -- and the buffer is filled up again once per FOUR pixels
-	// (which use 20 bytes at most): the three windows that may be missing then are requested at the start of the four and taken
-	// at their end, one wait per four pixels with four pixels' time for the loads to arrive.
+	// The op bytes come through aligned 64-bit windows: kWin of them in registers (from the window the next op starts in), the (up
+	// to) five bytes an op can have cut out of w[0] | w[1] at the stream position with one funnel shift.  A used-up window is
+	// shifted out on the spot -- moves of data that is there -- and the buffer is filled up again once per kGroup pixels (which
+	// use 5 kGroup bytes at most): the kReq windows that may be missing then are requested at the start of the group and taken at
+	// its end, one wait per group with a group's time for the loads to arrive (4 pixels: 0.39 ms; 8: the loads are there).
 	// Rounds 2 and 3 (first half) requested a window whenever one was used up: every lane of a wave does that at its own pixels,
 	// so the wave did it at nearly every pixel, and a request is waited for when its register is next moved -- in a wave whose
 	// lanes take turns, at the very next pixel: one memory round trip per pixel step, 1024 of them in a row for a 32x32 tile
@@ -1080,8 +1080,13 @@ __global__ void __launch_bounds__(64 * kQoiWaves) qoi_decode_kernel(const Decode
 	const unsigned long long *wp = reinterpret_cast<const unsigned long long *>(a.files + (first_byte & ~7ull));  // where w0 is from
 	const unsigned long long *w_last = reinterpret_cast<const unsigned long long *>(a.files + ((a.file_offsets[a.n_frames] - 1ull) & ~7ull));
 	auto window = [&](const unsigned long long *p) __attribute__((always_inline)) { return *(p < w_last ? p : w_last); };
-	unsigned long long w0 = window(wp), w1 = window(wp + 1), w2 = window(wp + 2), w3 = window(wp + 3), w4 = window(wp + 4);
-	uint32_t used_up = 0;  // windows shifted out since the buffer was last filled (0..3)
+	constexpr uint32_t kGroup = 8;                               // pixels between two refills
+	constexpr uint32_t kReq = (5u * kGroup + 7u) / 8u;           // windows they can use up (5 bytes a pixel)
+	constexpr uint32_t kWin = (7u + 5u * (kGroup - 1u) + 8u + 7u) / 8u + 1u;  // windows the last of them can reach into (+1: whole moves)
+	unsigned long long w[kWin];
+#pragma unroll
+	for (uint32_t k = 0; k < kWin; ++k) w[k] = window(wp + k);
+	uint32_t used_up = 0;  // windows shifted out since the buffer was last filled (0 .. kReq)
 	uint32_t pos = (uint32_t)(first_byte & 7ull);           // byte position of the next op inside w0 (0..7)
 	uint32_t left = len;                                    // op bytes not yet consumed
 	const uint32_t n = a.tile_w[t] * a.tile_h[t];
@@ -1092,7 +1097,7 @@ __global__ void __launch_bounds__(64 * kQoiWaves) qoi_decode_kernel(const Decode
 	// one pixel: the next op (or the run in progress) -> px
 	auto next_pixel = [&]() __attribute__((always_inline)) {
 		// the (up to) 8 bytes at the stream position
-		const unsigned long long at = pos ? (w0 >> (8u * pos)) | (w1 << (64u - 8u * pos)) : w0;
+		const unsigned long long at = pos ? (w[0] >> (8u * pos)) | (w[1] << (64u - 8u * pos)) : w[0];
 		const uint32_t b1 = (uint32_t)at & 255u, b2 = (uint32_t)(at >> 8) & 255u;
 		const uint32_t next4 = (uint32_t)(at >> 8);  // the four bytes behind the tag
 		const bool in_run = run > 0u;
@@ -1141,27 +1146,29 @@ __global__ void __launch_bounds__(64 * kQoiWaves) qoi_decode_kernel(const Decode
 		const uint32_t step = take ? used : 0u;
 		left = left > step ? left - step : 0u;
 		pos += step;
-		if (pos >= 8u) {  // the window is used up: the others move down (w4 is refilled with its neighbours, below)
+		if (pos >= 8u) {  // the window is used up: the others move down (the last ones are refilled below)
 			pos -= 8u;
-			w0 = w1;
-			w1 = w2;
-			w2 = w3;
-			w3 = w4;
+#pragma unroll
+			for (uint32_t k = 0; k + 1u < kWin; ++k) w[k] = w[k + 1u];
 			++used_up;
 		}
 	};
-	// four pixels with the refill around them
-	unsigned long long l0 = 0, l1 = 0, l2 = 0;
+	// kGroup pixels with the refill around them
+	unsigned long long l[kReq];
 	auto request = [&]() __attribute__((always_inline)) {
-		l0 = window(wp + 5);
-		l1 = window(wp + 6);
-		l2 = window(wp + 7);
+#pragma unroll
+		for (uint32_t k = 0; k < kReq; ++k) l[k] = window(wp + kWin + k);
 	};
 	auto refill = [&]() __attribute__((always_inline)) {
-		// used_up = 1: w4 <- l0;  2: w3, w4 <- l0, l1;  3: w2, w3, w4 <- l0, l1, l2
-		w2 = used_up == 3u ? l0 : w2;
-		w3 = used_up == 3u ? l1 : (used_up == 2u ? l0 : w3);
-		w4 = used_up == 3u ? l2 : (used_up == 2u ? l1 : (used_up == 1u ? l0 : w4));
+		// u = used_up windows were shifted out: w[kWin - u + j] <- l[j] for j < u
+#pragma unroll
+		for (uint32_t k = kWin - kReq; k < kWin; ++k) {
+			unsigned long long v = w[k];
+#pragma unroll
+			for (uint32_t j = 0; j < kReq; ++j)
+				if (j + kWin >= k + 1u && j + kWin - k <= kReq) v = used_up == j + kWin - k ? l[j] : v;  // k = kWin - u + j  <=>  u = kWin + j - k
+			w[k] = v;
+		}
 		wp += used_up;
 		used_up = 0u;
 	};
@@ -1170,13 +1177,24 @@ __global__ void __launch_bounds__(64 * kQoiWaves) qoi_decode_kernel(const Decode
 		// lane's pixel loop is one dependent chain, and every instruction on it counts (the kernel lasts as long as its longest
 		// lanes; the per-pixel tests of which quarter of the store a pixel is were scalar instructions on that chain)
 		uint32_t i = 0;
-		for (; i + 4u <= n; i += 4u) {
+		for (; i + kGroup <= n; i += kGroup) {
 			request();
+#pragma unroll
+			for (uint32_t q = 0; q < kGroup / 4u; ++q) {
+				next_pixel(); hold.x = px;
+				next_pixel(); hold.y = px;
+				next_pixel(); hold.z = px;
+				next_pixel(); hold.w = px;
+				reinterpret_cast<uint4 *>(dst)[(i >> 2) + q] = hold;
+			}
+			refill();
+		}
+		// (what is left of the tile: fewer than kGroup pixels, within what the buffer holds after a refill)
+		for (; i + 4u <= n; i += 4u) {
 			next_pixel(); hold.x = px;
 			next_pixel(); hold.y = px;
 			next_pixel(); hold.z = px;
 			next_pixel(); hold.w = px;
-			refill();
 			reinterpret_cast<uint4 *>(dst)[i >> 2] = hold;
 		}
 		hold = make_uint4(0, 0, 0, 0);
@@ -1185,10 +1203,10 @@ __global__ void __launch_bounds__(64 * kQoiWaves) qoi_decode_kernel(const Decode
 		if (i + 2u < n) { next_pixel(); hold.z = px; }
 	} else {
 		uint32_t i = 0;
-		for (; i + 4u <= n; i += 4u) {
+		for (; i + kGroup <= n; i += kGroup) {
 			request();
 #pragma unroll
-			for (uint32_t k = 0; k < 4; ++k) {
+			for (uint32_t k = 0; k < kGroup; ++k) {
 				next_pixel();
 				dst[3 * (i + k)] = (uint8_t)px;
 				dst[3 * (i + k) + 1] = (uint8_t)(px >> 8);
