@@ -1069,7 +1069,7 @@ __global__ void __launch_bounds__(64 * kQoiWaves) qoi_decode_kernel(const Decode
 	// to) five bytes an op can have cut out of w[0] | w[1] at the stream position with one funnel shift.  A used-up window is
 	// shifted out on the spot -- moves of data that is there -- and the buffer is filled up again once per kGroup pixels (which
 	// use 5 kGroup bytes at most): the kReq windows that may be missing then are requested at the start of the group and taken at
-	// its end, one wait per group with a group's time for the loads to arrive (4 pixels: 0.39 ms; 8: the loads are there).
+	// its end, one wait per group with a group's time for the loads to arrive (4 pixels: 0.39 ms; 8: 0.34; 16: 0.35 -- more windows to move).
 	// Rounds 2 and 3 (first half) requested a window whenever one was used up: every lane of a wave does that at its own pixels,
 	// so the wave did it at nearly every pixel, and a request is waited for when its register is next moved -- in a wave whose
 	// lanes take turns, at the very next pixel: one memory round trip per pixel step, 1024 of them in a row for a 32x32 tile
