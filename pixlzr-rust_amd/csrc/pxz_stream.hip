@@ -21,11 +21,22 @@ __global__ void __launch_bounds__(256) pack_scan_local_kernel(const PackArgs a)
 {
 	__shared__ uint32_t s_wave[4];
 	const uint32_t base = blockIdx.x * kPackChunk + threadIdx.x * 16u;
+	// (indices clamped, loads unconditional and all sixteen in one block: behind a condition each sat in a block of its own and was
+	// waited for before the next was issued)
 	uint32_t sz[16], run = 0;
+	if (a.sizes) {
+#pragma unroll
+		for (uint32_t i = 0; i < 16; ++i) sz[i] = a.sizes[base + i < a.n_tiles ? base + i : a.n_tiles - 1u];
+	} else {
+#pragma unroll
+		for (uint32_t i = 0; i < 16; ++i) {
+			const uint32_t tc = base + i < a.n_tiles ? base + i : a.n_tiles - 1u;
+			sz[i] = a.w[tc] * a.h[tc] * a.channels;
+		}
+	}
 #pragma unroll
 	for (uint32_t i = 0; i < 16; ++i) {
-		const uint32_t t = base + i;
-		sz[i] = t < a.n_tiles ? (a.sizes ? a.sizes[t] : a.w[t] * a.h[t] * a.channels) : 0u;
+		sz[i] = base + i < a.n_tiles ? sz[i] : 0u;
 		run += sz[i];
 	}
 	// exclusive scan of the per-thread totals inside the block
@@ -171,10 +182,19 @@ __global__ void __launch_bounds__(256) qoi_bin_count_kernel(const QoiArgs a)
 	__shared__ uint32_t s_last;
 	if (threadIdx.x < 32) s_hist[threadIdx.x] = 0;
 	__syncthreads();
-#pragma unroll 4
-	for (uint32_t i = 0; i < kBinChunk / 256u; ++i) {
-		const uint32_t t = blockIdx.x * kBinChunk + i * 256u + threadIdx.x;
-		if (t < a.n_tiles) atomicAdd(&s_hist[qoi_tile_class(a, t)], 1u);
+	{
+		// (the sizes of the block's tiles first -- indices clamped, loads unconditional, all in flight together --, then the counting)
+		uint32_t cls[kBinChunk / 256u];
+#pragma unroll
+		for (uint32_t i = 0; i < kBinChunk / 256u; ++i) {
+			const uint32_t t = blockIdx.x * kBinChunk + i * 256u + threadIdx.x;
+			cls[i] = qoi_tile_class(a, t < a.n_tiles ? t : a.n_tiles - 1u);
+		}
+#pragma unroll
+		for (uint32_t i = 0; i < kBinChunk / 256u; ++i) {
+			const uint32_t t = blockIdx.x * kBinChunk + i * 256u + threadIdx.x;
+			if (t < a.n_tiles) atomicAdd(&s_hist[cls[i]], 1u);
+		}
 	}
 	__syncthreads();
 	if (threadIdx.x < 32) {
@@ -228,13 +248,14 @@ __global__ void __launch_bounds__(256) qoi_bin_scatter_kernel(const QoiArgs a)
 	__syncthreads();
 	uint32_t where[kBinChunk / 256u];  // class | place inside the block's share of the class << 5
 #pragma unroll
+	for (uint32_t i = 0; i < kBinChunk / 256u; ++i) {  // (loads first, as in the counting kernel)
+		const uint32_t t = blockIdx.x * kBinChunk + i * 256u + threadIdx.x;
+		where[i] = qoi_tile_class(a, t < a.n_tiles ? t : a.n_tiles - 1u);
+	}
+#pragma unroll
 	for (uint32_t i = 0; i < kBinChunk / 256u; ++i) {
 		const uint32_t t = blockIdx.x * kBinChunk + i * 256u + threadIdx.x;
-		where[i] = 0;
-		if (t < a.n_tiles) {
-			const uint32_t cls = qoi_tile_class(a, t);
-			where[i] = cls | (atomicAdd(&s_hist[cls], 1u) << 5);
-		}
+		if (t < a.n_tiles) where[i] |= atomicAdd(&s_hist[where[i]], 1u) << 5;
 	}
 	__syncthreads();
 	if (threadIdx.x < 32 && s_hist[threadIdx.x]) s_base[threadIdx.x] = atomicAdd(&a.bins[kBinCursor + threadIdx.x], s_hist[threadIdx.x]);
