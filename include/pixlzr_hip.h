@@ -320,6 +320,9 @@ int pxz_last_first_kernel_ms(pxz_handle *h, float *ms);
  * handle's stream (the in-kernel phase stamps of the -DPXZ_STAMPS build land there; tools/stamps_run.py).  Not part of
  * the path; PXZ_ERR_INVALID_ARG when the range lies outside the buffer. */
 int pxz_debug_read_work(pxz_handle *h, void *dst, size_t offset, size_t bytes);
+/* The same for the status buffer of the decode side (the -DPXZ_STAMPS build keeps expand_kernel's phase stamps behind the
+ * status word; tools/stamps_expand.py). */
+int pxz_debug_read_status(pxz_handle *h, void *dst, size_t offset, size_t bytes);
 
 #ifdef __cplusplus
 }

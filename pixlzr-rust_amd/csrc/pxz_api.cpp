@@ -1157,9 +1157,15 @@ static int expand_launch(pxz_handle *h, const pxz_frames *frames, uint32_t slot_
 	a.fast32 = pxz::knobs().no_expand_fast32 ? 0u : 1u;
 	a.xmf = a.fast32 ? et->d_xmf : nullptr;
 	a.tile_dw = (2u * bw * bh + 5u * (bw + bh) + 3u) & ~3u;
+#ifdef PXZ_STAMPS
+	if ((rc = ensure(h, h->status, 256)) != PXZ_OK) return rc;  // (stamps behind the flag: pxz_debug_read_status)
+	a.status = (uint32_t *)h->status.ptr;
+	PXZ_HIP(h, hipMemsetAsync(a.status, 0, 4, h->stream));
+#else
 	if ((rc = ensure(h, h->status, 4)) != PXZ_OK) return rc;
 	a.status = (uint32_t *)h->status.ptr;
 	PXZ_HIP(h, hipMemsetAsync(a.status, 0, 4, h->stream));
+#endif
 	PXZ_HIP(h, pxz::launch_expand(a, h->n_cus, h->stream));
 	return PXZ_OK;
 }
@@ -2029,6 +2035,14 @@ int pxz_axis_table(uint32_t in_size, uint32_t out_size, uint32_t filter, int32_t
 	if (starts) std::memcpy(starts, w.starts.data(), sizeof(int32_t) * out_size);
 	if (sizes) std::memcpy(sizes, w.sizes.data(), sizeof(int32_t) * out_size);
 	if (coeffs && !w.coeffs.empty()) std::memcpy(coeffs, w.coeffs.data(), sizeof(int16_t) * w.coeffs.size());
+	return PXZ_OK;
+}
+
+// diagnostic builds only: the stamps of expand_kernel (behind its status word)
+int pxz_debug_read_status(pxz_handle *h, void *dst, size_t offset, size_t bytes)
+{
+	if (!h || !dst || !h->status.ptr || offset + bytes > h->status.cap) return PXZ_ERR_INVALID_ARG;
+	PXZ_HIP(h, hipMemcpy(dst, (const uint8_t *)h->status.ptr + offset, bytes, hipMemcpyDeviceToHost));
 	return PXZ_OK;
 }
 

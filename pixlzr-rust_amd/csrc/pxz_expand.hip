@@ -26,7 +26,11 @@ typedef int v16i32 __attribute__((ext_vector_type(16)));
 // s_wave: the wave's LDS (planes: 1 KB; the row: 128 B behind them).
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ void expand_tile_mfma(const ExpandArgs &a, const uint32_t *s_xmf, uint32_t *s_wave, uint32_t lane,
-                                                 uint32_t tw, uint32_t th, const uint8_t *src, uint32_t first_px, uint8_t *dst)
+                                                 uint32_t tw, uint32_t th, const uint8_t *src, uint32_t first_px, uint8_t *dst
+#ifdef PXZ_STAMPS
+                                                 , unsigned long long (&st_acc)[8], unsigned long long &st_last
+#endif
+)
 {
 	const uint32_t n = lane & 31u, g = lane >> 5;
 	const uint32_t lw = 31u - (uint32_t)__builtin_clz(tw), lh = 31u - (uint32_t)__builtin_clz(th);
@@ -46,6 +50,7 @@ __device__ __forceinline__ void expand_tile_mfma(const ExpandArgs &a, const uint
 		d[3u * plane] = (uint8_t)(px >> 24);
 	}
 	tile_sync<1>();
+	PXZ_STAMP(3);  // planes staged
 	// ---- horizontal product(s)
 	const uint32_t px_ = __builtin_amdgcn_readfirstlane(mx[320]), py = __builtin_amdgcn_readfirstlane(my[320]);
 	const int32_t top_x = (int32_t)((256u << px_) - 1u), top_y = (int32_t)((256u << py) - 1u);
@@ -79,6 +84,7 @@ __device__ __forceinline__ void expand_tile_mfma(const ExpandArgs &a, const uint
 				put_byte(((r >> 2) & 1) ? t1[2u * blk + ((uint32_t)r >> 3)] : t0[2u * blk + ((uint32_t)r >> 3)], (uint32_t)r & 3u, v, px_);
 			});
 	}
+	PXZ_STAMP(4);  // horizontal products + clamp
 	uint32_t *s_row = s_wave + 256u;  // behind the planes
 	if (th == 1u && __builtin_amdgcn_readfirstlane(my[321]) != 0u) {
 		// ---- one stored row, copied by every window of the way up: un-premultiply it once, write it 32 times
@@ -93,6 +99,7 @@ __device__ __forceinline__ void expand_tile_mfma(const ExpandArgs &a, const uint
 #pragma unroll
 		for (uint32_t k = 0; k < 4; ++k)
 			__builtin_nontemporal_store(w, reinterpret_cast<u32q *>(dst + (size_t)(8u * k + (lane >> 3)) * a.pitch + 16u * (lane & 7u)));
+		PXZ_STAMP(5);  // one-row replicate
 		return;
 	}
 	// ---- vertical products, channel by channel
@@ -129,6 +136,7 @@ __device__ __forceinline__ void expand_tile_mfma(const ExpandArgs &a, const uint
 #pragma unroll
 	for (uint32_t r = 0; r < 16; ++r)
 		__builtin_nontemporal_store(pix[r], reinterpret_cast<uint32_t *>(dst + (size_t)xmf_row(0, r) * a.pitch + lane_off));
+	PXZ_STAMP(6);  // vertical products + clamp + stores
 }
 
 // ResizeAlg::Nearest of a full 32x32 RGBA tile stored as tw x th, both powers of two: the source index
@@ -158,6 +166,23 @@ __device__ __forceinline__ void expand_tile_nearest_pow2(const ExpandArgs &a, ui
 			w = u32q{v.x, v.y, v.z, v.w};
 		}
 		__builtin_nontemporal_store(w, reinterpret_cast<u32q *>(dst + (size_t)oy * a.pitch + 16u * q));
+	}
+}
+
+// A full 32x32 RGBA tile stored at full size (block.rs:279-281: clone): the slot's 4 KB straight into the frame, four 16-byte
+// moves per lane, all four requested before the first is stored.  (Through the general form -- a dword per lane and round into
+// LDS, sixteen load -> store rounds, then out again -- these tiles, an eighth of a typical frame, were 40 % of the kernel's time:
+// tools/stamps_expand.py.)
+__device__ __forceinline__ void expand_tile_clone32(const ExpandArgs &a, uint32_t lane, const uint8_t *src, uint8_t *dst)
+{
+	typedef uint32_t u32q __attribute__((ext_vector_type(4)));
+	u32q v[4];
+#pragma unroll
+	for (uint32_t k = 0; k < 4; ++k) v[k] = __builtin_nontemporal_load(reinterpret_cast<const u32q *>(src) + 64u * k + lane);
+#pragma unroll
+	for (uint32_t k = 0; k < 4; ++k) {
+		const uint32_t c = 64u * k + lane;  // 16-byte chunk c of the tile: row c / 8, columns 4 (c % 8) ..
+		__builtin_nontemporal_store(v[k], reinterpret_cast<u32q *>(dst + (size_t)(c >> 3) * a.pitch + 16u * (c & 7u)));
 	}
 }
 
@@ -204,12 +229,21 @@ __global__ void __launch_bounds__(F32 ? 1024 : 256) expand_kernel(const ExpandAr
 	};
 	uint32_t t = tile_of(sub);
 	prefetch(t);
+#ifdef PXZ_STAMPS
+	unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+	unsigned long long st_last = stamp_now();
+#endif
 	while (t != 0xffffffffu) {
 		uint32_t nt = 0;
 		if (lane == 0) nt = atomicAdd(s_ticket, 1u);
 		const uint32_t t_next = tile_of(__builtin_amdgcn_readfirstlane(nt));
+		PXZ_STAMP(0);  // ticket
 		const uint32_t tw = __builtin_amdgcn_readfirstlane(p_tw), th = __builtin_amdgcn_readfirstlane(p_th);
-		const uint32_t first_px = p_px;
+		uint32_t first_px = p_px;
+#ifdef PXZ_STAMPS
+		asm volatile("" : "+v"(first_px));
+#endif
+		PXZ_STAMP(1);  // wait for what was requested a tile ago
 		prefetch(t_next);  // in flight while this tile is expanded
 		const uint32_t frame = t / a.tiles_per_frame, tf = t - frame * a.tiles_per_frame;
 		const uint32_t ty = tf / a.cols, tx = tf - ty * a.cols;
@@ -229,12 +263,18 @@ __global__ void __launch_bounds__(F32 ? 1024 : 256) expand_kernel(const ExpandAr
 		};
 		if (tw == 0 || th == 0 || tw > fw || th > fh) {
 			if (lane == 0 && !(a.quiet_empty && tw == 0 && th == 0)) atomicOr(a.status, 1u);
+		} else if (F32 && fw == 32u && fh == 32u && tw == 32u && th == 32u) {
+			if constexpr (F32) expand_tile_clone32(a, lane, a.slots + (size_t)t * a.slot_bytes, dst);
 		} else if (F32 && fw == 32u && fh == 32u && (tw & (tw - 1u)) == 0u && (th & (th - 1u)) == 0u &&
 		           (a.filter == 0 ? tw * th < 1024u : (xmf_dw != 0u && tw <= 16u && th <= 16u))) {
 			if constexpr (F32) {
 				const uint8_t *src = a.slots + (size_t)t * a.slot_bytes;
 				if (a.filter == 0) expand_tile_nearest_pow2(a, s_src, lane, tw, th, src, first_px, dst);
-				else expand_tile_mfma(a, s_xmf, s_src, lane, tw, th, src, first_px, dst);
+				else expand_tile_mfma(a, s_xmf, s_src, lane, tw, th, src, first_px, dst
+#ifdef PXZ_STAMPS
+				                      , st_acc, st_last
+#endif
+				);
 			}
 		} else {
 			// ---- stored pixels -> one dword per pixel
@@ -490,9 +530,17 @@ __global__ void __launch_bounds__(F32 ? 1024 : 256) expand_kernel(const ExpandAr
 				}
 			}
 		}
+		PXZ_STAMP(2);  // the other paths (clone, general, nearest), and what of the matrix-core path is not stamped inside
 		t = t_next;
 		tile_sync<1>();  // the next tile reuses this wave's LDS
+		PXZ_STAMP(7);  // closing sync
 	}
+#ifdef PXZ_STAMPS
+	if (lane == 0) {
+		unsigned long long *out = reinterpret_cast<unsigned long long *>(a.status + 2);
+		for (int i = 0; i < 8; ++i) atomicAdd(out + i, st_acc[i]);
+	}
+#endif
 }
 
 hipError_t launch_expand(const ExpandArgs &a, uint32_t n_cus, hipStream_t stream)
