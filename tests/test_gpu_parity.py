@@ -519,6 +519,35 @@ def test_expand_of_power_of_two_tiles(gpu, oracle, filt):
         raise AssertionError(f"filter {filt}: {int(bad.sum())} pixels differ, tiles {[(t, int(tw[t]), int(th[t])) for t in t_bad[:8]]}")
 
 
+@pytest.mark.parametrize("filt", [0, 4])
+def test_expand_into_rows_at_any_alignment(gpu, oracle, filt):
+    """A frame 289 px wide: its rows start 4 (mod 16) bytes apart, so the 16-byte moves of the 32x32 fast paths (full-size
+    tiles copied from their slots, shift-indexed Nearest, the one-row replicate) land on addresses that are only 4-byte
+    aligned; the ragged last column and row take the general forms beside them.  Equal to the oracle's expand."""
+    rng = np.random.default_rng(77 + filt)
+    width, height = 289, 3 * 32 + 7
+    cols, rows = 10, 4
+    n = cols * rows
+    tw = np.ones(n, np.uint32); th = np.ones(n, np.uint32)
+    slots = np.zeros((n, 32 * 32 * 4), np.uint8)
+    sizes = [32, 32, 1, 2, 4, 8, 16]
+    for t in range(n):
+        fw = 32 if t % cols < cols - 1 else 1
+        fh = 32 if t // cols < rows - 1 else 7
+        w = min(sizes[int(rng.integers(0, len(sizes)))], fw); h = min(sizes[int(rng.integers(0, len(sizes)))], fh)
+        if t % 5 == 0: w, h = fw, fh  # stored at full size
+        if t % 11 == 3: w, h = 2, 1
+        w, h = min(w, fw), min(h, fh)
+        tw[t], th[t] = w, h
+        px = rng.integers(0, 256, (h * w, 4), dtype=np.uint8)
+        if t % 3 == 0: px[:, 3] = 255
+        slots[t, : h * w * 4] = px.ravel()
+    exp = oracle.expand_image(width, height, 32, 32, 4, filt, tw, th, slots)
+    got = gpu.expand_image(width, height, 4, 32, 32, filt, tw, th, slots)
+    bad = (got != exp).any(axis=2)
+    assert not bad.any(), f"filter {filt}: {int(bad.sum())} pixels differ"
+
+
 def test_expand_frames_device_round_trip_properties(gpu, oracle):
     """Device-resident batch: shrink -> expand.  Tiles kept at full size come back unchanged; the batch equals
     the per-frame oracle; an invalid stored size is flagged and leaves the tile untouched."""
