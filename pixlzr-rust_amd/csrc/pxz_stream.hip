@@ -912,8 +912,8 @@ constexpr uint32_t kIdxHeader = 23;    // "block" + value + length + QOI header 
 __global__ void __launch_bounds__(256) pixlzr_index_kernel(const DecodeArgs a)
 {
 	__shared__ __attribute__((aligned(16))) uint32_t s_chunk[4][kIdxChunk / 4u + 8u];
-	__shared__ uint32_t s_pos[4][64];  // positions (relative to the chunk's first byte) of the records of a batch
-	const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+	// (the wave's number and everything derived from it as scalars: the walk below then runs on scalar branches)
+	const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63u;
 	const uint32_t i = blockIdx.x * 4u + wave;
 	if (i >= a.n_frames * a.rows) return;
 	const uint32_t f = i / a.rows, r = i - f * a.rows;
@@ -930,11 +930,21 @@ __global__ void __launch_bounds__(256) pixlzr_index_kernel(const DecodeArgs a)
 			a.tile_h[t_row + c] = 0u;
 		}
 	};
-	const uint8_t magic[9] = {'P', 'I', 'X', 'L', 'Z', 'R', 0, 0, 2};  // constants.rs:10-11: v0.0.2 (filter byte + line table)
+	// the fixed header, a byte per lane: "PIXLZR", 0, 0, 2 (constants.rs:10-11: v0.0.2, filter byte + line table), the filter byte
+	// (any), then width, height and the block sides as BE dwords -- ONE round trip (as `a && file[k] == ..` chains the 25 byte
+	// loads were 25 dependent round trips in front of every row's walk)
 	bool ok = flen >= hdr;
-	if (ok) {
-		for (int k = 0; k < 9; ++k) ok = ok && file[k] == magic[k];
-		ok = ok && be32(file + 10) == a.width && be32(file + 14) == a.height && be32(file + 18) == a.bw && be32(file + 22) == a.bh;
+	{
+		uint32_t got = 0, want = 0;
+		if (ok && lane < 26u) got = file[lane];
+		if (lane < 8u) want = (uint32_t)(0x0000525a4c584950ull >> (8u * lane)) & 255u;
+		else if (lane == 8u) want = 2u;
+		else if (lane == 9u) want = got;
+		else if (lane < 26u) {
+			const uint32_t k = lane - 10u, field = k < 4u ? a.width : (k < 8u ? a.height : (k < 12u ? a.bw : a.bh));
+			want = (field >> (8u * (3u - (k & 3u)))) & 255u;
+		}
+		ok = ok && __builtin_amdgcn_ballot_w64(got != want) == 0ull;
 	}
 	if (!ok) {
 		bad_from(0);
@@ -955,8 +965,11 @@ __global__ void __launch_bounds__(256) pixlzr_index_kernel(const DecodeArgs a)
 		bad_from(0);
 		return;
 	}
-	unsigned long long p = hdr + before;
-	const unsigned long long row_end = p + be32(file + 26 + 4 * r);
+	auto uniform64 = [](unsigned long long v) -> unsigned long long {
+		return ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(v >> 32)) << 32) | __builtin_amdgcn_readfirstlane((uint32_t)v);
+	};
+	unsigned long long p = uniform64(hdr + before);
+	const unsigned long long row_end = p + __builtin_amdgcn_readfirstlane(be32(file + 26 + 4 * r));
 	lds_byte_cptr cb = (lds_byte_cptr) reinterpret_cast<const uint8_t *>(s_chunk[wave]);
 	uint32_t c = 0;
 	while (c < a.cols) {
@@ -970,21 +983,25 @@ __global__ void __launch_bounds__(256) pixlzr_index_kernel(const DecodeArgs a)
 		const uintptr_t buf_end = reinterpret_cast<uintptr_t>(a.files) + a.file_offsets[a.n_frames];
 		constexpr uint32_t kRounds = (kIdxChunk / 16u + 1u + 63u) / 64u;
 		uint4 gv[kRounds];
+		typedef uint32_t u32q __attribute__((ext_vector_type(4)));
+		// (every load unconditional, at a clamped address -- the first bytes of the buffer stand in for granules that are not
+		// wanted or not whole: a load under a condition is waited for where it is issued, round by round)
 #pragma unroll
 		for (uint32_t k = 0; k < kRounds; ++k) {
 			const uint32_t d = lane + 64u * k;
 			const uintptr_t ga = (g - skew) + 16ull * d;
-			gv[k] = make_uint4(0, 0, 0, 0);
-			if (d < granules) {
-				if (ga + 16u <= buf_end) {
-					typedef uint32_t u32q __attribute__((ext_vector_type(4)));
-					const u32q q4 = *(const __attribute__((address_space(1))) u32q *)ga;
-					gv[k] = make_uint4(q4.x, q4.y, q4.z, q4.w);
-				} else {  // (the last granule of the buffer: byte by byte)
-					uint32_t w4[4] = {0, 0, 0, 0};
-					for (uint32_t b = 0; b < 16u && ga + b < buf_end; ++b) w4[b >> 2] |= (uint32_t) * (global_byte_cptr)(ga + b) << (8u * (b & 3u));
-					gv[k] = make_uint4(w4[0], w4[1], w4[2], w4[3]);
-				}
+			const bool whole = d < granules && ga + 16u <= buf_end;
+			const u32q q4 = *(const __attribute__((address_space(1))) u32q *)(whole ? ga : reinterpret_cast<uintptr_t>(a.files));
+			gv[k] = make_uint4(q4.x, q4.y, q4.z, q4.w);
+		}
+#pragma unroll
+		for (uint32_t k = 0; k < kRounds; ++k) {
+			const uint32_t d = lane + 64u * k;
+			const uintptr_t ga = (g - skew) + 16ull * d;
+			if (d < granules && ga + 16u > buf_end) {  // (the last granule of the buffer: byte by byte)
+				uint32_t w4[4] = {0, 0, 0, 0};
+				for (uint32_t b = 0; b < 16u && ga + b < buf_end; ++b) w4[b >> 2] |= (uint32_t) * (global_byte_cptr)(ga + b) << (8u * (b & 3u));
+				gv[k] = make_uint4(w4[0], w4[1], w4[2], w4[3]);
 			}
 		}
 #pragma unroll
@@ -994,58 +1011,58 @@ __global__ void __launch_bounds__(256) pixlzr_index_kernel(const DecodeArgs a)
 		}
 		tile_sync<1>();
 		const uint32_t have = (uint32_t)want;  // valid bytes behind cb + skew
-		// ---- lane 0: positions of up to 64 records whose headers lie inside the chunk
+		// ---- the walk: positions of up to 64 records whose headers lie inside the chunk.  Every lane runs it with the same
+		// values (the length field is read by all lanes and made scalar), so its tests are scalar branches, and lane n keeps the
+		// position of record n in a register.  (As `if (lane == 0) { .. }` a step was sixty instructions, half of them on the
+		// execution mask of its four nested branches, and the positions went through LDS: the walk was most of the kernel.)
+		const unsigned long long rem64 = row_end - p;
+		const uint32_t rem = rem64 < 0xffffffffull ? (uint32_t)rem64 : 0xffffffffu;  // bytes left of the row, saturated
 		uint32_t n_rec = 0, walked = 0;  // walked: bytes of the chunk consumed by the records found
-		bool broken = false;             // a record that cannot be walked past (it is the last of the batch)
-		if (lane == 0) {
+		uint32_t pos = 0;
+		{
 			uint32_t o = 0;
-			while (n_rec < 64u && c + n_rec < a.cols) {
-				if (p + o + 13ull + 10ull + 8ull > row_end) {  // no room for a record: broken row
-					s_pos[wave][n_rec++] = o;
-					broken = true;
+			const uint32_t cols_left = a.cols - c;
+			while (n_rec < 64u && n_rec < cols_left) {
+				pos = lane == n_rec ? o : pos;
+				if (o + 31u > rem) {  // no room for a record (13 + 10 + 8 bytes): broken row, found again by the checks below
+					++n_rec;
 					break;
 				}
 				if (o + kIdxHeader > have) break;  // header not in this chunk: restage from here
-				const uint32_t qlen = be32(cb + skew + o + 9u);
-				s_pos[wave][n_rec++] = o;
-				if (qlen < 18u || p + o + 13ull + qlen > row_end) {
-					broken = true;
-					break;
-				}
+				const uint32_t qlen = __builtin_amdgcn_readfirstlane(be32(cb + skew + o + 9u));
+				++n_rec;
+				if (qlen < 18u || (unsigned long long)o + 13ull + qlen > (unsigned long long)rem) break;  // broken, as above
 				o += 13u + qlen;
-				if (o >= have && p + o < row_end && c + n_rec < a.cols) break;  // next record starts beyond the chunk
+				if (o >= have && o < rem && n_rec < cols_left) break;  // next record starts beyond the chunk
 			}
 			walked = o;
 		}
-		n_rec = __builtin_amdgcn_readfirstlane(n_rec);
-		walked = __builtin_amdgcn_readfirstlane(walked);
-		broken = __builtin_amdgcn_readfirstlane(broken ? 1u : 0u) != 0u;
-		tile_sync<1>();
-		// ---- all lanes: check and publish the batch
+		// ---- all lanes: check and publish the batch (header bytes read without conditions, compared afterwards)
 		bool good = true;
 		if (lane < n_rec) {
-			const uint32_t o = s_pos[wave][lane];
+			const uint32_t o = pos;
 			const uint32_t cc = c + lane;
 			const uint32_t fw = (cc == a.cols - 1) ? a.edge_w : a.bw, fh = (r == a.rows - 1) ? a.edge_h : a.bh;
-			good = p + o + 13ull + 10ull + 8ull <= row_end;
+			good = o + 31u <= rem;
 			if (good) {
 				lds_byte_cptr rec = cb + skew + o;
-				good = rec[0] == 'b' && rec[1] == 'l' && rec[2] == 'o' && rec[3] == 'c' && rec[4] == 'k';
-				const uint32_t qlen = be32(rec + 9);
-				good = good && qlen >= 18u && p + o + 13ull + qlen <= row_end;
+				uint32_t b[22];
+#pragma unroll
+				for (int k = 0; k < 22; ++k) b[k] = rec[k];
+				auto be = [&](int k) -> uint32_t { return (b[k] << 24) | (b[k + 1] << 16) | (b[k + 2] << 8) | b[k + 3]; };
+				const uint32_t qlen = be(9), w = be(13), h = be(17), ch = b[21];
+				const bool magic = (b[0] == 'b') & (b[1] == 'l') & (b[2] == 'o') & (b[3] == 'c') & (b[4] == 'k');
+				// (the walk used this record's length whether or not its other fields are sound, as the
+				// sequential reader does not: a bad record ends the row there, see below)
+				good = magic & (qlen >= 18u) & ((unsigned long long)o + 13ull + qlen <= (unsigned long long)rem) & (ch == a.channels) &
+				       (w >= 1u) & (h >= 1u) & (w <= fw) & (h <= fh);
 				if (good) {
-					const uint32_t w = be32(rec + 13), h = be32(rec + 17), ch = rec[21];
-					good = ch == a.channels && w >= 1 && h >= 1 && w <= fw && h <= fh;
-					// (the walk used this record's length whether or not its other fields are sound, as the
-					// sequential reader does not: a bad record ends the row there, see below)
-					if (good) {
-						const uint32_t t = t_row + cc;
-						a.value[t] = __uint_as_float(be32(rec + 5));
-						a.tile_w[t] = w;
-						a.tile_h[t] = h;
-						a.rec_off[t] = f0 + p + o + 13ull + 10ull;  // first op byte
-						a.rec_len[t] = qlen - 10u - 8u;             // ops only: without the header and the end marker
-					}
+					const uint32_t t = t_row + cc;
+					a.value[t] = __uint_as_float(be(5));
+					a.tile_w[t] = w;
+					a.tile_h[t] = h;
+					a.rec_off[t] = f0 + p + o + 13ull + 10ull;  // first op byte
+					a.rec_len[t] = qlen - 10u - 8u;             // ops only: without the header and the end marker
 				}
 			}
 		}
@@ -1056,7 +1073,6 @@ __global__ void __launch_bounds__(256) pixlzr_index_kernel(const DecodeArgs a)
 			bad_from(c + (uint32_t)__builtin_ctzll(bad));
 			return;
 		}
-		(void)broken;  // (a broken record fails the checks above)
 		if (n_rec == 0) {
 			// a header that does not fit the rest of the row although a record is due: broken row
 			bad_from(c);
