@@ -1532,7 +1532,7 @@ int pxz_decode_frames_device(pxz_handle *h, const pxz_frames *frames, const pxz_
 	a.rec_len = (uint32_t *)((uint8_t *)h->dmeta.ptr + (size_t)a.n_tiles * 8u);
 	a.perm = a.rec_len + a.n_tiles;
 	a.bins = a.perm + a.n_tiles;
-	if ((rc = ensure(h, h->status, 4)) != PXZ_OK) return rc;
+	if ((rc = ensure(h, h->status, 256)) != PXZ_OK) return rc;  // (room for the stamps of the diagnostic build: pxz_debug_read_status)
 	a.status = (uint32_t *)h->status.ptr;
 	PXZ_HIP(h, hipMemsetAsync(a.status, 0, 4, h->stream));
 	PXZ_HIP(h, pxz::launch_decode(a, h->stream));

@@ -916,6 +916,16 @@ __global__ void __launch_bounds__(256) pixlzr_index_kernel(const DecodeArgs a)
 	const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63u;
 	const uint32_t i = blockIdx.x * 4u + wave;
 	if (i >= a.n_frames * a.rows) return;
+#ifdef PXZ_STAMPS
+	unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+	unsigned long long st_last = stamp_now();
+	auto st_flush = [&]() {
+		if (lane == 0) {
+			unsigned long long *out = reinterpret_cast<unsigned long long *>(a.status + 2);
+			for (int k = 0; k < 8; ++k) atomicAdd(out + k, st_acc[k]);
+		}
+	};
+#endif
 	const uint32_t f = i / a.rows, r = i - f * a.rows;
 	const unsigned long long f0 = a.file_offsets[f], f1 = a.file_offsets[f + 1];
 	global_byte_cptr file = (global_byte_cptr)(a.files + f0);
@@ -972,6 +982,7 @@ __global__ void __launch_bounds__(256) pixlzr_index_kernel(const DecodeArgs a)
 	const unsigned long long row_end = p + __builtin_amdgcn_readfirstlane(be32(file + 26 + 4 * r));
 	lds_byte_cptr cb = (lds_byte_cptr) reinterpret_cast<const uint8_t *>(s_chunk[wave]);
 	uint32_t c = 0;
+	PXZ_STAMP(0);  // file header, line table
 	while (c < a.cols) {
 		// ---- stage file bytes [p, p + kIdxChunk) of the row: whole aligned 16-byte granules of the buffer, every load of the
 		// chunk issued before the first one is written to LDS (round 2 staged dwords, one load -> store round per 256 bytes: a
@@ -1010,6 +1021,7 @@ __global__ void __launch_bounds__(256) pixlzr_index_kernel(const DecodeArgs a)
 			if (d < granules) reinterpret_cast<uint4 *>(s_chunk[wave])[d] = gv[k];
 		}
 		tile_sync<1>();
+		PXZ_STAMP(1);  // chunk staged
 		const uint32_t have = (uint32_t)want;  // valid bytes behind cb + skew
 		// ---- the walk: positions of up to 64 records whose headers lie inside the chunk.  Every lane runs it with the same
 		// values (the length field is read by all lanes and made scalar), so its tests are scalar branches, and lane n keeps the
@@ -1037,6 +1049,7 @@ __global__ void __launch_bounds__(256) pixlzr_index_kernel(const DecodeArgs a)
 			}
 			walked = o;
 		}
+		PXZ_STAMP(2);  // walk
 		// ---- all lanes: check and publish the batch (header bytes read without conditions, compared afterwards)
 		bool good = true;
 		if (lane < n_rec) {
@@ -1081,8 +1094,16 @@ __global__ void __launch_bounds__(256) pixlzr_index_kernel(const DecodeArgs a)
 		c += n_rec;
 		p += walked;
 		tile_sync<1>();  // the chunk is restaged
+		PXZ_STAMP(3);  // checks, publishing, closing sync
+#ifdef PXZ_STAMPS
+		st_acc[4] += 1;      // batches
+		st_acc[5] += n_rec;  // records
+#endif
 	}
 	if (p != row_end && lane == 0) atomicOr(a.status, 2u);
+#ifdef PXZ_STAMPS
+	st_flush();
+#endif
 }
 
 template <int C>
