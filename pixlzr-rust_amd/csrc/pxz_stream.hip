@@ -1044,8 +1044,7 @@ __global__ void __launch_bounds__(256) pixlzr_index_kernel(const DecodeArgs a)
 				const uint32_t qlen = __builtin_amdgcn_readfirstlane(be32(cb + skew + o + 9u));
 				++n_rec;
 				if (qlen < 18u || (unsigned long long)o + 13ull + qlen > (unsigned long long)rem) break;  // broken, as above
-				o += 13u + qlen;
-				if (o >= have && o < rem && n_rec < cols_left) break;  // next record starts beyond the chunk
+				o += 13u + qlen;  // (a next record beyond the chunk leaves through the header test above)
 			}
 			walked = o;
 		}
