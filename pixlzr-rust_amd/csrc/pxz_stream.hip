@@ -1033,19 +1033,29 @@ __global__ void __launch_bounds__(256) pixlzr_index_kernel(const DecodeArgs a)
 		uint32_t pos = 0;
 		{
 			uint32_t o = 0;
-			const uint32_t cols_left = a.cols - c;
-			while (n_rec < 64u && n_rec < cols_left) {
+			const uint32_t cols_left = a.cols - c, n_max = cols_left < 64u ? cols_left : 64u;
+			// a record can be walked from o if it has room (13 + 10 + 8 bytes: o + 31 <= rem) and its header lies in the chunk
+			// (o + 23 <= have; have <= rem): o <= lim, one test
+			const bool none = rem < 31u;
+			const uint32_t lim = none ? 0u : (rem - 31u < have - kIdxHeader ? rem - 31u : have - kIdxHeader);
+			bool at_top = false;
+			while (n_rec < n_max) {
 				pos = lane == n_rec ? o : pos;
-				if (o + 31u > rem) {  // no room for a record (13 + 10 + 8 bytes): broken row, found again by the checks below
-					++n_rec;
+				if (none | (o > lim)) {
+					at_top = true;
 					break;
 				}
-				if (o + kIdxHeader > have) break;  // header not in this chunk: restage from here
-				const uint32_t qlen = __builtin_amdgcn_readfirstlane(be32(cb + skew + o + 9u));
+				// the length field: the two aligned dwords around it, shifted (one LDS instruction instead of four byte reads)
+				const uint32_t x = skew + o + 9u;
+				const uint32_t *w2 = s_chunk[wave] + (x >> 2);
+				const uint32_t qlen = __builtin_amdgcn_readfirstlane(__builtin_bswap32(__builtin_amdgcn_alignbyte(w2[1], w2[0], x & 3u)));
 				++n_rec;
-				if (qlen < 18u || (unsigned long long)o + 13ull + qlen > (unsigned long long)rem) break;  // broken, as above
-				o += 13u + qlen;  // (a next record beyond the chunk leaves through the header test above)
+				const unsigned long long next = (unsigned long long)o + 13ull + qlen;
+				if ((qlen < 18u) | (next > (unsigned long long)rem)) break;  // broken: found again by the checks below
+				o = (uint32_t)next;  // (a next record beyond the chunk leaves through the test at the top)
 			}
+			// no room for a record although one is due: a broken row, counted so that the checks below flag it
+			if (at_top && (none || (unsigned long long)o + 31ull > (unsigned long long)rem)) ++n_rec;
 			walked = o;
 		}
 		PXZ_STAMP(2);  // walk
