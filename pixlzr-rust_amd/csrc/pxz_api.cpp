@@ -34,7 +34,7 @@ bool fast32_applicable(const ShrinkArgs &a, uint32_t channels);
 bool fast64_applicable(const ShrinkArgs &a, uint32_t channels);
 bool fast16_applicable(const ShrinkArgs &a, uint32_t channels);
 hipError_t launch_expand(const ExpandArgs &a, uint32_t n_cus, hipStream_t stream);
-hipError_t launch_decode(const DecodeArgs &a, hipStream_t stream);
+hipError_t launch_decode(const DecodeArgs &a, bool bins_clean, hipStream_t stream);
 hipError_t launch_widen(const WidenArgs &a, hipStream_t stream);
 hipError_t launch_narrow(const NarrowArgs &a, hipStream_t stream);
 hipError_t launch_pack(const PackArgs &a, hipStream_t stream);
@@ -110,6 +110,7 @@ struct pxz_handle {
 	uint32_t *dev_stats = nullptr;   //   (its device-side address); read without synchronisation, steers only the kernel choice
 	bool work_ready = false;   // both worklist counters are zero / consistent with work_slot
 	const uint32_t *qbins_clean = nullptr;  // the writer's binning counters at this address were left zeroed by the last launch_qoi
+	const uint32_t *dbins_clean = nullptr;  // the same for the reader's (launch_decode)
 	uint32_t work_slot = 0;    // the counter the next 32x32 launch uses
 	bool timing = false;
 	uint32_t timing_stride = 1, timing_count = 0;  // every stride-th step is bracketed by events
@@ -940,6 +941,7 @@ int pxz_trim(pxz_handle *h)
 	h->packed_len = 0;
 	h->work_ready = false;  // (the worklist counters went with their buffer)
 	h->qbins_clean = nullptr;
+	h->dbins_clean = nullptr;
 	return PXZ_OK;
 }
 
@@ -1527,7 +1529,9 @@ int pxz_decode_frames_device(pxz_handle *h, const pxz_frames *frames, const pxz_
 	a.slot_bytes = p.block_w * p.block_h * f.channels;
 	a.edge_w = f.width - (cols - 1) * p.block_w;
 	a.edge_h = f.height - (rows - 1) * p.block_h;
+	const size_t dmeta_cap = h->dmeta.cap;
 	if ((rc = ensure(h, h->dmeta, (size_t)a.n_tiles * 16u + 4u * pxz::qoi_bins_dwords())) != PXZ_OK) return rc;  // rec_off, rec_len, perm, the bin counters
+	if (h->dmeta.cap != dmeta_cap) h->dbins_clean = nullptr;  // a new allocation: nothing in it is zero
 	a.rec_off = (unsigned long long *)h->dmeta.ptr;
 	a.rec_len = (uint32_t *)((uint8_t *)h->dmeta.ptr + (size_t)a.n_tiles * 8u);
 	a.perm = a.rec_len + a.n_tiles;
@@ -1535,7 +1539,10 @@ int pxz_decode_frames_device(pxz_handle *h, const pxz_frames *frames, const pxz_
 	if ((rc = ensure(h, h->status, 256)) != PXZ_OK) return rc;  // (room for the stamps of the diagnostic build: pxz_debug_read_status)
 	a.status = (uint32_t *)h->status.ptr;
 	PXZ_HIP(h, hipMemsetAsync(a.status, 0, 4, h->stream));
-	PXZ_HIP(h, pxz::launch_decode(a, h->stream));
+	const bool bins_clean = h->dbins_clean == a.bins;
+	h->dbins_clean = nullptr;
+	PXZ_HIP(h, pxz::launch_decode(a, bins_clean, h->stream));
+	h->dbins_clean = a.bins;
 	return PXZ_OK;
 }
 
@@ -1970,7 +1977,9 @@ int pxz_encode_frames_device(pxz_handle *h, const pxz_frames *frames, const pxz_
 	// perm | rec_len | bins as u32, then offsets (n+1) and chunk totals as u64
 	const size_t meta_u32 = (size_t)n_tiles * 2 + pxz::qoi_bins_dwords();
 	const size_t meta_bytes = ((meta_u32 * 4 + 7) & ~(size_t)7) + ((size_t)n_tiles + 1 + n_chunks) * 8;
+	const size_t qmeta_cap = h->qmeta.cap;
 	if ((rc = ensure(h, h->qmeta, meta_bytes)) != PXZ_OK) return rc;
+	if (h->qmeta.cap != qmeta_cap) h->qbins_clean = nullptr;  // a new allocation: nothing in it is zero
 	uint32_t *m32 = (uint32_t *)h->qmeta.ptr;
 	unsigned long long *m64 = (unsigned long long *)((uint8_t *)h->qmeta.ptr + ((meta_u32 * 4 + 7) & ~(size_t)7));
 	pxz::QoiArgs a{};

@@ -1306,10 +1306,11 @@ __global__ void __launch_bounds__(64 * kQoiWaves) qoi_decode_kernel(const Decode
 	}
 }
 
-hipError_t launch_decode(const DecodeArgs &a, hipStream_t stream)
+hipError_t launch_decode(const DecodeArgs &a, bool bins_clean, hipStream_t stream)
 {
-	hipError_t e = hipMemsetAsync(a.bins, 0, kBinDwords * sizeof(uint32_t), stream);
-	if (e != hipSuccess) return e;
+	// (the binning counters are left zeroed by the previous launch on the same buffer: bins_clean, as in launch_qoi)
+	hipError_t e;
+	if (!bins_clean && (e = hipMemsetAsync(a.bins, 0, kBinDwords * sizeof(uint32_t), stream)) != hipSuccess) return e;
 	hipLaunchKernelGGL(pixlzr_index_kernel, dim3((a.n_frames * a.rows + 3u) / 4u), dim3(256), 0, stream, a);
 	const uint32_t tb = (a.n_tiles + kBinChunk - 1u) / kBinChunk;
 	QoiArgs q{};  // the encoder's binning by pixel count, on the sizes the index kernel has just read
