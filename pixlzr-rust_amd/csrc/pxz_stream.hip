@@ -348,19 +348,16 @@ __device__ __forceinline__ void qoi_load4(const uint8_t *src, uint32_t base, boo
 		const uint4 v = *reinterpret_cast<const uint4 *>(src + (size_t)base * 4u);
 		px4[0] = v.x; px4[1] = v.y; px4[2] = v.z; px4[3] = v.w;
 	} else {
-		if (dword_aligned) {
-			const uint32_t *p = reinterpret_cast<const uint32_t *>(src + (size_t)base * 3u);
-			const uint32_t d0 = p[0], d1 = p[1], d2 = p[2];
-			px4[0] = d0 & 0xffffffu;
-			px4[1] = (d0 >> 24) | ((d1 & 0xffffu) << 8);
-			px4[2] = (d1 >> 16) | ((d2 & 0xffu) << 16);
-			px4[3] = d2 >> 8;
-		} else {
-			for (int j = 0; j < 4; ++j) {
-				const uint8_t *p = src + (size_t)(base + j) * 3u;
-				px4[j] = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16);
-			}
-		}
+		// twelve bytes as three dwords at whatever address the slot has (gfx950 loads them from any byte address; the byte-wise
+		// form for slots that are not dword multiples was twelve loads at each of the encoder's call sites)
+		(void)dword_aligned;
+		typedef uint32_t u32_a1 __attribute__((aligned(1)));
+		const u32_a1 *p = reinterpret_cast<const u32_a1 *>(src + (size_t)base * 3u);
+		const uint32_t d0 = p[0], d1 = p[1], d2 = p[2];
+		px4[0] = d0 & 0xffffffu;
+		px4[1] = (d0 >> 24) | ((d1 & 0xffffu) << 8);
+		px4[2] = (d1 >> 16) | ((d2 & 0xffu) << 16);
+		px4[3] = d2 >> 8;
 #pragma unroll
 		for (int j = 0; j < 4; ++j) px4[j] |= 0xff000000u;
 	}
