@@ -363,6 +363,34 @@ __device__ __forceinline__ void qoi_load4(const uint8_t *src, uint32_t base, boo
 	}
 }
 
+// sixteen pixels from pixel `base` on, all inside the tile (base + 16 <= its pixels).  RGB: the 48 bytes as three 16-byte
+// loads from whatever byte address they have (three vector memory instructions instead of twelve dwords), cut into pixels
+// with byte shifts.
+template <int C>
+__device__ __forceinline__ void qoi_load16(const uint8_t *src, uint32_t base, bool dword_aligned, uint32_t slot_px, uint32_t (&px)[16])
+{
+	if constexpr (C == 4) {
+#pragma unroll
+		for (int q = 0; q < 4; ++q) {
+			uint32_t t4[4];
+			qoi_load4<4>(src, base + 4u * (uint32_t)q, dword_aligned, slot_px, t4);
+#pragma unroll
+			for (int j = 0; j < 4; ++j) px[4 * q + j] = t4[j];
+		}
+	} else {
+		typedef uint32_t u32q_a1 __attribute__((ext_vector_type(4), aligned(1)));
+		const u32q_a1 *p = reinterpret_cast<const u32q_a1 *>(src + (size_t)base * 3u);
+		const u32q_a1 v0 = p[0], v1 = p[1], v2 = p[2];
+		const uint32_t d[13] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w, 0u};
+#pragma unroll
+		for (int j = 0; j < 16; ++j) {
+			const int k = (3 * j) >> 2, sh = (3 * j) & 3;
+			const uint32_t v = sh == 0 ? d[k] : __builtin_amdgcn_alignbyte(d[k + 1], d[k], (uint32_t)sh);
+			px[j] = v | 0xff000000u;
+		}
+	}
+}
+
 // One wave per block: the 16 KB index table of a wave is what limits residency (nine waves per CU), and the lanes'
 // pixel loops are latency chains that only other waves can hide.
 constexpr uint32_t kQoiWaves = 1;  // waves per block of the decoder (one 16 KB table per wave)
@@ -415,15 +443,7 @@ __global__ void __launch_bounds__(64) qoi_tiles_kernel(const QoiArgs a)
 		uint32_t base = start;
 		if (base + 16u <= end) {
 			uint32_t ahead[16];
-			auto load16 = [&](uint32_t from) __attribute__((always_inline)) {
-#pragma unroll
-				for (int q = 0; q < 4; ++q) {
-					uint32_t t4[4];
-					qoi_load4<C>(src, from + 4u * (uint32_t)q, aligned, slot_px, t4);
-#pragma unroll
-					for (int j = 0; j < 4; ++j) ahead[4 * q + j] = t4[j];
-				}
-			};
+			auto load16 = [&](uint32_t from) __attribute__((always_inline)) { qoi_load16<C>(src, from, aligned, slot_px, ahead); };
 			load16(base);
 			for (; base + 16u <= end; base += 16u) {
 				uint32_t cur[16];
@@ -557,15 +577,7 @@ __global__ void __launch_bounds__(64) qoi_tiles_kernel(const QoiArgs a)
 	uint32_t base = start;
 	if (base + (uint32_t)kGroup <= end) {
 		uint32_t ahead[kGroup];
-		auto load_group = [&](uint32_t from, uint32_t (&dst)[kGroup]) __attribute__((always_inline)) {
-#pragma unroll
-			for (int q = 0; q < kGroup / 4; ++q) {
-				uint32_t t4[4];
-				qoi_load4<C>(src, from + 4u * (uint32_t)q, aligned, slot_px, t4);
-#pragma unroll
-				for (int j = 0; j < 4; ++j) dst[4 * q + j] = t4[j];
-			}
-		};
+		auto load_group = [&](uint32_t from, uint32_t (&dst)[kGroup]) __attribute__((always_inline)) { qoi_load16<C>(src, from, aligned, slot_px, dst); };
 		load_group(base, ahead);
 		for (; base + (uint32_t)kGroup <= end; base += (uint32_t)kGroup) {
 			uint32_t cur[kGroup];
