@@ -1285,13 +1285,20 @@ __global__ void __launch_bounds__(64 * kQoiWaves) qoi_decode_kernel(const Decode
 		uint32_t i = 0;
 		for (; i + kGroup <= n; i += kGroup) {
 			request();
+			// the group's 24 bytes as six dwords, two stores (three byte stores per pixel before)
+			static_assert(kGroup == 8, "the packing below is for groups of eight pixels");
+			uint32_t g8[8];
 #pragma unroll
 			for (uint32_t k = 0; k < kGroup; ++k) {
 				next_pixel();
-				dst[3 * (i + k)] = (uint8_t)px;
-				dst[3 * (i + k) + 1] = (uint8_t)(px >> 8);
-				dst[3 * (i + k) + 2] = (uint8_t)(px >> 16);
+				g8[k] = px & 0xffffffu;
 			}
+			typedef uint32_t u32q_a1 __attribute__((ext_vector_type(4), aligned(1)));
+			typedef uint32_t u32d_a1 __attribute__((ext_vector_type(2), aligned(1)));
+			const u32q_a1 lo = {g8[0] | (g8[1] << 24), (g8[1] >> 8) | (g8[2] << 16), (g8[2] >> 16) | (g8[3] << 8), g8[4] | (g8[5] << 24)};
+			const u32d_a1 hi = {(g8[5] >> 8) | (g8[6] << 16), (g8[6] >> 16) | (g8[7] << 8)};
+			*reinterpret_cast<u32q_a1 *>(dst + 3u * i) = lo;
+			*reinterpret_cast<u32d_a1 *>(dst + 3u * i + 16u) = hi;
 			refill();
 		}
 		for (; i < n; ++i) {
