@@ -1,4 +1,4 @@
-"""Decode side: expand of 8 x 8K RGBA frames (32x32 tiles, shrunk at factor 16), per filter: step time (wall clock)."""
+"""Decode side: expand of 8 x 8K frames (32x32 tiles, shrunk at factor 16; CH=3|4 channels), per filter: step time (wall clock)."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -6,7 +6,8 @@ import torch
 from __graft_entry__ import load_product
 P = load_product()
 h = P.Handle(0)
-frames = h.synth_frames_device(8, 4320, 7680, 4, 0, 0)
+ch = int(os.environ.get('CH', '4'))
+frames = h.synth_frames_device(8, 4320, 7680, ch, 0, 0)
 vals, ow, oh, slots = h.shrink_frames_device(frames, 32, 32, 1, 4, 16.0)
 for filt in (0, 2, 4):
     out = h.expand_frames_device(tuple(frames.shape), 32, 32, filt, ow, oh, slots)
@@ -15,4 +16,4 @@ for filt in (0, 2, 4):
     t0 = time.perf_counter()
     for _ in range(100): h.expand_frames_device(tuple(frames.shape), 32, 32, filt, ow, oh, slots, out=out)
     torch.cuda.synchronize()
-    print("expand filter %d: %.4f ms" % (filt, (time.perf_counter() - t0) * 10), flush=True)
+    print("expand channels %d filter %d: %.4f ms" % (ch, filt, (time.perf_counter() - t0) * 10), flush=True)
