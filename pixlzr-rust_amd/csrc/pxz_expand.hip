@@ -287,7 +287,14 @@ __global__ void __launch_bounds__(F32 ? 1024 : 256) expand_kernel(const ExpandAr
 					px = i == lane ? first_px : reinterpret_cast<const uint32_t *>(src)[i];
 					if (conv) px = premultiply(px);  // fir: U8x4 is alpha-premultiplied before a convolution
 				} else {
-					px = (uint32_t)src[3 * i] | ((uint32_t)src[3 * i + 1] << 8) | ((uint32_t)src[3 * i + 2] << 16) | 0xff000000u;
+					// one dword from the pixel's byte address (the slot's last pixel: from a byte earlier, shifted)
+					typedef uint32_t u32_a1 __attribute__((aligned(1)));
+					if (a.slot_bytes >= 4u) {
+						const uint32_t at = 3u * i + 4u <= a.slot_bytes ? 3u * i : a.slot_bytes - 4u;
+						px = (*reinterpret_cast<const u32_a1 *>(src + at) >> (8u * (3u * i - at))) | 0xff000000u;
+					} else {  // (1x1 blocks)
+						px = (uint32_t)src[3 * i] | ((uint32_t)src[3 * i + 1] << 8) | ((uint32_t)src[3 * i + 2] << 16) | 0xff000000u;
+					}
 				}
 				s_src[i] = px;
 			}
@@ -299,13 +306,36 @@ __global__ void __launch_bounds__(F32 ? 1024 : 256) expand_kernel(const ExpandAr
 			// are staged into LDS once, a lane then makes 4 rows (horizontal pass) or 4 adjacent columns (vertical
 			// pass, nearest, clone) per item, so weights are fetched once per 16 multiply-adds and the frame is
 			// written 16 bytes per lane.  Same arithmetic as the scalar form below.
-			if (C == 4 && (fw & 3u) == 0 && tab_x.window <= 8 && tab_y.window <= 8) {
+			if ((fw & 3u) == 0 && tab_x.window <= 8 && tab_y.window <= 8) {
 				const uint32_t q4 = fw >> 2;
+				// RGB instance: the clamp spelled as an instruction.  Left to the compiler, clip8(a) | clip8(b) << 8 of an RGB pixel became
+				// v_ashr_pk_u8_i32, whose result it then ORs as if bits 31:16 were zero -- on gfx950 they keep what the destination
+				// register held (the previous pixel's blue: every third pixel of a quad came out with a wrong blue, ROCm 7.2)
+				auto clipv = [](int32_t acc, int prec) __attribute__((always_inline)) -> uint32_t {
+					if constexpr (C == 4) {
+						return clip8(acc, prec);
+					} else {
+						const int32_t v = acc >> prec;
+						int32_t r;
+						asm("v_med3_i32 %0, %1, 0, %2" : "=v"(r) : "v"(v), "v"(255));
+						return (uint32_t)r;
+					}
+				};
 				auto put4 = [&](uint32_t q, uint32_t oy, uint4 px) {
 					// (the frame is written once and not read by this launch: streaming stores, 13 % off the kernel)
-					typedef uint32_t u32q __attribute__((ext_vector_type(4)));
-					const u32q w = {px.x, px.y, px.z, px.w};
-					__builtin_nontemporal_store(w, reinterpret_cast<u32q *>(dst + (size_t)oy * a.pitch + q * 16u));
+					if (C == 4 || widen) {
+						typedef uint32_t u32q __attribute__((ext_vector_type(4)));
+						const uint32_t opaque = C == 3 ? 0xff000000u : 0u;  // RGB tiles in an RGBA frame: the fourth lane of the arithmetic is not an alpha
+						const u32q w = {px.x | opaque, px.y | opaque, px.z | opaque, px.w | opaque};
+						__builtin_nontemporal_store(w, reinterpret_cast<u32q *>(dst + (size_t)oy * a.pitch + q * 16u));
+					} else {
+						// RGB rows: the four pixels as twelve bytes, three dwords at whatever byte address they have
+						typedef uint32_t u32_a1 __attribute__((aligned(1)));
+						u32_a1 *o = reinterpret_cast<u32_a1 *>(dst + (size_t)oy * a.pitch + q * 12u);
+						o[0] = (px.x & 0xffffffu) | (px.y << 24);
+						o[1] = ((px.y >> 8) & 0xffffu) | (px.z << 16);
+						o[2] = ((px.z >> 16) & 0xffu) | (px.w << 8);
+					}
 				};
 				// per output sample 5 dwords: first | count << 16, then 8 weights (i16); x windows, then y windows
 				uint32_t *s_wx = s_tmp + a.bw * a.bh, *s_wy = s_wx + 5u * a.bw;
@@ -384,12 +414,12 @@ __global__ void __launch_bounds__(F32 ? 1024 : 256) expand_kernel(const ExpandAr
 							for (uint32_t r = 0; r < 4; ++r) {
 								const uint32_t y = 4u * yq + r;
 								if (y < th) {
-									uint32_t px = clip8(acc[r][0], prec) | (clip8(acc[r][1], prec) << 8) | (clip8(acc[r][2], prec) << 16) |
-									              (clip8(acc[r][3], prec) << 24);
+									uint32_t px = clipv(acc[r][0], prec) | (clipv(acc[r][1], prec) << 8) | (clipv(acc[r][2], prec) << 16) |
+									              (clipv(acc[r][3], prec) << 24);
 									if (need_v) {
 										s_tmp[y * fw + ox] = px;
 									} else {
-										put(ox, y, unpremultiply(px));
+										put(ox, y, C == 4 ? unpremultiply(px) : (px | 0xff000000u));  // (RGB: the fourth lane of the arithmetic is not an alpha)
 									}
 								}
 							}
@@ -407,7 +437,7 @@ __global__ void __launch_bounds__(F32 ? 1024 : 256) expand_kernel(const ExpandAr
 							const uint32_t oy = small_div(i, q4), q = i - oy * q4;
 							uint4 v = *reinterpret_cast<const uint4 *>(cur + 4u * q);
 							const uint32_t alpha_and = (v.x & v.y & v.z & v.w) >> 24;
-							if (__builtin_amdgcn_ballot_w64(alpha_and != 255u) != 0ull) {
+							if (C == 4 && __builtin_amdgcn_ballot_w64(alpha_and != 255u) != 0ull) {
 								v.x = unpremultiply(v.x); v.y = unpremultiply(v.y); v.z = unpremultiply(v.z); v.w = unpremultiply(v.w);
 							}
 							put4(q, oy, v);
@@ -441,12 +471,12 @@ __global__ void __launch_bounds__(F32 ? 1024 : 256) expand_kernel(const ExpandAr
 							uint32_t o4[4];
 #pragma unroll
 							for (int r = 0; r < 4; ++r)
-								o4[r] = clip8(acc[r][0], prec) | (clip8(acc[r][1], prec) << 8) | (clip8(acc[r][2], prec) << 16) |
-								        (clip8(acc[r][3], prec) << 24);
+								o4[r] = clipv(acc[r][0], prec) | (clipv(acc[r][1], prec) << 8) | (clipv(acc[r][2], prec) << 16) |
+								        (clipv(acc[r][3], prec) << 24);
 							// un-premultiplying is the identity at alpha 255: skipped (table look-up and three divisions-by-
 							// multiplication per pixel) when no lane of the wave holds anything else
 							const uint32_t alpha_and = (o4[0] & o4[1] & o4[2] & o4[3]) >> 24;
-							if (__builtin_amdgcn_ballot_w64(alpha_and != 255u) != 0ull) {
+							if (C == 4 && __builtin_amdgcn_ballot_w64(alpha_and != 255u) != 0ull) {
 #pragma unroll
 								for (int r = 0; r < 4; ++r) o4[r] = unpremultiply(o4[r]);
 							}
