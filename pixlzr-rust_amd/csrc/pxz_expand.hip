@@ -276,6 +276,31 @@ __global__ void __launch_bounds__(F32 ? 1024 : 256) expand_kernel(const ExpandAr
 #endif
 				);
 			}
+		} else if (!F32 && C == 4 && !widen && tw == fw && th == fh && (fw & 3u) == 0u) {
+			// a tile stored at full size (block.rs:279-281: clone), any block size: its slot straight into the frame rows, 16 bytes per
+			// lane and move, four moves requested before the first is stored -- not through the LDS image (a 64x64 tile: 64 load ->
+			// LDS rounds, a barrier, then 16 rounds out again; these tiles are half of the pixels of a typical frame)
+			if constexpr (!F32 && C == 4) {
+				typedef uint32_t u32q __attribute__((ext_vector_type(4), aligned(4)));  // (slots and rows of any block size: dword aligned)
+				const u32q *src = reinterpret_cast<const u32q *>(a.slots + (size_t)t * a.slot_bytes);
+				const uint32_t q4 = fw >> 2, total = q4 * fh;
+				for (uint32_t g0 = lane; g0 < total; g0 += 256u) {
+					u32q v[4];
+#pragma unroll
+					for (uint32_t k = 0; k < 4; ++k) {
+						const uint32_t g = g0 + 64u * k;
+						v[k] = __builtin_nontemporal_load(src + (g < total ? g : g0));
+					}
+#pragma unroll
+					for (uint32_t k = 0; k < 4; ++k) {
+						const uint32_t g = g0 + 64u * k;
+						if (g < total) {
+							const uint32_t oy = small_div(g, q4), q = g - oy * q4;
+							__builtin_nontemporal_store(v[k], reinterpret_cast<u32q *>(dst + (size_t)oy * a.pitch + q * 16u));
+						}
+					}
+				}
+			}
 		} else {
 			// ---- stored pixels -> one dword per pixel
 			const uint8_t *src = a.slots + (size_t)t * a.slot_bytes;

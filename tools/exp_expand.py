@@ -6,14 +6,15 @@ import torch
 from __graft_entry__ import load_product
 P = load_product()
 h = P.Handle(0)
+bs = int(os.environ.get('BS', '32'))
 ch = int(os.environ.get('CH', '4'))
 frames = h.synth_frames_device(8, 4320, 7680, ch, 0, 0)
-vals, ow, oh, slots = h.shrink_frames_device(frames, 32, 32, 1, 4, 16.0)
+vals, ow, oh, slots = h.shrink_frames_device(frames, bs, bs, 1, 4, 16.0)
 for filt in (0, 2, 4):
-    out = h.expand_frames_device(tuple(frames.shape), 32, 32, filt, ow, oh, slots)
-    for _ in range(60): h.expand_frames_device(tuple(frames.shape), 32, 32, filt, ow, oh, slots, out=out)
+    out = h.expand_frames_device(tuple(frames.shape), bs, bs, filt, ow, oh, slots)
+    for _ in range(60): h.expand_frames_device(tuple(frames.shape), bs, bs, filt, ow, oh, slots, out=out)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(100): h.expand_frames_device(tuple(frames.shape), 32, 32, filt, ow, oh, slots, out=out)
+    for _ in range(100): h.expand_frames_device(tuple(frames.shape), bs, bs, filt, ow, oh, slots, out=out)
     torch.cuda.synchronize()
-    print("expand channels %d filter %d: %.4f ms" % (ch, filt, (time.perf_counter() - t0) * 10), flush=True)
+    print("expand %dx%d channels %d filter %d: %.4f ms" % (bs, bs, ch, filt, (time.perf_counter() - t0) * 10), flush=True)
