@@ -338,7 +338,7 @@ __device__ __forceinline__ uint32_t qoi_pixel(const uint8_t *src, uint32_t i)
 // four pixels from pixel `base` on (base a multiple of 4); may run past the tile's pixels, never past its slot of
 // `slot_px` pixels (RGBA slots are whole pixel quads)
 template <int C>
-__device__ __forceinline__ void qoi_load4(const uint8_t *src, uint32_t base, bool dword_aligned, uint32_t slot_px, uint32_t (&px4)[4])
+__device__ __forceinline__ void qoi_load4(const uint8_t *src, uint32_t base, uint32_t slot_px, uint32_t (&px4)[4])
 {
 	if (C == 3 && base + 4u > slot_px) {
 		for (int j = 0; j < 4; ++j) px4[j] = base + (uint32_t)j < slot_px ? qoi_pixel<3>(src, base + (uint32_t)j) : 0u;
@@ -350,7 +350,6 @@ __device__ __forceinline__ void qoi_load4(const uint8_t *src, uint32_t base, boo
 	} else {
 		// twelve bytes as three dwords at whatever address the slot has (gfx950 loads them from any byte address; the byte-wise
 		// form for slots that are not dword multiples was twelve loads at each of the encoder's call sites)
-		(void)dword_aligned;
 		typedef uint32_t u32_a1 __attribute__((aligned(1)));
 		const u32_a1 *p = reinterpret_cast<const u32_a1 *>(src + (size_t)base * 3u);
 		const uint32_t d0 = p[0], d1 = p[1], d2 = p[2];
@@ -367,13 +366,13 @@ __device__ __forceinline__ void qoi_load4(const uint8_t *src, uint32_t base, boo
 // loads from whatever byte address they have (three vector memory instructions instead of twelve dwords), cut into pixels
 // with byte shifts.
 template <int C>
-__device__ __forceinline__ void qoi_load16(const uint8_t *src, uint32_t base, bool dword_aligned, uint32_t slot_px, uint32_t (&px)[16])
+__device__ __forceinline__ void qoi_load16(const uint8_t *src, uint32_t base, uint32_t slot_px, uint32_t (&px)[16])
 {
 	if constexpr (C == 4) {
 #pragma unroll
 		for (int q = 0; q < 4; ++q) {
 			uint32_t t4[4];
-			qoi_load4<4>(src, base + 4u * (uint32_t)q, dword_aligned, slot_px, t4);
+			qoi_load4<4>(src, base + 4u * (uint32_t)q, slot_px, t4);
 #pragma unroll
 			for (int j = 0; j < 4; ++j) px[4 * q + j] = t4[j];
 		}
@@ -411,7 +410,6 @@ __global__ void __launch_bounds__(64) qoi_tiles_kernel(const QoiArgs a)
 	const uint32_t start = seg * seg_px, end = start + seg_px < n ? start + seg_px : n;
 	const uint32_t len = start < n ? end - start : 0u;
 	const uint8_t *src = a.slots + (size_t)t * a.slot_bytes;
-	const bool aligned = C == 4 ? true : ((a.slot_bytes & 3u) == 0);
 	const uint32_t slot_px = a.slot_bytes / (uint32_t)C;
 	uint32_t *index = s_index + lane * kQoiRow;
 #pragma unroll 8
@@ -443,7 +441,7 @@ __global__ void __launch_bounds__(64) qoi_tiles_kernel(const QoiArgs a)
 		uint32_t base = start;
 		if (base + 16u <= end) {
 			uint32_t ahead[16];
-			auto load16 = [&](uint32_t from) __attribute__((always_inline)) { qoi_load16<C>(src, from, aligned, slot_px, ahead); };
+			auto load16 = [&](uint32_t from) __attribute__((always_inline)) { qoi_load16<C>(src, from, slot_px, ahead); };
 			load16(base);
 			for (; base + 16u <= end; base += 16u) {
 				uint32_t cur[16];
@@ -456,7 +454,7 @@ __global__ void __launch_bounds__(64) qoi_tiles_kernel(const QoiArgs a)
 		}
 		for (; base < end; base += 4u) {
 			uint32_t px4[4];
-			qoi_load4<C>(src, base, aligned, slot_px, px4);
+			qoi_load4<C>(src, base, slot_px, px4);
 #pragma unroll
 			for (int j = 0; j < 4; ++j) {
 				if (base + (uint32_t)j >= end) break;
@@ -577,7 +575,7 @@ __global__ void __launch_bounds__(64) qoi_tiles_kernel(const QoiArgs a)
 	uint32_t base = start;
 	if (base + (uint32_t)kGroup <= end) {
 		uint32_t ahead[kGroup];
-		auto load_group = [&](uint32_t from, uint32_t (&dst)[kGroup]) __attribute__((always_inline)) { qoi_load16<C>(src, from, aligned, slot_px, dst); };
+		auto load_group = [&](uint32_t from, uint32_t (&dst)[kGroup]) __attribute__((always_inline)) { qoi_load16<C>(src, from, slot_px, dst); };
 		load_group(base, ahead);
 		for (; base + (uint32_t)kGroup <= end; base += (uint32_t)kGroup) {
 			uint32_t cur[kGroup];
@@ -601,7 +599,7 @@ __global__ void __launch_bounds__(64) qoi_tiles_kernel(const QoiArgs a)
 	}
 	for (; base < end; base += 4u) {
 		uint32_t px4[4];
-		qoi_load4<C>(src, base, aligned, slot_px, px4);
+		qoi_load4<C>(src, base, slot_px, px4);
 #pragma unroll
 		for (int j = 0; j < 4; ++j) {
 			if (base + (uint32_t)j >= end) break;
