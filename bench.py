@@ -58,6 +58,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-sizes", action="store_true", help="skip the 64x64 / 16x16 side measurements")
     ap.add_argument("--no-encode-mode", action="store_true", help="skip the shrink + device writer measurement")
+    ap.add_argument("--no-block-sweep", action="store_true", help="skip the 16384x16384 block-size sweep (BASELINE configs[3])")
     ap.add_argument("--frames-total", type=int, default=0,
                     help="strong-scaling leg: a fixed batch of this many frames over all ranks (default: 64 when N > 1, off at N = 1)")
     ap.add_argument("--strong-steps", type=int, default=20)
@@ -154,6 +155,8 @@ def run_mode(args, handle, frames, mode_name, world, dist_mod, with_writer=False
         "mp_per_s_per_gpu": N * H * W / 1e6 * steps / elapsed,
         "algo_bytes_per_launch": algo_bytes, "read_bytes": read_bytes, "write_bytes": out_bytes + 12 * tiles,
         "histogram": histogram(ow[0], oh[0]),
+        # which kernels the handle picked for the timed steps (read AFTER them: the state the last of them ran in)
+        "handle_state": handle.state(),
     }
     if with_writer:
         # (the handle's events bracket the shrink's kernels only; the writer's share is the rest of the step)
@@ -385,14 +388,18 @@ def mode_roofline(name, r):
     bytes at all -- what it is bound by"""
     if name == ENCODE_MODE:
         ach = r["achieved_gbps"]
-        out = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS,
+        sq = load_sq("qoi_tiles_kernel")
+        out = {"bound": "issue", "bound_is": "the writer's dominant kernel (qoi_tiles_kernel) is bound by vector-instruction issue at the occupancy its LDS "
+                                             "index tables allow, not by bytes; hbm_utilisation is the step's algorithmic bytes over its wall clock",
+               "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS, "hbm_utilisation": ach / HBM_PEAK_GBPS,
+               "valu_busy": (sq or {}).get("valu_busy_at_4_waves_per_simd"),
                "traffic": load_traffic(ENCODE_MODE), "algorithmic_bytes_per_launch": r["algo_bytes_per_launch"],
                "time_ms": r["ms_per_step"], "time_is": "wall clock of the step (shrink + writer)",
                "kernels": "shrink32_kernel<1> + qoi_bin_* + qoi_tiles_kernel<4> + pack_scan_* + qoi_splice_* + qoi_headers_kernel",
                "writer_traffic": load_flow_traffic("enc32"),
                "what_bounds_it": "qoi_tiles_kernel: a lane per segment of 64..128 pixels, ~100 vector instructions per pixel at 9 waves per CU "
                                  "(its 16 KB index table per wave fills LDS); its 8-byte piece stores reach HBM as partial sectors (see writer_traffic)",
-               "sq": load_sq("qoi_tiles_kernel")}
+               "sq": sq}
         return out
     ach = r["achieved_gbps_all_kernels"]
     out = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS,
@@ -400,12 +407,19 @@ def mode_roofline(name, r):
            "time_ms": r["step_kernels_ms"], "time_is": "all kernels of the step, HIP events",
            "dominant_kernel_ms": r["dominant_kernel_ms"]}
     if name == "shrink_by":
+        sq = load_sq("oklab2_kernel<32")
+        # the dominant kernel is bound by vector-instruction issue: the machine-readable bound says so, `frac` is the share of SIMD
+        # cycles with a vector instruction executing (committed SQ counter passes), and the byte rate is kept as hbm_utilisation
+        out.update({"bound": "valu", "hbm_utilisation": ach / HBM_PEAK_GBPS, "achieved_gbps": ach})
+        busy = (sq or {}).get("valu_busy_at_4_waves_per_simd")  # (the detector's blocks are 16 waves: 4 per SIMD)
+        if busy is not None:
+            out.update({"achieved": busy, "peak": 1.0, "unit": "share of SIMD cycles with a vector instruction executing", "frac": busy})
         out["kernels"] = "oklab2_kernel<32> (dominant) + shrink32_kernel<0> + worklist kernel"
         out["flow_traffic"] = load_flow_traffic("by32")
         out["what_bounds_it"] = ("vector-instruction issue, not bytes: the detector reproduces glibc's cbrtf bit for bit (three per pixel, f64 path) "
                                  "and replays the reference's sequential f32 sums; sq.valu_busy is the share of SIMD cycles with a vector "
                                  "instruction executing")
-        out["sq"] = load_sq("oklab2_kernel<32")
+        out["sq"] = sq
     return out
 
 
@@ -450,23 +464,44 @@ def main():
         results[ENCODE_MODE] = run_mode(args, handle, frames, "shrink_directionally", world, dist, with_writer=True,
                                         steps=min(args.steps, 200))
 
-    # not the metric: the same frames at the reference CLI's default 64x64 tiles and at 16x16 (kernel time only)
+    def timed_shrink(fr, bs, pxz_mode, factor, flow):
+        """one configuration off the headline: 20 untimed + 40 timed launches, every launch bracketed by events; a roofline
+        object of its own (algorithmic bytes of SURVEY 8d over the time of ALL kernels of the step; the dominant kernel's own
+        time beside it; counter bytes from the committed PMC pass of the same flow)"""
+        out = handle.shrink_frames_device(fr, bs, bs, pxz_mode, args.filter, factor)
+        for _ in range(20):
+            handle.shrink_frames_device(fr, bs, bs, pxz_mode, args.filter, factor, out=out)
+        torch.cuda.synchronize()
+        handle.enable_timing(True)
+        for _ in range(40):
+            handle.shrink_frames_device(fr, bs, bs, pxz_mode, args.filter, factor, out=out)
+        first = handle.last_first_kernel_ms()
+        ms = handle.last_kernel_ms()
+        handle.enable_timing(False)
+        _, ow, oh, _ = out
+        algo = fr.numel() + int((ow.long() * oh.long()).sum().item()) * fr.shape[-1] + 12 * ow.numel()
+        mp = fr.shape[0] * fr.shape[1] * fr.shape[2] / 1e6
+        tr = load_flow_traffic(flow)
+        rec = {"kernel_ms": ms, "dominant_kernel_ms": first, "mp_per_s": mp / (ms * 1e-3), "tiles": int(ow.numel()),
+               "handle_state": handle.state(),
+               "roofline": {"bound": "hbm" if pxz_mode == 1 else "valu", "achieved": algo / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                            "frac": algo / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "frac_dominant_kernel": algo / (first * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                            "algorithmic_bytes_per_launch": algo, "time_is": "all kernels of the step, HIP events on the launch stream, 40 launches",
+                            "traffic": (tr or {}).get("hbm_bytes_per_step"),
+                            "traffic_over_algorithmic": (tr or {}).get("traffic_over_algorithmic"),
+                            "traffic_source": f"profiles/pmc_traffic.json flow {flow} (committed rocprofv3 --pmc passes), not measured in this run"}}
+        if pxz_mode == 0:
+            rec["roofline"]["bound_is"] = ("the Oklab detector in front of the shrink kernel is bound by vector-instruction issue (bit-exact glibc cbrtf), "
+                                           "not bytes: frac is the byte rate it leaves, for comparison only")
+        del out
+        return rec
+
+    # not the metric: the same frames at the reference CLI's default 64x64 tiles and at 16x16
     others = {}
     if world == 1 and not args.no_other_sizes:
         for bs in (64, 16):
             for name, (pxz_mode, factor) in MODES.items():
-                out = handle.shrink_frames_device(frames, bs, bs, pxz_mode, args.filter, factor)
-                for _ in range(20):
-                    handle.shrink_frames_device(frames, bs, bs, pxz_mode, args.filter, factor, out=out)
-                torch.cuda.synchronize()
-                handle.enable_timing(True)
-                for _ in range(40):
-                    handle.shrink_frames_device(frames, bs, bs, pxz_mode, args.filter, factor, out=out)
-                ms = handle.last_kernel_ms()
-                handle.enable_timing(False)
-                others[f"{bs}x{bs} {name}"] = {"kernel_ms": ms, "mp_per_s": nf * args.width * args.height / 1e6 / (ms * 1e-3),
-                                               "traffic": load_flow_traffic(("dir" if pxz_mode == 1 else "by") + str(bs))}
-                del out
+                others[f"{bs}x{bs} {name}"] = timed_shrink(frames, bs, pxz_mode, factor, ("dir" if pxz_mode == 1 else "by") + str(bs))
 
     # not the metric either: the way back (Pixlzr::expand + to_image, SURVEY 8 f2) of what shrink_directionally left, per filter
     decode_side = {}
@@ -502,16 +537,38 @@ def main():
             handle.decode_frames_device(buf, offs, tuple(frames.shape), args.block, args.block, out=dec)
         e1.record()
         torch.cuda.synchronize()
-        decode_side["decode (reader)"] = {"ms_per_step": e0.elapsed_time(e1) / 20.0, "file_bytes": int(offs[-1].item()),
+        rd_ms = e0.elapsed_time(e1) / 20.0
+        rd_algo = int(offs[-1].item()) + int((ow2.long() * oh2.long()).sum().item()) * 4 + 12 * ow2.numel()  # files read; pixels, values, sizes written
+        rd_tr = load_flow_traffic("dec32")
+        decode_side["decode (reader)"] = {"ms_per_step": rd_ms, "file_bytes": int(offs[-1].item()),
                                           "time_is": "20 launches between two events on the launch stream",
-                                          "what_bounds_it": "the QOI decoder's longest lanes: 1024 dependent pixel steps of a 32x32 tile (DESIGN 6c)"}
+                                          "roofline": {"bound": "latency", "bound_is": "one lane per tile walks a serial op stream: the launch lasts as long as its longest lanes "
+                                                       "(1024 dependent pixel steps of a full 32x32 tile, DESIGN 6c); the byte rate is for comparison only",
+                                                       "achieved": rd_algo / (rd_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                                       "frac": rd_algo / (rd_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "algorithmic_bytes_per_launch": rd_algo,
+                                                       "traffic": (rd_tr or {}).get("hbm_bytes_per_step"),
+                                                       "traffic_over_algorithmic": (rd_tr or {}).get("traffic_over_algorithmic")}}
         del ow, oh, slots, vals2, ow2, oh2, slots2, offs, buf, dec
+
+    # BASELINE configs[3]: ONE 16384 x 16384 RGBA frame (1.07 GB), tiles of 16 / 32 / 64 px, both callers
+    block_sweep = {}
+    if world == 1 and not args.no_other_sizes and not args.no_block_sweep:
+        note("block sweep on one 16384x16384 frame")
+        del frames
+        torch.cuda.empty_cache()
+        big = handle.synth_frames_device(1, 16384, 16384, 4, first_frame=0, dist=args.dist)
+        for bs in (16, 32, 64):
+            for name, (pxz_mode, factor) in MODES.items():
+                block_sweep[f"{bs}x{bs} {name}"] = timed_shrink(big, bs, pxz_mode, factor, ("sqdir" if pxz_mode == 1 else "sqby") + str(bs))
+        del big
+        torch.cuda.empty_cache()
+        frames = None
 
     line = None
     if rank == 0:
         r = results[primary]
         total_mp = world * nf * args.width * args.height / 1e6
-        keep = ("ms_per_step", "mp_per_s_per_gpu", "steps", "event_sampled_steps", "dominant_kernel_ms", "step_kernels_ms", "kernel_ms",
+        keep = ("ms_per_step", "mp_per_s_per_gpu", "steps", "handle_state", "event_sampled_steps", "dominant_kernel_ms", "step_kernels_ms", "kernel_ms",
                 "shrink_kernels_ms", "writer_ms", "file_bytes", "achieved_gbps", "achieved_gbps_all_kernels", "algo_bytes_per_launch", "histogram")
         line = {
             "metric": "encode megapixels/sec (per-tile LOD detection + block-wise downsample), 8K RGBA",
@@ -529,14 +586,21 @@ def main():
                        "parallelism": f"{world} ranks x {nf} frames, frames sharded over ranks, no collective in the timed steps"
                                       + ("; see strong_scaling for the fixed 64-frame batch with the gather to rank 0 in the step" if world > 1 else ""),
                        "tile_size_histogram_frame0": r["histogram"]},
-            "roofline": {"bound": "hbm", "achieved": r["achieved_gbps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": r["achieved_gbps"] / HBM_PEAK_GBPS, "frac_all_kernels_of_step": r["achieved_gbps_all_kernels"] / HBM_PEAK_GBPS,
+            # `achieved` / `frac`: the step's algorithmic bytes over the step's WALL CLOCK (the conservative figure: launch gaps and the
+            # worklist kernel are inside it); the dominant kernel's own duration by HIP events -- the figure a rocprofv3 kernel trace
+            # shows for it -- is beside it
+            "roofline": {"bound": "hbm", "achieved": r["algo_bytes_per_launch"] / (r["ms_per_step"] * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": r["algo_bytes_per_launch"] / (r["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                         "frac_is": "algorithmic bytes / wall clock of the timed steps",
+                         "achieved_dominant_kernel": r["achieved_gbps"], "frac_dominant_kernel": r["achieved_gbps"] / HBM_PEAK_GBPS,
+                         "frac_all_kernels_of_step": r["achieved_gbps_all_kernels"] / HBM_PEAK_GBPS,
+                         "handle_state": r["handle_state"],
                          "traffic": load_traffic(primary),
                          "traffic_source": "profiles/pmc_traffic.json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (committed), not measured in this run",
                          "kernel_ms": r["kernel_ms"], "dominant_kernel_ms": r["dominant_kernel_ms"], "step_kernels_ms": r["step_kernels_ms"],
                          "event_sampled_steps": r["event_sampled_steps"],
                          "algorithmic_bytes_per_launch": r["algo_bytes_per_launch"],
-                         "kernel": "pxz::shrink32_kernel<1, true> (achieved = the step's algorithmic bytes / this kernel's average duration; frac_all_kernels_of_step adds the worklist kernel's time)"
+                         "kernel": "pxz::shrink32_kernel<1, true> (achieved_dominant_kernel = the step's algorithmic bytes / this kernel's average duration by HIP events; frac_all_kernels_of_step adds the worklist kernel's time)"
                                    if primary == "shrink_directionally" else "pxz::oklab2_kernel<32> + pxz::shrink32_kernel<0, true>"},
             "modes": {k: {kk: v[kk] for kk in keep if kk in v} for k, v in results.items()},
         }
@@ -547,6 +611,8 @@ def main():
             line["other_tile_sizes"] = others
         if decode_side:
             line["decode_side"] = decode_side
+        if block_sweep:
+            line["block_sweep"] = {"workload": "1x 16384x16384 RGBA8 frame (BASELINE configs[3]), factor as in MODES, filter as --filter", **block_sweep}
         if world == 1 and not args.no_cpu_baseline:
             note("cpu baseline")
             line["cpu_baseline"] = cpu_baseline(args, primary, names)

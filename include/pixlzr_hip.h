@@ -43,7 +43,8 @@ typedef enum pxz_status {
 	                               the reference underflows usize and panics (operations.rs:220-221) */
 	PXZ_ERR_UNSUPPORTED = -5,   /* tile does not fit LDS residency (block_w*block_h too large) */
 	PXZ_ERR_NOMEM = -6,
-	PXZ_ERR_BUFFER_TOO_SMALL = -7
+	PXZ_ERR_BUFFER_TOO_SMALL = -7,
+	PXZ_ERR_INTERNAL = -8       /* a device-side consistency check failed (never expected; see pxz_last_error) */
 } pxz_status;
 
 /* FilterType, repr(u8): src/data_types/mod.rs:10-30 */
@@ -248,8 +249,8 @@ int pxz_process_frames_device(pxz_handle *h, const pxz_frames *frames, const pxz
  * halve evenly down to the last level run one detector + shrink + expand pass per level over that level's regular
  * grid; everything else -- 128-px blocks, halvings that go odd (50 -> 25 -> 12 + 12 + 1: every tile is cut from its own
  * corner, tree.rs:70-79) -- goes level by level over lists of rectangles, one block of threads per open tile, with one
- * 4-byte read-back per level (so that form is asynchronous only from its last level on).  Blocks above 128 px:
- * PXZ_ERR_UNSUPPORTED.  params->mode and factor are ignored. */
+ * 8-byte read-back per level: the next level's tile count and a consistency flag (a tile whose axis tables the host
+ * did not list -> PXZ_ERR_INTERNAL; so that form is synchronous).  Blocks above 128 px: PXZ_ERR_UNSUPPORTED.  params->mode and factor are ignored. */
 int pxz_tree_process_frames_device(pxz_handle *h, const pxz_frames *frames, const pxz_params *params,
                                    uint32_t filter_upscale, float threshold, uint32_t min_block_w, uint32_t min_block_h,
                                    const uint8_t *d_pixels, uint8_t *d_out_rgba, uint32_t out_pitch_bytes,
@@ -315,6 +316,14 @@ int pxz_last_kernel_ms(pxz_handle *h, float *ms);
 /* The same average for the FIRST kernel of each step alone (shrink32/64/16_kernel; oklab_kernel in shrink_by
  * steps): the figure a per-kernel profile shows for it.  Call before pxz_last_kernel_ms, which resets the record. */
 int pxz_last_first_kernel_ms(pxz_handle *h, float *ms);
+
+/* Diagnostics: the handle's kernel-selection state.  Two dwords in pinned memory, written by the worklist kernel of the last
+ * FINISHED fast-path launch and read without synchronisation when the next one is set up, pick which kernels run (never what
+ * they compute): state[0] = full tiles with transparency that launch saw (>= 2048: the four-plane kernel is launched; >= half
+ * the tiles: it goes first), state[1] = tiles it listed for the worklist kernel (sizes that kernel's grid), state[2] = 1 if the
+ * LAST launch set up through this handle ran the four-plane kernel, state[3] = 1 if it ran it first.  A timing is only
+ * comparable with another taken in the same state; bench.py prints it beside its numbers. */
+int pxz_handle_state(pxz_handle *h, uint32_t state[4]);
 
 /* Diagnostics: copies `bytes` bytes at byte `offset` of the handle's worklist buffer to `dst` after waiting for the
  * handle's stream (the in-kernel phase stamps of the -DPXZ_STAMPS build land there; tools/stamps_run.py).  Not part of

@@ -18,13 +18,13 @@ EXPORTED_SYMBOLS = [
     "pxz_version", "pxz_device_count", "pxz_create", "pxz_destroy", "pxz_last_error", "pxz_set_stream",
     "pxz_synchronize", "pxz_grid", "pxz_shrink_image", "pxz_shrink_image_packed", "pxz_fetch_packed", "pxz_shrink_images", "pxz_shrink_images_packed", "pxz_shrink_frames_device", "pxz_lod_frames_device", "pxz_oklab_pixels_device",
     "pxz_pack_tiles_device", "pxz_encode_frames_device", "pxz_encode_container", "pxz_qoi_encode", "pxz_qoi_bound", "pxz_synth_frames_device", "pxz_axis_table",
-    "pxz_enable_timing", "pxz_last_kernel_ms", "pxz_last_first_kernel_ms",
+    "pxz_enable_timing", "pxz_last_kernel_ms", "pxz_last_first_kernel_ms", "pxz_handle_state",
     "pxz_debug_read_work", "pxz_expand_frames_device", "pxz_expand_image", "pxz_decode_frames_device", "pxz_decode_file", "pxz_decode_status", "pxz_process_frames_device", "pxz_tree_process_frames_device", "pxz_trim", "pxz_debug_read_status",
 ]
 
 STATUS = {0: "PXZ_OK", -1: "PXZ_ERR_INVALID_ARG", -2: "PXZ_ERR_NO_DEVICE", -3: "PXZ_ERR_HIP",
           -4: "PXZ_ERR_TILE_TOO_SMALL", -5: "PXZ_ERR_UNSUPPORTED", -6: "PXZ_ERR_NOMEM",
-          -7: "PXZ_ERR_BUFFER_TOO_SMALL"}
+          -7: "PXZ_ERR_BUFFER_TOO_SMALL", -8: "PXZ_ERR_INTERNAL"}
 
 
 class PxzError(RuntimeError):
@@ -145,6 +145,8 @@ def load_library():
     L.pxz_last_first_kernel_ms.argtypes = [vp, C.POINTER(f32)]
     L.pxz_last_kernel_ms.restype = C.c_int
     L.pxz_last_kernel_ms.argtypes = [vp, C.POINTER(f32)]
+    L.pxz_handle_state.restype = C.c_int
+    L.pxz_handle_state.argtypes = [vp, C.POINTER(C.c_uint32)]
     _lib = L
     return L
 
@@ -252,6 +254,14 @@ class Handle:
         ms = C.c_float()
         self._check(self._L.pxz_last_first_kernel_ms(self._h, C.byref(ms)))
         return ms.value
+
+    def state(self):
+        """which kernels the fast paths pick (pxz_handle_state): a timing is comparable only with one taken in the same state"""
+        st = (C.c_uint32 * 4)()
+        self._check(self._L.pxz_handle_state(self._h, st))
+        return {"transparent_tiles_seen_by_last_finished_launch": int(st[0]),
+                "tiles_listed_by_last_finished_launch": None if st[1] == 0xffffffff else int(st[1]),
+                "alpha_kernel": bool(st[2]), "alpha_first": bool(st[3])}
 
     def last_kernel_ms(self):
         ms = C.c_float()

@@ -108,6 +108,7 @@ struct pxz_handle {
 	DeviceBuffer tree_rects[2], tree_count;
 	uint32_t *host_stats = nullptr;  // pinned, device-visible: [0] = tiles with transparency the last finished 32x32 launch saw
 	uint32_t *dev_stats = nullptr;   //   (its device-side address); read without synchronisation, steers only the kernel choice
+	uint32_t last_alpha_kernel = 0, last_alpha_first = 0;  // what the last launch set up through this handle chose (pxz_handle_state)
 	bool work_ready = false;   // both worklist counters are zero / consistent with work_slot
 	const uint32_t *qbins_clean = nullptr;  // the writer's binning counters at this address were left zeroed by the last launch_qoi
 	const uint32_t *dbins_clean = nullptr;  // the same for the reader's (launch_decode)
@@ -132,6 +133,17 @@ int fail(pxz_handle *h, int code, const char *fmt, ...)
 		h->error = buf;
 	}
 	return code;
+}
+
+void drop_tree_tables(pxz_handle *h)
+{
+	for (auto &kv : h->tree_tables) {
+		(void)hipFree(kv.second.d_dir);
+		(void)hipFree(kv.second.d_starts);
+		(void)hipFree(kv.second.d_sizes);
+		(void)hipFree(kv.second.d_coeffs);
+	}
+	h->tree_tables.clear();
 }
 
 #define PXZ_HIP(h, call)                                                                      \
@@ -657,6 +669,8 @@ int timed_launch(pxz_handle *h, pxz::ShrinkArgs &a, uint32_t channels, float *va
 	// ... and past half of the tiles the lean kernel would only read, test and list them: the four-plane kernel goes first
 	a.alpha_first = a.alpha_kernel && h->host_stats && *const_cast<volatile uint32_t *>(h->host_stats) >= a.n_tiles / 2u &&
 	                        *const_cast<volatile uint32_t *>(h->host_stats) >= 2048u && !pxz::knobs().no_alpha_first ? 1u : 0u;
+	h->last_alpha_kernel = a.alpha_kernel;
+	h->last_alpha_first = a.alpha_first;
 	// 32x32 fast path: which tiles are full-size, and whether every tile row of the batch is 16-byte aligned
 	a.full_cols = a.full_rows = a.ok_rows = 0;
 	const bool aligned16 = channels == 4 &&
@@ -898,12 +912,7 @@ void pxz_destroy(pxz_handle *h)
 		(void)hipFree(kv.second.d_coeffs);
 		(void)hipFree(kv.second.d_xmf);
 	}
-	for (auto &kv : h->tree_tables) {
-		(void)hipFree(kv.second.d_dir);
-		(void)hipFree(kv.second.d_starts);
-		(void)hipFree(kv.second.d_sizes);
-		(void)hipFree(kv.second.d_coeffs);
-	}
+	drop_tree_tables(h);
 	for (DeviceBuffer *b : {&h->in, &h->val, &h->ow, &h->oh, &h->out, &h->sums, &h->chunks, &h->work, &h->qscratch, &h->qmeta, &h->status, &h->dmeta, &h->okscratch, &h->rgba, &h->slots4, &h->pk, &h->pkoff, &h->tree, &h->tree_rects[0], &h->tree_rects[1], &h->tree_count})
 		if (b->ptr) (void)hipFree(b->ptr);
 	for (int i = 0; i < pxz_handle::kRing; ++i)
@@ -938,6 +947,7 @@ int pxz_trim(pxz_handle *h)
 	for (int i = 0; i < pxz_handle::kRing; ++i)
 		for (DeviceBuffer *b : {&h->ring_in[i], &h->ring_val[i], &h->ring_ow[i], &h->ring_oh[i], &h->ring_out[i], &h->ring_pk[i], &h->ring_pkoff[i]})
 			drop(*b);
+	drop_tree_tables(h);
 	h->packed_len = 0;
 	h->work_ready = false;  // (the worklist counters went with their buffer)
 	h->qbins_clean = nullptr;
@@ -1249,6 +1259,10 @@ int tree_process_rects(pxz_handle *h, const pxz_frames *frames, const pxz_params
 	const auto key = std::make_tuple(frames->width, frames->height, levels[0].first, levels[0].second, mbw, mbh, p.filter, filter_upscale);
 	auto it = h->tree_tables.find(key);
 	if (it == h->tree_tables.end()) {
+		if (h->tree_tables.size() >= 16) {  // a cache, not a log: varying geometries (tools/fuzz_tree.py) must not grow it without bound
+			PXZ_HIP(h, hipStreamSynchronize(h->stream));  // (a queued launch may still read a table)
+			drop_tree_tables(h);
+		}
 		std::set<std::tuple<uint32_t, uint32_t, uint32_t>> pairs;  // (in, out, up)
 		for (int ax = 0; ax < 2; ++ax)
 			for (uint32_t sz : all[ax])
@@ -1334,6 +1348,7 @@ int tree_process_rects(pxz_handle *h, const pxz_frames *frames, const pxz_params
 	a.sizes = tt.d_sizes;
 	a.coeffs = tt.d_coeffs;
 	std::memcpy(a.thresholds, h->thresholds, sizeof a.thresholds);
+	PXZ_HIP(h, hipMemsetAsync(h->tree_count.ptr, 0, 8, h->stream));  // [0] the next level's tile count, [1] "an axis table was missing"
 	for (size_t l = 0; l < levels.size() && n != 0; ++l) {
 		const bool leaf_next = l + 1 == levels.size();
 		const uint32_t nbw = levels[l].first >> 1, nbh = levels[l].second >> 1;
@@ -1355,12 +1370,13 @@ int tree_process_rects(pxz_handle *h, const pxz_frames *frames, const pxz_params
 		a.next_count = (uint32_t *)h->tree_count.ptr;
 		a.next_capacity = (uint32_t)cap;
 		PXZ_HIP(h, pxz::launch_tree_rects(a, h->stream));
-		if (leaf_next) break;
-		uint32_t count = 0;
-		PXZ_HIP(h, hipMemcpyAsync(&count, h->tree_count.ptr, 4, hipMemcpyDeviceToHost, h->stream));
+		uint32_t back[2] = {0, 0};
+		PXZ_HIP(h, hipMemcpyAsync(back, h->tree_count.ptr, 8, hipMemcpyDeviceToHost, h->stream));
 		PXZ_HIP(h, hipStreamSynchronize(h->stream));
-		if (count > cap) return fail(h, PXZ_ERR_HIP, "tree::process: %u tiles for a list of %llu", count, (unsigned long long)cap);
-		n = count;
+		if (back[1] != 0) return fail(h, PXZ_ERR_INTERNAL, "tree::process: level %zu met a tile size the axis tables do not list", l);
+		if (leaf_next) break;
+		if (back[0] > cap) return fail(h, PXZ_ERR_HIP, "tree::process: %u tiles for a list of %llu", back[0], (unsigned long long)cap);
+		n = back[0];
 	}
 	return PXZ_OK;
 }
@@ -2104,6 +2120,16 @@ int pxz_last_first_kernel_ms(pxz_handle *h, float *ms)
 		total += t;
 	}
 	*ms = (float)(total / (double)h->events_used);
+	return PXZ_OK;
+}
+
+int pxz_handle_state(pxz_handle *h, uint32_t state[4])
+{
+	if (!h || !state) return PXZ_ERR_INVALID_ARG;
+	state[0] = h->host_stats ? const_cast<volatile uint32_t *>(h->host_stats)[0] : 0u;
+	state[1] = h->host_stats ? const_cast<volatile uint32_t *>(h->host_stats)[1] : 0xffffffffu;
+	state[2] = h->last_alpha_kernel;
+	state[3] = h->last_alpha_first;
 	return PXZ_OK;
 }
 

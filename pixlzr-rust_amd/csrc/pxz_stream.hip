@@ -801,6 +801,12 @@ __device__ __forceinline__ void qoi_headers(const QoiArgs &a, uint32_t block)
 	const unsigned long long lo = record_offset(t0);
 	const unsigned long long hi = record_offset(t0 + a.cols);
 	const unsigned long long file0 = (unsigned long long)f * a.hdr_bytes + record_offset(f * a.tiles_per_frame);
+	if (r == 0) {
+		// the offsets are valid whatever the room: only the byte stores below are guarded (a caller sizes its next
+		// buffer, and dist.gather_files its sends, from file_offsets[frames])
+		a.file_offsets[f] = file0;
+		if (f + 1 == frames) a.file_offsets[frames] = (unsigned long long)frames * a.hdr_bytes + a.offsets[a.n_tiles];
+	}
 	if (file0 + a.hdr_bytes > a.capacity) return;
 	uint8_t *hd = a.out + file0;
 	const uint32_t len = (uint32_t)(hi - lo);
@@ -816,8 +822,6 @@ __device__ __forceinline__ void qoi_headers(const QoiArgs &a, uint32_t block)
 			hd[12 + 4 * k] = (uint8_t)(v[k] >> 8);
 			hd[13 + 4 * k] = (uint8_t)v[k];
 		}
-		a.file_offsets[f] = file0;
-		if (f + 1 == frames) a.file_offsets[frames] = (unsigned long long)frames * a.hdr_bytes + a.offsets[a.n_tiles];
 	}
 }
 
@@ -1154,9 +1158,13 @@ __global__ void __launch_bounds__(64 * kQoiWaves) qoi_decode_kernel(const Decode
 	// (0.69 ms; 0.52 once the request no longer went through a temporary that was copied, and waited for, on the spot).
 	// Windows are requested without a condition but never past the last one of the files (what lies behind a record's ops is its
 	// own end marker).  As in the encoder there are no branches per op: every op's result is worked out and selects keep the right one.
-	const unsigned long long first_byte = a.rec_off[t];
-	const unsigned long long *wp = reinterpret_cast<const unsigned long long *>(a.files + (first_byte & ~7ull));  // where w0 is from
-	const unsigned long long *w_last = reinterpret_cast<const unsigned long long *>(a.files + ((a.file_offsets[a.n_frames] - 1ull) & ~7ull));
+	// (the windows are 8-byte words at ABSOLUTE aligned addresses, whatever the alignment of `files`: the first may begin up to 7
+	// bytes before the record and the last end up to 7 bytes behind the files' last byte, but an aligned word never crosses a page,
+	// so an exactly sized buffer that ends on a page boundary is never read past its page)
+	const uintptr_t first_addr = reinterpret_cast<uintptr_t>(a.files) + a.rec_off[t];
+	const uintptr_t last_addr = reinterpret_cast<uintptr_t>(a.files) + (a.file_offsets[a.n_frames] - 1ull);
+	const unsigned long long *wp = reinterpret_cast<const unsigned long long *>(first_addr & ~(uintptr_t)7);  // where w0 is from
+	const unsigned long long *w_last = reinterpret_cast<const unsigned long long *>(last_addr & ~(uintptr_t)7);
 	auto window = [&](const unsigned long long *p) __attribute__((always_inline)) { return *(p < w_last ? p : w_last); };
 	constexpr uint32_t kGroup = 8;                               // pixels between two refills
 	constexpr uint32_t kReq = (5u * kGroup + 7u) / 8u;           // windows they can use up (5 bytes a pixel)
@@ -1165,7 +1173,7 @@ __global__ void __launch_bounds__(64 * kQoiWaves) qoi_decode_kernel(const Decode
 #pragma unroll
 	for (uint32_t k = 0; k < kWin; ++k) w[k] = window(wp + k);
 	uint32_t used_up = 0;  // windows shifted out since the buffer was last filled (0 .. kReq)
-	uint32_t pos = (uint32_t)(first_byte & 7ull);           // byte position of the next op inside w0 (0..7)
+	uint32_t pos = (uint32_t)(first_addr & 7u);             // byte position of the next op inside w0 (0..7)
 	uint32_t left = len;                                    // op bytes not yet consumed
 	const uint32_t n = a.tile_w[t] * a.tile_h[t];
 	uint8_t *dst = a.slots + (size_t)t * a.slot_bytes;

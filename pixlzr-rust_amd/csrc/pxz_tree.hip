@@ -254,7 +254,12 @@ __global__ void __launch_bounds__(256) tree_rect_kernel(const TreeRectArgs a)
 	__syncthreads();
 	{
 		const uint32_t need = (nw != w ? 5u : 0u) | (nh != h ? 10u : 0u);
-		if ((s_found & need) != need) return;  // (cannot happen: the host lists every size pair of every level)
+		if ((s_found & need) != need) {
+			// (cannot happen while the host's enumeration of size pairs and the kernel's child sizing agree; if it ever does, the
+			// tile's region stays unwritten and the host turns the flag into PXZ_ERR_INTERNAL after the level's read-back)
+			if (tid == 0u) atomicOr(a.next_count + 1, 1u);
+			return;
+		}
 	}
 	// the tile into LDS
 	uint8_t *s_src = s_x;

@@ -134,3 +134,83 @@ def test_batch_of_64_8k_frames_in_one_call(gpu, oracle, mode, factor):
     for n in range(N):
         valid = (ow[n].long() * oh[n].long() * 4)[:, None]
         assert not ((s2[n] != slots[n]) & (lane < valid)).any(), n
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# The decode side and the legacy filter at full size: Pixlzr::expand + to_image (pixlzr.rs:77-122,
+# pixlzr_image.rs:24-74) and process (process/mod.rs:71-121) against the oracle on whole 8K and 16384^2 frames, and a
+# batch whose output passes 4 GiB.
+# ---------------------------------------------------------------------------------------------------------------
+def assert_same_image_device(got, exp, what):
+    """got: device tensor [H, W, C]; exp: the oracle's numpy image.  Compared on the device in bands of rows."""
+    import torch
+    H = got.shape[0]
+    band = max(1, (256 << 20) // (got.shape[1] * got.shape[2]))
+    bad = 0
+    for y0 in range(0, H, band):
+        e = torch.from_numpy(exp[y0:y0 + band]).to(got.device)
+        bad += int((got[y0:y0 + band] != e).sum())
+    assert bad == 0, f"{what}: {bad} bytes differ"
+
+
+@pytest.mark.parametrize("size,block,filt", [((4320, 7680), 32, 0), ((4320, 7680), 32, 4), ((4320, 7680), 64, 4),
+                                              ((16384, 16384), 32, 0), ((16384, 16384), 32, 4), ((16384, 16384), 64, 4),
+                                              ((16384, 16384), 16, 4)])
+def test_expand_of_a_whole_frame(gpu, oracle, size, block, filt):
+    """Pixlzr::expand + to_image of one whole frame (8K; 16384^2 = 1 GiB of output) at the reference's tile sizes against
+    orc_expand_image, fed with the same stored tiles (what shrink_directionally(Lanczos3, 16) left: every size class)."""
+    import torch
+    H, W = size
+    frames = gpu.synth_frames_device(1, H, W, 4, first_frame=2, dist=0)
+    _, ow, oh, slots = gpu.shrink_frames_device(frames, block, block, 1, 4, 16.0)
+    del frames
+    back = gpu.expand_frames_device((1, H, W, 4), block, block, filt, ow, oh, slots)
+    torch.cuda.synchronize()
+    assert gpu.decode_status() == 0
+    assert torch.unique(ow[0] * 256 + oh[0]).numel() >= 6
+    exp = oracle.expand_image(W, H, block, block, 4, filt, ow[0].cpu().numpy(), oh[0].cpu().numpy(), slots[0].cpu().numpy())
+    assert_same_image_device(back[0], exp, f"expand {W}x{H} b{block} filter {filt}")
+
+
+def test_expand_of_a_batch_beyond_4_gib(gpu, oracle):
+    """34 x 8K RGBA frames in ONE expand call: 4.51 GB of output, the last frame's rows lie beyond 4 GiB.  Frames 33, 0 and 17
+    equal the oracle's expand of their own tiles; frame 33 equals its own single-frame call."""
+    import torch
+    N, H, W = 34, 4320, 7680
+    frames = gpu.synth_frames_device(N, H, W, 4, first_frame=0, dist=0)
+    _, ow, oh, slots = gpu.shrink_frames_device(frames, 32, 32, 1, 4, 16.0)
+    del frames
+    back = gpu.expand_frames_device((N, H, W, 4), 32, 32, 4, ow, oh, slots)
+    torch.cuda.synchronize()
+    assert back.stride(0) * (N - 1) > (1 << 32)
+    assert gpu.decode_status() == 0
+    for n in (N - 1, 0, 17):
+        exp = oracle.expand_image(W, H, 32, 32, 4, 4, ow[n].cpu().numpy(), oh[n].cpu().numpy(), slots[n].cpu().numpy())
+        assert_same_image_device(back[n], exp, f"expand batch frame {n}")
+    alone = gpu.expand_frames_device((1, H, W, 4), 32, 32, 4, ow[N - 1:N].contiguous(), oh[N - 1:N].contiguous(), slots[N - 1:N].contiguous())
+    assert torch.equal(alone[0], back[N - 1])
+
+
+@pytest.mark.parametrize("block", [32, 64])
+def test_process_of_a_whole_8k_frame(gpu, oracle, block):
+    """process (process/mod.rs:107-121: Lanczos3 down, Nearest up, |x - avg|, identity) on one 8K frame against
+    orc_process_image, pixel for pixel."""
+    import torch
+    H, W = 4320, 7680
+    frames = gpu.synth_frames_device(1, H, W, 4, first_frame=5, dist=0)
+    out = gpu.process_frames_device(frames, block, block)
+    torch.cuda.synchronize()
+    exp = oracle.process_image(frames[0].cpu().numpy(), block, block)
+    assert_same_image_device(out[0], exp, f"process 8K b{block}")
+
+
+def test_tree_process_of_a_whole_8k_frame(gpu, oracle):
+    """tree::process (process/tree.rs:89-109) with the 128-px blocks of src/bin/tree.rs:6 on one 8K frame against
+    orc_tree_process_image, pixel for pixel."""
+    import torch
+    H, W = 4320, 7680
+    frames = gpu.synth_frames_device(1, H, W, 4, first_frame=6, dist=0)
+    out = gpu.tree_process_frames_device(frames, 128, 128, 0.05)
+    torch.cuda.synchronize()
+    exp = oracle.tree_process_image(frames[0].cpu().numpy(), 128, 128, 0.05)
+    assert_same_image_device(out[0], exp, "tree::process 8K b128")

@@ -649,6 +649,18 @@ def test_writer_with_too_little_room(gpu, oracle):
     # (a byte that was written is the byte the full files have there; bytes of value 0xA5 cannot be told apart and are skipped)
     assert (got[:cap][written] == full[:cap][written]).all()
     assert written.mean() > 0.5
+    # a capacity below file 0's length: file 1's header does not fit at all, and the offsets (here a reused array with
+    # stale contents from another call) are still the full files'
+    cap0 = int(offs[1].item()) // 2
+    small.fill_(0xA5)
+    offs3 = torch.full_like(offs, 12345)
+    gpu.encode_frames_device(tuple(frames.shape), 32, 32, *out, out=(offs3, small[:cap0]))
+    torch.cuda.synchronize()
+    assert (offs3.cpu().numpy() == offs.cpu().numpy()).all()
+    got = small.cpu().numpy()
+    assert (got[cap0:] == 0xA5).all(), "bytes behind the capacity were written"
+    written = got[:cap0] != 0xA5
+    assert (got[:cap0][written] == full[:cap0][written]).all()
 
 
 @pytest.mark.parametrize("c", [4, 3])
@@ -905,7 +917,10 @@ def test_decoder_on_streams_the_crate_encoder_never_writes(gpu, oracle):
     """The qoi 0.4.1 decoder stores a pixel in its index after RGB / RGBA / DIFF / LUMA ops only: a stream that OPENS
     with a run of the implicit opaque black and later names that slot with an INDEX op gets the zero pixel there, not
     opaque black.  And a 3-channel stream has no RGBA op: at 0xff the crate's decoder stops consuming and repeats its pixel.
-    Oracle and device decoder agree."""
+    Oracle and device decoder agree.
+    UNVERIFIED AGAINST THE CRATE: both behaviours are restated from memory of qoi 0.4.1's decode_impl_slice (its source is not
+    in this environment and no reference fixture holds such a stream -- the crate's own encoder never writes one), and
+    oracle and device were changed together, so this test shows that the two agree, not that either equals the crate."""
     import torch
     # RUN of 3 (opaque black x3), INDEX 53 (= hash of opaque black: (255 * 11) % 64) -> zero pixel, then RGB
     ops = [0xc0 | 2, 53, 0xfe, 10, 20, 30, 0xc0 | 0]

@@ -21,6 +21,29 @@ def test_library_exports_every_declared_symbol(product):
     assert b"gfx950" in L.pxz_version()
 
 
+def test_no_instruction_the_toolchain_miscompiles(product, tmp_path):
+    """hipcc of ROCm 7.2 ORs the result of v_ashr_pk_u8_i32 / v_ashr_pk_i8_i32 as if bits 31:16 were zero; gfx950 leaves them as
+    the destination register held them (a wrong blue in every third pixel of the RGB expand until its clamp was spelled
+    out).  The device code of every unit of the built library is disassembled and searched, so a toolchain bump or a new
+    `clip8(a) | clip8(b) << 8` cannot bring the instruction back unnoticed (tools/check_isa.sh does the same from the sources)."""
+    import subprocess
+    product.build_library()
+    llvm = "/opt/rocm/lib/llvm/bin"
+    csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "pixlzr-rust_amd", "csrc")
+    units = [f[:-4] for f in sorted(os.listdir(csrc)) if f.endswith(".hip")]
+    assert len(units) >= 8
+    for u in units:
+        obj = os.path.join(csrc, u + ".o")
+        assert os.path.exists(obj), obj
+        fat, co = str(tmp_path / (u + ".fatbin")), str(tmp_path / (u + ".co"))
+        subprocess.run([f"{llvm}/llvm-objcopy", "-O", "binary", "--only-section=.hip_fatbin", obj, fat], check=True)
+        subprocess.run([f"{llvm}/clang-offload-bundler", "--unbundle", "--type=o", f"--input={fat}",
+                        "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--output={co}"], check=True)
+        asm = subprocess.run([f"{llvm}/llvm-objdump", "-d", "--mcpu=gfx950", co], check=True, capture_output=True, text=True).stdout
+        assert asm.count("s_endpgm") >= 1, f"{u}: no device code found"
+        assert "v_ashr_pk_u8_i32" not in asm and "v_ashr_pk_i8_i32" not in asm, u
+
+
 def test_no_cpu_fallback_without_device(product):
     import torch
     if torch.cuda.is_available():

@@ -2,7 +2,7 @@
 the flow's algorithmic bytes per step beside the counters (source once + shrunk pixels + 12 B per tile; the
 writer: valid slot bytes + value/w/h read, file bytes written).
 
-  python3 tools/pmc_run.py <variant>       variant = dir | by | enc | dec | exp | dirlod | bylod     (dir_full = dir, kept for old scripts)
+  python3 tools/pmc_run.py <variant>       variant = dir | by | enc | dec | exp | dirlod | bylod | sqdir | sqby (one 16384^2 frame)     (dir_full = dir, kept for old scripts)
   env: BLOCK (tile side, 32), NF (frames, 8), N (steps, 3), DIST (0 opaque .. 3 noise), FACTOR, FILTER (4), OUTJSON
 """
 import json, os, sys
@@ -18,7 +18,10 @@ dist = int(os.environ.get("DIST", "0"))
 bs = int(os.environ.get("BLOCK", "32"))  # tile size (square)
 flt = int(os.environ.get("FILTER", "4"))
 h = P.Handle(0)
-frames = h.synth_frames_device(nf, 4320, 7680, 4, 0, dist)
+W, H = 7680, 4320
+if variant.startswith("sq"):  # BASELINE configs[3]: ONE 16384 x 16384 frame (sqdir / sqby)
+    variant, nf, W, H = variant[2:], 1, 16384, 16384
+frames = h.synth_frames_device(nf, H, W, 4, 0, dist)
 mode, factor = (1, 16.0) if variant.startswith("dir") else (0, 1.0)
 if os.environ.get("FACTOR"):
     factor = float(os.environ["FACTOR"])  # with DIST=3 (noise) the factor picks ONE size class for every tile
@@ -45,7 +48,7 @@ elif variant == "exp":  # shrink once (directional, factor 16, Lanczos3), then e
                 algo_bytes=int((ow.long() * oh.long()).sum().item()) * 4 + 8 * ow.numel() + frames.numel())
 elif variant.endswith("lod"):
     for _ in range(n): h.lod_frames_device(frames, bs, bs, mode, factor)
-    info.update(step_kernels="", algo_bytes=frames.numel() + 8 * (frames.shape[0] * ((4320 + bs - 1) // bs) * ((7680 + bs - 1) // bs)))
+    info.update(step_kernels="", algo_bytes=frames.numel() + 8 * (frames.shape[0] * ((H + bs - 1) // bs) * ((W + bs - 1) // bs)))
 else:
     out = h.shrink_frames_device(frames, bs, bs, mode, flt, factor)
     for _ in range(n - 1): h.shrink_frames_device(frames, bs, bs, mode, flt, factor, out=out)
