@@ -145,8 +145,9 @@ def load_library():
     L.pxz_last_first_kernel_ms.argtypes = [vp, C.POINTER(f32)]
     L.pxz_last_kernel_ms.restype = C.c_int
     L.pxz_last_kernel_ms.argtypes = [vp, C.POINTER(f32)]
-    L.pxz_handle_state.restype = C.c_int
-    L.pxz_handle_state.argtypes = [vp, C.POINTER(C.c_uint32)]
+    if hasattr(L, "pxz_handle_state"):  # (an older diagnostic build named by PXZ_LIB may lack it)
+        L.pxz_handle_state.restype = C.c_int
+        L.pxz_handle_state.argtypes = [vp, C.POINTER(C.c_uint32)]
     _lib = L
     return L
 
@@ -258,6 +259,8 @@ class Handle:
     def state(self):
         """which kernels the fast paths pick (pxz_handle_state): a timing is comparable only with one taken in the same state"""
         st = (C.c_uint32 * 4)()
+        if not hasattr(self._L, "pxz_handle_state"):
+            return None
         self._check(self._L.pxz_handle_state(self._h, st))
         return {"transparent_tiles_seen_by_last_finished_launch": int(st[0]),
                 "tiles_listed_by_last_finished_launch": None if st[1] == 0xffffffff else int(st[1]),

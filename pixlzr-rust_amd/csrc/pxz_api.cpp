@@ -299,6 +299,35 @@ int get_tables(pxz_handle *h, uint32_t bw, uint32_t bh, uint32_t edge_w, uint32_
 						rows.insert(rows.end(), mf.begin(), mf.end());
 					}
 				}
+				// 16x16 tiles: operands of the group-of-four matrix-core resample (resample_group16_mfma): 16 -> 8 | 4 | 2 | 1
+				if (axis == 0 && cls == 0 && bw == 16 && bh == 16 && outsz <= 8) {
+					std::vector<uint32_t> mf(pxz::kMf16Dwords, 0u);
+					bool fits = true, opaque_stays = true;
+					const int32_t half = 1 << (win.precision - 1);
+					for (uint32_t o = 0; o < outsz; ++o) {
+						int32_t k[16] = {0};
+						int32_t total = 0;
+						for (uint32_t i = 0; i < (uint32_t)win.sizes[o]; ++i) {
+							k[(uint32_t)win.starts[o] + i] = win.coeffs[(size_t)o * win.window + i];
+							total += k[(uint32_t)win.starts[o] + i];
+						}
+						for (uint32_t i = 0; i < 16; ++i) {
+							const int32_t lo = ((k[i] + 128) & 255) - 128, hi = (k[i] - lo) / 256;
+							if (hi < -128 || hi > 127) fits = false;
+							mf[o * 4 + i / 4] |= (uint32_t)(uint8_t)lo << (8 * (i & 3));
+							mf[32 + o * 4 + i / 4] |= (uint32_t)(uint8_t)hi << (8 * (i & 3));
+						}
+						mf[64 + o] = (uint32_t)(128 * total + half);
+						mf[72 + o] = (uint32_t)total;
+						if (((half + 255 * total) >> win.precision) < 255) opaque_stays = false;
+					}
+					mf[80] = opaque_stays ? 1u : 0u;
+					mf[81] = (uint32_t)win.precision;
+					if (fits && opaque_stays) {  // (the group form writes alpha 255: only where the windows keep it)
+						t.mf_off = (uint32_t)rows.size();
+						rows.insert(rows.end(), mf.begin(), mf.end());
+					}
+				}
 				// 64x64 tiles: operands of shrink64_kernel (Fast64Args), every level from 32 px down to 1 px
 				if (axis == 0 && cls == 0 && bw == 64 && bh == 64 && outsz < 64) {
 					const uint32_t nblk = outsz > 16 ? outsz / 16 : 1;

@@ -452,9 +452,13 @@ __device__ __forceinline__ void fast32_v(const uint32_t *trows, const AxisTab &t
 // single-pass cases of the fast path (one axis keeps its 32 samples), opaque tile.
 // Vertical only: item = (pair of columns, output row) straight on the [y][x] planes; the (row j,
 // row j+1) sample pairs dot2 needs are built with two perms per column pair and row pair.
+// T = 32: a whole 32x32 LDS image, pixels parked as dwords (out).  T = 16: a 16x16 tile somewhere inside the image (s_pl points at
+// its first pixel pair), pixels stored straight to its slot (C bytes each).
+template <int T = 32, int C = 4>
 __device__ __forceinline__ void fast32_v_only(const uint32_t *trows, const AxisTab &ty, const uint32_t *s_pl, uint32_t lane,
                                               uint32_t nh, uint32_t *out)
 {
+	constexpr uint32_t kPairs = T / 2;  // column pairs of a row
 	const uint32_t lgy = 31u - (uint32_t)__builtin_clz(nh);
 	const uint32_t oy = lane & (nh - 1u);  // invariant per lane: 64 is a multiple of nh
 	RowRegs r;
@@ -463,14 +467,14 @@ __device__ __forceinline__ void fast32_v_only(const uint32_t *trows, const AxisT
 	const int32_t init = 1 << (prec - 1);
 	const uint32_t al = clip8(init + 255 * r.ksum, prec);  // constant-255 alpha through the same window
 	const uint32_t wq = ty.wquads;
-	for (uint32_t i = lane; i < 16u * nh; i += 64u) {
+	for (uint32_t i = lane; i < kPairs * nh; i += 64u) {
 		const uint32_t qx = i >> lgy;  // column pair
 		const uint32_t *colp = s_pl + (r.fq * 4u) * kRS32 + qx;
 		int32_t acc[3][2];
 #pragma unroll
 		for (int c = 0; c < 3; ++c) acc[c][0] = acc[c][1] = init;
 #pragma unroll
-		for (int q = 0; q < 8; ++q) {
+		for (int q = 0; q < T / 4; ++q) {
 			if ((uint32_t)q < wq) {
 #pragma unroll
 				for (int c = 0; c < 3; ++c) {
@@ -490,11 +494,18 @@ __device__ __forceinline__ void fast32_v_only(const uint32_t *trows, const AxisT
 			o.x = unpremultiply(o.x);
 			o.y = unpremultiply(o.y);
 		}
-		*reinterpret_cast<uint2 *>(out + (oy * 16u + qx) * 2u) = o;  // pixels (2qx, 2qx+1) of output row oy, row length 32
+		// pixels (2qx, 2qx+1) of output row oy, row length T
+		if constexpr (C == 4) {
+			*reinterpret_cast<uint2 *>(out + (oy * kPairs + qx) * 2u) = o;
+		} else {
+			store_pixel<3>(reinterpret_cast<uint8_t *>(out), (oy * kPairs + qx) * 2u, o.x);
+			store_pixel<3>(reinterpret_cast<uint8_t *>(out), (oy * kPairs + qx) * 2u + 1u, o.y);
+		}
 	}
 }
 
 // Horizontal only: item = (output column, pair of rows), results go straight to the slot.
+template <int T = 32, int C = 4>
 __device__ __forceinline__ void fast32_h_only(const uint32_t *trows, const AxisTab &tx, const uint32_t *s_pl, uint32_t lane,
                                               uint32_t nw, uint32_t *out)
 {
@@ -506,14 +517,14 @@ __device__ __forceinline__ void fast32_h_only(const uint32_t *trows, const AxisT
 	const int32_t init = 1 << (prec - 1);
 	const uint32_t al = clip8(init + 255 * r.ksum, prec);
 	const uint32_t wq = tx.wquads;
-	for (uint32_t i = lane; i < nw * 16u; i += 64u) {
+	for (uint32_t i = lane; i < nw * (uint32_t)(T / 2); i += 64u) {  // T / 2 pairs of rows
 		const uint32_t yp = i >> lgx;
 		const uint32_t *row = s_pl + yp * (2 * kRS32) + r.fq * 2u;
 		int32_t acc[3][2];
 #pragma unroll
 		for (int c = 0; c < 3; ++c) acc[c][0] = acc[c][1] = init;
 #pragma unroll
-		for (int q = 0; q < 8; ++q) {
+		for (int q = 0; q < T / 4; ++q) {
 			if ((uint32_t)q < wq) {
 #pragma unroll
 				for (int c = 0; c < 3; ++c) {
@@ -528,7 +539,7 @@ __device__ __forceinline__ void fast32_h_only(const uint32_t *trows, const AxisT
 		for (uint32_t rr = 0; rr < 2; ++rr) {
 			uint32_t px = clip8(acc[0][rr], prec) | (clip8(acc[1][rr], prec) << 8) | (clip8(acc[2][rr], prec) << 16) | (al << 24);
 			if (al != 255u) px = unpremultiply(px);
-			out[(2u * yp + rr) * nw + ox] = px;
+			store_pixel<C>(reinterpret_cast<uint8_t *>(out), (2u * yp + rr) * nw + ox, px);
 		}
 	}
 }
@@ -806,6 +817,113 @@ __device__ __forceinline__ void resample_mfma32_narrow(const uint32_t *s_tab, co
 		if (nh > 2u) {
 			dst[2u * nw * 4u] = (uint8_t)(clamp_fixed(vhi[2], vlo[2], top_y) >> py);
 			dst[3u * nw * 4u] = (uint8_t)(clamp_fixed(vhi[3], vlo[3], top_y) >> py);
+		}
+	}
+}
+
+// The two-pass convolution of a GROUP of four 16x16 tiles (a 32x32 region of LDS planes, shrink16_kernel) as ONE set of
+// matrix-core products (round 4): the weight operands are block-diagonal.  A k slot (g, j) of v_mfma_i32_16x16x32_i8 stands for
+// sample 4g + j of the FIRST 16 (j < 4) or of the SECOND 16 (j >= 4) of the 32, so
+//   horizontal, half mb (rows 16 mb ..): B[k][n] = Wx of tile (dx = n >> 3, dy = mb) for output column n & 7 in the k slots of its
+//               own 16 source columns and zero in the other 16: one product gives T of the left tile in columns 0..7 and of the
+//               right tile in columns 8..15, each at its own level (a lane reads its own tile's table: levels are per lane);
+//   vertical    A[m][k] = Wy of the tile in row dy = m >> 3 for output row m & 7, in the k slots of its own 16 source rows.  The
+//               left and the right tiles of a row have different y levels, so there are two products into ONE accumulator:
+//               A of the left tiles times T with columns 8..15 zeroed, plus A of the right tiles times T with columns 0..7 zeroed
+//               (a zero byte is p - 128 = 0: it adds nothing, the bias of the lane's own tile carries its 128 * sum K).
+// 24 MFMAs and ~230 vector instructions for the four tiles; the dot2 form (resample_fast16_hv) took ~118 per tile.  Same
+// integers: the clamp after each pass, the precisions and the biases are those of the lane's tile.  Opaque tiles whose alpha
+// stays 255 (every table involved says so); tiles outside `mask` (clone, one-pass, nothing) ride along and are not stored.
+__device__ __forceinline__ uint32_t clamp_fixed_v(int32_t hi, int32_t lo, int32_t top)
+{
+	const int32_t v = (int32_t)(((uint32_t)hi << 8) + (uint32_t)lo);
+	int32_t r;
+	asm("v_med3_i32 %0, %1, 0, %2" : "=v"(r) : "v"(v), "v"(top));
+	return (uint32_t)r;
+}
+
+// Per-lane views of the group (set up by shrink16_kernel while it decides the tiles one by one, so that no per-tile scalar
+// outlives its tile): tx[mb] = table of the tile in this lane's COLUMN half (n >> 3) and row half mb (the B operand of the
+// horizontal product of half mb); ty[side] = table of the tile in column `side` and the ROW half this lane stands for as a row
+// of the weight operand (m >> 3, m = lane & 15); tyo / nw / nh / dst / ok = the tile this lane's outputs belong to (column half
+// n >> 3, row half g >> 1): its y table, reduced size, slot, and whether it is one of the two-pass tiles at all.  Tables of
+// views without a two-pass tile: any valid one (those columns and rows are not stored).
+template <int C>
+__device__ __forceinline__ void resample_group16_mfma(const uint32_t *s_tab, const uint32_t (&tx)[2], const uint32_t (&ty)[2], uint32_t tyo,
+                                                      const uint32_t *s_pl, uint32_t lane, uint32_t nw, uint32_t nh, bool ok, uint8_t *dst)
+{
+	const uint32_t n = lane & 15u, g = lane >> 4, o = n & 7u;
+	const bool second = n >= 8u;  // as a column: a right tile; as a row of a weight operand: a bottom tile
+	const v4i32 zero = {0, 0, 0, 0};
+	auto operand = [&](uint32_t w) -> long {  // the lane's four weight bytes in the k slots of its own 16 samples
+		return (long)(second ? (unsigned long long)w << 32 : (unsigned long long)w);
+	};
+	long kx_lo[2], kx_hi[2], ky_lo[2], ky_hi[2];
+	int32_t bx[2], top_x[2];
+	uint32_t px_[2];
+#pragma unroll
+	for (uint32_t mb = 0; mb < 2; ++mb) {
+		const uint32_t *t = s_tab + tx[mb];
+		kx_lo[mb] = operand(t[o * 4u + g]);
+		kx_hi[mb] = operand(t[32u + o * 4u + g]);
+		bx[mb] = (int32_t)t[64u + o];
+		px_[mb] = t[81];
+		top_x[mb] = (int32_t)((256u << px_[mb]) - 1u);
+	}
+#pragma unroll
+	for (uint32_t side = 0; side < 2; ++side) {
+		const uint32_t *t = s_tab + ty[side];
+		ky_lo[side] = operand(t[o * 4u + g]);
+		ky_hi[side] = operand(t[32u + o * 4u + g]);
+	}
+	// this lane's outputs: column n, rows 4g + r -> pixel (ox = o, oy = 4 (g & 1) + r) of its tile
+	const uint32_t *to = s_tab + tyo;
+	const v4i32 cy = *reinterpret_cast<const v4i32 *>(to + 64u + 4u * (g & 1u));
+	const uint32_t py = to[81];
+	const int32_t top_y = (int32_t)((256u << py) - 1u);
+	uint32_t pix[4] = {0xff000000u, 0xff000000u, 0xff000000u, 0xff000000u};
+	const uint32_t *rowp = s_pl + n * kRS32 + 2u * g;
+#pragma unroll
+	for (uint32_t c = 0; c < 3; ++c) {
+		uint32_t t[2];
+#pragma unroll
+		for (uint32_t mb = 0; mb < 2; ++mb) {
+			const uint32_t *row = rowp + c * kPD32 + mb * (16u * kRS32);
+			const uint2 d0 = lds_load2(row);       // columns 4g .. 4g+3 (left tile)
+			const uint2 d1 = lds_load2(row + 8u);  // columns 16+4g .. 16+4g+3 (right tile)
+			const uint32_t a0 = __builtin_amdgcn_perm(d0.y, d0.x, 0x06040200u) ^ 0x80808080u;
+			const uint32_t a1 = __builtin_amdgcn_perm(d1.y, d1.x, 0x06040200u) ^ 0x80808080u;
+			const long av = (long)(((unsigned long long)a1 << 32) | (unsigned long long)a0);
+			const v4i32 cx = {bx[mb], bx[mb], bx[mb], bx[mb]};
+			const v4i32 lo = __builtin_amdgcn_mfma_i32_16x16x32_i8(av, kx_lo[mb], cx, 0, 0, 0);
+			const v4i32 hi = __builtin_amdgcn_mfma_i32_16x16x32_i8(av, kx_hi[mb], zero, 0, 0, 0);
+			uint32_t packed = 0;
+			put_byte_shr<0>(packed, clamp_fixed_v(hi[0], lo[0], top_x[mb]), px_[mb]);
+			put_byte_shr<1>(packed, clamp_fixed_v(hi[1], lo[1], top_x[mb]), px_[mb]);
+			put_byte_shr<2>(packed, clamp_fixed_v(hi[2], lo[2], top_x[mb]), px_[mb]);
+			put_byte_shr<3>(packed, clamp_fixed_v(hi[3], lo[3], top_x[mb]), px_[mb]);
+			t[mb] = packed ^ 0x80808080u;
+		}
+		const uint32_t l0 = second ? 0u : t[0], l1 = second ? 0u : t[1], r0 = second ? t[0] : 0u, r1 = second ? t[1] : 0u;
+		const long tl = (long)(((unsigned long long)l1 << 32) | (unsigned long long)l0);
+		const long tr = (long)(((unsigned long long)r1 << 32) | (unsigned long long)r0);
+		v4i32 lo = __builtin_amdgcn_mfma_i32_16x16x32_i8(ky_lo[0], tl, cy, 0, 0, 0);
+		lo = __builtin_amdgcn_mfma_i32_16x16x32_i8(ky_lo[1], tr, lo, 0, 0, 0);
+		v4i32 hi = __builtin_amdgcn_mfma_i32_16x16x32_i8(ky_hi[0], tl, zero, 0, 0, 0);
+		hi = __builtin_amdgcn_mfma_i32_16x16x32_i8(ky_hi[1], tr, hi, 0, 0, 0);
+#pragma unroll
+		for (int r = 0; r < 4; ++r) {
+			const uint32_t v = clamp_fixed_v(hi[r], lo[r], top_y);
+			if (c == 0) put_byte_shr<0>(pix[r], v, py);
+			else if (c == 1) put_byte_shr<1>(pix[r], v, py);
+			else put_byte_shr<2>(pix[r], v, py);
+		}
+	}
+	if (ok && o < nw) {
+#pragma unroll
+		for (uint32_t r = 0; r < 4; ++r) {
+			const uint32_t oy = 4u * (g & 1u) + r;
+			if (oy < nh) store_pixel<C>(dst, oy * nw + o, pix[r]);
 		}
 	}
 }

@@ -37,6 +37,10 @@ struct AxisTab {
 // src(g, j) = 4g + j (j < 4), 16 + 4g + (j - 4) (j >= 4): the order in which the first product's
 // accumulator registers hand their rows to the second product.
 constexpr uint32_t kMfDwords = 292;
+// Matrix-core operand table of one 16 -> out axis (out = 8, 4, 2 or 1; resample_group16_mfma): dwords [0..31] the low weight
+// bytes, dword o * 4 + g = W[o][4g .. 4g+3] (rows o >= out are zero); [32..63] the high bytes; [64..71] bias = 128 * sum + half;
+// [72..79] the weight sums; [80] 1 if a constant-255 alpha convolves to 255 at every output; [81] the precision
+constexpr uint32_t kMf16Dwords = 84;
 
 // Layout of the handle's worklist buffer (dwords): [0], [1] the two worklist counters (list B: tiles for the
 // generic kernel) used alternately, [2 + 64*s, 2 + 64*s + 64) the tile-ticket counters of shrink64_kernel for
@@ -142,6 +146,7 @@ struct Fast32Args {
 	uint32_t finish_here;    // shrink32_kernel: every block finishes the tiles it completed (value / lod outputs) at its end
 	uint32_t all_tiles;      // shrink32a_kernel: every tile of the batch (not list A): the launch that skips shrink32_kernel
 	uint32_t narrow;         // shrink32_kernel: 4/2/1-px-wide outputs take resample_mfma32_narrow (0: PXZ_NO_NARROW=1, the round-1 forms)
+	uint32_t group16;        // shrink16_kernel: the two-pass tiles of a group go through resample_group16_mfma (0: PXZ_NO_GROUP16=1)
 	float factor;            //   with these, as the worklist kernel's scan over all tiles would
 	float *value, *lod0, *lod1;
 	uint32_t breaks[kMaxLevel];
@@ -187,6 +192,7 @@ struct Knobs {
 	bool no_native_rgb;     // PXZ_NO_NATIVE_RGB: RGB batches are widened to RGBA even where a kernel reads RGB itself
 	bool no_alpha_first;    // PXZ_NO_ALPHA_FIRST: transparent batches keep the two-kernel flow (shrink32_kernel lists, shrink32a_kernel takes the list)
 	bool no_narrow;         // PXZ_NO_NARROW: 4/2/1-px-wide outputs of 32x32 tiles keep the round-1 resample forms
+	bool no_group16;        // PXZ_NO_GROUP16: the two-pass tiles of a 16x16 group keep their own dot2 resamples (no block-diagonal matrix-core products)
 	bool oklab_v1;          // PXZ_OKLAB_V1: round-1 detector (one chain wave, two barriers per band; 64-px tiles parked in HBM)
 	bool no_expand_fast32;    // PXZ_NO_EXPAND_FAST32: expand_kernel keeps its general forms for 32x32 RGBA tiles (no matrix-core convolutions, no shift-indexed Nearest)
 	bool tree_rects;        // PXZ_TREE_RECTS: tree::process always goes over rectangle lists (pxz_tree.hip), also where the per-level grids apply

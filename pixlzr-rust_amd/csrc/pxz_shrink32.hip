@@ -768,9 +768,8 @@ __global__ void __launch_bounds__(1024) shrink16_kernel(const Fast32Args a)
 		}
 		tile_sync<1>();
 		// ---- detector: as shrink32_kernel, minus the windows that would straddle two tiles
-		uint32_t m0[4], m1[4], key0[4], key1[4];
+		uint32_t sum_hz = 0, sum_vr = 0;
 		if constexpr (MODE == 1) {
-			uint32_t sum_hz = 0, sum_vr = 0;
 			const uint32_t q = tid & 15u, g = tid >> 4;
 			const uint32_t two = 0x00020002u;
 			const uint32_t *pc[3];
@@ -814,52 +813,51 @@ __global__ void __launch_bounds__(1024) shrink16_kernel(const Fast32Args a)
 			// per tile: 8 lanes (q >> 3) of two 16-lane rows (g >> 1): sum inside the 8-lane groups, then pick
 			sum_hz = (uint32_t)group_sum<8>((int32_t)sum_hz);
 			sum_vr = (uint32_t)group_sum<8>((int32_t)sum_vr);
-#pragma unroll
-			for (uint32_t k = 0; k < 4; ++k) {
-				const uint32_t l0 = 32u * (k >> 1) + 8u * (k & 1u);  // first lane of tile k's first row; its second row is 16 on
-				key0[k] = (uint32_t)__builtin_amdgcn_readlane((int)sum_hz, l0) + (uint32_t)__builtin_amdgcn_readlane((int)sum_hz, l0 + 16u);
-				key1[k] = (uint32_t)__builtin_amdgcn_readlane((int)sum_vr, l0) + (uint32_t)__builtin_amdgcn_readlane((int)sum_vr, l0 + 16u);
-				m0[k] = level_of(key0[k]);
-				m1[k] = level_of(key1[k]);
-			}
-		} else {
-#pragma unroll
-			for (uint32_t k = 0; k < 4; ++k) {
-				const uint32_t vb = __builtin_amdgcn_readfirstlane(given[k]);
-				key0[k] = key1[k] = vb;
-				m0[k] = m1[k] = level_of(__float_as_uint(parse_value(__uint_as_float(vb))));
-			}
 		}
-		uint32_t nw[4], nh[4];
-#pragma unroll
-		for (uint32_t k = 0; k < 4; ++k) {
-			nw[k] = reduced_size(16u, m0[k]);
-			nh[k] = reduced_size(16u, m1[k]);
-		}
-		// ---- per tile: metadata, then clone / nearest / two-pass resample straight into its slot
+		// ---- per tile: level decision, metadata, then clone / nearest straight into its slot; the two-pass tiles of the group
+		// go through the matrix cores together (resample_group16_mfma) when they have their operand tables (built only where a
+		// constant-255 alpha stays 255), else each through its own dot2 form.  Everything the group form needs is kept per LANE
+		// (its three views of the 2x2 tiles), so that no per-tile scalar outlives its tile: the kernel sits at its scalar-register
+		// limit, and a spilled scalar costs vector instructions.
 		uint32_t filt = a.filter;
 		asm volatile("" : "+s"(filt));  // scalar compares per use instead of a hoisted mask
+		const bool want_px = FULL || a.out_px != nullptr;
+		const bool group16 = a.group16 != 0u && filt != 0u && want_px;
+		const bool second = (tid & 8u) != 0u, low = (tid & 32u) != 0u;  // lane & 15 >= 8; lane >> 4 >= 2
+		uint32_t v_tx[2] = {0u, 0u}, v_ty[2] = {0u, 0u}, v_tyo = 0u, v_nw = 0u, v_nh = 0u;
+		bool v_ok = false;
+		uint8_t *v_dst = nullptr;
+		uint32_t any_x = 0u, any_y = 0u;  // (scalar: a table of one of the two-pass tiles, 0 = there is none)
 #pragma unroll
 		for (uint32_t k = 0; k < 4; ++k) {
-			const uint32_t t = tile_id(k);
-			const bool one_pass = (FULL || a.out_px != nullptr) && (nw[k] == 16u) != (nh[k] == 16u) && filt != 0;
-			if (one_pass) {  // 16 x n, n x 16: generic kernel (it writes the tile's metadata itself)
-				defer_tile(t);
-				continue;
+			uint32_t key0, key1, m0, m1;
+			if constexpr (MODE == 1) {
+				const uint32_t l0 = 32u * (k >> 1) + 8u * (k & 1u);  // first lane of tile k's first row; its second row is 16 on
+				key0 = (uint32_t)__builtin_amdgcn_readlane((int)sum_hz, l0) + (uint32_t)__builtin_amdgcn_readlane((int)sum_hz, l0 + 16u);
+				key1 = (uint32_t)__builtin_amdgcn_readlane((int)sum_vr, l0) + (uint32_t)__builtin_amdgcn_readlane((int)sum_vr, l0 + 16u);
+				m0 = level_of(key0);
+				m1 = level_of(key1);
+			} else {
+				const uint32_t vb = __builtin_amdgcn_readfirstlane(given[k]);
+				key0 = key1 = vb;
+				m0 = m1 = level_of(__float_as_uint(parse_value(__uint_as_float(vb))));
 			}
+			const uint32_t nw = reduced_size(16u, m0), nh = reduced_size(16u, m1);
+			const uint32_t t = tile_id(k);
+			const bool one_pass = want_px && (nw == 16u) != (nh == 16u) && filt != 0;
 			{
 				uint32_t lane = tid;
 				asm volatile("" : "+v"(lane));  // a fresh compare, not a hoisted (and spilled) lane mask
 				if (lane == 0) {
-					reinterpret_cast<uint2 *>(a.sums)[t] = make_uint2(key0[k], key1[k]);
-					if (FULL || a.out_w) a.out_w[t] = nw[k];
-					if (FULL || a.out_h) a.out_h[t] = nh[k];
+					reinterpret_cast<uint2 *>(a.sums)[t] = make_uint2(key0, key1);
+					if (FULL || a.out_w) a.out_w[t] = nw;
+					if (FULL || a.out_h) a.out_h[t] = nh;
 				}
 			}
-			if (!FULL && a.out_px == nullptr) continue;
+			if (!want_px) continue;
 			uint32_t *dst = reinterpret_cast<uint32_t *>(a.out_px + (size_t)t * (256u * (uint32_t)C));
 			const uint32_t *tile_pl = s_pl + (16u * (k >> 1)) * kRS32 + 8u * (k & 1u);  // first pixel pair of the tile
-			if (nw[k] == 16u && nh[k] == 16u) {
+			if (nw == 16u && nh == 16u) {
 				// clone (block.rs:279-281): 64 groups of 4 pixels, one per lane
 				const uint32_t row = tid >> 2, c4 = tid & 3u;
 				const uint32_t *p = tile_pl + row * kRS32 + c4 * 2u;
@@ -885,13 +883,12 @@ __global__ void __launch_bounds__(1024) shrink16_kernel(const Fast32Args a)
 				}
 			} else if (filt == 0) {
 				// ResizeAlg::Nearest: source index = floor((o + 0.5) * 2^m); any (nw, nh)
-				const uint32_t mx = m0[k], my = m1[k];
-				const uint32_t lgx = 31u - (uint32_t)__builtin_clz(nw[k]);
+				const uint32_t lgx = 31u - (uint32_t)__builtin_clz(nw);
 				const uint16_t *pl16 = reinterpret_cast<const uint16_t *>(tile_pl);
-				for (uint32_t i = tid; i < nw[k] * nh[k]; i += 64u) {
-					const uint32_t ox = i & (nw[k] - 1u), oy = i >> lgx;
-					const uint32_t x = mx == 0 ? ox : (mx < 5u ? (2u * ox + 1u) << (mx - 1u) : 8u);
-					const uint32_t y = my == 0 ? oy : (my < 5u ? (2u * oy + 1u) << (my - 1u) : 8u);
+				for (uint32_t i = tid; i < nw * nh; i += 64u) {
+					const uint32_t ox = i & (nw - 1u), oy = i >> lgx;
+					const uint32_t x = m0 == 0 ? ox : (m0 < 5u ? (2u * ox + 1u) << (m0 - 1u) : 8u);
+					const uint32_t y = m1 == 0 ? oy : (m1 < 5u ? (2u * oy + 1u) << (m1 - 1u) : 8u);
 					const uint32_t idx = y * (2u * kRS32) + x;
 					if constexpr (C == 4) {
 						dst[i] = (uint32_t)pl16[idx] | ((uint32_t)pl16[idx + 2u * kPD32] << 8) | ((uint32_t)pl16[idx + 4u * kPD32] << 16) | 0xff000000u;
@@ -902,11 +899,44 @@ __global__ void __launch_bounds__(1024) shrink16_kernel(const Fast32Args a)
 						o3[2] = (uint8_t)pl16[idx + 4u * kPD32];
 					}
 				}
+			} else if (one_pass) {
+				// 16 x n, n x 16 (round 4: here, not in the worklist kernel -- 0.9 % of the tiles cost it 36 us of a 0.41-ms step)
+				const uint32_t lx = m0 < (uint32_t)kMaxLevel ? m0 : (uint32_t)kMaxLevel - 1;
+				const uint32_t ly = m1 < (uint32_t)kMaxLevel ? m1 : (uint32_t)kMaxLevel - 1;
+				if (nw == 16u) fast32_v_only<16, C>(s_tab, a.tabs[ly], tile_pl, tid, nh, dst);
+				else fast32_h_only<16, C>(s_tab, a.tabs[lx], tile_pl, tid, nw, dst);
 			} else {
-				const uint32_t lx = m0[k] < (uint32_t)kMaxLevel ? m0[k] : (uint32_t)kMaxLevel - 1;
-				const uint32_t ly = m1[k] < (uint32_t)kMaxLevel ? m1[k] : (uint32_t)kMaxLevel - 1;
-				resample_fast16_hv<C>(s_tab, a.tabs[lx], a.tabs[ly], tile_pl, s_tmp, tid, nw[k], nh[k], dst);
+				const uint32_t lx = m0 < (uint32_t)kMaxLevel ? m0 : (uint32_t)kMaxLevel - 1;
+				const uint32_t ly = m1 < (uint32_t)kMaxLevel ? m1 : (uint32_t)kMaxLevel - 1;
+				const uint32_t txk = a.tabs[lx].mf_off, tyk = a.tabs[ly].mf_off;
+				if (group16 && txk != 0u && tyk != 0u) {
+					// tile k = (dx, dy) in this lane's three views
+					const bool dx = (k & 1u) != 0u, dy = (k >> 1) != 0u;
+					v_tx[k >> 1] = second == dx ? txk : v_tx[k >> 1];
+					v_ty[k & 1u] = second == dy ? tyk : v_ty[k & 1u];
+					if (second == dx && low == dy) {
+						v_tyo = tyk;
+						v_nw = nw;
+						v_nh = nh;
+						v_dst = reinterpret_cast<uint8_t *>(dst);
+						v_ok = true;
+					}
+					any_x = txk;
+					any_y = tyk;
+				} else {
+					resample_fast16_hv<C>(s_tab, a.tabs[lx], a.tabs[ly], tile_pl, s_tmp, tid, nw, nh, dst);
+				}
 			}
+		}
+		if (any_x != 0u) {
+			// (views without a two-pass tile ride along with any valid table: their columns and rows are not stored)
+#pragma unroll
+			for (int i = 0; i < 2; ++i) {
+				v_tx[i] = v_tx[i] != 0u ? v_tx[i] : any_x;
+				v_ty[i] = v_ty[i] != 0u ? v_ty[i] : any_y;
+			}
+			v_tyo = v_tyo != 0u ? v_tyo : any_y;
+			resample_group16_mfma<C>(s_tab, v_tx, v_ty, v_tyo, s_pl, tid, v_nw, v_nh, v_ok, v_dst);
 		}
 		tile_sync<1>();  // the next group reuses this wave's LDS image
 		grp = grp_next;
@@ -947,6 +977,7 @@ hipError_t launch_fast32_16(const ShrinkArgs &a, ShrinkArgs &ga, uint32_t channe
 	f.work_slot = a.work_slot;
 	f.finish_here = groups16 ? 0u : 1u;
 	f.narrow = knobs().no_narrow ? 0u : 1u;
+	f.group16 = knobs().no_group16 ? 0u : 1u;
 	f.factor = a.factor;
 	f.value = a.value;
 	f.lod0 = a.lod0;

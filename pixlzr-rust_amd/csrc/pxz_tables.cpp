@@ -207,6 +207,7 @@ const Knobs &knobs()
 		v.no_widen = on("PXZ_NO_WIDEN");
 		v.no_native_rgb = on("PXZ_NO_NATIVE_RGB");
 		v.no_narrow = on("PXZ_NO_NARROW");
+		v.no_group16 = on("PXZ_NO_GROUP16");
 		v.no_alpha_first = on("PXZ_NO_ALPHA_FIRST");
 		v.oklab_v1 = on("PXZ_OKLAB_V1");
 		v.tree_rects = on("PXZ_TREE_RECTS");

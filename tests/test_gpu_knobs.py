@@ -13,6 +13,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 KNOBS = [
     ("PXZ_NO_NARROW", "test_every_filter_on_opaque_fast_path or test_rgb_frames_on_the_square_fast_paths"),
+    # (the per-tile dot2 resamples of shrink16_kernel, which the block-diagonal matrix-core form of a whole group replaces by default)
+    ("PXZ_NO_GROUP16", "test_block16_group_kernel_every_class or test_rgb_frames_on_the_square_fast_paths"),
     ("PXZ_NO_NATIVE_RGB", "test_rgb_frames_on_the_square_fast_paths or test_strided_batches_on_the_fast_paths"),
     ("PXZ_NO_REPITCH", "test_pitch_and_unaligned_rows or test_strided_batches_on_the_fast_paths"),
     # (the generic kernel on RGB: without the widening, large RGB tiles in shrink_by do not fit LDS -- documented -- so only the
