@@ -178,6 +178,9 @@ struct Fast64Args {
 	uint32_t precision[kMaxLevel];
 	uint32_t breaks[kMaxLevel];
 	uint32_t breaks_asc;
+	uint32_t finish_here;    // every block finishes the tiles it completed (value / lod outputs) at its end, as shrink32_kernel does
+	float factor;
+	float *value, *lod0, *lod1;
 };
 
 // Diagnostic switches (PXZ_* environment variables), read ONCE per process -- never on the call path.  Every one of

@@ -942,6 +942,26 @@ __global__ void __launch_bounds__(1024) shrink16_kernel(const Fast32Args a)
 		grp = grp_next;
 	}
 	list_flush(s_batch, n_listb, a.work + kWorkList, a.work + a.work_slot, tid);
+	if (a.finish_here) {
+		// as shrink32_kernel: detector sums -> stored value for the tiles of the groups this block dealt to its waves, one tile per
+		// thread (round 4; the worklist kernel scanned all 1 036 800 tiles of 8 x 8K frames for it)
+		__threadfence_block();  // the sums were written by other waves of this block
+		__syncthreads();
+		for (uint32_t i = threadIdx.x;; i += blockDim.x) {
+			const uint32_t gi = i >> 2, k = i & 3u;
+			const unsigned long long run = (unsigned long long)(gi >> a.chunk_lg) * gridDim.x + blockIdx.x;
+			const unsigned long long g = (run << a.chunk_lg) + (gi & ((1u << a.chunk_lg) - 1u));
+			if (g >= (unsigned long long)a.n_groups) break;  // (g grows with i)
+			const uint32_t frame = fastdiv((uint32_t)g, a.div_gpf), r = (uint32_t)g - frame * gpf;
+			const uint32_t gy = fastdiv(r, a.div_gcols), gx = r - gy * gcols;
+			const uint32_t tx = 2u * gx + (k & 1u), ty = 2u * gy + (k >> 1);
+			if (tx >= a.cols || ty >= a.rows) continue;
+			const uint32_t t = frame * a.tiles_per_frame + ty * a.cols + tx;
+			const uint2 key = reinterpret_cast<const uint2 *>(a.sums)[t];
+			if (key.x == kDeferredKey && key.y == kDeferredKey) continue;
+			finish_tile(key, 16u, 16u, (uint32_t)MODE, a.factor, a.value, a.lod0, a.lod1, t);
+		}
+	}
 }
 
 // 32x32 / 16x16 flow, first part: shrink32_kernel (+ shrink32a_kernel) or shrink16_kernel; ga = the arguments of
@@ -975,14 +995,14 @@ hipError_t launch_fast32_16(const ShrinkArgs &a, ShrinkArgs &ga, uint32_t channe
 	f.out_px = a.out_px;
 	f.work = a.work;
 	f.work_slot = a.work_slot;
-	f.finish_here = groups16 ? 0u : 1u;
+	f.finish_here = 1u;
 	f.narrow = knobs().no_narrow ? 0u : 1u;
 	f.group16 = knobs().no_group16 ? 0u : 1u;
 	f.factor = a.factor;
 	f.value = a.value;
 	f.lod0 = a.lod0;
 	f.lod1 = a.lod1;
-	ga.finish_scan = groups16 ? 1u : 0u;
+	ga.finish_scan = 0u;
 	// full tiles with transparency always go to list A; shrink32a_kernel takes it when transparency was announced
 	// or seen before, else the worklist kernel walks it after list B
 	f.alpha_list = (!groups16 && channels == 4 && a.out_px != nullptr && (a.filter == 0 || a.tab_dw != 0)) ? 1u : 0u;

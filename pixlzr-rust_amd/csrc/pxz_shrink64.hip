@@ -24,8 +24,9 @@ namespace pxz {
 constexpr uint32_t kRS64 = 36, kPD64 = 36 * 64;  // plane row stride (32 + 4 dwords: bank skew, rows stay 16-byte aligned), plane size
 constexpr uint32_t kTS64 = 20;                   // dwords per column of the horizontal pass: 16 (64 bytes of y) + 4 of bank skew
 constexpr uint32_t kRed64 = 48;                  // partial sums, flags, ticket, two worklist batches
+constexpr uint32_t kFin64 = 256;                 // tiles a block completed, for their finish at its end (a block takes ~64 of 8 x 8K frames)
 constexpr uint32_t kTail64 = 72, kTailLevels = 8;  // per level: bias[32], weight sums[32], "opaque stays opaque" + pad; levels 0..7 (7 = every level whose output is 1 px)
-constexpr uint32_t lds64_dwords(uint32_t nch) { return nch * kPD64 + nch * 32u * kTS64 + kRed64 + kTailLevels * kTail64; }  // planes + [channel][ox < 32][kTS64] + s_red + tails
+constexpr uint32_t lds64_dwords(uint32_t nch) { return nch * kPD64 + nch * 32u * kTS64 + kRed64 + kTailLevels * kTail64 + kFin64; }  // planes + [channel][ox < 32][kTS64] + s_red + tails + finish list
 
 template <int C = 4, class Args>
 __device__ __forceinline__ bool fast64_tile_src(const Args &a, uint32_t tile_g, const uint8_t *&src)
@@ -67,6 +68,8 @@ __global__ void __launch_bounds__(256) shrink64_kernel(const Fast64Args a)
 	// where they are used, each was a dependent L2 round trip between a tile's level decision and its last store -- with one
 	// tile per block in flight.  (The whole tables in LDS, 16 KB, cost a block per CU and bought nothing.)
 	uint32_t *s_tail = s_red + kRed64;
+	uint32_t *s_fin = s_tail + kTailLevels * kTail64;  // tiles this block completed (thread 0 appends), finished at the block's end
+	uint32_t n_fin = 0;                                  // (thread 0's count)
 	for (uint32_t i = threadIdx.x; i < kTailLevels * kTail64; i += blockDim.x) {
 		const uint32_t lv = i / kTail64, k = i - lv * kTail64;
 		const uint32_t out = (64u >> lv) ? (64u >> lv) : 1u, nblk = out > 16u ? 2u : 1u;
@@ -82,11 +85,13 @@ __global__ void __launch_bounds__(256) shrink64_kernel(const Fast64Args a)
 	// this lane's share of a tile: rows 16w + (lane >> 4) + 4k, 16 bytes at column quad lane & 15
 	uint4 pre[4];
 	bool pre_valid = false;
+	const uint8_t *pre_p = nullptr, *cur_p = nullptr;  // this lane's first piece of the tile being prefetched / being processed
 	auto prefetch = [&](uint32_t tile_g) {
 		const uint8_t *src;
 		pre_valid = fast64_tile_src<C>(a, tile_g, src);
 		if (pre_valid) {
 			const uint8_t *p = src + (size_t)(16u * wave + (lane >> 4)) * a.pitch + (lane & 15u) * (4u * (uint32_t)C);
+			pre_p = p;
 #pragma unroll
 			for (int k = 0; k < 4; ++k) {
 				if constexpr (C == 4) {
@@ -160,6 +165,7 @@ __global__ void __launch_bounds__(256) shrink64_kernel(const Fast64Args a)
 			advance();
 			continue;
 		}
+		cur_p = pre_p;
 		// ---- stage: registers -> planar u16 pairs
 		// (every alpha byte is 255 iff the smallest of the 16 pixel dwords is >= 0xff000000: three-way minima)
 		uint32_t least = 0xffffffffu;
@@ -283,6 +289,10 @@ __global__ void __launch_bounds__(256) shrink64_kernel(const Fast64Args a)
 			reinterpret_cast<uint2 *>(a.sums)[this_tile] = make_uint2(sum_hz, sum_vr);
 			if (FULL || a.out_w) a.out_w[this_tile] = nw;
 			if (FULL || a.out_h) a.out_h[this_tile] = nh;
+			if (a.finish_here) {
+				if (n_fin < kFin64) s_fin[n_fin++] = this_tile;
+				else finish_tile(make_uint2(sum_hz, sum_vr), 64u, 64u, (uint32_t)MODE, a.factor, a.value, a.lod0, a.lod1, this_tile);  // (list full: on the spot)
+			}
 		}
 		if (!FULL && a.out_px == nullptr) {
 			__syncthreads();  // s_red is rewritten by the next tile
@@ -290,32 +300,16 @@ __global__ void __launch_bounds__(256) shrink64_kernel(const Fast64Args a)
 		}
 		uint8_t *dst = a.out_px + (size_t)this_tile * (64u * 64u * (uint32_t)C);
 		if (nw == 64u && nh == 64u) {
-			// clone (block.rs:279-281): re-interleave this wave's 16 rows, 16 bytes per lane and step
+			// clone (block.rs:279-281): the tile's own bytes, 16 (RGB: 12) per lane and step, straight from the frame to the slot
+			// (round 4: the rows are in L2 -- this block fetched them a few microseconds ago -- and a copy is 8 memory instructions
+			// where re-interleaving the LDS planes took 12 LDS reads and 32 byte permutes per lane)
 #pragma unroll
 			for (int k = 0; k < 4; ++k) {
-				const uint32_t i = lane + 64u * (uint32_t)k;  // 256 groups of 4 pixels
-				const uint32_t row = 16u * wave + (i >> 4), c4 = i & 15u;
-				const uint32_t *p = s_pl + row * kRS64 + c4 * 2u;
-				const uint2 r = *reinterpret_cast<const uint2 *>(p), g = *reinterpret_cast<const uint2 *>(p + kPD64);
-				const uint2 b = *reinterpret_cast<const uint2 *>(p + 2 * kPD64);
-				uint2 al = make_uint2(0x00ff00ffu, 0x00ff00ffu);
-				if constexpr (ALPHA) al = *reinterpret_cast<const uint2 *>(p + 3 * kPD64);
-				const uint32_t rg01 = __builtin_amdgcn_perm(g.x, r.x, 0x06020400u), rg23 = __builtin_amdgcn_perm(g.y, r.y, 0x06020400u);
+				const uint32_t row = 16u * wave + (lane >> 4) + 4u * (uint32_t)k, c4 = lane & 15u;
 				if constexpr (C == 4) {
-					const uint32_t ba01 = __builtin_amdgcn_perm(al.x, b.x, 0x06020400u), ba23 = __builtin_amdgcn_perm(al.y, b.y, 0x06020400u);
-					uint4 o;
-					o.x = __builtin_amdgcn_perm(ba01, rg01, 0x05040100u);
-					o.y = __builtin_amdgcn_perm(ba01, rg01, 0x07060302u);
-					o.z = __builtin_amdgcn_perm(ba23, rg23, 0x05040100u);
-					o.w = __builtin_amdgcn_perm(ba23, rg23, 0x07060302u);
-					reinterpret_cast<uint4 *>(dst)[row * 16u + c4] = o;
+					reinterpret_cast<uint4 *>(dst)[row * 16u + c4] = *reinterpret_cast<const uint4 *>(cur_p + (size_t)(4 * k) * a.pitch);
 				} else {
-					uint3 o;
-					o.x = __builtin_amdgcn_perm(b.x, rg01, 0x02040100u);                  // R0 G0 B0 R1
-					const uint32_t gb1 = __builtin_amdgcn_perm(b.x, rg01, 0x0c0c0603u);   // G1 B1 . .
-					o.y = __builtin_amdgcn_perm(rg23, gb1, 0x05040100u);                  // G1 B1 R2 G2
-					o.z = __builtin_amdgcn_perm(b.y, rg23, 0x06030204u);                  // B2 R3 G3 B3
-					reinterpret_cast<uint3 *>(dst)[row * 16u + c4] = o;
+					reinterpret_cast<uint3 *>(dst)[row * 16u + c4] = *reinterpret_cast<const uint3 *>(cur_p + (size_t)(4 * k) * a.pitch);
 				}
 			}
 			__syncthreads();
@@ -353,7 +347,7 @@ __global__ void __launch_bounds__(256) shrink64_kernel(const Fast64Args a)
 		const uint32_t o = lane & 15u, g = lane >> 4;
 		const v4i32 zero = {0, 0, 0, 0};
 		// horizontal pass of this wave's 16 rows into s_t[c][ox][y]; A = pixels of row 16w + o, columns 16g .. 16g+15
-		auto hpass = [&]() {
+		auto hpass = [&](const bool signed_t) {
 			v4i32 wlo[2], whi[2];
 			int32_t bx[2];
 #pragma unroll
@@ -385,8 +379,9 @@ __global__ void __launch_bounds__(256) shrink64_kernel(const Fast64Args a)
 						put_byte_shr<1>(packed, clamp_fixed(hi[1], lo[1], top_x), px_);
 						put_byte_shr<2>(packed, clamp_fixed(hi[2], lo[2], top_x), px_);
 						put_byte_shr<3>(packed, clamp_fixed(hi[3], lo[3], top_x), px_);
-						// rows 16w + 4g .. +3 of column ox = 16nb + o
-						s_t[(c * 32u + 16u * nb + o) * kTS64 + 4u * wave + g] = packed;
+						// rows 16w + 4g .. +3 of column ox = 16nb + o; kept as p - 128 (the vertical product's operand form) when a
+						// vertical pass follows: one xor here instead of four per channel on the one or two waves that run that pass
+						s_t[(c * 32u + 16u * nb + o) * kTS64 + 4u * wave + g] = signed_t ? packed ^ 0x80808080u : packed;
 					}
 				}
 			}
@@ -405,10 +400,10 @@ __global__ void __launch_bounds__(256) shrink64_kernel(const Fast64Args a)
 				for (uint32_t c = 0; c < NCH; ++c) {
 					const uint4 tv = *reinterpret_cast<const uint4 *>(s_t + (c * 32u + 16u * nb + o) * kTS64 + 4u * g);
 					v4i32 bv;
-					bv[0] = (int)(tv.x ^ 0x80808080u);
-					bv[1] = (int)(tv.y ^ 0x80808080u);
-					bv[2] = (int)(tv.z ^ 0x80808080u);
-					bv[3] = (int)(tv.w ^ 0x80808080u);
+					bv[0] = (int)tv.x;  // (bytes are p - 128 already: hpass(true) / the width-kept staging below)
+					bv[1] = (int)tv.y;
+					bv[2] = (int)tv.z;
+					bv[3] = (int)tv.w;
 					const v4i32 lo = __builtin_amdgcn_mfma_i32_16x16x64_i8(klo, bv, cy, 0, 0, 0);
 					const v4i32 hi = __builtin_amdgcn_mfma_i32_16x16x64_i8(khi, bv, zero, 0, 0, 0);
 #pragma unroll
@@ -444,7 +439,7 @@ __global__ void __launch_bounds__(256) shrink64_kernel(const Fast64Args a)
 			}
 		};
 		if (need_h && need_v) {
-			hpass();
+			hpass(true);
 			__syncthreads();  // B3: all 64 rows of the horizontal pass are in LDS
 			vpass(0u, nw, nbx, true);
 			// no barrier here: the next tile's B1/B2 separate this vertical pass from the next horizontal one
@@ -460,7 +455,7 @@ __global__ void __launch_bounds__(256) shrink64_kernel(const Fast64Args a)
 						const uint32_t j = jj + 2u * it, y0 = 16u * wave + 4u * j;
 						const uint32_t b0 = p16[(y0 + 0u) * (2u * kRS64)], b1 = p16[(y0 + 1u) * (2u * kRS64)];
 						const uint32_t b2 = p16[(y0 + 2u) * (2u * kRS64)], b3 = p16[(y0 + 3u) * (2u * kRS64)];
-						s_t[(c * 32u + xl) * kTS64 + 4u * wave + j] = b0 | (b1 << 8) | (b2 << 16) | (b3 << 24);
+						s_t[(c * 32u + xl) * kTS64 + 4u * wave + j] = (b0 | (b1 << 8) | (b2 << 16) | (b3 << 24)) ^ 0x80808080u;
 					}
 				}
 				__syncthreads();
@@ -469,7 +464,7 @@ __global__ void __launch_bounds__(256) shrink64_kernel(const Fast64Args a)
 			}
 		} else {
 			// height kept: the horizontal pass is the result; gather [c][ox][y] bytes into pixels
-			hpass();
+			hpass(false);
 			__syncthreads();
 			const bool opaque_stays = (mx_tail[64] & 1u) != 0u;
 			for (uint32_t i = threadIdx.x; i < nw * 16u; i += 256u) {
@@ -491,6 +486,20 @@ __global__ void __launch_bounds__(256) shrink64_kernel(const Fast64Args a)
 	}
 	list_flush(s_red + 16, n_listb, a.work + kWorkList, a.work + a.work_slot, threadIdx.x);
 	list_flush(s_red + 32, n_lista, a.work + kWorkList + a.n_tiles, a.work + kWorkA + a.work_slot, threadIdx.x);
+	if (a.finish_here) {
+		// Detector sums -> stored value (f64 normalisation, hypot: finish_tile), one tile per thread, for the tiles this block
+		// completed -- instead of a scan over every tile of the batch in the worklist kernel (round 4: that kernel then only walks
+		// its lists, with a grid sized for them).  Tiles handed to a list carry the marker and are finished by whoever completes them.
+		if (threadIdx.x == 0) s_red[14] = n_fin;
+		__syncthreads();  // (s_fin / s_red were written by thread 0; the sums it wrote to memory are re-read by other threads: same CU, L2-coherent stores)
+		const uint32_t n = s_red[14];
+		for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+			const uint32_t t = s_fin[i];
+			const unsigned long long k2 = __builtin_nontemporal_load(reinterpret_cast<const unsigned long long *>(a.sums) + t);  // (past L1)
+			const uint2 key = make_uint2((uint32_t)k2, (uint32_t)(k2 >> 32));
+			finish_tile(key, 64u, 64u, (uint32_t)MODE, a.factor, a.value, a.lod0, a.lod1, t);
+		}
+	}
 	if constexpr (ALPHA) {
 		if (a.all_tiles && threadIdx.x == 0 && n_transparent != 0u) atomicAdd(a.work + kWorkA + a.work_slot, n_transparent);
 	}
@@ -529,6 +538,10 @@ hipError_t launch_fast64(const ShrinkArgs &a, ShrinkArgs &ga, uint32_t channels,
 		f.breaks[j] = a.breaks[0][j];
 	}
 	f.breaks_asc = a.breaks_asc[0];
+	f.factor = a.factor;
+	f.value = a.value;
+	f.lod0 = a.lod0;
+	f.lod1 = a.lod1;
 	const uint32_t lds_bytes = lds64_dwords(3) * 4u;
 	constexpr uint32_t kLds = 160u * 1024u;
 	const uint32_t per_cu = kLds / lds_bytes;
@@ -540,6 +553,10 @@ hipError_t launch_fast64(const ShrinkArgs &a, ShrinkArgs &ga, uint32_t channels,
 	// transparency the four-plane instance takes EVERY tile and the opaque instance is not launched.
 	const bool run_alpha = channels == 4 && a.out_px != nullptr && a.out_w != nullptr && a.out_h != nullptr && a.alpha_kernel != 0;
 	const bool alpha_first = run_alpha && a.alpha_first != 0;
+	// the opaque instance finishes the tiles it completes itself; the worklist kernel then finishes only what the lists hold (and
+	// the tiles the four-plane instance completed).  With the four-plane instance first nobody finishes in passing: that kernel scans.
+	f.finish_here = alpha_first ? 0u : 1u;
+	ga.finish_scan = alpha_first ? 1u : 0u;
 	if (!alpha_first) {
 		const bool full = a.out_px != nullptr && a.out_w != nullptr && a.out_h != nullptr;
 		void (*k)(const Fast64Args) = a.mode == 1 ? (full ? shrink64_kernel<1, false, true> : shrink64_kernel<1, false, false>)
@@ -556,6 +573,7 @@ hipError_t launch_fast64(const ShrinkArgs &a, ShrinkArgs &ga, uint32_t channels,
 	ga.list_a_too = channels == 4 && a.out_px != nullptr && !run_alpha ? 1u : 0u;
 	if (run_alpha) {
 		f.all_tiles = alpha_first ? 1u : 0u;
+		f.finish_here = 0u;  // (its tiles are finished by the worklist kernel: list A, or the scan)
 		const uint32_t lds_a = lds64_dwords(4) * 4u;
 		const uint32_t blocks_a = n_cus * (kLds / lds_a);
 		if (a.mode == 1) {

@@ -580,14 +580,24 @@ __global__ void __launch_bounds__(NW == 1 ? 768 : 64 * NW) shrink_kernel(const S
 			__syncthreads();
 		}
 		if (a.work) {
-			// as in the single-wave form: finish the tiles the fast kernel completed, zero the next launch's counter
-			for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < a.n_tiles; t += gridDim.x * blockDim.x) {
-				const uint2 key = reinterpret_cast<const uint2 *>(a.sums)[t];
-				if (key.x == kDeferredKey && key.y == kDeferredKey) continue;
-				const uint32_t tf = t % a.tiles_per_frame;
-				const uint32_t ty = tf / a.cols, tx = tf - ty * a.cols;
-				finish_tile(key, (tx == a.cols - 1) ? a.edge_w : a.bw, (ty == a.rows - 1) ? a.edge_h : a.bh, (uint32_t)MODE, a.factor,
-				            a.value, a.lod0, a.lod1, t);
+			// as in the single-wave form: finish the tiles the fast kernel completed (a scan, or -- when that kernel finished its
+			// own -- only the full tiles its four-plane instance took from list A), zero the next launch's counter
+			if (a.finish_scan) {
+				for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < a.n_tiles; t += gridDim.x * blockDim.x) {
+					const uint2 key = reinterpret_cast<const uint2 *>(a.sums)[t];
+					if (key.x == kDeferredKey && key.y == kDeferredKey) continue;
+					const uint32_t tf = t % a.tiles_per_frame;
+					const uint32_t ty = tf / a.cols, tx = tf - ty * a.cols;
+					finish_tile(key, (tx == a.cols - 1) ? a.edge_w : a.bw, (ty == a.rows - 1) ? a.edge_h : a.bh, (uint32_t)MODE, a.factor,
+					            a.value, a.lod0, a.lod1, t);
+				}
+			} else if (!a.list_a_too) {
+				for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count_a; i += gridDim.x * blockDim.x) {
+					const uint32_t t = a.work[kWorkList + a.n_tiles + i];
+					const uint2 key = reinterpret_cast<const uint2 *>(a.sums)[t];
+					if (key.x == kDeferredKey && key.y == kDeferredKey) continue;  // (went on to list B: finished above)
+					finish_tile(key, a.bw, a.bh, (uint32_t)MODE, a.factor, a.value, a.lod0, a.lod1, t);
+				}
 			}
 			if (blockIdx.x == 0) {  // the other set of counters is the next launch's
 				if (threadIdx.x == 0) {
@@ -687,6 +697,12 @@ LaunchGeom plan_launch(const ShrinkArgs &a, uint32_t channels, uint32_t n_cus)
 		const uint32_t per_cu = kLds / g.lds_bytes > 0 ? kLds / g.lds_bytes : 1u;
 		const uint32_t resident = n_cus * per_cu * 2u;
 		g.blocks = a.n_tiles < resident ? a.n_tiles : resident;
+		// (behind a fast kernel that finished its own tiles: a block per listed tile of the last finished launch, twice that and 8 more)
+		if (a.work && !a.finish_scan && a.expect_listed != 0xffffffffu) {
+			const uint32_t expect = a.expect_listed < a.n_tiles ? a.expect_listed : a.n_tiles;
+			const uint32_t few = 2u * expect + 8u;
+			if (few < g.blocks) g.blocks = few;
+		}
 	}
 	return g;
 }
