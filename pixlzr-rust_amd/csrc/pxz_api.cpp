@@ -69,6 +69,7 @@ struct ExpandTables {
 	int16_t *d_coeffs = nullptr;
 	uint32_t dir_stride = 0;
 	uint32_t *d_xmf = nullptr;  // 32x32 tiles, convolutions: matrix-core operand tables (pxz_internal.h: kXmfDw)
+	uint32_t *d_xmf16 = nullptr;  // 16x16 tiles, convolutions: the same for expand16_kernel (kXmf16Dw)
 };
 
 struct DeviceBuffer {
@@ -99,7 +100,7 @@ struct pxz_handle {
 	// level breakpoints per (mode, factor bits, bw, bh, edge_w, edge_h)
 	struct Breaks { uint32_t b[4][pxz::kMaxLevel]; uint32_t asc[4]; };
 	std::map<std::tuple<uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t>, Breaks> breaks;
-	DeviceBuffer in, val, ow, oh, out, sums, chunks, work, qscratch, qmeta, status, dmeta, okscratch, rgba, slots4, pk, pkoff, tree;
+	DeviceBuffer in, val, ow, oh, out, sums, chunks, work, qscratch, qmeta, status, dmeta, okscratch, rgba, slots4, pk, pkoff, tree, xlist;
 	uint64_t packed_len = 0;   // bytes of the stream pxz_shrink_image_packed left in `pk` (0: none)
 	static constexpr int kRing = 3;  // buffer sets of the pipelined host boundary (pxz_shrink_images*)
 	DeviceBuffer ring_in[kRing], ring_val[kRing], ring_ow[kRing], ring_oh[kRing], ring_out[kRing], ring_pk[kRing], ring_pkoff[kRing];
@@ -477,6 +478,40 @@ int get_expand_tables(pxz_handle *h, uint32_t bw, uint32_t bh, uint32_t edge_w, 
 		if (fits) {
 			PXZ_HIP(h, hipMalloc((void **)&et.d_xmf, xmf.size() * sizeof(uint32_t)));
 			PXZ_HIP(h, hipMemcpy(et.d_xmf, xmf.data(), xmf.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+		}
+	}
+	// 16x16 tiles: the up-scales 1, 2, 4, 8 -> 16 as matrix-core operands of expand16_kernel (layout: pxz_internal.h)
+	if (bw == 16 && bh == 16 && filter != 0) {
+		std::vector<uint32_t> xmf((size_t)pxz::kXmf16Levels * pxz::kXmf16Dw, 0u);
+		bool fits = true;
+		for (uint32_t li = 0; li < pxz::kXmf16Levels; ++li) {
+			const uint32_t in = 1u << li;
+			pxz::AxisWindows win;
+			if (!pxz::build_axis(in, 16, filter, &win, true)) return fail(h, PXZ_ERR_INVALID_ARG, "unknown filter %u", filter);
+			uint32_t *mf = xmf.data() + (size_t)li * pxz::kXmf16Dw;
+			const int32_t half = 1 << (win.precision - 1);
+			for (uint32_t o = 0; o < 16; ++o) {
+				int32_t k[8] = {0};
+				int32_t total = 0;
+				for (uint32_t i = 0; i < (uint32_t)win.sizes[o]; ++i) {
+					k[(uint32_t)win.starts[o] + i] = win.coeffs[(size_t)o * win.window + i];
+					total += k[(uint32_t)win.starts[o] + i];
+				}
+				for (uint32_t i = 0; i < 8; ++i) {
+					const int32_t lo = ((k[i] + 128) & 255) - 128, hi = (k[i] - lo) / 256;
+					if (hi < -128 || hi > 127) fits = false;
+					mf[o * 2 + i / 4] |= (uint32_t)(uint8_t)lo << (8 * (i & 3));
+					mf[32 + o * 2 + i / 4] |= (uint32_t)(uint8_t)hi << (8 * (i & 3));
+				}
+				mf[64 + o] = (uint32_t)(128 * total + half);
+			}
+			for (uint32_t g = 0; g < 2; ++g)
+				for (uint32_t r = 0; r < 8; ++r) mf[80 + 8 * g + r] = mf[64 + (r & 3) + 8 * (r >> 2) + 4 * g];
+			mf[96] = (uint32_t)win.precision;
+		}
+		if (fits) {
+			PXZ_HIP(h, hipMalloc((void **)&et.d_xmf16, xmf.size() * sizeof(uint32_t)));
+			PXZ_HIP(h, hipMemcpy(et.d_xmf16, xmf.data(), xmf.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
 		}
 	}
 	PXZ_HIP(h, hipMalloc((void **)&et.d_dir, dir.size() * sizeof(pxz::ExpandTab)));
@@ -940,9 +975,10 @@ void pxz_destroy(pxz_handle *h)
 		(void)hipFree(kv.second.d_sizes);
 		(void)hipFree(kv.second.d_coeffs);
 		(void)hipFree(kv.second.d_xmf);
+		(void)hipFree(kv.second.d_xmf16);
 	}
 	drop_tree_tables(h);
-	for (DeviceBuffer *b : {&h->in, &h->val, &h->ow, &h->oh, &h->out, &h->sums, &h->chunks, &h->work, &h->qscratch, &h->qmeta, &h->status, &h->dmeta, &h->okscratch, &h->rgba, &h->slots4, &h->pk, &h->pkoff, &h->tree, &h->tree_rects[0], &h->tree_rects[1], &h->tree_count})
+	for (DeviceBuffer *b : {&h->in, &h->val, &h->ow, &h->oh, &h->out, &h->sums, &h->chunks, &h->work, &h->qscratch, &h->qmeta, &h->status, &h->dmeta, &h->okscratch, &h->rgba, &h->slots4, &h->pk, &h->pkoff, &h->tree, &h->xlist, &h->tree_rects[0], &h->tree_rects[1], &h->tree_count})
 		if (b->ptr) (void)hipFree(b->ptr);
 	for (int i = 0; i < pxz_handle::kRing; ++i)
 		for (DeviceBuffer *b : {&h->ring_in[i], &h->ring_val[i], &h->ring_ow[i], &h->ring_oh[i], &h->ring_out[i], &h->ring_pk[i], &h->ring_pkoff[i]})
@@ -971,7 +1007,7 @@ int pxz_trim(pxz_handle *h)
 		b.ptr = nullptr;
 		b.cap = 0;
 	};
-	for (DeviceBuffer *b : {&h->in, &h->val, &h->ow, &h->oh, &h->out, &h->sums, &h->chunks, &h->work, &h->qscratch, &h->qmeta, &h->status, &h->dmeta, &h->okscratch, &h->rgba, &h->slots4, &h->pk, &h->pkoff, &h->tree, &h->tree_rects[0], &h->tree_rects[1], &h->tree_count})
+	for (DeviceBuffer *b : {&h->in, &h->val, &h->ow, &h->oh, &h->out, &h->sums, &h->chunks, &h->work, &h->qscratch, &h->qmeta, &h->status, &h->dmeta, &h->okscratch, &h->rgba, &h->slots4, &h->pk, &h->pkoff, &h->tree, &h->xlist, &h->tree_rects[0], &h->tree_rects[1], &h->tree_count})
 		drop(*b);
 	for (int i = 0; i < pxz_handle::kRing; ++i)
 		for (DeviceBuffer *b : {&h->ring_in[i], &h->ring_val[i], &h->ring_ow[i], &h->ring_oh[i], &h->ring_out[i], &h->ring_pk[i], &h->ring_pkoff[i]})
@@ -1198,14 +1234,25 @@ static int expand_launch(pxz_handle *h, const pxz_frames *frames, uint32_t slot_
 	a.fast32 = pxz::knobs().no_expand_fast32 ? 0u : 1u;
 	a.xmf = a.fast32 ? et->d_xmf : nullptr;
 	a.tile_dw = (2u * bw * bh + 5u * (bw + bh) + 3u) & ~3u;
+	// 16x16 RGBA tiles in RGBA frames: expand16_kernel takes the 2x2 groups of full tiles (clones, powers of two), the rest -- and
+	// what it leaves -- goes to expand_kernel through a list (status[1] counts it)
+	const bool groups16 = a.fast32 && bw == 16 && bh == 16 && slot_channels == 4 && frames->channels == 4 && cols >= 2 && rows >= 2 &&
+	                      (p.filter == 0 || et->d_xmf16 != nullptr);
+	if (groups16) {
+		if ((rc = ensure(h, h->xlist, (size_t)a.n_tiles * 4u)) != PXZ_OK) return rc;
+		a.list = (uint32_t *)h->xlist.ptr;
+		a.xmf16 = et->d_xmf16;
+		a.div_gpf = make_fastdiv(((cols + 1u) / 2u) * ((rows + 1u) / 2u));
+		a.div_gcols = make_fastdiv((cols + 1u) / 2u);
+	}
 #ifdef PXZ_STAMPS
 	if ((rc = ensure(h, h->status, 256)) != PXZ_OK) return rc;  // (stamps behind the flag: pxz_debug_read_status)
 	a.status = (uint32_t *)h->status.ptr;
-	PXZ_HIP(h, hipMemsetAsync(a.status, 0, 4, h->stream));
+	PXZ_HIP(h, hipMemsetAsync(a.status, 0, 8, h->stream));
 #else
-	if ((rc = ensure(h, h->status, 4)) != PXZ_OK) return rc;
+	if ((rc = ensure(h, h->status, 8)) != PXZ_OK) return rc;
 	a.status = (uint32_t *)h->status.ptr;
-	PXZ_HIP(h, hipMemsetAsync(a.status, 0, 4, h->stream));
+	PXZ_HIP(h, hipMemsetAsync(a.status, 0, 8, h->stream));
 #endif
 	PXZ_HIP(h, pxz::launch_expand(a, h->n_cus, h->stream));
 	return PXZ_OK;

@@ -187,6 +187,292 @@ __device__ __forceinline__ void expand_tile_clone32(const ExpandArgs &a, uint32_
 }
 
 // ---------------------------------------------------------------------------
+// expand16_kernel (round 4): Pixlzr::expand + to_image for 16x16 RGBA tiles, FOUR at a time -- a 2x2 group of full tiles is one
+// 32x32 region of the frame, written with the store pattern of the 32x32 instance (16 dwords per lane, half-waves covering 128-byte
+// row segments).  One wave per group, persistent, groups dealt by an LDS ticket counter; sizes and the first 64 pixels of each of
+// the four slots are requested one group ahead.  Per tile of the group:
+//   stored 16x16 (block.rs:279-281, clone)           its 1 KB slot straight into the frame, one 16-byte move per lane
+//   stored tw x th, both in {1, 2, 4, 8}, Nearest    source index o >> (4 - log2 size), from the staged pixels
+//   the same, a convolution                          ALL such tiles of the group in one set of matrix-core products (below)
+//   anything else (16 x n, n x 16, sizes a foreign file may hold, empty, tiles of partial groups)  appended to a list that
+//                                                    expand_kernel takes in a second launch (status[1] counts it)
+// The convolutions (same integers as expand_kernel's vector form, block.rs:273-334): the four stored tiles are ONE virtual 16x16
+// source -- tile (dx, dy) at columns 8 dx .., rows 8 dy .. of premultiplied byte planes [c][16][16] -- and the weight operands are
+// block-diagonal, as in resample_group16_mfma on the encode side: a k slot (kg, j) of v_mfma_i32_32x32x16_i8 stands for sample
+// 4 kg + j of the FIRST tile (j < 4) or of the SECOND (j >= 4).
+//   horizontal, tile row dy: rows (c, y < 8) of that row's planes times B[k][n] = Kx of tile (n >> 4, dy) for output column n & 15 in
+//               the slots of its own tile: a lane reads its own tile's table, bias and precision.  The accumulator of lane (n, g)
+//               holds, per channel, rows y = 4 g + j of that tile row as four bytes -- for both tile rows together exactly a B
+//               operand of the vertical product (first tile = top, second = bottom): T never leaves the registers;
+//   vertical, per channel: A[m][k] = Ky of the tile in row m >> 4 for output row m & 15.  Left and right tiles have their own
+//               stored heights, so two products into one accumulator: the left tiles' weights times T with columns 16..31 zeroed,
+//               plus the right tiles' times T with columns 0..15 zeroed (a zero byte is p - 128 = 0: it adds nothing).
+// 20 MFMAs per group.  Tiles outside the mask ride along with any valid table; their part of the region is not stored.
+// ---------------------------------------------------------------------------
+constexpr uint32_t kX16Wave = 256;  // dwords of LDS per wave: the byte planes [c][16][16] / the staged pixels [tile][64] of Nearest
+
+__global__ void __launch_bounds__(1024) expand16_kernel(const ExpandArgs a)
+{
+	extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+	const uint32_t wpb = blockDim.x / 64u, sub = threadIdx.x / 64u, lane = threadIdx.x % 64u;
+	const uint32_t xmf_dw = a.xmf16 ? kXmf16Levels * kXmf16Dw : 0u;
+	for (uint32_t i = threadIdx.x; i < xmf_dw / 4u; i += blockDim.x)
+		reinterpret_cast<uint4 *>(lds)[i] = reinterpret_cast<const uint4 *>(a.xmf16)[i];
+	const uint32_t *s_xmf = lds;
+	uint32_t *s_ticket = lds + xmf_dw + wpb * kX16Wave;
+	if (threadIdx.x == 0) *s_ticket = wpb;
+	__syncthreads();
+	uint32_t *s_wave = lds + xmf_dw + sub * kX16Wave;
+	const uint32_t gcols = (a.cols + 1u) >> 1, grows = (a.rows + 1u) >> 1, gpf = gcols * grows;
+	const uint32_t n_frames = a.n_tiles / a.tiles_per_frame, n_groups = n_frames * gpf;
+	const uint32_t full_cols = a.edge_w == 16u ? a.cols : a.cols - 1u, full_rows = a.edge_h == 16u ? a.rows : a.rows - 1u;
+	struct Place {
+		uint32_t t00;  // tile (0, 0) of the group
+		uint32_t gx, gy, frame;
+		bool full;     // all four tiles exist and are 16x16
+	};
+	auto place_of = [&](uint32_t grp) -> Place {
+		Place p{0, 0, 0, 0, false};
+		if (grp >= n_groups) return p;
+		p.frame = fastdiv(grp, a.div_gpf);
+		const uint32_t r = grp - p.frame * gpf;
+		p.gy = fastdiv(r, a.div_gcols);
+		p.gx = r - p.gy * gcols;
+		p.t00 = p.frame * a.tiles_per_frame + (2u * p.gy) * a.cols + 2u * p.gx;
+		p.full = 2u * p.gx + 1u < full_cols && 2u * p.gy + 1u < full_rows;
+		return p;
+	};
+	auto group_of = [&](uint32_t tk) -> uint32_t {
+		const unsigned long long g = (unsigned long long)blockIdx.x + (unsigned long long)tk * gridDim.x;
+		return g < (unsigned long long)n_groups ? (uint32_t)g : 0xffffffffu;
+	};
+	auto list_tile = [&](uint32_t t) {  // (wave-uniform; rare: one atomic per tile)
+		if (lane == 0) a.list[atomicAdd(a.status + 1, 1u)] = t;
+	};
+	// requested one group ahead: lane k < 4 the stored size of tile k, every lane dword `lane` of each of the four slots
+	uint32_t p_tw = 0, p_th = 0, p_px[4] = {0, 0, 0, 0};
+	auto prefetch = [&](uint32_t grp) {
+		if (grp == 0xffffffffu) return;
+		const Place p = place_of(grp);
+		if (!p.full) return;
+		const uint32_t tk = p.t00 + (lane & 1u) + ((lane >> 1) & 1u) * a.cols;  // (lanes >= 4 repeat the four)
+		p_tw = a.tile_w[tk];
+		p_th = a.tile_h[tk];
+#pragma unroll
+		for (uint32_t k = 0; k < 4; ++k)
+			p_px[k] = reinterpret_cast<const uint32_t *>(a.slots + (size_t)(p.t00 + (k & 1u) + (k >> 1) * a.cols) * a.slot_bytes)[lane];
+	};
+	uint32_t grp = group_of(sub);
+	prefetch(grp);
+	auto put_byte = [&](uint32_t &d, uint32_t j, uint32_t v, uint32_t sh) __attribute__((always_inline)) {
+		if (j == 0) put_byte_shr<0>(d, v, sh);
+		else if (j == 1) put_byte_shr<1>(d, v, sh);
+		else if (j == 2) put_byte_shr<2>(d, v, sh);
+		else put_byte_shr<3>(d, v, sh);
+	};
+	typedef uint32_t u32q __attribute__((ext_vector_type(4), aligned(4)));  // (frame rows and slots: dword aligned)
+	while (grp != 0xffffffffu) {
+		uint32_t nt = 0;
+		if (lane == 0) nt = atomicAdd(s_ticket, 1u);
+		const uint32_t grp_next = group_of(__builtin_amdgcn_readfirstlane(nt));
+		const Place pl = place_of(grp);
+		if (!pl.full) {
+			// a partial group (ragged edge, odd tile counts): its tiles one by one to expand_kernel
+#pragma unroll
+			for (uint32_t k = 0; k < 4; ++k)
+				if (2u * pl.gx + (k & 1u) < a.cols && 2u * pl.gy + (k >> 1) < a.rows) list_tile(pl.t00 + (k & 1u) + (k >> 1) * a.cols);
+			prefetch(grp_next);
+			grp = grp_next;
+			continue;
+		}
+		uint32_t tw[4], th[4], px[4];
+#pragma unroll
+		for (uint32_t k = 0; k < 4; ++k) {
+			tw[k] = (uint32_t)__builtin_amdgcn_readlane((int)p_tw, k);
+			th[k] = (uint32_t)__builtin_amdgcn_readlane((int)p_th, k);
+			px[k] = p_px[k];
+		}
+		uint8_t *dst = a.dst + (size_t)pl.frame * a.frame_stride + (size_t)(pl.gy * 32u) * a.pitch + (size_t)(pl.gx * 32u) * 4u;
+		// ---- per tile: clone / eligible for the group forms / listed
+		uint32_t mask = 0, clones = 0;  // tiles that take the group form (stored tw x th, both in {1, 2, 4, 8}); tiles stored at 16x16
+#pragma unroll
+		for (uint32_t k = 0; k < 4; ++k) {
+			const bool small = tw[k] >= 1u && tw[k] <= 8u && th[k] >= 1u && th[k] <= 8u && (tw[k] & (tw[k] - 1u)) == 0u && (th[k] & (th[k] - 1u)) == 0u;
+			if (tw[k] == 16u && th[k] == 16u) clones |= 1u << k;
+			else if (small && (a.filter == 0u || xmf_dw != 0u)) mask |= 1u << k;
+			else list_tile(pl.t00 + (k & 1u) + (k >> 1) * a.cols);
+		}
+		const uint32_t near = a.filter == 0u ? mask : 0u;
+		const uint32_t dxl = (lane >> 2) & 1u, q = lane & 7u;
+		// the clones' bytes are requested BEFORE the next group's prefetch: loads come back in order, so behind it their wait would be
+		// a wait for the whole prefetch -- a full memory round trip per group with a clone in it
+		u32q wc[4] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
+		if (clones != 0u) {
+#pragma unroll
+			for (uint32_t k = 0; k < 4; ++k) {
+				const uint32_t dy = k >> 1, oy = 8u * k + (lane >> 3), tk = dxl + 2u * dy;
+				if ((clones >> tk) & 1u) {
+					const uint32_t t = pl.t00 + dxl + dy * a.cols;
+					wc[k] = __builtin_nontemporal_load(reinterpret_cast<const u32q *>(a.slots + (size_t)t * a.slot_bytes) + (oy & 15u) * 4u + (q & 3u));
+				}
+			}
+		}
+		prefetch(grp_next);  // in flight while this group is expanded
+		if ((clones | near) != 0u) {
+			// ---- clones (block.rs:279-281: the slot's own bytes) and ResizeAlg::Nearest (source index floor((o + 0.5) * size / 16) =
+			// o >> (4 - log2 size), from the staged pixels), written in the pattern of whole frame rows: a lane makes the 16 bytes
+			// of quad q = lane & 7 of row 8 k + (lane >> 3) of the 32x32 region -- the tile is a matter of the lane (a store
+			// instruction covers eight whole 128-byte rows; tile by tile it was sixteen half rows)
+			if (near != 0u) {
+#pragma unroll
+				for (uint32_t k = 0; k < 4; ++k) s_wave[64u * k + lane] = px[k];
+				tile_sync<1>();
+			}
+			uint32_t lwk[4], syk[4];  // (scalar: log2 of the stored width, row shift)
+#pragma unroll
+			for (uint32_t k = 0; k < 4; ++k) {
+				lwk[k] = 31u - (uint32_t)__builtin_clz(tw[k] | 1u);
+				syk[k] = 4u - (31u - (uint32_t)__builtin_clz(th[k] | 1u));
+			}
+#pragma unroll
+			for (uint32_t k = 0; k < 4; ++k) {
+				const uint32_t dy = k >> 1, oy = 8u * k + (lane >> 3), tk = dxl + 2u * dy;
+				const bool is_clone = ((clones >> tk) & 1u) != 0u, is_near = ((near >> tk) & 1u) != 0u;
+				u32q w = wc[k];
+				if (is_near) {
+					const uint32_t lw = dxl ? lwk[2u * dy + 1u] : lwk[2u * dy], sy = dxl ? syk[2u * dy + 1u] : syk[2u * dy], sx = 4u - lw;
+					const uint32_t *row = s_wave + 64u * tk + (((oy & 15u) >> sy) << lw);
+					const uint32_t x = 4u * (q & 3u);
+					w = u32q{row[x >> sx], row[(x + 1u) >> sx], row[(x + 2u) >> sx], row[(x + 3u) >> sx]};
+				}
+				if (is_clone || is_near) __builtin_nontemporal_store(w, reinterpret_cast<u32q *>(dst + (size_t)oy * a.pitch + 16u * q));
+			}
+			if (near != 0u) tile_sync<1>();
+		}
+		if (mask != 0u && a.filter != 0u) {
+			// ---- the convolutions of the group's eligible tiles on the matrix cores
+			// stored pixels -> premultiplied byte planes [c][8 dy + y][8 dx + x]
+			uint8_t *s_pl = reinterpret_cast<uint8_t *>(s_wave);
+			bool any_alpha = false;
+#pragma unroll
+			for (uint32_t k = 0; k < 4; ++k)
+				any_alpha = any_alpha || (((mask >> k) & 1u) && lane < tw[k] * th[k] && (px[k] >> 24) != 255u);
+			const bool premul = __builtin_amdgcn_ballot_w64(any_alpha) != 0ull;
+#pragma unroll
+			for (uint32_t k = 0; k < 4; ++k) {
+				if (((mask >> k) & 1u) && lane < tw[k] * th[k]) {
+					uint32_t v = px[k];
+					if (premul) v = premultiply(v);  // fir: U8x4 is alpha-premultiplied before a convolution
+					const uint32_t lw = 31u - (uint32_t)__builtin_clz(tw[k]);
+					uint8_t *d = s_pl + (8u * (k >> 1) + (lane >> lw)) * 16u + 8u * (k & 1u) + (lane & (tw[k] - 1u));
+					d[0] = (uint8_t)v;
+					d[256] = (uint8_t)(v >> 8);
+					d[512] = (uint8_t)(v >> 16);
+					d[768] = (uint8_t)(v >> 24);
+				}
+			}
+			tile_sync<1>();
+			// a valid table for every view (tiles outside the mask: that of any eligible tile)
+			uint32_t lx[4], ly[4];
+			{
+				uint32_t ax = 0, ay = 0;
+#pragma unroll
+				for (uint32_t k = 0; k < 4; ++k)
+					if ((mask >> k) & 1u) { ax = 31u - (uint32_t)__builtin_clz(tw[k]); ay = 31u - (uint32_t)__builtin_clz(th[k]); }
+#pragma unroll
+				for (uint32_t k = 0; k < 4; ++k) {
+					const bool in = ((mask >> k) & 1u) != 0u;
+					lx[k] = (in ? 31u - (uint32_t)__builtin_clz(tw[k]) : ax) * kXmf16Dw;
+					ly[k] = (in ? 31u - (uint32_t)__builtin_clz(th[k]) : ay) * kXmf16Dw;
+				}
+			}
+			const uint32_t n = lane & 31u, g = lane >> 5, o = n & 15u;
+			const bool second = n >= 16u;  // as a column: a right tile; as a row of a weight operand: a bottom tile
+			auto operand = [&](uint32_t w) -> long { return (long)(second ? (unsigned long long)w << 32 : (unsigned long long)w); };
+			v16i32 zero;
+#pragma unroll
+			for (int r = 0; r < 16; ++r) zero[r] = 0;
+			// ---- horizontal products, one per tile row: t[dy][c] = rows y = 4 g + j of column n as bytes
+			uint32_t t[2][4];
+#pragma unroll
+			for (uint32_t dy = 0; dy < 2; ++dy) {
+				const uint32_t *tb = s_xmf + (second ? lx[2u * dy + 1u] : lx[2u * dy]);
+				const long k_lo = operand(tb[o * 2u + g]), k_hi = operand(tb[32u + o * 2u + g]);
+				const int32_t bx = (int32_t)tb[64u + o];
+				const uint32_t px_ = tb[96];
+				const int32_t top_x = (int32_t)((256u << px_) - 1u);
+				v16i32 cx;
+#pragma unroll
+				for (int r = 0; r < 16; ++r) cx[r] = bx;
+				// row (c, y) = n of this tile row's planes: columns 4 g .. (left tile), 8 + 4 g .. (right tile)
+				const uint32_t *row = reinterpret_cast<const uint32_t *>(s_pl + (n >> 3) * 256u + (8u * dy + (n & 7u)) * 16u + 4u * g);
+				const uint32_t a0 = row[0] ^ 0x80808080u, a1 = row[2] ^ 0x80808080u;
+				const long av = (long)(((unsigned long long)a1 << 32) | (unsigned long long)a0);
+				const v16i32 lo = __builtin_amdgcn_mfma_i32_32x32x16_i8(av, k_lo, cx, 0, 0, 0);
+				const v16i32 hi = __builtin_amdgcn_mfma_i32_32x32x16_i8(av, k_hi, zero, 0, 0, 0);
+#pragma unroll
+				for (uint32_t c = 0; c < 4; ++c) t[dy][c] = 0u;
+#pragma unroll
+				for (int r = 0; r < 16; ++r) put_byte(t[dy][r >> 2], (uint32_t)r & 3u, clamp_fixed_v(hi[r], lo[r], top_x), px_);  // reg = 4 c + j
+			}
+			// ---- vertical products, channel by channel
+			long ky_lo[2], ky_hi[2];
+#pragma unroll
+			for (uint32_t side = 0; side < 2; ++side) {
+				const uint32_t *tb = s_xmf + (second ? ly[2u + side] : ly[side]);
+				ky_lo[side] = operand(tb[o * 2u + g]);
+				ky_hi[side] = operand(tb[32u + o * 2u + g]);
+			}
+			// this lane's outputs: column n, rows (r & 3) + 8 (r >> 2) + 4 g: regs 0..7 the top tile of its column half, 8..15 the bottom one
+			const uint32_t *tt = s_xmf + (second ? ly[1] : ly[0]), *tbm = s_xmf + (second ? ly[3] : ly[2]);
+			const uint32_t py_t = tt[96], py_b = tbm[96];
+			const int32_t top_t = (int32_t)((256u << py_t) - 1u), top_b = (int32_t)((256u << py_b) - 1u);
+			v16i32 cy;
+			{
+				const uint4 b0 = *reinterpret_cast<const uint4 *>(tt + 80u + 8u * g), b1 = *reinterpret_cast<const uint4 *>(tt + 84u + 8u * g);
+				const uint4 b2 = *reinterpret_cast<const uint4 *>(tbm + 80u + 8u * g), b3 = *reinterpret_cast<const uint4 *>(tbm + 84u + 8u * g);
+				cy[0] = (int)b0.x; cy[1] = (int)b0.y; cy[2] = (int)b0.z; cy[3] = (int)b0.w;
+				cy[4] = (int)b1.x; cy[5] = (int)b1.y; cy[6] = (int)b1.z; cy[7] = (int)b1.w;
+				cy[8] = (int)b2.x; cy[9] = (int)b2.y; cy[10] = (int)b2.z; cy[11] = (int)b2.w;
+				cy[12] = (int)b3.x; cy[13] = (int)b3.y; cy[14] = (int)b3.z; cy[15] = (int)b3.w;
+			}
+			uint32_t pix[16];
+#pragma unroll
+			for (int r = 0; r < 16; ++r) pix[r] = 0;
+#pragma unroll
+			for (uint32_t c = 0; c < 4; ++c) {
+				const uint32_t b0 = t[0][c] ^ 0x80808080u, b1 = t[1][c] ^ 0x80808080u;
+				const long tl = (long)(((unsigned long long)(second ? 0u : b1) << 32) | (unsigned long long)(second ? 0u : b0));
+				const long tr = (long)(((unsigned long long)(second ? b1 : 0u) << 32) | (unsigned long long)(second ? b0 : 0u));
+				v16i32 lo = __builtin_amdgcn_mfma_i32_32x32x16_i8(ky_lo[0], tl, cy, 0, 0, 0);
+				lo = __builtin_amdgcn_mfma_i32_32x32x16_i8(ky_lo[1], tr, lo, 0, 0, 0);
+				v16i32 hi = __builtin_amdgcn_mfma_i32_32x32x16_i8(ky_hi[0], tl, zero, 0, 0, 0);
+				hi = __builtin_amdgcn_mfma_i32_32x32x16_i8(ky_hi[1], tr, hi, 0, 0, 0);
+#pragma unroll
+				for (int r = 0; r < 16; ++r) put_byte(pix[r], c, clamp_fixed_v(hi[r], lo[r], r < 8 ? top_t : top_b), r < 8 ? py_t : py_b);
+			}
+			// un-premultiplying is the identity at alpha 255: skipped when no lane of the wave holds anything else
+			uint32_t alpha_and = 0xffffffffu;
+#pragma unroll
+			for (int r = 0; r < 16; ++r) alpha_and &= pix[r];
+			if (premul || __builtin_amdgcn_ballot_w64((alpha_and >> 24) != 255u) != 0ull) {
+#pragma unroll
+				for (int r = 0; r < 16; ++r) pix[r] = unpremultiply(pix[r]);
+			}
+			const bool ok_t = ((mask >> (second ? 1u : 0u)) & 1u) != 0u, ok_b = ((mask >> (second ? 3u : 2u)) & 1u) != 0u;
+			uint8_t *lane_dst = dst + (size_t)(4u * g) * a.pitch + 4u * n;
+#pragma unroll
+			for (uint32_t r = 0; r < 16; ++r) {
+				if (r < 8 ? ok_t : ok_b)
+					__builtin_nontemporal_store(pix[r], reinterpret_cast<uint32_t *>(lane_dst + (size_t)xmf_row(0, r) * a.pitch));
+			}
+			tile_sync<1>();  // the next group restages the planes
+		}
+		grp = grp_next;
+	}
+}
+
+// ---------------------------------------------------------------------------
 // Decode side: Pixlzr::expand (reference pixlzr.rs:77-122) + to_image
 // (pixlzr_image.rs:24-74) in one pass: every stored tile is resized back to its full size with
 // PixlzrBlock::resize (block.rs:273-334: clone, ResizeAlg::Nearest, or the two-pass convolution with
@@ -214,9 +500,12 @@ __global__ void __launch_bounds__(F32 ? 1024 : 256) expand_kernel(const ExpandAr
 	uint32_t *s_tmp = s_src + a.bw * a.bh;
 	// A tile's stored size and its first 64 pixels (all of them for most tiles) are requested one tile ahead: the
 	// size -> pixels -> windows chain of dependent memory round trips was most of a tile's time.
+	// (list mode: the tiles expand16_kernel left -- status[1] of them, complete when this launch starts)
+	const uint32_t n_items = a.list_mode ? __builtin_amdgcn_readfirstlane(a.status[1]) : a.n_tiles;
 	auto tile_of = [&](uint32_t tk) -> uint32_t {
 		const unsigned long long tl = (unsigned long long)blockIdx.x + (unsigned long long)tk * gridDim.x;
-		return tl < (unsigned long long)a.n_tiles ? (uint32_t)tl : 0xffffffffu;
+		if (tl >= (unsigned long long)n_items) return 0xffffffffu;
+		return a.list_mode ? __builtin_amdgcn_readfirstlane(a.list[(uint32_t)tl]) : (uint32_t)tl;
 	};
 	uint32_t p_tw = 0, p_th = 0, p_px = 0;
 	auto prefetch = [&](uint32_t tn) {
@@ -598,7 +887,27 @@ __global__ void __launch_bounds__(F32 ? 1024 : 256) expand_kernel(const ExpandAr
 #endif
 }
 
+hipError_t launch_expand_general(const ExpandArgs &a, uint32_t n_cus, hipStream_t stream, uint32_t max_blocks);
+
 hipError_t launch_expand(const ExpandArgs &a, uint32_t n_cus, hipStream_t stream)
+{
+	if (a.list != nullptr) {
+		// 16x16 RGBA tiles: the 2x2 groups first, then what they left (partial groups, one-pass and odd sizes) through the list
+		const uint32_t xmf_bytes = a.xmf16 ? kXmf16Levels * kXmf16Dw * 4u : 0u;
+		const uint32_t wpb = 16u, lds_bytes = xmf_bytes + wpb * kX16Wave * 4u + 16u;
+		const uint32_t gcols = (a.cols + 1u) >> 1, grows = (a.rows + 1u) >> 1, n_groups = (a.n_tiles / a.tiles_per_frame) * gcols * grows;
+		const uint32_t need = (n_groups + wpb - 1u) / wpb, resident = 2u * n_cus;
+		hipLaunchKernelGGL(expand16_kernel, dim3(need < resident ? need : resident), dim3(64u * wpb), lds_bytes, stream, a);
+		hipError_t e = hipGetLastError();
+		if (e != hipSuccess) return e;
+		ExpandArgs b = a;
+		b.list_mode = 1u;
+		return launch_expand_general(b, n_cus, stream, 2u * n_cus);  // (the list is short: a grid the size of the chip)
+	}
+	return launch_expand_general(a, n_cus, stream, 0xffffffffu);
+}
+
+hipError_t launch_expand_general(const ExpandArgs &a, uint32_t n_cus, hipStream_t stream, uint32_t max_blocks)
 {
 	constexpr uint32_t kLds = 160u * 1024u;
 	const uint32_t tile_bytes = a.tile_dw * 4u;
@@ -614,7 +923,8 @@ hipError_t launch_expand(const ExpandArgs &a, uint32_t n_cus, hipStream_t stream
 	if (per_cu > 4u) per_cu = 4u;
 	if (per_cu < 1u) per_cu = 1u;
 	const uint32_t need = (a.n_tiles + wpb - 1u) / wpb, resident = n_cus * per_cu;
-	const uint32_t blocks = need < resident ? need : resident;
+	uint32_t blocks = need < resident ? need : resident;
+	if (blocks > max_blocks) blocks = max_blocks;
 	hipError_t e;
 	if (f32) {
 		auto k = expand_kernel<4, true>;

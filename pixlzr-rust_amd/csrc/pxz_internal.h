@@ -266,6 +266,15 @@ constexpr uint32_t kXmfLevels = 5, kXmfDw = 324;
 constexpr uint32_t xmf_src(uint32_t kg, uint32_t j) { return j < 4u ? 4u * kg + j : 8u + 4u * kg + (j - 4u); }
 constexpr uint32_t xmf_row(uint32_t g, uint32_t reg) { return (reg & 3u) + 8u * (reg >> 2) + 4u * g; }  // accumulator reg -> row
 
+// expand16_kernel's matrix-core tables (16x16 tiles in 2x2 groups, the convolutions): one block of kXmf16Dw dwords per stored size
+// 2^li, li = 0 .. kXmf16Levels-1 (1, 2, 4, 8 px -> 16 px; one table serves both axes):
+//   [0, 32)   low bytes of the weights: dword o * 2 + kg = K[o][4 kg .. 4 kg + 3] for output sample o < 16 (source samples >= the
+//             stored size carry zero)                       [32, 64)  high bytes
+//   [64, 80)  bias per output sample (128 * weight sum + half)
+//   [80, 96)  the same in accumulator order: [g][r], r < 8, for output sample (r & 3) + 8 (r >> 2) + 4 g
+//   [96]      precision
+constexpr uint32_t kXmf16Levels = 4, kXmf16Dw = 100;
+
 struct ExpandArgs {
 	const uint32_t *tile_w, *tile_h;  // per tile: stored size
 	const uint8_t *slots;             // per tile slot_bytes, tile_w*tile_h*channels valid, tightly packed
@@ -285,6 +294,10 @@ struct ExpandArgs {
 	uint32_t fast32;                  // 0: the general forms only (PXZ_NO_EXPAND_FAST32)
 	uint32_t *status;                 // set to 1 when a tile's stored size is 0 or exceeds its full size
 	uint32_t quiet_empty;             // 1: tiles of stored size 0 x 0 are simply not written (tree::process: not this level's)
+	const uint32_t *xmf16;            // kXmf16Levels * kXmf16Dw dwords (16x16 tiles, a convolution filter), or null
+	uint32_t *list;                   // 16x16 flow: tiles expand16_kernel left to expand_kernel (status[1] counts them), or null
+	uint32_t list_mode;               // expand_kernel: 1 = take the tiles of `list` (status[1] of them) instead of every tile
+	FastDiv div_gpf, div_gcols;       // expand16_kernel: divisors for its 2x2 tile groups (groups per frame, group columns)
 };
 
 // Decode side: .pixlzr files -> tile values, sizes and pixel slots (pixlzr_index_kernel, qoi_decode_kernel)

@@ -429,7 +429,13 @@ constexpr uint32_t kOk2Tables = 3072u + 256u + 2u * 128u + 64u; // dwords: matri
 template <int T>
 struct Ok2Geom {
 	static constexpr uint32_t G = T == 64 ? 4u : 1u;                  // producer waves per tile
+#if defined(PXZ_EXP) && (PXZ_EXP == 21 || PXZ_EXP == 22)
+	// (experiment builds of round 4: what the detector alone takes with 12 / 10 producer waves and the other waves idle -- the
+	// lower bound of any fused form that gives waves of this block to the shrink step; results are unchanged)
+	static constexpr uint32_t kProd = T == 64 ? 12u : (PXZ_EXP == 21 ? 12u : 10u);
+#else
 	static constexpr uint32_t kProd = T == 64 ? 12u : 14u;            // producer waves per block
+#endif
 	static constexpr uint32_t kTiles = kProd / G;                     // tiles per batch: 14 | 3
 	static constexpr uint32_t NB = T == 64 ? 8u : T * T / 128u;       // bands per producer and tile = intervals per period: 2 | 8 | 8
 	static constexpr uint32_t kLanesPerRow = T / 2;                   // 8 | 16 | 32

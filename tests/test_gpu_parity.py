@@ -481,7 +481,7 @@ def test_expand_matches_oracle(gpu, oracle, c, filt):
     expand with every FilterType: clone, nearest, one-pass and two-pass convolutions, RGB and RGBA with
     transparency (premultiplied convolution)."""
     img = oracle.synth_frame(500, 300, c, 3, 1 if c == 4 else 0)
-    for bw, bh, factor in ((32, 32, 16.0), (32, 32, 2.0), (48, 20, 8.0), (64, 64, 16.0)):
+    for bw, bh, factor in ((32, 32, 16.0), (32, 32, 2.0), (48, 20, 8.0), (64, 64, 16.0), (16, 16, 16.0), (16, 16, 2.0)):
         vals, ow, oh, slots = oracle.shrink_image(img, bw, bh, 1, 4, factor)
         exp = oracle.expand_image(500, 300, bw, bh, c, filt, ow, oh, slots)
         got = gpu.expand_image(500, 300, c, bw, bh, filt, ow, oh, slots)
@@ -489,19 +489,23 @@ def test_expand_matches_oracle(gpu, oracle, c, filt):
         assert not bad.any(), f"c{c} f{filt} {bw}x{bh} k{factor}: {int(bad.sum())} pixels differ"
 
 
+@pytest.mark.parametrize("block", [32, 16, 64])
 @pytest.mark.parametrize("filt", [0, 1, 2, 3, 4])
-def test_expand_of_power_of_two_tiles(gpu, oracle, filt):
-    """32x32 RGBA tiles stored at every combination of 1, 2, 4, 8, 16, 32 (also the ones no shrink produces from a level
-    pair, and a few odd sizes between them): the matrix-core convolutions and the shift-indexed Nearest of expand_kernel
-    against the oracle's PixlzrBlock::resize (block.rs:273-334).  Random pixels; a third of the tiles opaque, a third
-    with random alpha, a third with alpha in {0, 255} (premultiplied convolution, fir's U8x4 default)."""
-    rng = np.random.default_rng(40 + filt)
-    sizes = [1, 2, 4, 8, 16, 32]
-    pairs = [(a, b) for a in sizes for b in sizes] * 3 + [(3, 8), (8, 5), (31, 16), (16, 17), (12, 12)]
+def test_expand_of_power_of_two_tiles(gpu, oracle, filt, block):
+    """RGBA tiles of 32x32, 16x16 (expand16_kernel: 2x2 groups of tiles, mixed sizes inside a group, an odd column count and so a
+    partial group per row) and 64x64 stored at every combination of 1, 2, 4, ... up to the full size (also the ones no shrink
+    produces from a level pair, and a few odd sizes between them, which take the general forms): the matrix-core convolutions
+    and the shift-indexed Nearest against the oracle's PixlzrBlock::resize (block.rs:273-334).  Random pixels; a third of the
+    tiles opaque, a third with random alpha, a third with alpha in {0, 255} (premultiplied convolution, fir's U8x4 default)."""
+    rng = np.random.default_rng(40 + filt + block)
+    sizes = [s for s in (1, 2, 4, 8, 16, 32, 64) if s <= block]
+    odd = [(3, 8), (8, 5), (block - 1, block // 2), (block // 2, block // 2 + 1), (12, 12)]
+    pairs = [(a, b) for a in sizes for b in sizes] * 3 + odd
+    pairs = [pairs[i] for i in rng.permutation(len(pairs))]  # every group of a 16x16 grid holds a mix
     cols, rows = 9, (len(pairs) + 8) // 9
     n = cols * rows
     tw = np.ones(n, np.uint32); th = np.ones(n, np.uint32)
-    slots = np.zeros((n, 32 * 32 * 4), np.uint8)
+    slots = np.zeros((n, block * block * 4), np.uint8)
     for t in range(n):
         w, h = pairs[t % len(pairs)]
         tw[t], th[t] = w, h
@@ -511,12 +515,12 @@ def test_expand_of_power_of_two_tiles(gpu, oracle, filt):
         elif kind == 2: px[:, 3] = rng.choice(np.array([0, 255], np.uint8), h * w)
         if t % 7 == 0: px[:, :3] = rng.choice(np.array([0, 255], np.uint8), (h * w, 3))  # extremes: the clamps
         slots[t, : h * w * 4] = px.ravel()
-    exp = oracle.expand_image(cols * 32, rows * 32, 32, 32, 4, filt, tw, th, slots)
-    got = gpu.expand_image(cols * 32, rows * 32, 4, 32, 32, filt, tw, th, slots)
+    exp = oracle.expand_image(cols * block, rows * block, block, block, 4, filt, tw, th, slots)
+    got = gpu.expand_image(cols * block, rows * block, 4, block, block, filt, tw, th, slots)
     bad = (got != exp).any(axis=2)
     if bad.any():
-        t_bad = sorted({int((y // 32) * cols + x // 32) for y, x in zip(*np.nonzero(bad))})
-        raise AssertionError(f"filter {filt}: {int(bad.sum())} pixels differ, tiles {[(t, int(tw[t]), int(th[t])) for t in t_bad[:8]]}")
+        t_bad = sorted({int((y // block) * cols + x // block) for y, x in zip(*np.nonzero(bad))})
+        raise AssertionError(f"filter {filt} block {block}: {int(bad.sum())} pixels differ, tiles {[(t, int(tw[t]), int(th[t])) for t in t_bad[:8]]}")
 
 
 @pytest.mark.parametrize("filt", [0, 4])
