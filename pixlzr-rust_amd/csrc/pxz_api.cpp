@@ -70,6 +70,7 @@ struct ExpandTables {
 	uint32_t dir_stride = 0;
 	uint32_t *d_xmf = nullptr;  // 32x32 tiles, convolutions: matrix-core operand tables (pxz_internal.h: kXmfDw)
 	uint32_t *d_xmf16 = nullptr;  // 16x16 tiles, convolutions: the same for expand16_kernel (kXmf16Dw)
+	uint32_t *d_xmf64 = nullptr;  // 64x64 tiles, convolutions: the same for expand64_kernel (kXmf64Dw)
 };
 
 struct DeviceBuffer {
@@ -512,6 +513,46 @@ int get_expand_tables(pxz_handle *h, uint32_t bw, uint32_t bh, uint32_t edge_w, 
 		if (fits) {
 			PXZ_HIP(h, hipMalloc((void **)&et.d_xmf16, xmf.size() * sizeof(uint32_t)));
 			PXZ_HIP(h, hipMemcpy(et.d_xmf16, xmf.data(), xmf.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+		}
+	}
+	// 64x64 tiles: the up-scales 1 .. 32 -> 64 as matrix-core operands of expand64_kernel (layout: pxz_internal.h)
+	if (bw == 64 && bh == 64 && filter != 0) {
+		std::vector<uint32_t> xmf((size_t)pxz::kXmf64Levels * pxz::kXmf64Dw, 0u);
+		bool fits = true;
+		for (uint32_t li = 0; li < pxz::kXmf64Levels; ++li) {
+			const uint32_t in = 1u << li;
+			pxz::AxisWindows win;
+			if (!pxz::build_axis(in, 64, filter, &win, true)) return fail(h, PXZ_ERR_INVALID_ARG, "unknown filter %u", filter);
+			uint32_t *mf = xmf.data() + (size_t)li * pxz::kXmf64Dw;
+			const int32_t half = 1 << (win.precision - 1);
+			for (uint32_t o = 0; o < 64; ++o) {
+				int32_t k[32] = {0};
+				int32_t total = 0;
+				for (uint32_t i = 0; i < (uint32_t)win.sizes[o]; ++i) {
+					k[(uint32_t)win.starts[o] + i] = win.coeffs[(size_t)o * win.window + i];
+					total += k[(uint32_t)win.starts[o] + i];
+				}
+				const uint32_t q = o >> 5, ol = o & 31u;
+				for (uint32_t st = 0; st < 2; ++st)
+					for (uint32_t kg = 0; kg < 2; ++kg)
+						for (uint32_t j = 0; j < 8; ++j) {
+							const int32_t v = k[16 * st + pxz::xmf_src(kg, j)];
+							const int32_t lo = ((v + 128) & 255) - 128, hi = (v - lo) / 256;
+							if (hi < -128 || hi > 127) fits = false;
+							const uint32_t lane = kg * 32 + ol, dw = ((q * 2 + st) * 2) * 128 + 2 * lane + j / 4, sh = 8 * (j & 3);
+							mf[dw] |= (uint32_t)(uint8_t)lo << sh;
+							mf[128 + dw] |= (uint32_t)(uint8_t)hi << sh;
+						}
+				mf[1024 + o] = (uint32_t)(128 * total + half);
+			}
+			for (uint32_t q = 0; q < 2; ++q)
+				for (uint32_t g = 0; g < 2; ++g)
+					for (uint32_t reg = 0; reg < 16; ++reg) mf[1088 + (q * 2 + g) * 16 + reg] = mf[1024 + 32 * q + pxz::xmf_row(g, reg)];
+			mf[1152] = (uint32_t)win.precision;
+		}
+		if (fits) {
+			PXZ_HIP(h, hipMalloc((void **)&et.d_xmf64, xmf.size() * sizeof(uint32_t)));
+			PXZ_HIP(h, hipMemcpy(et.d_xmf64, xmf.data(), xmf.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
 		}
 	}
 	PXZ_HIP(h, hipMalloc((void **)&et.d_dir, dir.size() * sizeof(pxz::ExpandTab)));
@@ -976,6 +1017,7 @@ void pxz_destroy(pxz_handle *h)
 		(void)hipFree(kv.second.d_coeffs);
 		(void)hipFree(kv.second.d_xmf);
 		(void)hipFree(kv.second.d_xmf16);
+		(void)hipFree(kv.second.d_xmf64);
 	}
 	drop_tree_tables(h);
 	for (DeviceBuffer *b : {&h->in, &h->val, &h->ow, &h->oh, &h->out, &h->sums, &h->chunks, &h->work, &h->qscratch, &h->qmeta, &h->status, &h->dmeta, &h->okscratch, &h->rgba, &h->slots4, &h->pk, &h->pkoff, &h->tree, &h->xlist, &h->tree_rects[0], &h->tree_rects[1], &h->tree_count})
@@ -1244,6 +1286,17 @@ static int expand_launch(pxz_handle *h, const pxz_frames *frames, uint32_t slot_
 		a.xmf16 = et->d_xmf16;
 		a.div_gpf = make_fastdiv(((cols + 1u) / 2u) * ((rows + 1u) / 2u));
 		a.div_gcols = make_fastdiv((cols + 1u) / 2u);
+	}
+	// 64x64 RGBA tiles in RGBA frames (the reference CLI's default block): expand64_kernel takes the full tiles stored at powers
+	// of two (clones, Nearest, the two-pass convolutions), expand_kernel the rest through the list
+	const bool fast64 = a.fast32 && bw == 64 && bh == 64 && slot_channels == 4 && frames->channels == 4 &&
+	                    (p.filter == 0 || et->d_xmf64 != nullptr);
+	if (fast64) {
+		if ((rc = ensure(h, h->xlist, (size_t)a.n_tiles * 4u)) != PXZ_OK) return rc;
+		a.list = (uint32_t *)h->xlist.ptr;
+		a.xmf64 = et->d_xmf64;
+		a.div_gpf = make_fastdiv(cols * rows);  // (tiles per frame, tile columns)
+		a.div_gcols = make_fastdiv(cols);
 	}
 #ifdef PXZ_STAMPS
 	if ((rc = ensure(h, h->status, 256)) != PXZ_OK) return rc;  // (stamps behind the flag: pxz_debug_read_status)

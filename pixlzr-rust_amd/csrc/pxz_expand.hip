@@ -473,6 +473,260 @@ __global__ void __launch_bounds__(1024) expand16_kernel(const ExpandArgs a)
 }
 
 // ---------------------------------------------------------------------------
+// expand64_kernel (round 4): Pixlzr::expand + to_image for 64x64 RGBA tiles -- the reference CLI's default block size
+// (src/bin/main.rs:19) -- one wave per tile, persistent, tiles dealt by an LDS ticket counter, stored size and first pixels
+// requested one tile ahead.  Per full tile:
+//   stored 64x64 (block.rs:279-281, clone)               its 16 KB slot straight into the frame rows, four 16-byte moves in flight
+//   stored tw x th, powers of two, Nearest               source index o >> (6 - log2 size) from the staged pixels
+//   stored tw x th, both in {1 .. 32}, a convolution     the matrix cores, as expand_tile_mfma does it for 32x32 tiles, looped:
+//       for each half qx of the 64 output columns: T[(c, y)][ox] = clip8(sum_x P_c[y][x] Kx[x][ox]) in NBLK row blocks of 32
+//       (1: th <= 8, rows (c, y < 8); 2: th = 16; 4: th = 32) and one or two steps of 16 source columns; the clamped bytes stay in
+//       registers in the k-slot order of the vertical product (xmf_src), whose weights are the same table; then for each half qy
+//       of the output rows and each channel: O_c[oy][ox] = clip8(sum_y Ky[oy][y] T_c[y][ox]), one or two steps of 16 stored rows,
+//       un-premultiplied and written as 16 dwords per lane (half-waves cover 128-byte row segments).  Same integers as
+//       expand_kernel's vector form (block.rs:273-334).
+//   anything else (64 x n and n x 64 under a convolution, sizes a foreign file may hold, empty, ragged-edge tiles)
+//                                                        appended to the list expand_kernel takes in a second launch
+// ---------------------------------------------------------------------------
+constexpr uint32_t kX64Wave = 2048;  // dwords of LDS per wave: byte planes [c][max(th, 8)][max(tw, 16)] / staged pixels of Nearest (<= 64 x 32)
+
+template <int NBLK>
+__device__ __forceinline__ void expand64_conv(const ExpandArgs &a, const uint32_t *s_xmf, const uint8_t *s_pl, uint32_t lane, uint32_t lw,
+                                              uint32_t lh, uint32_t P, uint8_t *dst)
+{
+	constexpr uint32_t KSY = NBLK == 4 ? 2u : 1u;                          // steps of 16 stored rows
+	constexpr uint32_t LTHP = NBLK == 1 ? 3u : (NBLK == 2 ? 4u : 5u);     // log2 of the rows a channel plane holds
+	const uint32_t n = lane & 31u, g = lane >> 5;
+	const uint32_t *mx = s_xmf + lw * kXmf64Dw, *my = s_xmf + lh * kXmf64Dw;
+	const uint32_t ksx = lw == 5u ? 2u : 1u;                              // steps of 16 stored columns
+	const uint32_t plane = P << LTHP;
+	const uint32_t px_ = __builtin_amdgcn_readfirstlane(mx[1152]), py = __builtin_amdgcn_readfirstlane(my[1152]);
+	const int32_t top_x = (int32_t)((256u << px_) - 1u), top_y = (int32_t)((256u << py) - 1u);
+	auto put_byte = [&](uint32_t &d, uint32_t j, uint32_t v, uint32_t sh) __attribute__((always_inline)) {
+		if (j == 0) put_byte_shr<0>(d, v, sh);
+		else if (j == 1) put_byte_shr<1>(d, v, sh);
+		else if (j == 2) put_byte_shr<2>(d, v, sh);
+		else put_byte_shr<3>(d, v, sh);
+	};
+	v16i32 zero;
+#pragma unroll
+	for (int r = 0; r < 16; ++r) zero[r] = 0;
+#pragma unroll 1
+	for (uint32_t qx = 0; qx < 2; ++qx) {
+		// ---- horizontal: this half's 32 output columns
+		long kxl[2], kxh[2];
+#pragma unroll
+		for (uint32_t st = 0; st < 2; ++st) {
+			const uint32_t *w = mx + ((qx * 2u + (st < ksx ? st : 0u)) * 2u) * 128u + 2u * lane;
+			kxl[st] = *reinterpret_cast<const long *>(w);
+			kxh[st] = *reinterpret_cast<const long *>(w + 128u);
+		}
+		const int32_t bx = (int32_t)mx[1024u + 32u * qx + n];
+		v16i32 cx;
+#pragma unroll
+		for (int r = 0; r < 16; ++r) cx[r] = bx;
+		uint32_t T[4][KSY][2];  // [channel][step of 16 rows][rows 4 g + j | 8 + 4 g + j] as bytes: the vertical product's B operand
+#pragma unroll
+		for (uint32_t c = 0; c < 4; ++c)
+#pragma unroll
+			for (uint32_t st = 0; st < KSY; ++st) T[c][st][0] = T[c][st][1] = 0u;
+#pragma unroll
+		for (uint32_t b = 0; b < (uint32_t)NBLK; ++b) {
+			const uint32_t G = 32u * b + n, c = G >> LTHP, y = G & ((1u << LTHP) - 1u);  // row n of this block: channel c, stored row y
+			const uint32_t *row = reinterpret_cast<const uint32_t *>(s_pl + c * plane + y * P + 4u * g);
+			v16i32 lo = cx, hi = zero;
+#pragma unroll
+			for (uint32_t st = 0; st < 2; ++st) {
+				if (st < ksx) {
+					const uint32_t a0 = row[4u * st] ^ 0x80808080u, a1 = row[4u * st + 2u] ^ 0x80808080u;  // columns 16 st + 4 g + j | + 8
+					const long av = (long)(((unsigned long long)a1 << 32) | (unsigned long long)a0);
+					lo = __builtin_amdgcn_mfma_i32_32x32x16_i8(av, kxl[st], lo, 0, 0, 0);
+					hi = __builtin_amdgcn_mfma_i32_32x32x16_i8(av, kxh[st], hi, 0, 0, 0);
+				}
+			}
+#pragma unroll
+			for (uint32_t r = 0; r < 16; ++r) {
+				const uint32_t q4 = r >> 2;  // four accumulator registers = rows 8 q4 + 4 g + j of the block
+				const uint32_t cc = NBLK == 1 ? q4 : (NBLK == 2 ? 2u * b + (q4 >> 1) : b);
+				const uint32_t st = NBLK == 4 ? q4 >> 1 : 0u, h = NBLK == 1 ? 0u : q4 & 1u;
+				put_byte(T[cc][st][h], r & 3u, clamp_fixed(hi[r], lo[r], top_x), px_);
+			}
+		}
+		// ---- vertical: the two 32x32 quadrants of this column half
+#pragma unroll 1
+		for (uint32_t qy = 0; qy < 2; ++qy) {
+			long kyl[KSY], kyh[KSY];
+#pragma unroll
+			for (uint32_t st = 0; st < KSY; ++st) {
+				const uint32_t *w = my + ((qy * 2u + st) * 2u) * 128u + 2u * lane;
+				kyl[st] = *reinterpret_cast<const long *>(w);
+				kyh[st] = *reinterpret_cast<const long *>(w + 128u);
+			}
+			v16i32 cy;
+			{
+				const uint4 *bp = reinterpret_cast<const uint4 *>(my + 1088u + (qy * 2u + g) * 16u);
+#pragma unroll
+				for (int q = 0; q < 4; ++q) {
+					const uint4 bb = bp[q];
+					cy[4 * q] = (int)bb.x; cy[4 * q + 1] = (int)bb.y; cy[4 * q + 2] = (int)bb.z; cy[4 * q + 3] = (int)bb.w;
+				}
+			}
+			uint32_t pix[16];
+#pragma unroll
+			for (int r = 0; r < 16; ++r) pix[r] = 0;
+#pragma unroll
+			for (uint32_t c = 0; c < 4; ++c) {
+				v16i32 lo = cy, hi = zero;
+#pragma unroll
+				for (uint32_t st = 0; st < KSY; ++st) {
+					const long tv = (long)(((unsigned long long)(T[c][st][1] ^ 0x80808080u) << 32) | (unsigned long long)(T[c][st][0] ^ 0x80808080u));
+					lo = __builtin_amdgcn_mfma_i32_32x32x16_i8(kyl[st], tv, lo, 0, 0, 0);
+					hi = __builtin_amdgcn_mfma_i32_32x32x16_i8(kyh[st], tv, hi, 0, 0, 0);
+				}
+#pragma unroll
+				for (uint32_t r = 0; r < 16; ++r) put_byte(pix[r], c, clamp_fixed(hi[r], lo[r], top_y), py);
+			}
+			// un-premultiplying is the identity at alpha 255: skipped when no lane of the wave holds anything else
+			uint32_t alpha_and = 0xffffffffu;
+#pragma unroll
+			for (int r = 0; r < 16; ++r) alpha_and &= pix[r];
+			if (__builtin_amdgcn_ballot_w64((alpha_and >> 24) != 255u) != 0ull) {
+#pragma unroll
+				for (int r = 0; r < 16; ++r) pix[r] = unpremultiply(pix[r]);
+			}
+			uint8_t *lane_dst = dst + (size_t)(32u * qy + 4u * g) * a.pitch + 4u * (32u * qx + n);
+#pragma unroll
+			for (uint32_t r = 0; r < 16; ++r)
+				__builtin_nontemporal_store(pix[r], reinterpret_cast<uint32_t *>(lane_dst + (size_t)xmf_row(0, r) * a.pitch));
+		}
+	}
+}
+
+__global__ void __launch_bounds__(1024) expand64_kernel(const ExpandArgs a)
+{
+	extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+	const uint32_t wpb = blockDim.x / 64u, sub = threadIdx.x / 64u, lane = threadIdx.x % 64u;
+	const uint32_t xmf_dw = a.xmf64 ? kXmf64Levels * kXmf64Dw : 0u;
+	for (uint32_t i = threadIdx.x; i < xmf_dw / 4u; i += blockDim.x)
+		reinterpret_cast<uint4 *>(lds)[i] = reinterpret_cast<const uint4 *>(a.xmf64)[i];
+	const uint32_t *s_xmf = lds;
+	uint32_t *s_ticket = lds + xmf_dw + wpb * kX64Wave;
+	if (threadIdx.x == 0) *s_ticket = wpb;
+	__syncthreads();
+	uint32_t *s_wave = lds + xmf_dw + sub * kX64Wave;
+	auto tile_of = [&](uint32_t tk) -> uint32_t {
+		const unsigned long long tl = (unsigned long long)blockIdx.x + (unsigned long long)tk * gridDim.x;
+		return tl < (unsigned long long)a.n_tiles ? (uint32_t)tl : 0xffffffffu;
+	};
+	uint32_t p_tw = 0, p_th = 0, p_px = 0;
+	auto prefetch = [&](uint32_t tn) {
+		if (tn == 0xffffffffu) return;
+		p_tw = a.tile_w[tn];
+		p_th = a.tile_h[tn];
+		p_px = reinterpret_cast<const uint32_t *>(a.slots + (size_t)tn * a.slot_bytes)[lane];
+	};
+	typedef uint32_t u32q __attribute__((ext_vector_type(4), aligned(4)));  // (frame rows and slots: dword aligned)
+	uint32_t t = tile_of(sub);
+	prefetch(t);
+	while (t != 0xffffffffu) {
+		uint32_t nt = 0;
+		if (lane == 0) nt = atomicAdd(s_ticket, 1u);
+		const uint32_t t_next = tile_of(__builtin_amdgcn_readfirstlane(nt));
+		const uint32_t tw = __builtin_amdgcn_readfirstlane(p_tw), th = __builtin_amdgcn_readfirstlane(p_th);
+		const uint32_t first_px = p_px;
+		const uint32_t frame = fastdiv(t, a.div_gpf), tf = t - frame * a.tiles_per_frame;
+		const uint32_t ty = fastdiv(tf, a.div_gcols), tx = tf - ty * a.cols;
+		const bool full = (tx + 1u < a.cols || a.edge_w == 64u) && (ty + 1u < a.rows || a.edge_h == 64u);
+		const bool pow2 = tw >= 1u && tw <= 64u && th >= 1u && th <= 64u && (tw & (tw - 1u)) == 0u && (th & (th - 1u)) == 0u;
+		const bool clone = full && tw == 64u && th == 64u;
+		const bool near = full && pow2 && !clone && a.filter == 0u;  // (one axis may be 64: at most 64 x 32 stored pixels)
+		const bool conv = full && pow2 && a.filter != 0u && xmf_dw != 0u && tw <= 32u && th <= 32u;
+		const uint8_t *src = a.slots + (size_t)t * a.slot_bytes;
+		uint8_t *dst = a.dst + (size_t)frame * a.frame_stride + (size_t)(ty * 64u) * a.pitch + (size_t)(tx * 64u) * 4u;
+		if (clone) {
+			// requested before the next tile's prefetch (loads come back in order), four 16-byte moves in flight
+			u32q v[4];
+#pragma unroll
+			for (uint32_t k = 0; k < 4; ++k) v[k] = __builtin_nontemporal_load(reinterpret_cast<const u32q *>(src) + 64u * k + lane);
+			prefetch(t_next);
+#pragma unroll 1
+			for (uint32_t k0 = 0; k0 < 16u; k0 += 4u) {
+				u32q w[4];
+				if (k0 + 4u < 16u) {
+#pragma unroll
+					for (uint32_t k = 0; k < 4; ++k) w[k] = __builtin_nontemporal_load(reinterpret_cast<const u32q *>(src) + 64u * (k0 + 4u + k) + lane);
+				}
+#pragma unroll
+				for (uint32_t k = 0; k < 4; ++k) {
+					const uint32_t c = 64u * (k0 + k) + lane;  // 16-byte chunk c of the tile: row c / 16, columns 4 (c % 16) ..
+					__builtin_nontemporal_store(v[k], reinterpret_cast<u32q *>(dst + (size_t)(c >> 4) * a.pitch + 16u * (c & 15u)));
+				}
+#pragma unroll
+				for (uint32_t k = 0; k < 4; ++k) v[k] = w[k];
+			}
+		} else if (near) {
+			prefetch(t_next);
+			const uint32_t lw = 31u - (uint32_t)__builtin_clz(tw), sx = 6u - lw, sy = 6u - (31u - (uint32_t)__builtin_clz(th));
+			const uint32_t npx = tw * th;
+			for (uint32_t i = lane; i < npx; i += 64u) s_wave[i] = i == lane ? first_px : reinterpret_cast<const uint32_t *>(src)[i];
+			tile_sync<1>();
+			const uint32_t q = lane & 15u, x = 4u * q;
+#pragma unroll 4
+			for (uint32_t k = 0; k < 16; ++k) {
+				const uint32_t oy = 4u * k + (lane >> 4);
+				const uint32_t *row = s_wave + ((oy >> sy) << lw);
+				const u32q w = {row[x >> sx], row[(x + 1u) >> sx], row[(x + 2u) >> sx], row[(x + 3u) >> sx]};
+				__builtin_nontemporal_store(w, reinterpret_cast<u32q *>(dst + (size_t)oy * a.pitch + 16u * q));
+			}
+			tile_sync<1>();
+		} else if (conv) {
+			// ---- stored pixels -> premultiplied byte planes [c][max(th, 8)][P], P = max(tw, 16)
+			const uint32_t lw = 31u - (uint32_t)__builtin_clz(tw), lh = 31u - (uint32_t)__builtin_clz(th);
+			const uint32_t P = tw < 16u ? 16u : tw, plane = P * (th < 8u ? 8u : th);
+			uint8_t *s_pl = reinterpret_cast<uint8_t *>(s_wave);
+			const uint32_t npx = tw * th;
+			if (tw < 4u || npx <= 64u) {
+				for (uint32_t i = lane; i < npx; i += 64u) {
+					uint32_t px = i == lane ? first_px : reinterpret_cast<const uint32_t *>(src)[i];
+					if (__builtin_amdgcn_ballot_w64((px >> 24) != 255u) != 0ull) px = premultiply(px);  // fir: U8x4 is alpha-premultiplied before a convolution
+					uint8_t *d = s_pl + (i >> lw) * P + (i & (tw - 1u));
+					d[0] = (uint8_t)px;
+					d[plane] = (uint8_t)(px >> 8);
+					d[2u * plane] = (uint8_t)(px >> 16);
+					d[3u * plane] = (uint8_t)(px >> 24);
+				}
+			} else {
+				// four adjacent pixels (one row: tw >= 4) per lane and round, a dword per channel
+				for (uint32_t i4 = lane; i4 < (npx >> 2); i4 += 64u) {
+					const u32q v = __builtin_nontemporal_load(reinterpret_cast<const u32q *>(src) + i4);
+					uint32_t p0 = v.x, p1 = v.y, p2 = v.z, p3 = v.w;
+					if (__builtin_amdgcn_ballot_w64(((p0 & p1 & p2 & p3) >> 24) != 255u) != 0ull) {
+						p0 = premultiply(p0); p1 = premultiply(p1); p2 = premultiply(p2); p3 = premultiply(p3);
+					}
+					uint8_t *d = s_pl + ((4u * i4) >> lw) * P + ((4u * i4) & (tw - 1u));
+#pragma unroll
+					for (uint32_t c = 0; c < 4; ++c) {
+						const uint32_t sel = c | ((4u + c) << 8) | 0x0c0c0000u;
+						const uint32_t lo2 = __builtin_amdgcn_perm(p1, p0, sel), hi2 = __builtin_amdgcn_perm(p3, p2, sel);
+						*reinterpret_cast<uint32_t *>(d + c * plane) = lo2 | (hi2 << 16);
+					}
+				}
+			}
+			prefetch(t_next);
+			tile_sync<1>();
+			if (th <= 8u) expand64_conv<1>(a, s_xmf, s_pl, lane, lw, lh, P, dst);
+			else if (th == 16u) expand64_conv<2>(a, s_xmf, s_pl, lane, lw, lh, P, dst);
+			else expand64_conv<4>(a, s_xmf, s_pl, lane, lw, lh, P, dst);
+			tile_sync<1>();  // the next tile restages the planes
+		} else {
+			prefetch(t_next);
+			if (lane == 0) a.list[atomicAdd(a.status + 1, 1u)] = t;  // expand_kernel's second launch takes it (and flags what is invalid)
+		}
+		t = t_next;
+	}
+}
+
+// ---------------------------------------------------------------------------
 // Decode side: Pixlzr::expand (reference pixlzr.rs:77-122) + to_image
 // (pixlzr_image.rs:24-74) in one pass: every stored tile is resized back to its full size with
 // PixlzrBlock::resize (block.rs:273-334: clone, ResizeAlg::Nearest, or the two-pass convolution with
@@ -891,6 +1145,21 @@ hipError_t launch_expand_general(const ExpandArgs &a, uint32_t n_cus, hipStream_
 
 hipError_t launch_expand(const ExpandArgs &a, uint32_t n_cus, hipStream_t stream)
 {
+	if (a.list != nullptr && a.bw == 64u) {
+		// 64x64 RGBA tiles: one wave per full tile stored at powers of two, then what that left through the list
+		const uint32_t xmf_bytes = a.xmf64 ? kXmf64Levels * kXmf64Dw * 4u : 0u;
+		uint32_t wpb = (160u * 1024u - 16u - xmf_bytes) / (kX64Wave * 4u);
+		if (wpb > 16u) wpb = 16u;
+		const uint32_t lds_bytes = xmf_bytes + wpb * kX64Wave * 4u + 16u;
+		const uint32_t need = (a.n_tiles + wpb - 1u) / wpb;
+		hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(expand64_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+		if (e != hipSuccess) return e;
+		hipLaunchKernelGGL(expand64_kernel, dim3(need < n_cus ? need : n_cus), dim3(64u * wpb), lds_bytes, stream, a);
+		if ((e = hipGetLastError()) != hipSuccess) return e;
+		ExpandArgs b = a;
+		b.list_mode = 1u;
+		return launch_expand_general(b, n_cus, stream, 4u * n_cus);
+	}
 	if (a.list != nullptr) {
 		// 16x16 RGBA tiles: the 2x2 groups first, then what they left (partial groups, one-pass and odd sizes) through the list
 		const uint32_t xmf_bytes = a.xmf16 ? kXmf16Levels * kXmf16Dw * 4u : 0u;

@@ -275,6 +275,16 @@ constexpr uint32_t xmf_row(uint32_t g, uint32_t reg) { return (reg & 3u) + 8u * 
 //   [96]      precision
 constexpr uint32_t kXmf16Levels = 4, kXmf16Dw = 100;
 
+// expand64_kernel's matrix-core tables (64x64 tiles, the convolutions): one block of kXmf64Dw dwords per stored size 2^li,
+// li = 0 .. kXmf64Levels-1 (1 .. 32 px -> 64 px; one table serves both axes).  The 64 outputs are two halves q of 32, the source
+// samples steps s of 16 (one step up to 16 px, two at 32):
+//   [((q * 2 + s) * 2 + piece) * 128 + 2 l, + 1]   lane l = kg * 32 + o: weight bytes (piece 0 low, 1 high) of output 32 q + o for
+//                                                  the source samples 16 s + xmf_src(kg, j), j = 0 .. 7
+//   [1024, 1088)  bias per output sample (128 * weight sum + half)
+//   [1088, 1152)  the same in accumulator order: [q][g][reg] for output 32 q + xmf_row(g, reg)
+//   [1152]        precision
+constexpr uint32_t kXmf64Levels = 6, kXmf64Dw = 1156;
+
 struct ExpandArgs {
 	const uint32_t *tile_w, *tile_h;  // per tile: stored size
 	const uint8_t *slots;             // per tile slot_bytes, tile_w*tile_h*channels valid, tightly packed
@@ -295,6 +305,7 @@ struct ExpandArgs {
 	uint32_t *status;                 // set to 1 when a tile's stored size is 0 or exceeds its full size
 	uint32_t quiet_empty;             // 1: tiles of stored size 0 x 0 are simply not written (tree::process: not this level's)
 	const uint32_t *xmf16;            // kXmf16Levels * kXmf16Dw dwords (16x16 tiles, a convolution filter), or null
+	const uint32_t *xmf64;            // kXmf64Levels * kXmf64Dw dwords (64x64 tiles, a convolution filter), or null
 	uint32_t *list;                   // 16x16 flow: tiles expand16_kernel left to expand_kernel (status[1] counts them), or null
 	uint32_t list_mode;               // expand_kernel: 1 = take the tiles of `list` (status[1] of them) instead of every tile
 	FastDiv div_gpf, div_gcols;       // expand16_kernel: divisors for its 2x2 tile groups (groups per frame, group columns)
