@@ -485,7 +485,8 @@ __global__ void __launch_bounds__(1024) expand16_kernel(const ExpandArgs a)
 //       of the output rows and each channel: O_c[oy][ox] = clip8(sum_y Ky[oy][y] T_c[y][ox]), one or two steps of 16 stored rows,
 //       un-premultiplied and written as 16 dwords per lane (half-waves cover 128-byte row segments).  Same integers as
 //       expand_kernel's vector form (block.rs:273-334).
-//   anything else (64 x n and n x 64 under a convolution, sizes a foreign file may hold, empty, ragged-edge tiles)
+//   stored 64 x th or tw x 64 (one axis kept)             the one product that axis needs (expand64_vonly / expand64_honly)
+//   anything else (sizes a foreign file may hold, empty, ragged-edge tiles)
 //                                                        appended to the list expand_kernel takes in a second launch
 // ---------------------------------------------------------------------------
 constexpr uint32_t kX64Wave = 2048;  // dwords of LDS per wave: byte planes [c][max(th, 8)][max(tw, 16)] / staged pixels of Nearest (<= 64 x 32)
@@ -522,9 +523,6 @@ __device__ __forceinline__ void expand64_conv(const ExpandArgs &a, const uint32_
 			kxh[st] = *reinterpret_cast<const long *>(w + 128u);
 		}
 		const int32_t bx = (int32_t)mx[1024u + 32u * qx + n];
-		v16i32 cx;
-#pragma unroll
-		for (int r = 0; r < 16; ++r) cx[r] = bx;
 		uint32_t T[4][KSY][2];  // [channel][step of 16 rows][rows 4 g + j | 8 + 4 g + j] as bytes: the vertical product's B operand
 #pragma unroll
 		for (uint32_t c = 0; c < 4; ++c)
@@ -534,7 +532,9 @@ __device__ __forceinline__ void expand64_conv(const ExpandArgs &a, const uint32_
 		for (uint32_t b = 0; b < (uint32_t)NBLK; ++b) {
 			const uint32_t G = 32u * b + n, c = G >> LTHP, y = G & ((1u << LTHP) - 1u);  // row n of this block: channel c, stored row y
 			const uint32_t *row = reinterpret_cast<const uint32_t *>(s_pl + c * plane + y * P + 4u * g);
-			v16i32 lo = cx, hi = zero;
+			v16i32 lo, hi = zero;  // (the bias: sixteen moves per block, not sixteen registers held across the tile)
+#pragma unroll
+			for (int r = 0; r < 16; ++r) lo[r] = bx;
 #pragma unroll
 			for (uint32_t st = 0; st < 2; ++st) {
 				if (st < ksx) {
@@ -562,21 +562,18 @@ __device__ __forceinline__ void expand64_conv(const ExpandArgs &a, const uint32_
 				kyl[st] = *reinterpret_cast<const long *>(w);
 				kyh[st] = *reinterpret_cast<const long *>(w + 128u);
 			}
-			v16i32 cy;
-			{
-				const uint4 *bp = reinterpret_cast<const uint4 *>(my + 1088u + (qy * 2u + g) * 16u);
-#pragma unroll
-				for (int q = 0; q < 4; ++q) {
-					const uint4 bb = bp[q];
-					cy[4 * q] = (int)bb.x; cy[4 * q + 1] = (int)bb.y; cy[4 * q + 2] = (int)bb.z; cy[4 * q + 3] = (int)bb.w;
-				}
-			}
+			const uint4 *bp = reinterpret_cast<const uint4 *>(my + 1088u + (qy * 2u + g) * 16u);  // the biases in accumulator order
 			uint32_t pix[16];
 #pragma unroll
 			for (int r = 0; r < 16; ++r) pix[r] = 0;
 #pragma unroll
 			for (uint32_t c = 0; c < 4; ++c) {
-				v16i32 lo = cy, hi = zero;
+				v16i32 lo, hi = zero;  // (the biases: four LDS reads per channel, not sixteen registers held across the quadrant)
+#pragma unroll
+				for (int q = 0; q < 4; ++q) {
+					const uint4 bb = bp[q];
+					lo[4 * q] = (int)bb.x; lo[4 * q + 1] = (int)bb.y; lo[4 * q + 2] = (int)bb.z; lo[4 * q + 3] = (int)bb.w;
+				}
 #pragma unroll
 				for (uint32_t st = 0; st < KSY; ++st) {
 					const long tv = (long)(((unsigned long long)(T[c][st][1] ^ 0x80808080u) << 32) | (unsigned long long)(T[c][st][0] ^ 0x80808080u));
@@ -595,6 +592,151 @@ __device__ __forceinline__ void expand64_conv(const ExpandArgs &a, const uint32_
 				for (int r = 0; r < 16; ++r) pix[r] = unpremultiply(pix[r]);
 			}
 			uint8_t *lane_dst = dst + (size_t)(32u * qy + 4u * g) * a.pitch + 4u * (32u * qx + n);
+#pragma unroll
+			for (uint32_t r = 0; r < 16; ++r)
+				__builtin_nontemporal_store(pix[r], reinterpret_cast<uint32_t *>(lane_dst + (size_t)xmf_row(0, r) * a.pitch));
+		}
+	}
+}
+
+// The one-pass classes of a 64x64 tile (fir resizes an axis only where its size changes, block.rs:292-322).
+// Width kept (stored 64 x th, th <= 32): the vertical product alone; its B operand -- four stored rows of a column as bytes -- is
+// gathered from the premultiplied planes [c][th][64].
+template <int KSY>
+__device__ __forceinline__ void expand64_vonly(const ExpandArgs &a, const uint32_t *s_xmf, const uint8_t *s_pl, uint32_t lane, uint32_t lh,
+                                               uint32_t plane, uint8_t *dst)
+{
+	const uint32_t n = lane & 31u, g = lane >> 5;
+	const uint32_t *my = s_xmf + lh * kXmf64Dw;
+	const uint32_t py = __builtin_amdgcn_readfirstlane(my[1152]);
+	const int32_t top_y = (int32_t)((256u << py) - 1u);
+	auto put_byte = [&](uint32_t &d, uint32_t j, uint32_t v, uint32_t sh) __attribute__((always_inline)) {
+		if (j == 0) put_byte_shr<0>(d, v, sh);
+		else if (j == 1) put_byte_shr<1>(d, v, sh);
+		else if (j == 2) put_byte_shr<2>(d, v, sh);
+		else put_byte_shr<3>(d, v, sh);
+	};
+	v16i32 zero;
+#pragma unroll
+	for (int r = 0; r < 16; ++r) zero[r] = 0;
+#pragma unroll 1
+	for (uint32_t qx = 0; qx < 2; ++qx) {
+		uint32_t T[4][KSY][2];
+#pragma unroll
+		for (uint32_t c = 0; c < 4; ++c)
+#pragma unroll
+			for (uint32_t st = 0; st < (uint32_t)KSY; ++st)
+#pragma unroll
+				for (uint32_t h = 0; h < 2; ++h) {
+					const uint8_t *col = s_pl + c * plane + (16u * st + 8u * h + 4u * g) * 64u + 32u * qx + n;  // rows .. + 3 of column 32 qx + n
+					T[c][st][h] = ((uint32_t)col[0] | ((uint32_t)col[64] << 8) | ((uint32_t)col[128] << 16) | ((uint32_t)col[192] << 24)) ^ 0x80808080u;
+				}
+#pragma unroll 1
+		for (uint32_t qy = 0; qy < 2; ++qy) {
+			long kyl[KSY], kyh[KSY];
+#pragma unroll
+			for (uint32_t st = 0; st < (uint32_t)KSY; ++st) {
+				const uint32_t *w = my + ((qy * 2u + st) * 2u) * 128u + 2u * lane;
+				kyl[st] = *reinterpret_cast<const long *>(w);
+				kyh[st] = *reinterpret_cast<const long *>(w + 128u);
+			}
+			const uint4 *bp = reinterpret_cast<const uint4 *>(my + 1088u + (qy * 2u + g) * 16u);  // the biases in accumulator order
+			uint32_t pix[16];
+#pragma unroll
+			for (int r = 0; r < 16; ++r) pix[r] = 0;
+#pragma unroll
+			for (uint32_t c = 0; c < 4; ++c) {
+				v16i32 lo, hi = zero;
+#pragma unroll
+				for (int q = 0; q < 4; ++q) {
+					const uint4 bb = bp[q];
+					lo[4 * q] = (int)bb.x; lo[4 * q + 1] = (int)bb.y; lo[4 * q + 2] = (int)bb.z; lo[4 * q + 3] = (int)bb.w;
+				}
+#pragma unroll
+				for (uint32_t st = 0; st < (uint32_t)KSY; ++st) {
+					const long tv = (long)(((unsigned long long)T[c][st][1] << 32) | (unsigned long long)T[c][st][0]);
+					lo = __builtin_amdgcn_mfma_i32_32x32x16_i8(kyl[st], tv, lo, 0, 0, 0);
+					hi = __builtin_amdgcn_mfma_i32_32x32x16_i8(kyh[st], tv, hi, 0, 0, 0);
+				}
+#pragma unroll
+				for (uint32_t r = 0; r < 16; ++r) put_byte(pix[r], c, clamp_fixed(hi[r], lo[r], top_y), py);
+			}
+			uint32_t alpha_and = 0xffffffffu;
+#pragma unroll
+			for (int r = 0; r < 16; ++r) alpha_and &= pix[r];
+			if (__builtin_amdgcn_ballot_w64((alpha_and >> 24) != 255u) != 0ull) {
+#pragma unroll
+				for (int r = 0; r < 16; ++r) pix[r] = unpremultiply(pix[r]);
+			}
+			uint8_t *lane_dst = dst + (size_t)(32u * qy + 4u * g) * a.pitch + 4u * (32u * qx + n);
+#pragma unroll
+			for (uint32_t r = 0; r < 16; ++r)
+				__builtin_nontemporal_store(pix[r], reinterpret_cast<uint32_t *>(lane_dst + (size_t)xmf_row(0, r) * a.pitch));
+		}
+	}
+}
+
+// Height kept (stored tw x 64, tw <= 32): the horizontal product alone, planes [c][64][P]; a block of rows is 32 output rows of
+// one channel, the four channels of a (column half, row half) make its pixels.
+__device__ __forceinline__ void expand64_honly(const ExpandArgs &a, const uint32_t *s_xmf, const uint8_t *s_pl, uint32_t lane, uint32_t lw,
+                                               uint32_t P, uint8_t *dst)
+{
+	const uint32_t n = lane & 31u, g = lane >> 5;
+	const uint32_t *mx = s_xmf + lw * kXmf64Dw;
+	const uint32_t ksx = lw == 5u ? 2u : 1u;
+	const uint32_t plane = P * 64u;
+	const uint32_t px_ = __builtin_amdgcn_readfirstlane(mx[1152]);
+	const int32_t top_x = (int32_t)((256u << px_) - 1u);
+	auto put_byte = [&](uint32_t &d, uint32_t j, uint32_t v, uint32_t sh) __attribute__((always_inline)) {
+		if (j == 0) put_byte_shr<0>(d, v, sh);
+		else if (j == 1) put_byte_shr<1>(d, v, sh);
+		else if (j == 2) put_byte_shr<2>(d, v, sh);
+		else put_byte_shr<3>(d, v, sh);
+	};
+	v16i32 zero;
+#pragma unroll
+	for (int r = 0; r < 16; ++r) zero[r] = 0;
+#pragma unroll 1
+	for (uint32_t qx = 0; qx < 2; ++qx) {
+		long kxl[2], kxh[2];
+#pragma unroll
+		for (uint32_t st = 0; st < 2; ++st) {
+			const uint32_t *w = mx + ((qx * 2u + (st < ksx ? st : 0u)) * 2u) * 128u + 2u * lane;
+			kxl[st] = *reinterpret_cast<const long *>(w);
+			kxh[st] = *reinterpret_cast<const long *>(w + 128u);
+		}
+		const int32_t bx = (int32_t)mx[1024u + 32u * qx + n];
+#pragma unroll 1
+		for (uint32_t yb = 0; yb < 2; ++yb) {
+			uint32_t pix[16];
+#pragma unroll
+			for (int r = 0; r < 16; ++r) pix[r] = 0;
+#pragma unroll
+			for (uint32_t c = 0; c < 4; ++c) {
+				const uint32_t *row = reinterpret_cast<const uint32_t *>(s_pl + c * plane + (32u * yb + n) * P + 4u * g);
+				v16i32 lo, hi = zero;
+#pragma unroll
+				for (int r = 0; r < 16; ++r) lo[r] = bx;
+#pragma unroll
+				for (uint32_t st = 0; st < 2; ++st) {
+					if (st < ksx) {
+						const uint32_t a0 = row[4u * st] ^ 0x80808080u, a1 = row[4u * st + 2u] ^ 0x80808080u;
+						const long av = (long)(((unsigned long long)a1 << 32) | (unsigned long long)a0);
+						lo = __builtin_amdgcn_mfma_i32_32x32x16_i8(av, kxl[st], lo, 0, 0, 0);
+						hi = __builtin_amdgcn_mfma_i32_32x32x16_i8(av, kxh[st], hi, 0, 0, 0);
+					}
+				}
+#pragma unroll
+				for (uint32_t r = 0; r < 16; ++r) put_byte(pix[r], c, clamp_fixed(hi[r], lo[r], top_x), px_);
+			}
+			uint32_t alpha_and = 0xffffffffu;
+#pragma unroll
+			for (int r = 0; r < 16; ++r) alpha_and &= pix[r];
+			if (__builtin_amdgcn_ballot_w64((alpha_and >> 24) != 255u) != 0ull) {
+#pragma unroll
+				for (int r = 0; r < 16; ++r) pix[r] = unpremultiply(pix[r]);
+			}
+			uint8_t *lane_dst = dst + (size_t)(32u * yb + 4u * g) * a.pitch + 4u * (32u * qx + n);
 #pragma unroll
 			for (uint32_t r = 0; r < 16; ++r)
 				__builtin_nontemporal_store(pix[r], reinterpret_cast<uint32_t *>(lane_dst + (size_t)xmf_row(0, r) * a.pitch));
@@ -640,7 +782,7 @@ __global__ void __launch_bounds__(1024) expand64_kernel(const ExpandArgs a)
 		const bool pow2 = tw >= 1u && tw <= 64u && th >= 1u && th <= 64u && (tw & (tw - 1u)) == 0u && (th & (th - 1u)) == 0u;
 		const bool clone = full && tw == 64u && th == 64u;
 		const bool near = full && pow2 && !clone && a.filter == 0u;  // (one axis may be 64: at most 64 x 32 stored pixels)
-		const bool conv = full && pow2 && a.filter != 0u && xmf_dw != 0u && tw <= 32u && th <= 32u;
+		const bool conv = full && pow2 && !clone && a.filter != 0u && xmf_dw != 0u;  // (two passes, or one when an axis is stored at 64)
 		const uint8_t *src = a.slots + (size_t)t * a.slot_bytes;
 		uint8_t *dst = a.dst + (size_t)frame * a.frame_stride + (size_t)(ty * 64u) * a.pitch + (size_t)(tx * 64u) * 4u;
 		if (clone) {
@@ -682,7 +824,7 @@ __global__ void __launch_bounds__(1024) expand64_kernel(const ExpandArgs a)
 		} else if (conv) {
 			// ---- stored pixels -> premultiplied byte planes [c][max(th, 8)][P], P = max(tw, 16)
 			const uint32_t lw = 31u - (uint32_t)__builtin_clz(tw), lh = 31u - (uint32_t)__builtin_clz(th);
-			const uint32_t P = tw < 16u ? 16u : tw, plane = P * (th < 8u ? 8u : th);
+			const uint32_t P = tw < 16u ? 16u : tw, plane = P * (th < 8u ? 8u : th);  // (<= 2 KB: at most 64 x 32 or 32 x 64 stored pixels)
 			uint8_t *s_pl = reinterpret_cast<uint8_t *>(s_wave);
 			const uint32_t npx = tw * th;
 			if (tw < 4u || npx <= 64u) {
@@ -714,9 +856,18 @@ __global__ void __launch_bounds__(1024) expand64_kernel(const ExpandArgs a)
 			}
 			prefetch(t_next);
 			tile_sync<1>();
-			if (th <= 8u) expand64_conv<1>(a, s_xmf, s_pl, lane, lw, lh, P, dst);
-			else if (th == 16u) expand64_conv<2>(a, s_xmf, s_pl, lane, lw, lh, P, dst);
-			else expand64_conv<4>(a, s_xmf, s_pl, lane, lw, lh, P, dst);
+			if (tw == 64u) {
+				if (th <= 16u) expand64_vonly<1>(a, s_xmf, s_pl, lane, lh, plane, dst);
+				else expand64_vonly<2>(a, s_xmf, s_pl, lane, lh, plane, dst);
+			} else if (th == 64u) {
+				expand64_honly(a, s_xmf, s_pl, lane, lw, P, dst);
+			} else if (th <= 8u) {
+				expand64_conv<1>(a, s_xmf, s_pl, lane, lw, lh, P, dst);
+			} else if (th == 16u) {
+				expand64_conv<2>(a, s_xmf, s_pl, lane, lw, lh, P, dst);
+			} else {
+				expand64_conv<4>(a, s_xmf, s_pl, lane, lw, lh, P, dst);
+			}
 			tile_sync<1>();  // the next tile restages the planes
 		} else {
 			prefetch(t_next);
