@@ -504,51 +504,51 @@ def main():
                 others[f"{bs}x{bs} {name}"] = timed_shrink(frames, bs, pxz_mode, factor, ("dir" if pxz_mode == 1 else "by") + str(bs))
 
     # not the metric either: the way back (Pixlzr::expand + to_image) of what shrink_directionally left, per filter
+    # and tile size (32x32; the reference CLI's default 64x64; 16x16), and the reader in front of it
     decode_side = {}
-    if world == 1 and not args.no_other_sizes and args.block == 32:
-        _, ow, oh, slots = handle.shrink_frames_device(frames, args.block, args.block, 1, args.filter, MODES["shrink_directionally"][1])
-        stored = int((ow.long() * oh.long()).sum().item()) * 4
-        for label, filt in (("expand Nearest", 0), ("expand Lanczos3", 4)):
-            back = handle.expand_frames_device(tuple(frames.shape), args.block, args.block, filt, ow, oh, slots)
-            for _ in range(20):
-                handle.expand_frames_device(tuple(frames.shape), args.block, args.block, filt, ow, oh, slots, out=back)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(40):
-                handle.expand_frames_device(tuple(frames.shape), args.block, args.block, filt, ow, oh, slots, out=back)
-            e1.record()
-            torch.cuda.synchronize()
-            ms = e0.elapsed_time(e1) / 40.0
-            algo = stored + 8 * ow.numel() + back.numel()  # stored pixels + sizes read, frames written
-            decode_side[label] = {"ms_per_step": ms, "algo_bytes_per_launch": algo, "achieved_gbps": algo / (ms * 1e-3) / 1e9,
-                                  "frac_of_hbm_peak": algo / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "time_is": "40 launches between two events on the launch stream"}
-            if filt == args.filter:
-                decode_side[label]["traffic"] = load_flow_traffic("exp32")
-            del back
-        # ... and the reader in front of it (decode_from_vec: index of the records + the QOI decoder) on the files the writer makes
-        vals2, ow2, oh2, slots2 = handle.shrink_frames_device(frames, args.block, args.block, 1, args.filter, MODES["shrink_directionally"][1])
-        offs, buf = handle.encode_frames_device(tuple(frames.shape), args.block, args.block, vals2, ow2, oh2, slots2)
-        dec = handle.decode_frames_device(buf, offs, tuple(frames.shape), args.block, args.block)
-        for _ in range(5):
-            handle.decode_frames_device(buf, offs, tuple(frames.shape), args.block, args.block, out=dec)
+
+    def timed(fn, warm, n):
+        for _ in range(warm):
+            fn()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        for _ in range(20):
-            handle.decode_frames_device(buf, offs, tuple(frames.shape), args.block, args.block, out=dec)
+        for _ in range(n):
+            fn()
         e1.record()
         torch.cuda.synchronize()
-        rd_ms = e0.elapsed_time(e1) / 20.0
-        rd_algo = int(offs[-1].item()) + int((ow2.long() * oh2.long()).sum().item()) * 4 + 12 * ow2.numel()  # files read; pixels, values, sizes written
-        rd_tr = load_flow_traffic("dec32")
-        decode_side["decode (reader)"] = {"ms_per_step": rd_ms, "file_bytes": int(offs[-1].item()),
-                                          "time_is": "20 launches between two events on the launch stream",
-                                          "roofline": {"bound": "latency", "bound_is": "one lane per tile walks a serial op stream: the launch lasts as long as its longest lanes "
-                                                       "(1024 dependent pixel steps of a full 32x32 tile, DESIGN 6c); the byte rate is for comparison only",
-                                                       "achieved": rd_algo / (rd_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                                                       "frac": rd_algo / (rd_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "algorithmic_bytes_per_launch": rd_algo,
-                                                       "traffic": (rd_tr or {}).get("hbm_bytes_per_step"),
-                                                       "traffic_over_algorithmic": (rd_tr or {}).get("traffic_over_algorithmic")}}
-        del ow, oh, slots, vals2, ow2, oh2, slots2, offs, buf, dec
+        return e0.elapsed_time(e1) / n
+
+    if world == 1 and not args.no_other_sizes:
+        for bs in (32, 64, 16):
+            suffix = "" if bs == 32 else f" {bs}x{bs}"
+            vals2, ow, oh, slots = handle.shrink_frames_device(frames, bs, bs, 1, args.filter, MODES["shrink_directionally"][1])
+            stored = int((ow.long() * oh.long()).sum().item()) * 4
+            for label, filt in (("expand Nearest", 0), ("expand Lanczos3", 4)):
+                back = handle.expand_frames_device(tuple(frames.shape), bs, bs, filt, ow, oh, slots)
+                ms = timed(lambda: handle.expand_frames_device(tuple(frames.shape), bs, bs, filt, ow, oh, slots, out=back), 20, 40)
+                algo = stored + 8 * ow.numel() + back.numel()  # stored pixels + sizes read, frames written
+                tr = load_flow_traffic(f"exp{bs}") if filt == args.filter else None
+                decode_side[label + suffix] = {
+                    "ms_per_step": ms, "time_is": "40 launches between two events on the launch stream",
+                    "roofline": {"bound": "hbm", "achieved": algo / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                 "frac": algo / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "algorithmic_bytes_per_launch": algo,
+                                 "traffic": (tr or {}).get("hbm_bytes_per_step"), "traffic_over_algorithmic": (tr or {}).get("traffic_over_algorithmic")}}
+                del back
+            # the reader (decode_from_vec: index of the records + the QOI decoder) on the files the writer makes
+            offs, buf = handle.encode_frames_device(tuple(frames.shape), bs, bs, vals2, ow, oh, slots)
+            dec = handle.decode_frames_device(buf, offs, tuple(frames.shape), bs, bs)
+            rd_ms = timed(lambda: handle.decode_frames_device(buf, offs, tuple(frames.shape), bs, bs, out=dec), 5, 20)
+            rd_algo = int(offs[-1].item()) + stored + 12 * ow.numel()  # files read; pixels, values, sizes written
+            rd_tr = load_flow_traffic(f"dec{bs}")
+            decode_side["decode (reader)" + suffix] = {
+                "ms_per_step": rd_ms, "file_bytes": int(offs[-1].item()), "time_is": "20 launches between two events on the launch stream",
+                "roofline": {"bound": "latency", "bound_is": "one lane per tile walks a serial op stream: the launch lasts as long as its longest lanes "
+                             f"({bs * bs} dependent pixel steps of a full {bs}x{bs} tile, DESIGN 6c); the byte rate is for comparison only",
+                             "achieved": rd_algo / (rd_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                             "frac": rd_algo / (rd_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "algorithmic_bytes_per_launch": rd_algo,
+                             "traffic": (rd_tr or {}).get("hbm_bytes_per_step"),
+                             "traffic_over_algorithmic": (rd_tr or {}).get("traffic_over_algorithmic")}}
+            del vals2, ow, oh, slots, offs, buf, dec
 
     # BASELINE configs[3]: ONE 16384 x 16384 RGBA frame (1.07 GB), tiles of 16 / 32 / 64 px, both callers
     block_sweep = {}

@@ -101,7 +101,7 @@ struct pxz_handle {
 	// level breakpoints per (mode, factor bits, bw, bh, edge_w, edge_h)
 	struct Breaks { uint32_t b[4][pxz::kMaxLevel]; uint32_t asc[4]; };
 	std::map<std::tuple<uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t>, Breaks> breaks;
-	DeviceBuffer in, val, ow, oh, out, sums, chunks, work, qscratch, qmeta, status, dmeta, okscratch, rgba, slots4, pk, pkoff, tree, xlist;
+	DeviceBuffer in, val, ow, oh, out, sums, chunks, work, qscratch, qmeta, status, dmeta, okscratch, rgba, slots4, pk, pkoff, tree, xlist, bigscratch;
 	uint64_t packed_len = 0;   // bytes of the stream pxz_shrink_image_packed left in `pk` (0: none)
 	static constexpr int kRing = 3;  // buffer sets of the pipelined host boundary (pxz_shrink_images*)
 	DeviceBuffer ring_in[kRing], ring_val[kRing], ring_ow[kRing], ring_oh[kRing], ring_out[kRing], ring_pk[kRing], ring_pkoff[kRing];
@@ -701,9 +701,21 @@ int prepare(pxz_handle *h, const pxz_frames *f, const pxz_params *p, bool want_p
 	a->tile_dw = (4 * a->plane_dw + scratch + 4 * a->rs + 4 * a->hps + 3u) & ~3u;
 	const uint32_t nw = pxz::waves_per_tile(bw, bh);
 	const uint64_t lds_bytes = (uint64_t)a->tile_dw * 4u + (nw > 1 ? 16u * nw : 0u);
-	if (lds_bytes > 160u * 1024u)
-		return fail(h, PXZ_ERR_UNSUPPORTED, "a %ux%u tile needs %llu B of LDS (limit 163840)", bw, bh,
-		            (unsigned long long)lds_bytes);
+	a->big_scratch = nullptr;
+	a->big_blocks = 0;
+	if (lds_bytes > 160u * 1024u) {
+		// (round 4) a tile image beyond LDS lives in HBM, one per block of the generic kernel: any block size the reference's CLI
+		// accepts runs (src/bin/main.rs:19-24), at the speed of L2 round trips.  The kernel's index arithmetic (small_div, RowWalker)
+		// holds below 2^20 pixels per tile; the grid is capped so that the images stay under 2 GB.
+		if ((uint64_t)bw * bh >= (1u << 20) || pxz::knobs().no_big_tiles)
+			return fail(h, PXZ_ERR_UNSUPPORTED, "a %ux%u tile needs %llu B of LDS (limit 163840) and has too many pixels for the HBM-resident form (limit 2^20 - 1)", bw, bh,
+			            (unsigned long long)lds_bytes);
+		const uint64_t tile_bytes = (uint64_t)a->tile_dw * 4u;
+		uint64_t blocks = (2ull << 30) / tile_bytes;
+		if (blocks > 2ull * h->n_cus) blocks = 2ull * h->n_cus;
+		if (blocks < 1) blocks = 1;
+		a->big_blocks = (uint32_t)blocks;  // (capped by the tile count at launch)
+	}
 
 	a->frame_stride = f->n_frames > 1 ? f->frame_stride_bytes : (uint64_t)f->pitch_bytes * f->height;
 	a->pitch = f->pitch_bytes;
@@ -764,6 +776,11 @@ int timed_launch(pxz_handle *h, pxz::ShrinkArgs &a, uint32_t channels, float *va
 	a.value = value;
 	a.lod0 = lod0;
 	a.lod1 = lod1;
+	if (a.big_blocks != 0u) {
+		if (a.big_blocks > a.n_tiles) a.big_blocks = a.n_tiles;
+		if ((rc = ensure(h, h->bigscratch, (size_t)a.big_blocks * a.tile_dw * 4u)) != PXZ_OK) return rc;
+		a.big_scratch = (uint32_t *)h->bigscratch.ptr;
+	}
 	// Transparency without the caller's hint: the last finished launch reported how many full tiles had any
 	// (one dword in pinned memory, written by the worklist kernel).  Past ~2000 tiles shrink32a_kernel pays for
 	// its launch.  Either way the results are the same; only the kernel that produces them differs.
@@ -1020,7 +1037,7 @@ void pxz_destroy(pxz_handle *h)
 		(void)hipFree(kv.second.d_xmf64);
 	}
 	drop_tree_tables(h);
-	for (DeviceBuffer *b : {&h->in, &h->val, &h->ow, &h->oh, &h->out, &h->sums, &h->chunks, &h->work, &h->qscratch, &h->qmeta, &h->status, &h->dmeta, &h->okscratch, &h->rgba, &h->slots4, &h->pk, &h->pkoff, &h->tree, &h->xlist, &h->tree_rects[0], &h->tree_rects[1], &h->tree_count})
+	for (DeviceBuffer *b : {&h->in, &h->val, &h->ow, &h->oh, &h->out, &h->sums, &h->chunks, &h->work, &h->qscratch, &h->qmeta, &h->status, &h->dmeta, &h->okscratch, &h->rgba, &h->slots4, &h->pk, &h->pkoff, &h->tree, &h->xlist, &h->bigscratch, &h->tree_rects[0], &h->tree_rects[1], &h->tree_count})
 		if (b->ptr) (void)hipFree(b->ptr);
 	for (int i = 0; i < pxz_handle::kRing; ++i)
 		for (DeviceBuffer *b : {&h->ring_in[i], &h->ring_val[i], &h->ring_ow[i], &h->ring_oh[i], &h->ring_out[i], &h->ring_pk[i], &h->ring_pkoff[i]})
@@ -1049,7 +1066,7 @@ int pxz_trim(pxz_handle *h)
 		b.ptr = nullptr;
 		b.cap = 0;
 	};
-	for (DeviceBuffer *b : {&h->in, &h->val, &h->ow, &h->oh, &h->out, &h->sums, &h->chunks, &h->work, &h->qscratch, &h->qmeta, &h->status, &h->dmeta, &h->okscratch, &h->rgba, &h->slots4, &h->pk, &h->pkoff, &h->tree, &h->xlist, &h->tree_rects[0], &h->tree_rects[1], &h->tree_count})
+	for (DeviceBuffer *b : {&h->in, &h->val, &h->ow, &h->oh, &h->out, &h->sums, &h->chunks, &h->work, &h->qscratch, &h->qmeta, &h->status, &h->dmeta, &h->okscratch, &h->rgba, &h->slots4, &h->pk, &h->pkoff, &h->tree, &h->xlist, &h->bigscratch, &h->tree_rects[0], &h->tree_rects[1], &h->tree_count})
 		drop(*b);
 	for (int i = 0; i < pxz_handle::kRing; ++i)
 		for (DeviceBuffer *b : {&h->ring_in[i], &h->ring_val[i], &h->ring_ow[i], &h->ring_oh[i], &h->ring_out[i], &h->ring_pk[i], &h->ring_pkoff[i]})
@@ -1242,8 +1259,10 @@ static int expand_launch(pxz_handle *h, const pxz_frames *frames, uint32_t slot_
 	if (bw > 0xffffu || bh > 0xffffu) return fail(h, PXZ_ERR_UNSUPPORTED, "block side above 65535");
 	// one wave: source pixels + horizontal-pass result + the staged windows (5 dwords per output sample of both axes)
 	const uint64_t lds_bytes = (2ull * bw * bh + 5ull * (bw + bh) + 3ull) / 4ull * 16ull + 16ull;
-	if (lds_bytes > 160u * 1024u)
-		return fail(h, PXZ_ERR_UNSUPPORTED, "a %ux%u tile needs %llu B of LDS (limit 163840)", bw, bh, (unsigned long long)lds_bytes);
+	// (round 4) a tile image beyond LDS lives in HBM, one per wave of the grid (expand_kernel<C, false, true>)
+	const bool big = lds_bytes > 160u * 1024u;
+	if (big && ((uint64_t)bw * bh >= (1u << 20) || pxz::knobs().no_big_tiles))
+		return fail(h, PXZ_ERR_UNSUPPORTED, "a %ux%u tile needs %llu B of LDS (limit 163840) and has too many pixels for the HBM-resident form (limit 2^20 - 1)", bw, bh, (unsigned long long)lds_bytes);
 	pxz::ExpandArgs a{};
 	a.tile_w = d_tile_w;
 	a.tile_h = d_tile_h;
@@ -1276,6 +1295,15 @@ static int expand_launch(pxz_handle *h, const pxz_frames *frames, uint32_t slot_
 	a.fast32 = pxz::knobs().no_expand_fast32 ? 0u : 1u;
 	a.xmf = a.fast32 ? et->d_xmf : nullptr;
 	a.tile_dw = (2u * bw * bh + 5u * (bw + bh) + 3u) & ~3u;
+	if (big) {
+		uint64_t waves = (2ull << 30) / ((uint64_t)a.tile_dw * 4u);
+		if (waves > 8ull * h->n_cus) waves = 8ull * h->n_cus;
+		waves &= ~3ull;
+		if (waves < 4) waves = 4;
+		if ((rc = ensure(h, h->bigscratch, (size_t)waves * a.tile_dw * 4u)) != PXZ_OK) return rc;
+		a.big_scratch = (uint32_t *)h->bigscratch.ptr;
+		a.big_waves = (uint32_t)waves;
+	}
 	// 16x16 RGBA tiles in RGBA frames: expand16_kernel takes the 2x2 groups of full tiles (clones, powers of two), the rest -- and
 	// what it leaves -- goes to expand_kernel through a list (status[1] counts it)
 	const bool groups16 = a.fast32 && bw == 16 && bh == 16 && slot_channels == 4 && frames->channels == 4 && cols >= 2 && rows >= 2 &&

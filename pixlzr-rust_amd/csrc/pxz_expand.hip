@@ -888,20 +888,34 @@ __global__ void __launch_bounds__(1024) expand64_kernel(const ExpandArgs a)
 // ---------------------------------------------------------------------------
 // F32 (RGBA tiles of 32x32 in RGBA frames): blocks of up to 16 waves that share the matrix-core tables; full tiles stored
 // at power-of-two sizes take expand_tile_mfma / expand_tile_nearest_pow2, everything else the general forms below.
-template <int C, bool F32 = false>
+// BIG (round 4): tiles whose image (stored pixels + horizontal pass + windows) does not fit LDS keep it in HBM, one image per wave
+// of the grid (a.big_scratch): the same code on a pointer that is not LDS, with a fence that waits for the wave's own stores where
+// the LDS form only stops the compiler.  Any block size the reference accepts expands; not a fast path.
+template <int C, bool F32 = false, bool BIG = false>
 __global__ void __launch_bounds__(F32 ? 1024 : 256) expand_kernel(const ExpandArgs a)
 {
+	static_assert(!(F32 && BIG), "the 32x32 instance has its image in LDS");
 	extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
 	const uint32_t wpb = blockDim.x / 64u, sub = threadIdx.x / 64u, lane = threadIdx.x % 64u;
+	// (between a phase that writes the wave's image and one that reads it)
+	auto wsync = [&]() __attribute__((always_inline)) {
+		if constexpr (BIG) {
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // s_waitcnt vmcnt(0): the wave's stores to its image have landed
+			__builtin_amdgcn_wave_barrier();
+			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+		} else {
+			tile_sync<1>();
+		}
+	};
 	// the matrix-core tables of the block (32x32 tiles, convolutions), then the waves' tile images
 	const uint32_t xmf_dw = F32 && a.xmf ? kXmfLevels * kXmfDw : 0u;
 	for (uint32_t i = threadIdx.x; i < xmf_dw / 4u; i += blockDim.x)
 		reinterpret_cast<uint4 *>(lds)[i] = reinterpret_cast<const uint4 *>(a.xmf)[i];
 	const uint32_t *s_xmf = lds;
-	uint32_t *s_ticket = lds + xmf_dw + wpb * a.tile_dw;
+	uint32_t *s_ticket = lds + xmf_dw + (BIG ? 0u : wpb * a.tile_dw);
 	if (threadIdx.x == 0) *s_ticket = wpb;
 	__syncthreads();
-	uint32_t *s_src = lds + xmf_dw + sub * a.tile_dw;
+	uint32_t *s_src = BIG ? a.big_scratch + (size_t)(blockIdx.x * wpb + sub) * a.tile_dw : lds + xmf_dw + sub * a.tile_dw;
 	uint32_t *s_tmp = s_src + a.bw * a.bh;
 	// A tile's stored size and its first 64 pixels (all of them for most tiles) are requested one tile ahead: the
 	// size -> pixels -> windows chain of dependent memory round trips was most of a tile's time.
@@ -1017,7 +1031,7 @@ __global__ void __launch_bounds__(F32 ? 1024 : 256) expand_kernel(const ExpandAr
 				}
 				s_src[i] = px;
 			}
-			tile_sync<1>();
+			wsync();
 			const uint32_t cls_x = fw == a.bw ? 0u : 1u, cls_y = fh == a.bh ? 0u : 1u;
 			const ExpandTab tab_x = a.tabs[(0u * 2u + cls_x) * a.dir_stride + tw];
 			const ExpandTab tab_y = a.tabs[(1u * 2u + cls_y) * a.dir_stride + th];
@@ -1074,7 +1088,7 @@ __global__ void __launch_bounds__(F32 ? 1024 : 256) expand_kernel(const ExpandAr
 				};
 				if (tw != fw) stage_windows(s_wx, tab_x, fw);
 				if (th != fh) stage_windows(s_wy, tab_y, fh);
-				tile_sync<1>();
+				wsync();
 				if (tw == fw && th == fh) {  // block.rs:279-281: clone
 					for (uint32_t i = lane; i < q4 * fh; i += 64u) {
 						const uint32_t oy = small_div(i, q4), q = i - oy * q4;
@@ -1143,7 +1157,7 @@ __global__ void __launch_bounds__(F32 ? 1024 : 256) expand_kernel(const ExpandAr
 								}
 							}
 						}
-						tile_sync<1>();
+						wsync();
 					}
 					// A stored tile of ONE row (40 % of the tiles of a typical frame are 2x1): every window of the way up is that
 					// row with the single weight 2^precision, and clip8((2^(p-1) + v 2^p) >> p) = v -- the vertical pass is the
@@ -1247,7 +1261,7 @@ __global__ void __launch_bounds__(F32 ? 1024 : 256) expand_kernel(const ExpandAr
 						}
 					}
 					cur = s_tmp;
-					tile_sync<1>();
+					wsync();
 				}
 				if (need_v) {
 					// vertical pass: item = (ox, oy); the rows of `cur` are fw wide when the horizontal pass ran
@@ -1281,7 +1295,7 @@ __global__ void __launch_bounds__(F32 ? 1024 : 256) expand_kernel(const ExpandAr
 		}
 		PXZ_STAMP(2);  // the other paths (clone, general, nearest), and what of the matrix-core path is not stamped inside
 		t = t_next;
-		tile_sync<1>();  // the next tile reuses this wave's LDS
+		wsync();  // the next tile reuses this wave's LDS
 		PXZ_STAMP(7);  // closing sync
 	}
 #ifdef PXZ_STAMPS
@@ -1329,6 +1343,14 @@ hipError_t launch_expand(const ExpandArgs &a, uint32_t n_cus, hipStream_t stream
 
 hipError_t launch_expand_general(const ExpandArgs &a, uint32_t n_cus, hipStream_t stream, uint32_t max_blocks)
 {
+	if (a.big_waves != 0u) {
+		// tile images in HBM: blocks of 4 waves, as many as the scratch holds images for
+		const uint32_t wpb = 4u, blocks_max = a.big_waves / wpb, need = (a.n_tiles + wpb - 1u) / wpb;
+		const uint32_t blocks = need < blocks_max ? need : blocks_max;
+		if (a.channels == 4) hipLaunchKernelGGL((expand_kernel<4, false, true>), dim3(blocks), dim3(64u * wpb), 16u, stream, a);
+		else hipLaunchKernelGGL((expand_kernel<3, false, true>), dim3(blocks), dim3(64u * wpb), 16u, stream, a);
+		return hipGetLastError();
+	}
 	constexpr uint32_t kLds = 160u * 1024u;
 	const uint32_t tile_bytes = a.tile_dw * 4u;
 	const bool f32 = a.fast32 && a.channels == 4 && a.out_channels == 4 && a.bw == 32 && a.bh == 32 && (a.filter == 0 || a.xmf);

@@ -121,6 +121,8 @@ struct ShrinkArgs {
 	uint32_t tmp_dw;         // ceil(bw/2) * hps   (0 when no convolution)
 	uint32_t lab_dw;         // Oklab mode: 3*bw*bh floats (aliases the transposed planes), else 0
 	uint32_t tile_dw;        // total dwords per tile incl. over-read slack
+	uint32_t *big_scratch;   // tiles whose image exceeds LDS (round 4): big_blocks images of tile_dw dwords in HBM, one per block
+	uint32_t big_blocks;     //   of the generic kernel (0: the image is in LDS)
 };
 
 // Arguments of shrink32_kernel (full 32x32 RGBA tiles only): the subset of ShrinkArgs it needs
@@ -195,6 +197,7 @@ struct Knobs {
 	bool no_native_rgb;     // PXZ_NO_NATIVE_RGB: RGB batches are widened to RGBA even where a kernel reads RGB itself
 	bool no_alpha_first;    // PXZ_NO_ALPHA_FIRST: transparent batches keep the two-kernel flow (shrink32_kernel lists, shrink32a_kernel takes the list)
 	bool no_narrow;         // PXZ_NO_NARROW: 4/2/1-px-wide outputs of 32x32 tiles keep the round-1 resample forms
+	bool no_big_tiles;      // PXZ_NO_BIG_TILES: tiles whose image exceeds LDS are refused (PXZ_ERR_UNSUPPORTED), as before round 4
 	bool no_group16;        // PXZ_NO_GROUP16: the two-pass tiles of a 16x16 group keep their own dot2 resamples (no block-diagonal matrix-core products)
 	bool oklab_v1;          // PXZ_OKLAB_V1: round-1 detector (one chain wave, two barriers per band; 64-px tiles parked in HBM)
 	bool no_expand_fast32;    // PXZ_NO_EXPAND_FAST32: expand_kernel keeps its general forms for 32x32 RGBA tiles (no matrix-core convolutions, no shift-indexed Nearest)
@@ -309,6 +312,8 @@ struct ExpandArgs {
 	uint32_t *list;                   // 16x16 flow: tiles expand16_kernel left to expand_kernel (status[1] counts them), or null
 	uint32_t list_mode;               // expand_kernel: 1 = take the tiles of `list` (status[1] of them) instead of every tile
 	FastDiv div_gpf, div_gcols;       // expand16_kernel: divisors for its 2x2 tile groups (groups per frame, group columns)
+	uint32_t *big_scratch;            // tiles whose image exceeds LDS (round 4): one image of tile_dw dwords per wave of the grid in HBM
+	uint32_t big_waves;               //   (0: the images are in LDS)
 };
 
 // Decode side: .pixlzr files -> tile values, sizes and pixel slots (pixlzr_index_kernel, qoi_decode_kernel)

@@ -503,7 +503,11 @@ __device__ __forceinline__ void process_tile(const ShrinkArgs &a, const uint32_t
 // every wave of the block owns one LDS tile image and walks tiles wave_id, wave_id + total_waves, ...;
 // NW > 1: one tile per block iteration.
 // ---------------------------------------------------------------------------
-template <int NW, int C, int MODE>
+// BIG (NW = 16 only, round 4): a tile whose image does not fit the 160 KB of LDS (sides above ~141 px: any -b the reference's CLI
+// accepts, src/bin/main.rs:19-24) keeps it in HBM instead -- one image per block of the grid (a.big_scratch), the same code on
+// a pointer that is not LDS; the block barriers of tile_sync<NW> order the accesses (workgroup-scope fences: one CU, one L1).
+// Not a fast path: every access of the image is an L2 round trip.
+template <int NW, int C, int MODE, bool BIG = false>
 __global__ void __launch_bounds__(NW == 1 ? 768 : 64 * NW) shrink_kernel(const ShrinkArgs a)
 {
 	extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
@@ -576,7 +580,8 @@ __global__ void __launch_bounds__(NW == 1 ? 768 : 64 * NW) shrink_kernel(const S
 		for (uint32_t i = blockIdx.x; i < count; i += gridDim.x) {
 			uint32_t tile_g = i;
 			if (a.work) tile_g = __builtin_amdgcn_readfirstlane(a.work[kWorkList + (i < count_b ? i : a.n_tiles + (i - count_b))]);  // list B, then list A
-			process_tile<NW, C, MODE>(a, tile_g, lds, lds + a.tile_dw, threadIdx.x);
+			if constexpr (BIG) process_tile<NW, C, MODE>(a, tile_g, a.big_scratch + (size_t)blockIdx.x * a.tile_dw, lds, threadIdx.x);
+			else process_tile<NW, C, MODE>(a, tile_g, lds, lds + a.tile_dw, threadIdx.x);
 			__syncthreads();
 		}
 		if (a.work) {
@@ -634,6 +639,12 @@ __global__ void __launch_bounds__(256) finish_kernel(const FinishArgs f)
 template <int NW, int C, int MODE>
 static hipError_t launch_one(const ShrinkArgs &a, const LaunchGeom &g, hipStream_t stream)
 {
+	if constexpr (NW == 16) {
+		if (a.big_blocks != 0u) {
+			hipLaunchKernelGGL((shrink_kernel<NW, C, MODE, true>), dim3(g.blocks), dim3(g.threads), g.lds_bytes, stream, a);
+			return hipGetLastError();
+		}
+	}
 	auto kernel = shrink_kernel<NW, C, MODE>;
 	if (g.lds_bytes > 64u * 1024u) {
 		hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
@@ -691,6 +702,10 @@ LaunchGeom plan_launch(const ShrinkArgs &a, uint32_t channels, uint32_t n_cus)
 			if (few < need) need = few;
 		}
 		g.blocks = need < resident ? need : resident;
+	} else if (a.big_blocks != 0u) {
+		g.threads = 64u * nw;   // (nw = 16: a big tile has more than 8192 pixels)
+		g.lds_bytes = 16u * nw;  // the partial sums only: the image is in HBM
+		g.blocks = a.big_blocks;
 	} else {
 		g.threads = 64u * nw;
 		g.lds_bytes = tile_bytes + 16u * nw;

@@ -149,8 +149,27 @@ def test_error_behaviour(gpu, product, oracle):
         gpu.shrink_image(img, 32, 32, 1, 4, float("nan"))
     assert e.value.code == -1
     with pytest.raises(product.PxzError) as e:
-        gpu.shrink_image(oracle.synth_frame(512, 512, 4, 0, 0), 256, 256, 1, 4, 1.0)  # tile beyond LDS residency
+        # (tiles beyond LDS residency run since round 4 -- test_tiles_beyond_lds_residency -- up to 2^20 - 1 pixels)
+        gpu.shrink_image(oracle.synth_frame(1100, 1030, 4, 0, 0), 1024, 1024, 1, 4, 1.0)
     assert e.value.code == -5
+
+
+@pytest.mark.parametrize("bw,bh", [(192, 192), (256, 256), (300, 200)])
+@pytest.mark.parametrize("c,dist", [(4, 0), (4, 1), (3, 0)])
+def test_tiles_beyond_lds_residency(gpu, oracle, bw, bh, c, dist):
+    """Block sizes whose tile image does not fit the 160 KB of LDS (any -b the reference's CLI accepts, src/bin/main.rs:19-24):
+    the generic kernel and the expand kernel keep the image in HBM.  Both callers, Lanczos3 / Nearest / CatmullRom, a frame with
+    ragged edge tiles; shrink against the oracle (values as bits, sizes, pixels), then the way back (expand) against it too."""
+    W, H = 700, 500
+    img = oracle.synth_frame(W, H, c, 7, dist)
+    for mode, factor, filt in ((1, 16.0, 4), (1, 64.0, 0), (0, 1.0, 4), (0, 0.25, 2), (1, 4.0, 2)):
+        got = gpu.shrink_image(img, bw, bh, mode, filt, factor)
+        exp = oracle.shrink_image(img, bw, bh, mode, filt, factor, nthreads=8)
+        assert_same_tiles(got, exp, c, f"{bw}x{bh} c{c} dist{dist} mode{mode} filter {filt} k={factor}")
+        back = gpu.expand_image(W, H, c, bw, bh, filt, exp[1], exp[2], exp[3])
+        ref = oracle.expand_image(W, H, bw, bh, c, filt, exp[1], exp[2], exp[3])
+        bad = (back != ref).any(axis=2)
+        assert not bad.any(), f"expand {bw}x{bh} c{c} filter {filt}: {int(bad.sum())} pixels differ"
 
 
 @pytest.mark.parametrize("mode,factor", [(1, 16.0), (0, 1.0)])

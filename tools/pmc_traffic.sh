@@ -3,7 +3,7 @@
 # Usage (on the GPU box): bash tools/pmc_traffic.sh <tag> [flows...]   -> gpurun_out/<tag>_pmc/ + gpurun_out/<tag>_pmc_traffic.json
 set -e
 TAG=${1:-rXX}; shift || true
-FLOWS=${@:-dir32 by32 by64 dir64 by16 dir16 enc32 exp32 dec32 sqdir16 sqdir32 sqdir64 sqby16 sqby32 sqby64}
+FLOWS=${@:-dir32 by32 by64 dir64 by16 dir16 enc32 exp32 dec32 exp64 exp16 dec64 sqdir16 sqdir32 sqdir64 sqby16 sqby32 sqby64}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/${TAG}_pmc
 mkdir -p $OUT
