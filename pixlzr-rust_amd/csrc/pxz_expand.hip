@@ -891,7 +891,10 @@ __global__ void __launch_bounds__(1024) expand64_kernel(const ExpandArgs a)
 // BIG (round 4): tiles whose image (stored pixels + horizontal pass + windows) does not fit LDS keep it in HBM, one image per wave
 // of the grid (a.big_scratch): the same code on a pointer that is not LDS, with a fence that waits for the wave's own stores where
 // the LDS form only stops the compiler.  Any block size the reference accepts expands; not a fast path.
-template <int C, bool F32 = false, bool BIG = false>
+// LIST (round 4): the second launch of the 16x16 / 64x64 flows -- the tiles expand16_kernel / expand64_kernel left (a.list, status[1]
+// of them, complete when this launch starts) instead of every tile.  A template flag, not a run-time one: the 32x32 instance sits
+// at its register limit, and the two extra values in its tile loop cost it thirteen more spills (0.31 -> 0.35 ms).
+template <int C, bool F32 = false, bool BIG = false, bool LIST = false>
 __global__ void __launch_bounds__(F32 ? 1024 : 256) expand_kernel(const ExpandArgs a)
 {
 	static_assert(!(F32 && BIG), "the 32x32 instance has its image in LDS");
@@ -919,12 +922,13 @@ __global__ void __launch_bounds__(F32 ? 1024 : 256) expand_kernel(const ExpandAr
 	uint32_t *s_tmp = s_src + a.bw * a.bh;
 	// A tile's stored size and its first 64 pixels (all of them for most tiles) are requested one tile ahead: the
 	// size -> pixels -> windows chain of dependent memory round trips was most of a tile's time.
-	// (list mode: the tiles expand16_kernel left -- status[1] of them, complete when this launch starts)
-	const uint32_t n_items = a.list_mode ? __builtin_amdgcn_readfirstlane(a.status[1]) : a.n_tiles;
+	uint32_t n_items = a.n_tiles;
+	if constexpr (LIST) n_items = __builtin_amdgcn_readfirstlane(a.status[1]);
 	auto tile_of = [&](uint32_t tk) -> uint32_t {
 		const unsigned long long tl = (unsigned long long)blockIdx.x + (unsigned long long)tk * gridDim.x;
 		if (tl >= (unsigned long long)n_items) return 0xffffffffu;
-		return a.list_mode ? __builtin_amdgcn_readfirstlane(a.list[(uint32_t)tl]) : (uint32_t)tl;
+		if constexpr (LIST) return __builtin_amdgcn_readfirstlane(a.list[(uint32_t)tl]);
+		return (uint32_t)tl;
 	};
 	uint32_t p_tw = 0, p_th = 0, p_px = 0;
 	auto prefetch = [&](uint32_t tn) {
@@ -1370,6 +1374,10 @@ hipError_t launch_expand_general(const ExpandArgs &a, uint32_t n_cus, hipStream_
 	hipError_t e;
 	if (f32) {
 		auto k = expand_kernel<4, true>;
+		if (lds_bytes > 64u * 1024u && (e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)) != hipSuccess) return e;
+		hipLaunchKernelGGL(k, dim3(blocks), dim3(64u * wpb), lds_bytes, stream, a);
+	} else if (a.channels == 4 && a.list_mode) {
+		auto k = expand_kernel<4, false, false, true>;
 		if (lds_bytes > 64u * 1024u && (e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)) != hipSuccess) return e;
 		hipLaunchKernelGGL(k, dim3(blocks), dim3(64u * wpb), lds_bytes, stream, a);
 	} else if (a.channels == 4) {
