@@ -41,7 +41,8 @@ typedef enum pxz_status {
 	PXZ_ERR_HIP = -3,           /* a HIP runtime call failed; see pxz_last_error */
 	PXZ_ERR_TILE_TOO_SMALL = -4,/* directional mode with a tile narrower/lower than 2 px:
 	                               the reference underflows usize and panics (operations.rs:220-221) */
-	PXZ_ERR_UNSUPPORTED = -5,   /* tile does not fit LDS residency (block_w*block_h too large) */
+	PXZ_ERR_UNSUPPORTED = -5,   /* a tile of 2^20 pixels or more (smaller tiles whose image exceeds the 160 KB of LDS run from an
+	                             * HBM-resident image, slowly), an image side above 2^24, tree blocks above 128 px */
 	PXZ_ERR_NOMEM = -6,
 	PXZ_ERR_BUFFER_TOO_SMALL = -7,
 	PXZ_ERR_INTERNAL = -8       /* a device-side consistency check failed (never expected; see pxz_last_error) */

@@ -785,12 +785,19 @@ int timed_launch(pxz_handle *h, pxz::ShrinkArgs &a, uint32_t channels, float *va
 	// (one dword in pinned memory, written by the worklist kernel).  Past ~2000 tiles shrink32a_kernel pays for
 	// its launch.  Either way the results are the same; only the kernel that produces them differs.
 	a.stats = h->dev_stats;
-	a.expect_listed = h->host_stats ? const_cast<volatile uint32_t *>(h->host_stats)[1] : 0xffffffffu;
-	if (!a.alpha_kernel && h->host_stats && *const_cast<volatile uint32_t *>(h->host_stats) >= 2048u && !pxz::knobs().no_alpha_kernel)
+	// (the counts are only trusted when they come from a launch of THIS configuration: the kernel writes the signature beside them)
+	uint32_t factor_bits;
+	std::memcpy(&factor_bits, &a.factor, 4);
+	a.stats_sig = ((a.n_tiles * 2654435761u) ^ (a.bw << 20) ^ (a.bh << 8) ^ (a.mode << 31) ^ (channels << 28) ^ a.width ^ (a.height * 40503u) ^
+	               (a.filter * 0x9e3779b1u) ^ (factor_bits * 31u)) | 1u;
+	volatile uint32_t *hs = h->host_stats ? const_cast<volatile uint32_t *>(h->host_stats) : nullptr;
+	const bool stats_ours = hs != nullptr && hs[2] == a.stats_sig;
+	const uint32_t seen_transparent = stats_ours ? hs[0] : 0u;
+	a.expect_listed = stats_ours ? hs[1] : 0xffffffffu;
+	if (!a.alpha_kernel && seen_transparent >= 2048u && !pxz::knobs().no_alpha_kernel)
 		a.alpha_kernel = 1;
 	// ... and past half of the tiles the lean kernel would only read, test and list them: the four-plane kernel goes first
-	a.alpha_first = a.alpha_kernel && h->host_stats && *const_cast<volatile uint32_t *>(h->host_stats) >= a.n_tiles / 2u &&
-	                        *const_cast<volatile uint32_t *>(h->host_stats) >= 2048u && !pxz::knobs().no_alpha_first ? 1u : 0u;
+	a.alpha_first = a.alpha_kernel && seen_transparent >= a.n_tiles / 2u && seen_transparent >= 2048u && !pxz::knobs().no_alpha_first ? 1u : 0u;
 	h->last_alpha_kernel = a.alpha_kernel;
 	h->last_alpha_first = a.alpha_first;
 	// 32x32 fast path: which tiles are full-size, and whether every tile row of the batch is 16-byte aligned

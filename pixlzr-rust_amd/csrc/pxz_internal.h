@@ -92,6 +92,9 @@ struct ShrinkArgs {
 	void *mid_event;         // host side only: hipEvent_t to record behind the first kernel of the step, or null
 	uint32_t *stats;         // pinned host dwords (device address) <- [0] list-A tiles, [1] all listed tiles of this launch; may be null
 	uint32_t expect_listed;  // what [1] said after the last finished launch (0xffffffff: unknown): sizes the worklist kernel's grid, nothing else
+	uint32_t stats_sig;      // signature of this launch's configuration, written to stats[2] beside the counts: the host only trusts
+	                         //   counts whose signature is its next launch's (round 4: a handle that went from 32x32 tiles, nothing
+	                         //   listed, to 64x64 frames with a ragged bottom row ran its first launches with an 8-block worklist grid)
 	uint32_t *work;          // worklist: [work_slot] = count, [2..] = tile ids (null: all tiles).  The two
 	uint32_t work_slot;      //   counters alternate between launches; a launch zeroes the other one
 	float *value;            // worklist mode only: the kernel finishes its tiles itself (finish_tile) and,

@@ -85,13 +85,11 @@ __global__ void __launch_bounds__(256) shrink64_kernel(const Fast64Args a)
 	// this lane's share of a tile: rows 16w + (lane >> 4) + 4k, 16 bytes at column quad lane & 15
 	uint4 pre[4];
 	bool pre_valid = false;
-	const uint8_t *pre_p = nullptr, *cur_p = nullptr;  // this lane's first piece of the tile being prefetched / being processed
 	auto prefetch = [&](uint32_t tile_g) {
 		const uint8_t *src;
 		pre_valid = fast64_tile_src<C>(a, tile_g, src);
 		if (pre_valid) {
 			const uint8_t *p = src + (size_t)(16u * wave + (lane >> 4)) * a.pitch + (lane & 15u) * (4u * (uint32_t)C);
-			pre_p = p;
 #pragma unroll
 			for (int k = 0; k < 4; ++k) {
 				if constexpr (C == 4) {
@@ -165,7 +163,6 @@ __global__ void __launch_bounds__(256) shrink64_kernel(const Fast64Args a)
 			advance();
 			continue;
 		}
-		cur_p = pre_p;
 		// ---- stage: registers -> planar u16 pairs
 		// (every alpha byte is 255 iff the smallest of the 16 pixel dwords is >= 0xff000000: three-way minima)
 		uint32_t least = 0xffffffffu;
@@ -300,16 +297,34 @@ __global__ void __launch_bounds__(256) shrink64_kernel(const Fast64Args a)
 		}
 		uint8_t *dst = a.out_px + (size_t)this_tile * (64u * 64u * (uint32_t)C);
 		if (nw == 64u && nh == 64u) {
-			// clone (block.rs:279-281): the tile's own bytes, 16 (RGB: 12) per lane and step, straight from the frame to the slot
-			// (round 4: the rows are in L2 -- this block fetched them a few microseconds ago -- and a copy is 8 memory instructions
-			// where re-interleaving the LDS planes took 12 LDS reads and 32 byte permutes per lane)
+			// clone (block.rs:279-281): re-interleave this wave's 16 rows, 16 bytes per lane and step.  (Round 4 tried the copy straight
+			// from the frame rows instead -- 8 memory instructions for 12 LDS reads and 32 permutes per lane: no faster, and the rows
+			// are NOT in L2 any more by then: 0.68 GB more HBM traffic per 8 x 8K in shrink_by, where two thirds of the tiles are clones.)
 #pragma unroll
 			for (int k = 0; k < 4; ++k) {
-				const uint32_t row = 16u * wave + (lane >> 4) + 4u * (uint32_t)k, c4 = lane & 15u;
+				const uint32_t i = lane + 64u * (uint32_t)k;  // 256 groups of 4 pixels
+				const uint32_t row = 16u * wave + (i >> 4), c4 = i & 15u;
+				const uint32_t *p = s_pl + row * kRS64 + c4 * 2u;
+				const uint2 r = *reinterpret_cast<const uint2 *>(p), g = *reinterpret_cast<const uint2 *>(p + kPD64);
+				const uint2 b = *reinterpret_cast<const uint2 *>(p + 2 * kPD64);
+				uint2 al = make_uint2(0x00ff00ffu, 0x00ff00ffu);
+				if constexpr (ALPHA) al = *reinterpret_cast<const uint2 *>(p + 3 * kPD64);
+				const uint32_t rg01 = __builtin_amdgcn_perm(g.x, r.x, 0x06020400u), rg23 = __builtin_amdgcn_perm(g.y, r.y, 0x06020400u);
 				if constexpr (C == 4) {
-					reinterpret_cast<uint4 *>(dst)[row * 16u + c4] = *reinterpret_cast<const uint4 *>(cur_p + (size_t)(4 * k) * a.pitch);
+					const uint32_t ba01 = __builtin_amdgcn_perm(al.x, b.x, 0x06020400u), ba23 = __builtin_amdgcn_perm(al.y, b.y, 0x06020400u);
+					uint4 o;
+					o.x = __builtin_amdgcn_perm(ba01, rg01, 0x05040100u);
+					o.y = __builtin_amdgcn_perm(ba01, rg01, 0x07060302u);
+					o.z = __builtin_amdgcn_perm(ba23, rg23, 0x05040100u);
+					o.w = __builtin_amdgcn_perm(ba23, rg23, 0x07060302u);
+					reinterpret_cast<uint4 *>(dst)[row * 16u + c4] = o;
 				} else {
-					reinterpret_cast<uint3 *>(dst)[row * 16u + c4] = *reinterpret_cast<const uint3 *>(cur_p + (size_t)(4 * k) * a.pitch);
+					uint3 o;
+					o.x = __builtin_amdgcn_perm(b.x, rg01, 0x02040100u);                  // R0 G0 B0 R1
+					const uint32_t gb1 = __builtin_amdgcn_perm(b.x, rg01, 0x0c0c0603u);   // G1 B1 . .
+					o.y = __builtin_amdgcn_perm(rg23, gb1, 0x05040100u);                  // G1 B1 R2 G2
+					o.z = __builtin_amdgcn_perm(b.y, rg23, 0x06030204u);                  // B2 R3 G3 B3
+					reinterpret_cast<uint3 *>(dst)[row * 16u + c4] = o;
 				}
 			}
 			__syncthreads();

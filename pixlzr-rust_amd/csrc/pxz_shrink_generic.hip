@@ -567,6 +567,7 @@ __global__ void __launch_bounds__(NW == 1 ? 768 : 64 * NW) shrink_kernel(const S
 					if (a.stats) {  // steers the next launches' kernel choice and the size of this kernel's grid (pxz_api.cpp)
 						a.stats[0] = count_a;
 						a.stats[1] = count_b + count_a;
+						a.stats[2] = a.stats_sig;
 					}
 				}
 				if (threadIdx.x < kTicketCounters) a.work[2u + kTicketCounters * (a.work_slot ^ 1u) + threadIdx.x] = 0u;
@@ -611,6 +612,7 @@ __global__ void __launch_bounds__(NW == 1 ? 768 : 64 * NW) shrink_kernel(const S
 					if (a.stats) {
 						a.stats[0] = count_a;
 						a.stats[1] = count_b + count_a;
+						a.stats[2] = a.stats_sig;
 					}
 				}
 				if (threadIdx.x < kTicketCounters) a.work[2u + kTicketCounters * (a.work_slot ^ 1u) + threadIdx.x] = 0u;

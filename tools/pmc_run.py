@@ -44,7 +44,7 @@ elif variant == "exp":  # shrink once (directional, factor 16, Lanczos3), then e
     vals, ow, oh, slots = h.shrink_frames_device(frames, bs, bs, 1, 4, 16.0)
     out = h.expand_frames_device(tuple(frames.shape), bs, bs, flt, ow, oh, slots)
     for _ in range(n - 1): h.expand_frames_device(tuple(frames.shape), bs, bs, flt, ow, oh, slots, out=out)
-    info.update(step_kernels="expand_", setup_kernels="shrink,oklab",
+    info.update(step_kernels="expand", setup_kernels="shrink,oklab",
                 algo_bytes=int((ow.long() * oh.long()).sum().item()) * 4 + 8 * ow.numel() + frames.numel())
 elif variant.endswith("lod"):
     for _ in range(n): h.lod_frames_device(frames, bs, bs, mode, factor)
