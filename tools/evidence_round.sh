@@ -26,7 +26,7 @@ else
   BLOCK=64 bash $R/tools/sq_counters.sh ${TAG}_dir64 dir > /dev/null 2>&1
   FILTER=4 BLOCK=16 bash $R/tools/sq_counters.sh ${TAG}_exp16 exp > /dev/null 2>&1
   FILTER=4 BLOCK=64 bash $R/tools/sq_counters.sh ${TAG}_exp64 exp > /dev/null 2>&1
-  python3 tools/sq_summary.py $OUT/${TAG}_*_sq.txt > $OUT/${TAG}_sq_summary.json
+  python3 tools/sq_summary.py $OUT/${TAG}_*_sq.txt > $OUT/${TAG}_sq_summary.json  # (of THIS call only: gpurun_out does not travel -- run it again at home over all parts)
   echo "sq (c) done"
   python3 bench.py > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
   echo "bench done"
