@@ -1324,7 +1324,7 @@ static int expand_launch(pxz_handle *h, const pxz_frames *frames, uint32_t slot_
 	}
 	// 64x64 RGBA tiles in RGBA frames (the reference CLI's default block): expand64_kernel takes the full tiles stored at powers
 	// of two (clones, Nearest, the two-pass convolutions), expand_kernel the rest through the list
-	const bool fast64 = a.fast32 && bw == 64 && bh == 64 && slot_channels == 4 && frames->channels == 4 &&
+	const bool fast64 = a.fast32 && bw == 64 && bh == 64 && ((slot_channels == 4 && frames->channels == 4) || (slot_channels == 3 && frames->channels == 3)) &&
 	                    (p.filter == 0 || et->d_xmf64 != nullptr);
 	if (fast64) {
 		if ((rc = ensure(h, h->xlist, (size_t)a.n_tiles * 4u)) != PXZ_OK) return rc;

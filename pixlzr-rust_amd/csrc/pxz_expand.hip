@@ -489,11 +489,44 @@ __global__ void __launch_bounds__(1024) expand16_kernel(const ExpandArgs a)
 //   anything else (sizes a foreign file may hold, empty, ragged-edge tiles)
 //                                                        appended to the list expand_kernel takes in a second launch
 // ---------------------------------------------------------------------------
-constexpr uint32_t kX64Wave = 2048;  // dwords of LDS per wave: byte planes [c][max(th, 8)][max(tw, 16)] / staged pixels of Nearest (<= 64 x 32)
+// dwords of LDS per wave.  RGBA: byte planes [c][max(th, 8)][max(tw, 16)] / staged pixels of Nearest (<= 64 x 32).  RGB (C = 3, round 4:
+// what image::open yields for most photographs): three planes, and 1024 dwords through which a quadrant's pixels are turned round
+// so that a lane writes four adjacent ones as twelve bytes
+constexpr uint32_t kX64Wave = 2048, kX64Wave3 = 1536 + 1024;
 
-template <int NBLK>
+// One 32x32 quadrant of a 64x64 tile, first column col0 and first row row0: lane (n, g) holds column n of the rows xmf_row(g, r).
+// RGBA: 16 dword stores per lane (half-waves cover 128-byte row segments).  RGB: through s_out.
+template <int C>
+__device__ __forceinline__ void x64_store_quadrant(const ExpandArgs &a, const uint32_t (&pix)[16], uint32_t lane, uint32_t col0, uint32_t row0,
+                                                   uint8_t *dst, uint32_t *s_out)
+{
+	const uint32_t n = lane & 31u, g = lane >> 5;
+	if constexpr (C == 4) {
+		uint8_t *lane_dst = dst + (size_t)(row0 + 4u * g) * a.pitch + 4u * (col0 + n);
+#pragma unroll
+		for (uint32_t r = 0; r < 16; ++r)
+			__builtin_nontemporal_store(pix[r], reinterpret_cast<uint32_t *>(lane_dst + (size_t)xmf_row(0, r) * a.pitch));
+	} else {
+#pragma unroll
+		for (uint32_t r = 0; r < 16; ++r) s_out[(xmf_row(0, r) + 4u * g) * 32u + n] = pix[r];
+		tile_sync<1>();
+		typedef uint32_t u32_a1 __attribute__((aligned(1)));
+#pragma unroll
+		for (uint32_t k = 0; k < 4; ++k) {
+			const uint32_t i = lane + 64u * k, row = i >> 3, q = i & 7u;
+			const uint4 v = *reinterpret_cast<const uint4 *>(s_out + row * 32u + 4u * q);
+			u32_a1 *o = reinterpret_cast<u32_a1 *>(dst + (size_t)(row0 + row) * a.pitch + 3u * (col0 + 4u * q));
+			o[0] = (v.x & 0xffffffu) | (v.y << 24);
+			o[1] = ((v.y >> 8) & 0xffffu) | (v.z << 16);
+			o[2] = ((v.z >> 16) & 0xffu) | (v.w << 8);
+		}
+		tile_sync<1>();  // the next quadrant reuses s_out
+	}
+}
+
+template <int NBLK, int C>
 __device__ __forceinline__ void expand64_conv(const ExpandArgs &a, const uint32_t *s_xmf, const uint8_t *s_pl, uint32_t lane, uint32_t lw,
-                                              uint32_t lh, uint32_t P, uint8_t *dst)
+                                              uint32_t lh, uint32_t P, uint8_t *dst, uint32_t *s_out)
 {
 	constexpr uint32_t KSY = NBLK == 4 ? 2u : 1u;                          // steps of 16 stored rows
 	constexpr uint32_t LTHP = NBLK == 1 ? 3u : (NBLK == 2 ? 4u : 5u);     // log2 of the rows a channel plane holds
@@ -530,6 +563,7 @@ __device__ __forceinline__ void expand64_conv(const ExpandArgs &a, const uint32_
 			for (uint32_t st = 0; st < KSY; ++st) T[c][st][0] = T[c][st][1] = 0u;
 #pragma unroll
 		for (uint32_t b = 0; b < (uint32_t)NBLK; ++b) {
+			if (C == 3 && NBLK == 4 && b == 3u) continue;  // (RGB: no fourth channel)
 			const uint32_t G = 32u * b + n, c = G >> LTHP, y = G & ((1u << LTHP) - 1u);  // row n of this block: channel c, stored row y
 			const uint32_t *row = reinterpret_cast<const uint32_t *>(s_pl + c * plane + y * P + 4u * g);
 			v16i32 lo, hi = zero;  // (the bias: sixteen moves per block, not sixteen registers held across the tile)
@@ -549,7 +583,7 @@ __device__ __forceinline__ void expand64_conv(const ExpandArgs &a, const uint32_
 				const uint32_t q4 = r >> 2;  // four accumulator registers = rows 8 q4 + 4 g + j of the block
 				const uint32_t cc = NBLK == 1 ? q4 : (NBLK == 2 ? 2u * b + (q4 >> 1) : b);
 				const uint32_t st = NBLK == 4 ? q4 >> 1 : 0u, h = NBLK == 1 ? 0u : q4 & 1u;
-				put_byte(T[cc][st][h], r & 3u, clamp_fixed(hi[r], lo[r], top_x), px_);
+				if (cc < (uint32_t)C) put_byte(T[cc][st][h], r & 3u, clamp_fixed(hi[r], lo[r], top_x), px_);
 			}
 		}
 		// ---- vertical: the two 32x32 quadrants of this column half
@@ -567,7 +601,7 @@ __device__ __forceinline__ void expand64_conv(const ExpandArgs &a, const uint32_
 #pragma unroll
 			for (int r = 0; r < 16; ++r) pix[r] = 0;
 #pragma unroll
-			for (uint32_t c = 0; c < 4; ++c) {
+			for (uint32_t c = 0; c < (uint32_t)C; ++c) {
 				v16i32 lo, hi = zero;  // (the biases: four LDS reads per channel, not sixteen registers held across the quadrant)
 #pragma unroll
 				for (int q = 0; q < 4; ++q) {
@@ -583,18 +617,17 @@ __device__ __forceinline__ void expand64_conv(const ExpandArgs &a, const uint32_
 #pragma unroll
 				for (uint32_t r = 0; r < 16; ++r) put_byte(pix[r], c, clamp_fixed(hi[r], lo[r], top_y), py);
 			}
-			// un-premultiplying is the identity at alpha 255: skipped when no lane of the wave holds anything else
-			uint32_t alpha_and = 0xffffffffu;
+			if constexpr (C == 4) {
+				// un-premultiplying is the identity at alpha 255: skipped when no lane of the wave holds anything else
+				uint32_t alpha_and = 0xffffffffu;
 #pragma unroll
-			for (int r = 0; r < 16; ++r) alpha_and &= pix[r];
-			if (__builtin_amdgcn_ballot_w64((alpha_and >> 24) != 255u) != 0ull) {
+				for (int r = 0; r < 16; ++r) alpha_and &= pix[r];
+				if (__builtin_amdgcn_ballot_w64((alpha_and >> 24) != 255u) != 0ull) {
 #pragma unroll
-				for (int r = 0; r < 16; ++r) pix[r] = unpremultiply(pix[r]);
+					for (int r = 0; r < 16; ++r) pix[r] = unpremultiply(pix[r]);
+				}
 			}
-			uint8_t *lane_dst = dst + (size_t)(32u * qy + 4u * g) * a.pitch + 4u * (32u * qx + n);
-#pragma unroll
-			for (uint32_t r = 0; r < 16; ++r)
-				__builtin_nontemporal_store(pix[r], reinterpret_cast<uint32_t *>(lane_dst + (size_t)xmf_row(0, r) * a.pitch));
+			x64_store_quadrant<C>(a, pix, lane, 32u * qx, 32u * qy, dst, s_out);
 		}
 	}
 }
@@ -602,9 +635,9 @@ __device__ __forceinline__ void expand64_conv(const ExpandArgs &a, const uint32_
 // The one-pass classes of a 64x64 tile (fir resizes an axis only where its size changes, block.rs:292-322).
 // Width kept (stored 64 x th, th <= 32): the vertical product alone; its B operand -- four stored rows of a column as bytes -- is
 // gathered from the premultiplied planes [c][th][64].
-template <int KSY>
+template <int KSY, int C>
 __device__ __forceinline__ void expand64_vonly(const ExpandArgs &a, const uint32_t *s_xmf, const uint8_t *s_pl, uint32_t lane, uint32_t lh,
-                                               uint32_t plane, uint8_t *dst)
+                                               uint32_t plane, uint8_t *dst, uint32_t *s_out)
 {
 	const uint32_t n = lane & 31u, g = lane >> 5;
 	const uint32_t *my = s_xmf + lh * kXmf64Dw;
@@ -623,7 +656,7 @@ __device__ __forceinline__ void expand64_vonly(const ExpandArgs &a, const uint32
 	for (uint32_t qx = 0; qx < 2; ++qx) {
 		uint32_t T[4][KSY][2];
 #pragma unroll
-		for (uint32_t c = 0; c < 4; ++c)
+		for (uint32_t c = 0; c < (uint32_t)C; ++c)
 #pragma unroll
 			for (uint32_t st = 0; st < (uint32_t)KSY; ++st)
 #pragma unroll
@@ -645,7 +678,7 @@ __device__ __forceinline__ void expand64_vonly(const ExpandArgs &a, const uint32
 #pragma unroll
 			for (int r = 0; r < 16; ++r) pix[r] = 0;
 #pragma unroll
-			for (uint32_t c = 0; c < 4; ++c) {
+			for (uint32_t c = 0; c < (uint32_t)C; ++c) {
 				v16i32 lo, hi = zero;
 #pragma unroll
 				for (int q = 0; q < 4; ++q) {
@@ -661,25 +694,26 @@ __device__ __forceinline__ void expand64_vonly(const ExpandArgs &a, const uint32
 #pragma unroll
 				for (uint32_t r = 0; r < 16; ++r) put_byte(pix[r], c, clamp_fixed(hi[r], lo[r], top_y), py);
 			}
-			uint32_t alpha_and = 0xffffffffu;
+			if constexpr (C == 4) {
+				// un-premultiplying is the identity at alpha 255: skipped when no lane of the wave holds anything else
+				uint32_t alpha_and = 0xffffffffu;
 #pragma unroll
-			for (int r = 0; r < 16; ++r) alpha_and &= pix[r];
-			if (__builtin_amdgcn_ballot_w64((alpha_and >> 24) != 255u) != 0ull) {
+				for (int r = 0; r < 16; ++r) alpha_and &= pix[r];
+				if (__builtin_amdgcn_ballot_w64((alpha_and >> 24) != 255u) != 0ull) {
 #pragma unroll
-				for (int r = 0; r < 16; ++r) pix[r] = unpremultiply(pix[r]);
+					for (int r = 0; r < 16; ++r) pix[r] = unpremultiply(pix[r]);
+				}
 			}
-			uint8_t *lane_dst = dst + (size_t)(32u * qy + 4u * g) * a.pitch + 4u * (32u * qx + n);
-#pragma unroll
-			for (uint32_t r = 0; r < 16; ++r)
-				__builtin_nontemporal_store(pix[r], reinterpret_cast<uint32_t *>(lane_dst + (size_t)xmf_row(0, r) * a.pitch));
+			x64_store_quadrant<C>(a, pix, lane, 32u * qx, 32u * qy, dst, s_out);
 		}
 	}
 }
 
 // Height kept (stored tw x 64, tw <= 32): the horizontal product alone, planes [c][64][P]; a block of rows is 32 output rows of
 // one channel, the four channels of a (column half, row half) make its pixels.
+template <int C>
 __device__ __forceinline__ void expand64_honly(const ExpandArgs &a, const uint32_t *s_xmf, const uint8_t *s_pl, uint32_t lane, uint32_t lw,
-                                               uint32_t P, uint8_t *dst)
+                                               uint32_t P, uint8_t *dst, uint32_t *s_out)
 {
 	const uint32_t n = lane & 31u, g = lane >> 5;
 	const uint32_t *mx = s_xmf + lw * kXmf64Dw;
@@ -712,7 +746,7 @@ __device__ __forceinline__ void expand64_honly(const ExpandArgs &a, const uint32
 #pragma unroll
 			for (int r = 0; r < 16; ++r) pix[r] = 0;
 #pragma unroll
-			for (uint32_t c = 0; c < 4; ++c) {
+			for (uint32_t c = 0; c < (uint32_t)C; ++c) {
 				const uint32_t *row = reinterpret_cast<const uint32_t *>(s_pl + c * plane + (32u * yb + n) * P + 4u * g);
 				v16i32 lo, hi = zero;
 #pragma unroll
@@ -729,45 +763,57 @@ __device__ __forceinline__ void expand64_honly(const ExpandArgs &a, const uint32
 #pragma unroll
 				for (uint32_t r = 0; r < 16; ++r) put_byte(pix[r], c, clamp_fixed(hi[r], lo[r], top_x), px_);
 			}
-			uint32_t alpha_and = 0xffffffffu;
+			if constexpr (C == 4) {
+				// un-premultiplying is the identity at alpha 255: skipped when no lane of the wave holds anything else
+				uint32_t alpha_and = 0xffffffffu;
 #pragma unroll
-			for (int r = 0; r < 16; ++r) alpha_and &= pix[r];
-			if (__builtin_amdgcn_ballot_w64((alpha_and >> 24) != 255u) != 0ull) {
+				for (int r = 0; r < 16; ++r) alpha_and &= pix[r];
+				if (__builtin_amdgcn_ballot_w64((alpha_and >> 24) != 255u) != 0ull) {
 #pragma unroll
-				for (int r = 0; r < 16; ++r) pix[r] = unpremultiply(pix[r]);
+					for (int r = 0; r < 16; ++r) pix[r] = unpremultiply(pix[r]);
+				}
 			}
-			uint8_t *lane_dst = dst + (size_t)(32u * yb + 4u * g) * a.pitch + 4u * (32u * qx + n);
-#pragma unroll
-			for (uint32_t r = 0; r < 16; ++r)
-				__builtin_nontemporal_store(pix[r], reinterpret_cast<uint32_t *>(lane_dst + (size_t)xmf_row(0, r) * a.pitch));
+			x64_store_quadrant<C>(a, pix, lane, 32u * qx, 32u * yb, dst, s_out);
 		}
 	}
 }
 
+// C = 3 (round 4): RGB tiles into RGB frames -- 3-byte pixels in (a lane's four as twelve bytes), three planes, no premultiplication
+// (fir's U8x3), the quadrants written through LDS as twelve bytes per lane (x64_store_quadrant).
+template <int C>
 __global__ void __launch_bounds__(1024) expand64_kernel(const ExpandArgs a)
 {
 	extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+	constexpr uint32_t kWave = C == 4 ? kX64Wave : kX64Wave3;
 	const uint32_t wpb = blockDim.x / 64u, sub = threadIdx.x / 64u, lane = threadIdx.x % 64u;
 	const uint32_t xmf_dw = a.xmf64 ? kXmf64Levels * kXmf64Dw : 0u;
 	for (uint32_t i = threadIdx.x; i < xmf_dw / 4u; i += blockDim.x)
 		reinterpret_cast<uint4 *>(lds)[i] = reinterpret_cast<const uint4 *>(a.xmf64)[i];
 	const uint32_t *s_xmf = lds;
-	uint32_t *s_ticket = lds + xmf_dw + wpb * kX64Wave;
+	uint32_t *s_ticket = lds + xmf_dw + wpb * kWave;
 	if (threadIdx.x == 0) *s_ticket = wpb;
 	__syncthreads();
-	uint32_t *s_wave = lds + xmf_dw + sub * kX64Wave;
+	uint32_t *s_wave = lds + xmf_dw + sub * kWave;
+	uint32_t *s_out = s_wave + 1536;  // (C = 3 only)
 	auto tile_of = [&](uint32_t tk) -> uint32_t {
 		const unsigned long long tl = (unsigned long long)blockIdx.x + (unsigned long long)tk * gridDim.x;
 		return tl < (unsigned long long)a.n_tiles ? (uint32_t)tl : 0xffffffffu;
+	};
+	typedef uint32_t u32_a1 __attribute__((aligned(1)));
+	typedef uint32_t u32q __attribute__((ext_vector_type(4), aligned(4)));   // (frame rows and slots: dword aligned)
+	typedef uint32_t u32q_a1 __attribute__((ext_vector_type(4), aligned(1)));  // (RGB frame rows: any byte address)
+	// pixel i of a slot as a dword (RGB: alpha 255; the slot is 12 288 bytes, i < 2048 here: the dword at 3 i lies inside it)
+	auto slot_px = [&](const uint8_t *src, uint32_t i) -> uint32_t {
+		if constexpr (C == 4) return reinterpret_cast<const uint32_t *>(src)[i];
+		else return (*reinterpret_cast<const u32_a1 *>(src + 3u * i) & 0x00ffffffu) | 0xff000000u;
 	};
 	uint32_t p_tw = 0, p_th = 0, p_px = 0;
 	auto prefetch = [&](uint32_t tn) {
 		if (tn == 0xffffffffu) return;
 		p_tw = a.tile_w[tn];
 		p_th = a.tile_h[tn];
-		p_px = reinterpret_cast<const uint32_t *>(a.slots + (size_t)tn * a.slot_bytes)[lane];
+		p_px = slot_px(a.slots + (size_t)tn * a.slot_bytes, lane);
 	};
-	typedef uint32_t u32q __attribute__((ext_vector_type(4), aligned(4)));  // (frame rows and slots: dword aligned)
 	uint32_t t = tile_of(sub);
 	prefetch(t);
 	while (t != 0xffffffffu) {
@@ -784,24 +830,30 @@ __global__ void __launch_bounds__(1024) expand64_kernel(const ExpandArgs a)
 		const bool near = full && pow2 && !clone && a.filter == 0u;  // (one axis may be 64: at most 64 x 32 stored pixels)
 		const bool conv = full && pow2 && !clone && a.filter != 0u && xmf_dw != 0u;  // (two passes, or one when an axis is stored at 64)
 		const uint8_t *src = a.slots + (size_t)t * a.slot_bytes;
-		uint8_t *dst = a.dst + (size_t)frame * a.frame_stride + (size_t)(ty * 64u) * a.pitch + (size_t)(tx * 64u) * 4u;
+		uint8_t *dst = a.dst + (size_t)frame * a.frame_stride + (size_t)(ty * 64u) * a.pitch + (size_t)(tx * 64u) * (uint32_t)C;
 		if (clone) {
-			// requested before the next tile's prefetch (loads come back in order), four 16-byte moves in flight
+			// the slot's own bytes (block.rs:279-281) in 16-byte pieces, 16 (RGB: 12) per row; requested before the next tile's prefetch
+			// (loads come back in order), four moves in flight
+			constexpr uint32_t kPerRow = 4u * (uint32_t)C, kRounds = kPerRow;  // 64 rows x kPerRow pieces = 64 lanes x kRounds
+			auto piece_dst = [&](uint32_t c) -> uint8_t * {
+				const uint32_t row = C == 4 ? c >> 4 : small_div(c, 12u);
+				return dst + (size_t)row * a.pitch + 16u * (c - row * kPerRow);
+			};
 			u32q v[4];
 #pragma unroll
 			for (uint32_t k = 0; k < 4; ++k) v[k] = __builtin_nontemporal_load(reinterpret_cast<const u32q *>(src) + 64u * k + lane);
 			prefetch(t_next);
 #pragma unroll 1
-			for (uint32_t k0 = 0; k0 < 16u; k0 += 4u) {
-				u32q w[4];
-				if (k0 + 4u < 16u) {
+			for (uint32_t k0 = 0; k0 < kRounds; k0 += 4u) {
+				u32q w[4] = {v[0], v[1], v[2], v[3]};
+				if (k0 + 4u < kRounds) {
 #pragma unroll
 					for (uint32_t k = 0; k < 4; ++k) w[k] = __builtin_nontemporal_load(reinterpret_cast<const u32q *>(src) + 64u * (k0 + 4u + k) + lane);
 				}
 #pragma unroll
 				for (uint32_t k = 0; k < 4; ++k) {
-					const uint32_t c = 64u * (k0 + k) + lane;  // 16-byte chunk c of the tile: row c / 16, columns 4 (c % 16) ..
-					__builtin_nontemporal_store(v[k], reinterpret_cast<u32q *>(dst + (size_t)(c >> 4) * a.pitch + 16u * (c & 15u)));
+					const u32q_a1 o = {v[k].x, v[k].y, v[k].z, v[k].w};
+					__builtin_nontemporal_store(o, reinterpret_cast<u32q_a1 *>(piece_dst(64u * (k0 + k) + lane)));
 				}
 #pragma unroll
 				for (uint32_t k = 0; k < 4; ++k) v[k] = w[k];
@@ -810,44 +862,65 @@ __global__ void __launch_bounds__(1024) expand64_kernel(const ExpandArgs a)
 			prefetch(t_next);
 			const uint32_t lw = 31u - (uint32_t)__builtin_clz(tw), sx = 6u - lw, sy = 6u - (31u - (uint32_t)__builtin_clz(th));
 			const uint32_t npx = tw * th;
-			for (uint32_t i = lane; i < npx; i += 64u) s_wave[i] = i == lane ? first_px : reinterpret_cast<const uint32_t *>(src)[i];
+			for (uint32_t i = lane; i < npx; i += 64u) s_wave[i] = i == lane ? first_px : slot_px(src, i);
 			tile_sync<1>();
 			const uint32_t q = lane & 15u, x = 4u * q;
 #pragma unroll 4
 			for (uint32_t k = 0; k < 16; ++k) {
 				const uint32_t oy = 4u * k + (lane >> 4);
 				const uint32_t *row = s_wave + ((oy >> sy) << lw);
-				const u32q w = {row[x >> sx], row[(x + 1u) >> sx], row[(x + 2u) >> sx], row[(x + 3u) >> sx]};
-				__builtin_nontemporal_store(w, reinterpret_cast<u32q *>(dst + (size_t)oy * a.pitch + 16u * q));
+				const uint32_t v0 = row[x >> sx], v1 = row[(x + 1u) >> sx], v2 = row[(x + 2u) >> sx], v3 = row[(x + 3u) >> sx];
+				if constexpr (C == 4) {
+					const u32q_a1 w = {v0, v1, v2, v3};
+					__builtin_nontemporal_store(w, reinterpret_cast<u32q_a1 *>(dst + (size_t)oy * a.pitch + 16u * q));
+				} else {
+					u32_a1 *o = reinterpret_cast<u32_a1 *>(dst + (size_t)oy * a.pitch + 12u * q);
+					o[0] = (v0 & 0xffffffu) | (v1 << 24);
+					o[1] = ((v1 >> 8) & 0xffffu) | (v2 << 16);
+					o[2] = ((v2 >> 16) & 0xffu) | (v3 << 8);
+				}
 			}
 			tile_sync<1>();
 		} else if (conv) {
-			// ---- stored pixels -> premultiplied byte planes [c][max(th, 8)][P], P = max(tw, 16)
+			// ---- stored pixels -> (RGBA: premultiplied) byte planes [c][max(th, 8)][P], P = max(tw, 16)
 			const uint32_t lw = 31u - (uint32_t)__builtin_clz(tw), lh = 31u - (uint32_t)__builtin_clz(th);
 			const uint32_t P = tw < 16u ? 16u : tw, plane = P * (th < 8u ? 8u : th);  // (<= 2 KB: at most 64 x 32 or 32 x 64 stored pixels)
 			uint8_t *s_pl = reinterpret_cast<uint8_t *>(s_wave);
 			const uint32_t npx = tw * th;
 			if (tw < 4u || npx <= 64u) {
 				for (uint32_t i = lane; i < npx; i += 64u) {
-					uint32_t px = i == lane ? first_px : reinterpret_cast<const uint32_t *>(src)[i];
-					if (__builtin_amdgcn_ballot_w64((px >> 24) != 255u) != 0ull) px = premultiply(px);  // fir: U8x4 is alpha-premultiplied before a convolution
+					uint32_t px = i == lane ? first_px : slot_px(src, i);
+					if constexpr (C == 4) {
+						if (__builtin_amdgcn_ballot_w64((px >> 24) != 255u) != 0ull) px = premultiply(px);  // fir: U8x4 is alpha-premultiplied before a convolution
+					}
 					uint8_t *d = s_pl + (i >> lw) * P + (i & (tw - 1u));
 					d[0] = (uint8_t)px;
 					d[plane] = (uint8_t)(px >> 8);
 					d[2u * plane] = (uint8_t)(px >> 16);
-					d[3u * plane] = (uint8_t)(px >> 24);
+					if constexpr (C == 4) d[3u * plane] = (uint8_t)(px >> 24);
 				}
 			} else {
 				// four adjacent pixels (one row: tw >= 4) per lane and round, a dword per channel
 				for (uint32_t i4 = lane; i4 < (npx >> 2); i4 += 64u) {
-					const u32q v = __builtin_nontemporal_load(reinterpret_cast<const u32q *>(src) + i4);
-					uint32_t p0 = v.x, p1 = v.y, p2 = v.z, p3 = v.w;
-					if (__builtin_amdgcn_ballot_w64(((p0 & p1 & p2 & p3) >> 24) != 255u) != 0ull) {
-						p0 = premultiply(p0); p1 = premultiply(p1); p2 = premultiply(p2); p3 = premultiply(p3);
+					uint32_t p0, p1, p2, p3;
+					if constexpr (C == 4) {
+						const u32q v = __builtin_nontemporal_load(reinterpret_cast<const u32q *>(src) + i4);
+						p0 = v.x; p1 = v.y; p2 = v.z; p3 = v.w;
+						if (__builtin_amdgcn_ballot_w64(((p0 & p1 & p2 & p3) >> 24) != 255u) != 0ull) {
+							p0 = premultiply(p0); p1 = premultiply(p1); p2 = premultiply(p2); p3 = premultiply(p3);
+						}
+					} else {
+						// (twelve bytes at 12 i4 -- a three-element vector type is sixteen bytes wide: no pointer arithmetic on it)
+						const uint32_t *q3 = reinterpret_cast<const uint32_t *>(src + 12u * i4);
+						const uint32_t vx = q3[0], vy = q3[1], vz = q3[2];  // R0 G0 B0 R1 | G1 B1 R2 G2 | B2 R3 G3 B3
+						p0 = vx;
+						p1 = __builtin_amdgcn_alignbit(vy, vx, 24);
+						p2 = __builtin_amdgcn_alignbit(vz, vy, 16);
+						p3 = vz >> 8;
 					}
 					uint8_t *d = s_pl + ((4u * i4) >> lw) * P + ((4u * i4) & (tw - 1u));
 #pragma unroll
-					for (uint32_t c = 0; c < 4; ++c) {
+					for (uint32_t c = 0; c < (uint32_t)C; ++c) {
 						const uint32_t sel = c | ((4u + c) << 8) | 0x0c0c0000u;
 						const uint32_t lo2 = __builtin_amdgcn_perm(p1, p0, sel), hi2 = __builtin_amdgcn_perm(p3, p2, sel);
 						*reinterpret_cast<uint32_t *>(d + c * plane) = lo2 | (hi2 << 16);
@@ -857,16 +930,16 @@ __global__ void __launch_bounds__(1024) expand64_kernel(const ExpandArgs a)
 			prefetch(t_next);
 			tile_sync<1>();
 			if (tw == 64u) {
-				if (th <= 16u) expand64_vonly<1>(a, s_xmf, s_pl, lane, lh, plane, dst);
-				else expand64_vonly<2>(a, s_xmf, s_pl, lane, lh, plane, dst);
+				if (th <= 16u) expand64_vonly<1, C>(a, s_xmf, s_pl, lane, lh, plane, dst, s_out);
+				else expand64_vonly<2, C>(a, s_xmf, s_pl, lane, lh, plane, dst, s_out);
 			} else if (th == 64u) {
-				expand64_honly(a, s_xmf, s_pl, lane, lw, P, dst);
+				expand64_honly<C>(a, s_xmf, s_pl, lane, lw, P, dst, s_out);
 			} else if (th <= 8u) {
-				expand64_conv<1>(a, s_xmf, s_pl, lane, lw, lh, P, dst);
+				expand64_conv<1, C>(a, s_xmf, s_pl, lane, lw, lh, P, dst, s_out);
 			} else if (th == 16u) {
-				expand64_conv<2>(a, s_xmf, s_pl, lane, lw, lh, P, dst);
+				expand64_conv<2, C>(a, s_xmf, s_pl, lane, lw, lh, P, dst, s_out);
 			} else {
-				expand64_conv<4>(a, s_xmf, s_pl, lane, lw, lh, P, dst);
+				expand64_conv<4, C>(a, s_xmf, s_pl, lane, lw, lh, P, dst, s_out);
 			}
 			tile_sync<1>();  // the next tile restages the planes
 		} else {
@@ -1317,13 +1390,15 @@ hipError_t launch_expand(const ExpandArgs &a, uint32_t n_cus, hipStream_t stream
 	if (a.list != nullptr && a.bw == 64u) {
 		// 64x64 RGBA tiles: one wave per full tile stored at powers of two, then what that left through the list
 		const uint32_t xmf_bytes = a.xmf64 ? kXmf64Levels * kXmf64Dw * 4u : 0u;
-		uint32_t wpb = (160u * 1024u - 16u - xmf_bytes) / (kX64Wave * 4u);
+		const uint32_t wave_bytes = (a.channels == 4 ? kX64Wave : kX64Wave3) * 4u;
+		uint32_t wpb = (160u * 1024u - 16u - xmf_bytes) / wave_bytes;
 		if (wpb > 16u) wpb = 16u;
-		const uint32_t lds_bytes = xmf_bytes + wpb * kX64Wave * 4u + 16u;
+		const uint32_t lds_bytes = xmf_bytes + wpb * wave_bytes + 16u;
 		const uint32_t need = (a.n_tiles + wpb - 1u) / wpb;
-		hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(expand64_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+		void (*k64)(const ExpandArgs) = a.channels == 4 ? expand64_kernel<4> : expand64_kernel<3>;
+		hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k64), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
 		if (e != hipSuccess) return e;
-		hipLaunchKernelGGL(expand64_kernel, dim3(need < n_cus ? need : n_cus), dim3(64u * wpb), lds_bytes, stream, a);
+		hipLaunchKernelGGL(k64, dim3(need < n_cus ? need : n_cus), dim3(64u * wpb), lds_bytes, stream, a);
 		if ((e = hipGetLastError()) != hipSuccess) return e;
 		ExpandArgs b = a;
 		b.list_mode = 1u;
@@ -1382,6 +1457,10 @@ hipError_t launch_expand_general(const ExpandArgs &a, uint32_t n_cus, hipStream_
 		hipLaunchKernelGGL(k, dim3(blocks), dim3(64u * wpb), lds_bytes, stream, a);
 	} else if (a.channels == 4) {
 		auto k = expand_kernel<4>;
+		if (lds_bytes > 64u * 1024u && (e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)) != hipSuccess) return e;
+		hipLaunchKernelGGL(k, dim3(blocks), dim3(64u * wpb), lds_bytes, stream, a);
+	} else if (a.list_mode) {
+		auto k = expand_kernel<3, false, false, true>;
 		if (lds_bytes > 64u * 1024u && (e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)) != hipSuccess) return e;
 		hipLaunchKernelGGL(k, dim3(blocks), dim3(64u * wpb), lds_bytes, stream, a);
 	} else {

@@ -542,6 +542,40 @@ def test_expand_of_power_of_two_tiles(gpu, oracle, filt, block):
         raise AssertionError(f"filter {filt} block {block}: {int(bad.sum())} pixels differ, tiles {[(t, int(tw[t]), int(th[t])) for t in t_bad[:8]]}")
 
 
+@pytest.mark.parametrize("filt", [0, 1, 2, 3, 4])
+def test_expand_of_power_of_two_rgb_tiles_64(gpu, oracle, filt):
+    """RGB tiles of 64x64 (what image::open yields for most photographs, at the reference CLI's default block) stored at every
+    combination of 1 .. 64 and a few odd sizes, into an RGB frame whose width is not a multiple of 4 pixels beyond the last full
+    tile (rows at any byte alignment): expand64_kernel<3> -- three planes, no premultiplication, twelve-byte stores -- and the
+    general form for the ragged column, against the oracle's PixlzrBlock::resize with U8x3 (block.rs:273-334)."""
+    rng = np.random.default_rng(90 + filt)
+    sizes = [1, 2, 4, 8, 16, 32, 64]
+    pairs = [(a, b) for a in sizes for b in sizes] * 2 + [(3, 8), (63, 32), (32, 33), (12, 12)]
+    pairs = [pairs[i] for i in rng.permutation(len(pairs))]
+    cols, rows = 8, (len(pairs) + 6) // 7
+    edge = 7  # the last column of tiles is 7 px wide
+    W, H = (cols - 1) * 64 + edge, rows * 64
+    n = cols * rows
+    tw = np.ones(n, np.uint32); th = np.ones(n, np.uint32)
+    slots = np.zeros((n, 64 * 64 * 3), np.uint8)
+    k = 0
+    for t in range(n):
+        fw = 64 if t % cols < cols - 1 else edge
+        w, h = pairs[k % len(pairs)]
+        if fw == 64: k += 1
+        w = min(w, fw)
+        tw[t], th[t] = w, h
+        px = rng.integers(0, 256, (h * w, 3), dtype=np.uint8)
+        if t % 7 == 0: px[:] = rng.choice(np.array([0, 255], np.uint8), (h * w, 3))  # extremes: the clamps
+        slots[t, : h * w * 3] = px.ravel()
+    exp = oracle.expand_image(W, H, 64, 64, 3, filt, tw, th, slots)
+    got = gpu.expand_image(W, H, 3, 64, 64, filt, tw, th, slots)
+    bad = (got != exp).any(axis=2)
+    if bad.any():
+        t_bad = sorted({int((y // 64) * cols + x // 64) for y, x in zip(*np.nonzero(bad))})
+        raise AssertionError(f"filter {filt}: {int(bad.sum())} pixels differ, tiles {[(t, int(tw[t]), int(th[t])) for t in t_bad[:8]]}")
+
+
 @pytest.mark.parametrize("filt", [0, 4])
 def test_expand_into_rows_at_any_alignment(gpu, oracle, filt):
     """A frame 289 px wide: its rows start 4 (mod 16) bytes apart, so the 16-byte moves of the 32x32 fast paths (full-size
