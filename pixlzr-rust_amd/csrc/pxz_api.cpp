@@ -737,6 +737,7 @@ int prepare(pxz_handle *h, const pxz_frames *f, const pxz_params *p, bool want_p
 	a->scale2 = 10.0f;  // BASE_FACTOR, pixlzr.rs:15
 	a->alpha_kernel = (p->reserved & PXZ_HINT_TRANSPARENCY) != 0 && !pxz::knobs().no_alpha_kernel;
 	a->list_a_too = 0;
+	a->clone_ahead = 0;
 	a->finish_scan = 1;
 	a->stats = nullptr;
 	a->slot_bytes = bw * bh * f->channels;
@@ -770,9 +771,13 @@ int timed_launch(pxz_handle *h, pxz::ShrinkArgs &a, uint32_t channels, float *va
 	if (rc != PXZ_OK) return rc;
 	a.sums = (uint32_t *)h->sums.ptr;
 	const void *work_before = h->work.ptr;
-	if ((rc = ensure(h, h->work, (2u * (size_t)a.n_tiles + pxz::kWorkList + 4u) * 4u + 64u + 4608u * 8u)) != PXZ_OK) return rc;  // + diagnostic stamps (8 phase sums + 256 blocks x 17 qwords)
+	const size_t work_bytes = (2u * (size_t)a.n_tiles + pxz::kWorkList + 4u) * 4u + 64u + 4608u * 8u;  // + diagnostic stamps (8 phase sums + 256 blocks x 17 qwords)
+	// + the 2 KB spare bytes of the detector's copies (ahead_spare) + the list of clone_split64_kernel (8 + n_tiles dwords)
+	if ((rc = ensure(h, h->work, work_bytes + 2048u + 8u + (8u + (size_t)a.n_tiles) * 4u)) != PXZ_OK) return rc;
 	if (h->work.ptr != work_before) h->work_ready = false;
 	a.work = (uint32_t *)h->work.ptr;
+	a.ahead_spare = reinterpret_cast<uint32_t *>(static_cast<uint8_t *>(h->work.ptr) + ((work_bytes + 7u) & ~(size_t)7u));
+	a.clone_list = a.ahead_spare + 512u;
 	a.value = value;
 	a.lod0 = lod0;
 	a.lod1 = lod1;
@@ -880,6 +885,9 @@ int timed_launch(pxz_handle *h, pxz::ShrinkArgs &a, uint32_t channels, float *va
 			a.ok_scratch = (float *)h->okscratch.ptr;
 		}
 		a.oklab_given = 1;
+		// (round 4) the square detectors copy every tile into its slot while they have its pixels: the shrink kernel then
+		// skips the tiles that are stored at full size instead of reading them a second time
+		a.clone_ahead = square_fast && a.out_px != nullptr && !pxz::knobs().oklab_v1 && !pxz::knobs().no_clone_ahead ? 1u : 0u;
 		PXZ_HIP(h, pxz::launch_oklab(a, h->n_cus, h->stream));
 		if (a.mid_event) {
 			PXZ_HIP(h, hipEventRecord(static_cast<hipEvent_t>(a.mid_event), h->stream));

@@ -964,11 +964,11 @@ __device__ __forceinline__ bool fast32_tile_src(const Args &a, uint32_t tile_g, 
 // Issues the four loads of a lane's share of a fast tile: rows l/8 + 8k, pixel quad l%8 -- 16 bytes of an RGBA row, 12
 // of an RGB one (pre[k].w unused).
 template <int C = 4, class Args>
-__device__ __forceinline__ void fast32_prefetch(const Args &a, uint32_t tile_g, uint32_t lane, uint4 (&pre)[4], bool &valid)
+__device__ __forceinline__ void fast32_prefetch(const Args &a, uint32_t tile_g, uint32_t lane, uint4 (&pre)[4], bool &valid, bool skip_loads = false)
 {
 	const uint8_t *src;
 	valid = fast32_tile_src<C>(a, tile_g, src);
-	if (valid) {
+	if (valid && !skip_loads) {  // (skip_loads: the caller knows it will not look at the pixels -- a tile the detector already copied)
 		const uint8_t *p = src + (size_t)(lane >> 3) * a.pitch + (lane & 7u) * (4u * (uint32_t)C);
 #pragma unroll
 		for (int k = 0; k < 4; ++k) {

@@ -78,6 +78,10 @@ struct ShrinkArgs {
 	                         //   row (bw x edge_h), 3 the corner tile (edge_w x edge_h)
 	uint32_t ok_count;       //   and how many items it enumerates (region 0: n_tiles)
 	uint32_t ok_edges;       // consumers: edge regions whose values are in sums[] already (bit 0 right, 1 bottom, 2 corner)
+	uint32_t clone_ahead;    // shrink_by, square RGBA tiles (round 4): oklab2_kernel copies every tile it converts into its slot as if it
+	                         //   were stored at full size; the fast kernels behind it do not read such tiles again (PXZ_NO_CLONE_AHEAD=1: 0)
+	uint32_t *clone_list;    //   64x64: room for the list of the tiles that are NOT stored at full size (8 + n_tiles dwords; clone_split64_kernel)
+	uint32_t *ahead_spare;   //   2 KB nobody reads: where that kernel's copy of a band goes when there is no tile behind it
 	float *ok_scratch;       // Oklab detector on 64x64 tiles: 16 floats per pixel quad between its passes (HBM)
 	const uint32_t *mf64;    // 64x64 fast path: matrix-core operand tables (global memory), see Fast64Args
 	uint32_t ok_rows;        // tile rows the block-cooperative Oklab detector takes: full_rows, plus the ragged last row
@@ -152,6 +156,7 @@ struct Fast32Args {
 	uint32_t all_tiles;      // shrink32a_kernel: every tile of the batch (not list A): the launch that skips shrink32_kernel
 	uint32_t narrow;         // shrink32_kernel: 4/2/1-px-wide outputs take resample_mfma32_narrow (0: PXZ_NO_NARROW=1, the round-1 forms)
 	uint32_t group16;        // shrink16_kernel: the two-pass tiles of a group go through resample_group16_mfma (0: PXZ_NO_GROUP16=1)
+	uint32_t clone_ahead;    // MODE 0: tiles stored at full size are in their slots already (ShrinkArgs::clone_ahead)
 	float factor;            //   with these, as the worklist kernel's scan over all tiles would
 	float *value, *lod0, *lod1;
 	uint32_t breaks[kMaxLevel];
@@ -177,6 +182,8 @@ struct Fast64Args {
 	uint8_t *out_px;
 	uint32_t *work;
 	uint32_t work_slot;
+	uint32_t clone_ahead;    // MODE 0: tiles stored at full size are in their slots already (ShrinkArgs::clone_ahead)
+	uint32_t *clone_list;    //   and, when not null, finished: [0] = how many tiles are left, [8 ..] = which (clone_split64_kernel)
 	uint32_t all_tiles;      // ALPHA instance: every tile of the batch (not list A): the launch that skips the opaque instance
 	const uint32_t *mf64;
 	uint32_t mf_off[kMaxLevel];      // dword offset of the level's table in mf64 (0: none; the blob starts with a pad)
@@ -202,6 +209,7 @@ struct Knobs {
 	bool no_narrow;         // PXZ_NO_NARROW: 4/2/1-px-wide outputs of 32x32 tiles keep the round-1 resample forms
 	bool no_big_tiles;      // PXZ_NO_BIG_TILES: tiles whose image exceeds LDS are refused (PXZ_ERR_UNSUPPORTED), as before round 4
 	bool no_group16;        // PXZ_NO_GROUP16: the two-pass tiles of a 16x16 group keep their own dot2 resamples (no block-diagonal matrix-core products)
+	bool no_clone_ahead;    // PXZ_NO_CLONE_AHEAD: shrink_by's detector does not copy tiles into their slots ahead of the value (round-3 flow: the shrink kernel reads every tile again)
 	bool oklab_v1;          // PXZ_OKLAB_V1: round-1 detector (one chain wave, two barriers per band; 64-px tiles parked in HBM)
 	bool no_expand_fast32;    // PXZ_NO_EXPAND_FAST32: expand_kernel keeps its general forms for 32x32 RGBA tiles (no matrix-core convolutions, no shift-indexed Nearest)
 	bool tree_rects;        // PXZ_TREE_RECTS: tree::process always goes over rectangle lists (pxz_tree.hip), also where the per-level grids apply

@@ -474,9 +474,11 @@ __device__ __forceinline__ void quad_chain_add16(float &sum, float e0, float e1,
 
 // C = 3 (round 2): RGB frames read directly -- a lane's two pixels are six bytes inside an aligned eight (rows are 4-byte
 // aligned), cut out with two funnel shifts; there is no alpha (the plane is the constant 1).
-template <int T, int C = 4>
+// AHEAD (round 4, RGBA): every band is also stored where the tile's pixels go if the tile is stored at full size -- see the producers.
+template <int T, int C = 4, bool AHEAD = false>
 __global__ void __launch_bounds__(1024) oklab2_kernel(const ShrinkArgs a)
 {
+	static_assert(!AHEAD || C == 4, "the copy is of RGBA pixel pairs");
 	using Geo = Ok2Geom<T>;
 	constexpr uint32_t G = Geo::G, NB = Geo::NB, kProd = Geo::kProd, kTiles = Geo::kTiles;
 	constexpr uint32_t kLanesPerRow = Geo::kLanesPerRow, kRowsPerBand = Geo::kRowsPerBand;
@@ -491,7 +493,11 @@ __global__ void __launch_bounds__(1024) oklab2_kernel(const ShrinkArgs a)
 	float *s_mean = reinterpret_cast<float *>(s_scale + 128);
 	float *s_p1 = s_mean + 64;                  // [2][kBand]: converted values, pass 1
 	float *s_p2 = s_p1 + 2 * kBand;             // [3][kBand]: the same values of the batch before, pass 2
-	const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+	// (the wave number as a scalar: roles, tiles, source and slot addresses and every condition on them are then the scalar unit's
+	// business -- left as a function of threadIdx the compiler takes them to differ between the lanes of a wave)
+	// (T = 64 keeps the plain form: its detector came out 9 % SLOWER with the scalar one, 1.10 against 1.01 ms -- its chain waves set
+	// the pace, and their code is laid out differently behind scalar role branches)
+	const uint32_t wave = G == 1u ? (uint32_t)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : threadIdx.x >> 6, lane = threadIdx.x & 63u;
 	oklab_fill_tables(s_lms, s_alpha, s_scale, threadIdx.x);
 	__syncthreads();
 
@@ -528,15 +534,33 @@ __global__ void __launch_bounds__(1024) oklab2_kernel(const ShrinkArgs a)
 		const uint32_t rgb_off = (lane % kLanesPerRow) * 6u, rgb_shift = (rgb_off & 3u) * 8u;
 		const size_t lane_off = (size_t)(lane / kLanesPerRow + part * kRowsPerBand) * a.pitch + (C == 4 ? (lane % kLanesPerRow) * 8u : (rgb_off & ~3u));
 		const size_t band_step = (size_t)(G * kRowsPerBand) * a.pitch;  // from a producer's band k to its band k + 1
+		// clone_ahead (round 4, RGBA): every band is also stored, as it is, where the tile's pixels go if the tile is stored at full
+		// size (block.rs:279-281) -- the slot's rows are the tile's rows back to back, a band is 512 consecutive bytes of it, a lane's
+		// two pixels 8 of those.  Whether the tile IS stored whole is known two periods later; the shrink kernel behind this one then
+		// leaves such tiles alone instead of reading them a second time.  This kernel is bound by its arithmetic: the stores ride
+		// under it.
+		const uint32_t dst_lane_off = part * 512u + lane * 8u;
+		// (the slots as SCALAR addresses -- a tile is a matter of the wave -- so that a copy is one store with a scalar base, the lane's
+		// offset and an immediate: as per-lane pointers every store cost a 64-bit add and two selects)
+		unsigned long long dst0 = 0, dst1 = 0;  // slot of the tile in conversion / the next one
 		auto batch_src = [&](uint32_t j, uint32_t &bands) -> const uint8_t * {
 			const uint8_t *src;
 			bands = 0;
+			if constexpr (AHEAD) {
+				// (in front of the conditions below, which the compiler takes to differ between lanes: set behind them the address
+				// would live in vector registers; the item number IS the tile's number in this launch, whether the tile is taken or not)
+				const unsigned long long d = reinterpret_cast<unsigned long long>(a.out_px) +
+				                             (unsigned long long)((blockIdx.x + j * gridDim.x) * kTiles + pslot) * a.slot_bytes;
+				// (the builtin returns a signed int: the low half must not be sign-extended into the high one)
+				dst1 = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(d >> 32)) << 32) |
+				       (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)d);
+			}
 			if (j >= own) return nullptr;
-			uint32_t unused_tile;
-			const uint32_t th = oklab_tile_src<T, C>(a, (blockIdx.x + j * gridDim.x) * kTiles + pslot, src, unused_tile);
+			uint32_t tile_g;
+			const uint32_t th = oklab_tile_src<T, C>(a, (blockIdx.x + j * gridDim.x) * kTiles + pslot, src, tile_g);
 			if (th == 0) return nullptr;
 			bands = th / (G * kRowsPerBand);  // (a ragged tile is only taken when its height is a multiple of 8 rows)
-			return src + lane_off;
+			return src;  // (the tile's first byte, a scalar; a lane adds lane_off where it loads)
 		};
 		uint32_t nb0 = 0, nb1 = 0, nb_prev = 0;
 		const uint8_t *src0 = nullptr, *src1 = batch_src(0, nb1);
@@ -547,7 +571,14 @@ __global__ void __launch_bounds__(1024) oklab2_kernel(const ShrinkArgs a)
 			const uint32_t bo = ahead_of_k0 / NB, band = ahead_of_k0 % NB;
 			const uint8_t *base = bo == 0 ? s_a : s_b;
 			const uint32_t nbb = bo == 0 ? n_a : n_b;
-			if (base && band < nbb) dst = *reinterpret_cast<const uint2 *>(base + (size_t)band * band_step);
+			if constexpr (AHEAD) {
+				// (no branch around a memory instruction in this loop: behind one the compiler waits for EVERYTHING in flight, and the
+				// copies below must stay in flight across two intervals.  A band nobody converts reads the frame's first rows.)
+				const uint8_t *from = base && band < nbb ? base + (size_t)band * band_step : a.src;
+				dst = *reinterpret_cast<const uint2 *>(from + lane_off);
+			} else {
+				if (base && band < nbb) dst = *reinterpret_cast<const uint2 *>(base + (size_t)band * band_step + lane_off);
+			}
 		};
 		request(0, src1, nb1, nullptr, 0, q[0]);
 		request(1, src1, nb1, nullptr, 0, q[1]);
@@ -583,6 +614,21 @@ __global__ void __launch_bounds__(1024) oklab2_kernel(const ShrinkArgs a)
 		bool st_opaque = true;  // and its alpha: all 255 (wave-uniform)?
 		uint32_t st_ab = 0;     //   the two alpha bytes of this lane
 		bool st_valid = false;
+		// (the copy of a band is issued BEHIND the request of the band after next: loads and stores share one in-order counter, a store
+		// takes longer than an interval to be acknowledged, and in front of that load it made every wait for the load a wait for the
+		// store -- detector 0.87 -> 1.04-1.10 ms; behind it the wait leaves one operation in flight: s_waitcnt vmcnt(1))
+		auto copy_band = [&](const uint2 &px, unsigned long long band_of_slot) {
+			if constexpr (AHEAD) {
+				// (a band that is not converted -- past the last batch, a tile the detector leaves to the generic kernel -- goes to spare bytes)
+				// (G = 4: the flag is a lane mask there -- one lane's copy of it)
+				const bool v = G == 1u ? st_valid : __builtin_amdgcn_readfirstlane((uint32_t)st_valid) != 0u;
+				const unsigned long long base = v ? band_of_slot : reinterpret_cast<unsigned long long>(a.ahead_spare);
+				// (an address the compiler knows to be global: made from an integer it is generic, and the store a flat_store.  A plain
+				// store: marked non-temporal it cost the kernel 0.03 ms more -- experiment builds, detector 0.924 against 0.897 ms)
+				typedef __attribute__((address_space(1))) unsigned long long *global_qword;
+				*(global_qword)(base + dst_lane_off) = *reinterpret_cast<const unsigned long long *>(&px);
+			}
+		};
 		auto head = [&](bool valid, const uint2 &px) {
 			st_valid = valid;
 			if (valid) {
@@ -599,8 +645,10 @@ __global__ void __launch_bounds__(1024) oklab2_kernel(const ShrinkArgs a)
 			}
 		};
 		head(src1 != nullptr && nb1 > 0u, q[0]);
+		copy_band(q[0], dst1);
 		for (uint32_t p = 0; p < periods; ++p) {
 			src0 = src1;
+			dst0 = dst1;
 			nb_prev = nb0;
 			nb0 = nb1;
 			src1 = batch_src(p + 1u, nb1);
@@ -641,6 +689,7 @@ __global__ void __launch_bounds__(1024) oklab2_kernel(const ShrinkArgs a)
 				else head(src1 != nullptr && nb1 > 0u, q[0]);
 				// (after the head: the wait for its pixels is a wait for every load in flight)
 				request(k + 2u, src0, nb0, src1, nb1, q[k & 1u]);
+				copy_band(q[(k + 1u) & 1u], k + 1u < NB ? dst0 + (k + 1u) * (G * 512u) : dst1);
 				g3 = g3 == 2u ? 0u : g3 + 1u;
 				__syncthreads();
 			}
@@ -826,6 +875,7 @@ hipError_t launch_oklab(const ShrinkArgs &a, uint32_t n_cus, hipStream_t stream,
 			return hipGetLastError();
 		};
 		if (channels == 3) return a.bw == 16u ? go2(oklab2_kernel<16, 3>) : (a.bw == 32u ? go2(oklab2_kernel<32, 3>) : go2(oklab2_kernel<64, 3>));
+		if (a.clone_ahead) return a.bw == 16u ? go2(oklab2_kernel<16, 4, true>) : (a.bw == 32u ? go2(oklab2_kernel<32, 4, true>) : go2(oklab2_kernel<64, 4, true>));
 		return a.bw == 16u ? go2(oklab2_kernel<16>) : (a.bw == 32u ? go2(oklab2_kernel<32>) : go2(oklab2_kernel<64>));
 	}
 	if (channels == 3 && a.bw == 64u && a.bh == 64u && a.ok_region == 0u) return go(oklab_kernel<64, 0, 3>);

@@ -64,7 +64,25 @@ __global__ void __launch_bounds__(1024) shrink32_kernel(const Fast32Args a)
 	uint4 pre[4];
 	bool pre_valid = false;
 	const uint32_t first = tile_of_ticket(__builtin_amdgcn_readfirstlane(sub));
-	fast32_prefetch<C>(a, first, tid, pre, pre_valid);
+	// MODE 0 (round 4): the values travel TWO tiles ahead of the pixels.  With clone_ahead the detector has already copied every
+	// tile into its slot as if it were stored at full size (oklab2_kernel: the pixels pass through its producers' registers
+	// anyway, and it runs under an idle memory system); a tile whose value says so is finished -- it is not read a second time.
+	bool pre_skipped = false;       // the current tile's loads were left out: it is one of those
+	uint32_t vb_cur = 0, vb_next = 0;  // value bits of the current / the next tile
+	auto value_bits_of = [&](uint32_t t) -> uint32_t { return t < a.n_tiles ? a.sums[2u * t] : 0u; };
+	auto stored_whole = [&](uint32_t vb) -> bool {
+		return a.clone_ahead && level_of(__float_as_uint(parse_value(__uint_as_float(vb)))) == 0u;
+	};
+	uint32_t second = 0xffffffffu;
+	if constexpr (MODE == 0) {
+		second = next_ticket();
+		vb_cur = __builtin_amdgcn_readfirstlane(value_bits_of(first));  // (scalars from here on)
+		vb_next = __builtin_amdgcn_readfirstlane(value_bits_of(second));
+		pre_skipped = stored_whole(vb_cur);
+		fast32_prefetch<C>(a, first, tid, pre, pre_valid, pre_skipped);
+	} else {
+		fast32_prefetch<C>(a, first, tid, pre, pre_valid);
+	}
 #ifdef PXZ_STAMPS
 	unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 	unsigned long long st_last = stamp_now();
@@ -133,6 +151,14 @@ __global__ void __launch_bounds__(1024) shrink32_kernel(const Fast32Args a)
 		pend_kind = 0;
 	};
 	auto one_tile = [&](const uint32_t tile_g, const uint32_t tile_next) {
+		auto prefetch_next = [&]() __attribute__((always_inline)) {
+			if constexpr (MODE == 0) {
+				pre_skipped = stored_whole(vb_next);
+				fast32_prefetch<C>(a, tile_next, tid, pre, pre_valid, pre_skipped);
+			} else {
+				fast32_prefetch<C>(a, tile_next, tid, pre, pre_valid);
+			}
+		};
 		auto defer = [&]() {
 			list_push(s_batch, n_listb, tile_g, a.work + kWorkList, a.work + a.work_slot, tid);
 			if (tid == 0) {
@@ -148,17 +174,20 @@ __global__ void __launch_bounds__(1024) shrink32_kernel(const Fast32Args a)
 		if (!pre_valid) {  // ragged edge / unaligned rows: generic kernel
 			flush();
 			defer();
-			fast32_prefetch<C>(a, tile_next, tid, pre, pre_valid);
+			prefetch_next();
 			return;
 		}
 		uint32_t given_bits = 0;
-		if constexpr (MODE == 0) given_bits = a.sums[2 * tile_g];  // issued before the prefetch: its wait leaves the prefetch in flight
+		if constexpr (MODE == 0) given_bits = vb_cur;
+		// (MODE 0) stored at full size, and the detector has put it there (block.rs:279-281: a clone, whatever its alpha): nothing was
+		// requested, nothing is staged; the tile only passes the two points where the pipeline moves on
+		const bool skipped = MODE == 0 && pre_skipped;
 		// ---- wait for the prefetched registers (the opacity test is their first use), then emit the
 		// previous tile's parked pixels, then stage: registers -> planar u16 pairs
 		// every alpha byte is 255 iff the smallest of the 16 pixel dwords is >= 0xff000000 (alpha is the top byte): eight
 		// three-way minima instead of sixteen ANDs and a shift
 		bool transparent = false;
-		if constexpr (C == 4) {
+		if (C == 4 && !skipped) {
 			uint32_t least;
 			const uint32_t m0 = min(min(pre[0].x, pre[0].y), pre[0].z), m1 = min(min(pre[0].w, pre[1].x), pre[1].y);
 			const uint32_t m2 = min(min(pre[1].z, pre[1].w), pre[2].x), m3 = min(min(pre[2].y, pre[2].z), pre[2].w);
@@ -169,6 +198,7 @@ __global__ void __launch_bounds__(1024) shrink32_kernel(const Fast32Args a)
 		__builtin_amdgcn_sched_barrier(0);
 		flush();
 		__builtin_amdgcn_sched_barrier(0);
+		if (!skipped) {
 #pragma unroll
 		for (int k = 0; k < 4; ++k) {
 			const uint32_t row = (tid >> 3) + 8u * (uint32_t)k, col = tid & 7u;
@@ -190,8 +220,18 @@ __global__ void __launch_bounds__(1024) shrink32_kernel(const Fast32Args a)
 				lds_store2(d + 2 * kPD32, make_uint2(__builtin_amdgcn_perm(v.y, v.x, 0x0c050c02u), __builtin_amdgcn_perm(v.z, v.z, 0x0c070c00u)));
 			}
 		}
+		}
 		PXZ_STAMP(0);  // wait for the prefetched pixels + staging
-		fast32_prefetch<C>(a, tile_next, tid, pre, pre_valid);  // lands while this tile is processed
+		prefetch_next();  // lands while this tile is processed
+		if (skipped) {
+			uint32_t lane = tid;
+			asm volatile("" : "+v"(lane));
+			if (lane == 0) {
+				if (FULL || a.out_w) a.out_w[tile_g] = 32u;
+				if (FULL || a.out_h) a.out_h[tile_g] = 32u;
+			}
+			return;
+		}
 		if (transparent && (FULL || a.out_px != nullptr)) {
 			// transparency: the premultiplied convolution needs the alpha plane -- shrink32a_kernel (list A) when the
 			// caller announced transparent frames, else the generic kernel (list B).  (Detector-only launches do not
@@ -275,8 +315,7 @@ __global__ void __launch_bounds__(1024) shrink32_kernel(const Fast32Args a)
 			key0 = sum_hz;
 			key1 = sum_vr;
 		} else {
-			const uint32_t vb = __builtin_amdgcn_readfirstlane(given_bits);
-			m0 = m1 = level_of(__float_as_uint(parse_value(__uint_as_float(vb))));
+			m0 = m1 = level_of(__float_as_uint(parse_value(__uint_as_float(given_bits))));
 		}
 		const uint32_t nw = reduced_size(32u, m0), nh = reduced_size(32u, m1);
 		{
@@ -351,13 +390,23 @@ __global__ void __launch_bounds__(1024) shrink32_kernel(const Fast32Args a)
 #ifdef PXZ_STAMPS
 	uint32_t st_tiles = 0;
 #endif
-	for (uint32_t tile_g = first; tile_g < a.n_tiles;) {
+	for (uint32_t tile_g = first, tile_next = second; tile_g < a.n_tiles;) {
 #ifdef PXZ_STAMPS
 		++st_tiles;
 #endif
-		const uint32_t tile_next = next_ticket();
-		one_tile(tile_g, tile_next);
-		tile_g = tile_next;
+		if constexpr (MODE == 0) {
+			const uint32_t tile_after = next_ticket();
+			const uint32_t vb_after = value_bits_of(tile_after);  // needed at the next tile's prefetch: a whole tile's time away
+			one_tile(tile_g, tile_next);
+			tile_g = tile_next;
+			tile_next = tile_after;
+			vb_cur = vb_next;
+			vb_next = __builtin_amdgcn_readfirstlane(vb_after);
+		} else {
+			tile_next = next_ticket();
+			one_tile(tile_g, tile_next);
+			tile_g = tile_next;
+		}
 	}
 #ifdef PXZ_STAMPS
 	unsigned long long st_loop_end;
@@ -536,8 +585,7 @@ __global__ void __launch_bounds__(1024) shrink32a_kernel(const Fast32Args a)
 			m1 = level_of(sum_vr);
 			if (tid == 0) reinterpret_cast<uint2 *>(a.sums)[tile_g] = make_uint2(sum_hz, sum_vr);
 		} else {
-			const uint32_t vb = __builtin_amdgcn_readfirstlane(given_bits);
-			m0 = m1 = level_of(__float_as_uint(parse_value(__uint_as_float(vb))));
+			m0 = m1 = level_of(__float_as_uint(parse_value(__uint_as_float(given_bits))));
 		}
 		const uint32_t nw = reduced_size(32u, m0), nh = reduced_size(32u, m1);
 		const bool one_pass = (nw == 32u) != (nh == 32u) && a.filter != 0;
@@ -676,10 +724,27 @@ __global__ void __launch_bounds__(1024) shrink16_kernel(const Fast32Args a)
 	};
 	uint4 pre[4];
 	bool pre_valid = false;
-	auto prefetch = [&](uint32_t grp) {
+	// MODE 0 with clone_ahead (round 4): oklab2_kernel<16> has copied every tile into its slot as if it were stored at full size.  A
+	// tile whose value says it is keeps that copy (no clone here); a group of four such tiles is not even read.  The values of the
+	// NEXT group's tiles are requested as soon as the group is known (the top of an iteration) and decide its prefetch in mid-iteration;
+	// they then are that group's `given` values.
+	bool pre_skipped = false;
+	uint32_t gv[4] = {0, 0, 0, 0}, gvn[4] = {0, 0, 0, 0};
+	auto stored_whole = [&](uint32_t vb) -> bool {
+		return level_of(__float_as_uint(parse_value(__uint_as_float(__builtin_amdgcn_readfirstlane(vb))))) == 0u;
+	};
+	auto request_values = [&](uint32_t grp, uint32_t (&v)[4]) {
+		const Place p = place_of(grp);
+		if (p.full) {
+			const uint32_t t00 = p.frame * a.tiles_per_frame + (2u * p.gy) * a.cols + 2u * p.gx;
+#pragma unroll
+			for (uint32_t k = 0; k < 4; ++k) v[k] = a.sums[2u * (t00 + (k & 1u) + (k >> 1) * a.cols)];
+		}
+	};
+	auto prefetch = [&](uint32_t grp, bool skip_loads = false) {
 		const Place p = place_of(grp);
 		pre_valid = p.full;
-		if (pre_valid) {
+		if (pre_valid && !skip_loads) {
 			const uint8_t *q = p.src + (size_t)(tid >> 3) * a.pitch + (tid & 7u) * (4u * (uint32_t)C);
 #pragma unroll
 			for (int k = 0; k < 4; ++k) {
@@ -693,9 +758,30 @@ __global__ void __launch_bounds__(1024) shrink16_kernel(const Fast32Args a)
 		}
 	};
 	const uint32_t first = group_of_ticket(__builtin_amdgcn_readfirstlane(sub));
-	prefetch(first);
+	if constexpr (MODE == 0) {
+		request_values(first, gv);
+		pre_skipped = a.clone_ahead && place_of(first).full && stored_whole(gv[0]) && stored_whole(gv[1]) && stored_whole(gv[2]) && stored_whole(gv[3]);
+	}
+	prefetch(first, pre_skipped);
 	for (uint32_t grp = first; grp < a.n_groups;) {
 		const uint32_t grp_next = next_ticket();
+		if constexpr (MODE == 0) request_values(grp_next, gvn);
+		auto prefetch_next = [&]() __attribute__((always_inline)) {
+			if constexpr (MODE == 0) {
+				pre_skipped = a.clone_ahead && place_of(grp_next).full && stored_whole(gvn[0]) && stored_whole(gvn[1]) && stored_whole(gvn[2]) && stored_whole(gvn[3]);
+				prefetch(grp_next, pre_skipped);
+			} else {
+				prefetch(grp_next);
+			}
+		};
+		auto advance = [&]() __attribute__((always_inline)) {
+			grp = grp_next;
+			if constexpr (MODE == 0) {
+#pragma unroll
+				for (int k = 0; k < 4; ++k) gv[k] = gvn[k];
+			}
+		};
+		const bool skipped = MODE == 0 && pre_skipped;  // (this group's loads were left out)
 		const Place pl = place_of(grp);
 		// tile ids of the group: t(dx, dy) = frame * tiles_per_frame + (2 gy + dy) * cols + 2 gx + dx
 		const uint32_t t00 = pl.frame * a.tiles_per_frame + (2u * pl.gy) * a.cols + 2u * pl.gx;
@@ -717,14 +803,27 @@ __global__ void __launch_bounds__(1024) shrink16_kernel(const Fast32Args a)
 #pragma unroll
 			for (uint32_t k = 0; k < 4; ++k)
 				if (2u * pl.gx + (k & 1u) < a.cols && 2u * pl.gy + (k >> 1) < a.rows) defer_tile(tile_id(k));
-			prefetch(grp_next);
-			grp = grp_next;
+			prefetch_next();
+			advance();
+			continue;
+		}
+		if (skipped) {
+			// all four tiles are stored at full size, and the detector has put them there (block.rs:279-281: clones, whatever their alpha)
+			prefetch_next();
+			uint32_t lane = tid;
+			asm volatile("" : "+v"(lane));
+			if (lane < 4u) {
+				const uint32_t t = t00 + (lane & 1u) + (lane >> 1) * a.cols;
+				if (FULL || a.out_w) a.out_w[t] = 16u;
+				if (FULL || a.out_h) a.out_h[t] = 16u;
+			}
+			advance();
 			continue;
 		}
 		uint32_t given[4] = {0, 0, 0, 0};
 		if constexpr (MODE == 0) {
 #pragma unroll
-			for (uint32_t k = 0; k < 4; ++k) given[k] = a.sums[2 * tile_id(k)];
+			for (uint32_t k = 0; k < 4; ++k) given[k] = gv[k];
 		}
 		// ---- stage: registers -> planar u16 pairs (as shrink32_kernel)
 		// every alpha byte is 255 iff the smallest of the 16 pixel dwords is >= 0xff000000 (alpha is the top byte): eight
@@ -758,12 +857,12 @@ __global__ void __launch_bounds__(1024) shrink16_kernel(const Fast32Args a)
 				lds_store2(d + 2 * kPD32, make_uint2(__builtin_amdgcn_perm(v.y, v.x, 0x0c050c02u), __builtin_amdgcn_perm(v.z, v.z, 0x0c070c00u)));
 			}
 		}
-		prefetch(grp_next);
+		prefetch_next();
 		if (transparent) {
 			// (one transparent tile sends the whole group: the generic kernel has the alpha plane)
 #pragma unroll
 			for (uint32_t k = 0; k < 4; ++k) defer_tile(tile_id(k));
-			grp = grp_next;
+			advance();
 			continue;
 		}
 		tile_sync<1>();
@@ -858,6 +957,7 @@ __global__ void __launch_bounds__(1024) shrink16_kernel(const Fast32Args a)
 			uint32_t *dst = reinterpret_cast<uint32_t *>(a.out_px + (size_t)t * (256u * (uint32_t)C));
 			const uint32_t *tile_pl = s_pl + (16u * (k >> 1)) * kRS32 + 8u * (k & 1u);  // first pixel pair of the tile
 			if (nw == 16u && nh == 16u) {
+				if (MODE == 0 && a.clone_ahead) continue;  // (the detector's copy is in the slot)
 				// clone (block.rs:279-281): 64 groups of 4 pixels, one per lane
 				const uint32_t row = tid >> 2, c4 = tid & 3u;
 				const uint32_t *p = tile_pl + row * kRS32 + c4 * 2u;
@@ -939,7 +1039,7 @@ __global__ void __launch_bounds__(1024) shrink16_kernel(const Fast32Args a)
 			resample_group16_mfma<C>(s_tab, v_tx, v_ty, v_tyo, s_pl, tid, v_nw, v_nh, v_ok, v_dst);
 		}
 		tile_sync<1>();  // the next group reuses this wave's LDS image
-		grp = grp_next;
+		advance();
 	}
 	list_flush(s_batch, n_listb, a.work + kWorkList, a.work + a.work_slot, tid);
 	if (a.finish_here) {
@@ -998,6 +1098,7 @@ hipError_t launch_fast32_16(const ShrinkArgs &a, ShrinkArgs &ga, uint32_t channe
 	f.finish_here = 1u;
 	f.narrow = knobs().no_narrow ? 0u : 1u;
 	f.group16 = knobs().no_group16 ? 0u : 1u;
+	f.clone_ahead = a.mode == 0 ? a.clone_ahead : 0u;
 	f.factor = a.factor;
 	f.value = a.value;
 	f.lod0 = a.lod0;

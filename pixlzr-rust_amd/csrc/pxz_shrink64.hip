@@ -85,10 +85,19 @@ __global__ void __launch_bounds__(256) shrink64_kernel(const Fast64Args a)
 	// this lane's share of a tile: rows 16w + (lane >> 4) + 4k, 16 bytes at column quad lane & 15
 	uint4 pre[4];
 	bool pre_valid = false;
-	auto prefetch = [&](uint32_t tile_g) {
+	// MODE 0 with clone_ahead (round 4): oklab2_kernel<64> has copied every tile into its slot as if it were stored at full size; a
+	// tile whose value says it is (two thirds of them in shrink_by) is finished without being read again.  The value of the
+	// tile after this one is requested as soon as that tile is known, an iteration before its pixels would be.
+	bool pre_skipped = false;          // the current tile's loads were left out (block-uniform)
+	uint32_t vb_cur = 0, vb_next = 0;  // value bits of the current tile / the next one
+	auto value_bits_of = [&](uint32_t t) -> uint32_t { return t < a.n_tiles ? a.sums[2u * t] : 0u; };
+	auto stored_whole = [&](uint32_t vb) -> bool {
+		return a.clone_ahead && level_of(__float_as_uint(parse_value(__uint_as_float(__builtin_amdgcn_readfirstlane(vb))))) == 0u;
+	};
+	auto prefetch = [&](uint32_t tile_g, bool skip_loads = false) {
 		const uint8_t *src;
 		pre_valid = fast64_tile_src<C>(a, tile_g, src);
-		if (pre_valid) {
+		if (pre_valid && !skip_loads) {
 			const uint8_t *p = src + (size_t)(16u * wave + (lane >> 4)) * a.pitch + (lane & 15u) * (4u * (uint32_t)C);
 #pragma unroll
 			for (int k = 0; k < 4; ++k) {
@@ -113,7 +122,9 @@ __global__ void __launch_bounds__(256) shrink64_kernel(const Fast64Args a)
 	uint32_t *ctr = a.work + 2u + kTicketCounters * a.work_slot + cid;
 	// (ALPHA with all_tiles, round 2: every tile of the batch -- the launch that skips the opaque instance because most
 	// tiles of the last launch had transparency; an opaque tile comes out of the four-plane arithmetic unchanged)
-	const uint32_t n_items = (ALPHA && !a.all_tiles) ? a.work[kWorkA + a.work_slot] : a.n_tiles;
+	// (MODE 0 with a list, round 4: the tiles clone_split64_kernel left -- every tile that is NOT stored at full size)
+	const bool listed = !ALPHA && MODE == 0 && a.clone_list != nullptr;
+	const uint32_t n_items = (ALPHA && !a.all_tiles) ? a.work[kWorkA + a.work_slot] : (listed ? a.clone_list[0] : a.n_tiles);
 	uint32_t n_transparent = 0;  // all_tiles: what the list counter would have said (thread 0 counts)
 	auto tile_of = [&](uint32_t k) -> uint32_t {
 		const unsigned long long t = (unsigned long long)k * n_ctr + cid;
@@ -121,10 +132,16 @@ __global__ void __launch_bounds__(256) shrink64_kernel(const Fast64Args a)
 		if constexpr (ALPHA) {
 			if (!a.all_tiles) return a.work[kWorkList + a.n_tiles + (uint32_t)t];
 		}
+		if (listed) return a.clone_list[8u + (uint32_t)t];
 		return (uint32_t)t;
 	};
 	uint32_t tile_g = tile_of(blockIdx.x / n_ctr), tile_next = tile_of(blockIdx.x / n_ctr + nb_c);
-	prefetch(tile_g);
+	if constexpr (MODE == 0 && !ALPHA) {
+		vb_cur = value_bits_of(tile_g);
+		vb_next = value_bits_of(tile_next);
+		pre_skipped = stored_whole(vb_cur);
+	}
+	prefetch(tile_g, pre_skipped);
 	// detector-only launches: equal cost per tile, and an iteration is shorter than an atomic's round trip:
 	// there the "tickets" are simply this block's turn in a fixed rotation
 	const bool dynamic = !ALPHA && (FULL || a.out_px != nullptr);
@@ -141,6 +158,18 @@ __global__ void __launch_bounds__(256) shrink64_kernel(const Fast64Args a)
 		auto advance = [&]() {  // after the barrier that followed publish_ticket()
 			tile_g = tile_next;
 			tile_next = tile_of(2u * nb_c + s_red[13]);
+			if constexpr (MODE == 0 && !ALPHA) {
+				vb_cur = vb_next;
+				vb_next = value_bits_of(tile_next);
+			}
+		};
+		auto prefetch_next = [&]() {
+			if constexpr (MODE == 0 && !ALPHA) {
+				pre_skipped = stored_whole(vb_next);
+				prefetch(tile_next, pre_skipped);
+			} else {
+				prefetch(tile_next);
+			}
 		};
 		auto defer = [&]() {
 			// (block-uniform; only wave 0's lanes 0..15 ever touch the batch)
@@ -157,7 +186,24 @@ __global__ void __launch_bounds__(256) shrink64_kernel(const Fast64Args a)
 		};
 		if (!pre_valid) {  // ragged edge / unaligned batch (block-uniform)
 			defer();
-			prefetch(tile_next);
+			prefetch_next();
+			publish_ticket();
+			__syncthreads();
+			advance();
+			continue;
+		}
+		if (MODE == 0 && !ALPHA && pre_skipped) {
+			// stored at full size, and the detector has put it there (block.rs:279-281: a clone, whatever its alpha)
+			const uint32_t vb = __builtin_amdgcn_readfirstlane(vb_cur);
+			if (threadIdx.x == 0) {
+				if (FULL || a.out_w) a.out_w[tile_g] = 64u;
+				if (FULL || a.out_h) a.out_h[tile_g] = 64u;
+				if (a.finish_here) {
+					if (n_fin < kFin64) s_fin[n_fin++] = tile_g;
+					else finish_tile(make_uint2(vb, vb), 64u, 64u, (uint32_t)MODE, a.factor, a.value, a.lod0, a.lod1, tile_g);
+				}
+			}
+			prefetch_next();
 			publish_ticket();
 			__syncthreads();
 			advance();
@@ -195,7 +241,7 @@ __global__ void __launch_bounds__(256) shrink64_kernel(const Fast64Args a)
 		}
 		const bool wave_transparent = C == 4 && __builtin_amdgcn_ballot_w64(least < 0xff000000u) != 0ull;
 		if (lane == 0) s_red[8 + wave] = wave_transparent ? 1u : 0u;
-		prefetch(tile_next);  // lands while this tile is processed
+		prefetch_next();      // lands while this tile is processed
 		__syncthreads();      // B1: the whole tile is staged
 		if constexpr (ALPHA) {
 			if (a.all_tiles && threadIdx.x == 0 && (s_red[8] | s_red[9] | s_red[10] | s_red[11]) != 0u) ++n_transparent;
@@ -214,7 +260,7 @@ __global__ void __launch_bounds__(256) shrink64_kernel(const Fast64Args a)
 		// ---- detector: window rows 16w + 8gg .. +7, column pair q (windows 2q, 2q+1)
 		uint32_t sum_hz = 0, sum_vr = 0;
 		uint32_t given_bits = 0;
-		if constexpr (MODE == 0) given_bits = a.sums[2 * tile_g];  // MODE 0: the value is there already (oklab_kernel)
+		if constexpr (MODE == 0) given_bits = ALPHA ? a.sums[2 * tile_g] : vb_cur;  // MODE 0: the value is there already (oklab_kernel)
 		if constexpr (MODE == 1) {
 			const uint32_t q = lane & 31u, gg = lane >> 5;
 			const uint32_t two = 0x00020002u;
@@ -520,6 +566,49 @@ __global__ void __launch_bounds__(256) shrink64_kernel(const Fast64Args a)
 	}
 }
 
+// shrink_by on 64x64 tiles with clone_ahead (round 4): oklab2_kernel<64> has left every tile's value in sums[] and a copy of its
+// pixels in its slot.  Two thirds of the tiles are stored at full size: those are finished right here (size, stored value); the rest
+// -- and whatever is not a full tile -- is listed for shrink64_kernel<0>, which then never meets a finished tile.  (Skipping them
+// inside that kernel saved a tenth of its time only: a block has one tile in flight, and what a skipped tile still cost -- its
+// ticket's round trip, a block barrier -- is most of what a tile costs.)  One tile per thread; a block appends its tiles with one atomic.
+// list[0] = the count (zeroed by the host before the launch), list[8 ..] = the tiles.
+__global__ void __launch_bounds__(1024) clone_split64_kernel(const Fast64Args a)
+{
+	__shared__ uint32_t s_wave[16], s_base;
+	const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+	bool listed = false;
+	if (t < a.n_tiles) {
+		const uint32_t r = t - fastdiv(t, a.div_tpf) * a.tiles_per_frame;
+		const uint32_t ty = fastdiv(r, a.div_cols), tx = r - ty * a.cols;
+		const uint32_t vb = a.sums[2u * t];
+		const uint32_t key = __float_as_uint(parse_value(__uint_as_float(vb)));
+		uint32_t m = 0;  // the level, as the kernels' ballot form counts it
+#pragma unroll
+		for (int j = 0; j < kMaxLevel; ++j) m += ((key < a.breaks[j]) != (a.breaks_asc != 0u)) ? 1u : 0u;
+		if (tx < a.full_cols && ty < a.full_rows && m == 0u) {
+			a.out_w[t] = 64u;
+			a.out_h[t] = 64u;
+			finish_tile(make_uint2(vb, vb), 64u, 64u, 0u, a.factor, a.value, a.lod0, a.lod1, t);
+		} else {
+			listed = true;
+		}
+	}
+	const unsigned long long mask = __builtin_amdgcn_ballot_w64(listed);
+	if (lane == 0) s_wave[wave] = (uint32_t)__builtin_popcountll(mask);
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		uint32_t total = 0;
+		for (uint32_t w = 0; w < blockDim.x / 64u; ++w) {
+			const uint32_t n = s_wave[w];
+			s_wave[w] = total;
+			total += n;
+		}
+		s_base = total ? atomicAdd(a.clone_list, total) : 0u;
+	}
+	__syncthreads();
+	if (listed) a.clone_list[8u + s_base + s_wave[wave] + (uint32_t)__builtin_popcountll(mask & ((1ull << lane) - 1ull))] = t;
+}
+
 // 64x64 flow, first part: the four-wave kernel (and its four-plane instance); ga = the arguments of the worklist
 // kernel that follows (pxz_shrink_generic.hip: launch_shrink)
 hipError_t launch_fast64(const ShrinkArgs &a, ShrinkArgs &ga, uint32_t channels, uint32_t n_cus, hipStream_t stream)
@@ -539,6 +628,7 @@ hipError_t launch_fast64(const ShrinkArgs &a, ShrinkArgs &ga, uint32_t channels,
 	f.full_rows = a.full_rows;
 	f.ok_rows = a.ok_rows;
 	f.ok_edges = a.ok_edges;
+	f.clone_ahead = a.mode == 0 ? a.clone_ahead : 0u;
 	f.filter = a.filter;
 	f.sums = a.sums;
 	f.out_w = a.out_w;
@@ -572,6 +662,13 @@ hipError_t launch_fast64(const ShrinkArgs &a, ShrinkArgs &ga, uint32_t channels,
 	// the tiles the four-plane instance completed).  With the four-plane instance first nobody finishes in passing: that kernel scans.
 	f.finish_here = alpha_first ? 0u : 1u;
 	ga.finish_scan = alpha_first ? 1u : 0u;
+	f.clone_list = nullptr;
+	if (!alpha_first && f.clone_ahead != 0u && channels == 4 && a.clone_list != nullptr && a.out_w != nullptr && a.out_h != nullptr) {
+		f.clone_list = a.clone_list;
+		if ((e = hipMemsetAsync(a.clone_list, 0, 4, stream)) != hipSuccess) return e;
+		hipLaunchKernelGGL(clone_split64_kernel, dim3((a.n_tiles + 1023u) / 1024u), dim3(1024), 0, stream, f);
+		if ((e = hipGetLastError()) != hipSuccess) return e;
+	}
 	if (!alpha_first) {
 		const bool full = a.out_px != nullptr && a.out_w != nullptr && a.out_h != nullptr;
 		void (*k)(const Fast64Args) = a.mode == 1 ? (full ? shrink64_kernel<1, false, true> : shrink64_kernel<1, false, false>)

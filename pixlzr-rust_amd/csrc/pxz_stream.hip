@@ -987,10 +987,12 @@ __global__ void __launch_bounds__(256) pixlzr_index_kernel(const DecodeArgs a)
 		return;
 	}
 	auto uniform64 = [](unsigned long long v) -> unsigned long long {
-		return ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(v >> 32)) << 32) | __builtin_amdgcn_readfirstlane((uint32_t)v);
+		// (the builtin returns a signed int: without the casts a low half of 2^31 and more is sign-extended over the high one)
+		return ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(v >> 32)) << 32) |
+		       (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)v);
 	};
 	unsigned long long p = uniform64(hdr + before);
-	const unsigned long long row_end = p + __builtin_amdgcn_readfirstlane(be32(file + 26 + 4 * r));
+	const unsigned long long row_end = p + (uint32_t)__builtin_amdgcn_readfirstlane(be32(file + 26 + 4 * r));
 	uint32_t c = 0;
 	PXZ_STAMP(0);  // file header, line table
 	while (c < a.cols) {

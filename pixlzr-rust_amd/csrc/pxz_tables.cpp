@@ -208,6 +208,7 @@ const Knobs &knobs()
 		v.no_native_rgb = on("PXZ_NO_NATIVE_RGB");
 		v.no_narrow = on("PXZ_NO_NARROW");
 		v.no_group16 = on("PXZ_NO_GROUP16");
+		v.no_clone_ahead = on("PXZ_NO_CLONE_AHEAD");
 		v.no_big_tiles = on("PXZ_NO_BIG_TILES");
 		v.no_alpha_first = on("PXZ_NO_ALPHA_FIRST");
 		v.oklab_v1 = on("PXZ_OKLAB_V1");

@@ -21,6 +21,8 @@ KNOBS = [
     # cases that do)
     ("PXZ_NO_WIDEN", "test_process_matches_oracle or test_rgb_frames_on_the_square_fast_paths"),
     ("PXZ_OKLAB_V1", "test_shrink_1080p_rgba_32 or test_shrink_by_blocks_16_and_64"),
+    # (shrink_by without the detector's copy of every tile into its slot: the shrink kernel reads and clones the tiles stored at full size itself)
+    ("PXZ_NO_CLONE_AHEAD", "test_shrink_1080p_rgba_32 or test_shrink_by_blocks_16_and_64 or test_transparent_tiles_through_the_alpha_kernel"),
     # (the per-level grids and the rectangle lists are two implementations of the same recursion: where both apply, both run)
     ("PXZ_TREE_RECTS", "test_tree_process_matches_oracle or test_tree_process_edge_cases"),
     # (expand_kernel's general forms for 32x32 RGBA tiles, which the matrix-core / shift-indexed forms replace by default)
