@@ -331,6 +331,36 @@ def test_shrink_by_blocks_16_and_64(gpu, oracle, block, dist):
     assert len(seen) >= 3, seen
 
 
+@pytest.mark.parametrize("block", [16, 32, 64])
+def test_shrink_by_copies_ahead_of_the_value(product, oracle, block):
+    """shrink_by on the square RGBA tile sizes (round 4): the detector copies every tile into its slot while it converts it, and
+    the shrink kernel leaves the tiles that are stored at full size alone (32x32: skipped in the kernel; 64x64: finished by
+    clone_split64_kernel, the rest listed; 16x16: a group of four such tiles is not read, single ones are not cloned again).
+    A sequence on ONE handle and ONE set of output buffers: noise (every tile stored whole), flat frames (every tile small: the
+    copies are overwritten), the benchmark mix with transparency in some tiles, a ragged last tile row whose height is a whole
+    number of the detector's bands and one that is not, a single frame -- values, sizes and every valid payload byte equal the
+    oracle after each launch (pixlzr.rs:155-185, block.rs:279-281)."""
+    import torch
+    h = product.Handle(0)
+    hh, ww = 8 * block + block // 2, 12 * block  # a ragged last row of half a tile: whole bands at every size
+    seq = [(3, 1.0, 2, hh, ww), (0, 0.001, 2, hh, ww), (1, 1.0, 2, hh, ww), (0, 1.0, 2, hh, ww), (2, 4.0, 2, hh, ww),
+           (0, 1.0, 2, 8 * block + 3, 12 * block + 5), (0, 1.0, 1, 6 * block, 7 * block)]
+    out, shape, seen = None, None, set()
+    for k, (dist, factor, nf, fh, fw) in enumerate(seq):
+        frames = h.synth_frames_device(nf, fh, fw, 4, first_frame=11 + k, dist=dist)
+        if shape != (nf, fh, fw):
+            out, shape = None, (nf, fh, fw)
+        out = h.shrink_frames_device(frames, block, block, 0, 4, factor, out=out)
+        torch.cuda.synchronize()
+        f = frames.cpu().numpy()
+        for n in range(nf):
+            exp = oracle.shrink_image(f[n], block, block, 0, 4, factor, nthreads=8)
+            got = (out[0][n].cpu().numpy(), out[1][n].cpu().numpy().astype(np.uint32), out[2][n].cpu().numpy().astype(np.uint32), out[3][n].cpu().numpy())
+            assert_same_tiles(got, exp, 4, f"launch {k} (dist {dist}, k={factor}, {fw}x{fh}) frame {n}")
+            seen |= set(histogram(got[1], got[2]))
+    assert (block, block) in seen and len(seen) >= 4, seen
+
+
 def test_block64_one_pass_classes_and_transparency(gpu, oracle):
     """64 x n / n x 64 outputs (one matrix-core pass inside shrink64_kernel) and tiles with transparency
     (handed to the generic kernel through the worklist): results must not depend on who processed a tile."""
