@@ -478,7 +478,7 @@ __device__ __forceinline__ void quad_chain_add16(float &sum, float e0, float e1,
 template <int T, int C = 4, bool AHEAD = false>
 __global__ void __launch_bounds__(1024) oklab2_kernel(const ShrinkArgs a)
 {
-	static_assert(!AHEAD || C == 4, "the copy is of RGBA pixel pairs");
+
 	using Geo = Ok2Geom<T>;
 	constexpr uint32_t G = Geo::G, NB = Geo::NB, kProd = Geo::kProd, kTiles = Geo::kTiles;
 	constexpr uint32_t kLanesPerRow = Geo::kLanesPerRow, kRowsPerBand = Geo::kRowsPerBand;
@@ -539,7 +539,9 @@ __global__ void __launch_bounds__(1024) oklab2_kernel(const ShrinkArgs a)
 		// two pixels 8 of those.  Whether the tile IS stored whole is known two periods later; the shrink kernel behind this one then
 		// leaves such tiles alone instead of reading them a second time.  This kernel is bound by its arithmetic: the stores ride
 		// under it.
-		const uint32_t dst_lane_off = part * 512u + lane * 8u;
+		// (RGB slots: a band is 128 x 3 = 384 bytes, a lane's two pixels six of them)
+		const uint32_t dst_lane_off = C == 4 ? part * 512u + lane * 8u : part * 384u + lane * 6u;
+		constexpr uint32_t kBandBytes = C == 4 ? 512u : 384u;
 		// (the slots as SCALAR addresses -- a tile is a matter of the wave -- so that a copy is one store with a scalar base, the lane's
 		// offset and an immediate: as per-lane pointers every store cost a 64-bit add and two selects)
 		unsigned long long dst0 = 0, dst1 = 0;  // slot of the tile in conversion / the next one
@@ -625,8 +627,16 @@ __global__ void __launch_bounds__(1024) oklab2_kernel(const ShrinkArgs a)
 				const unsigned long long base = v ? band_of_slot : reinterpret_cast<unsigned long long>(a.ahead_spare);
 				// (an address the compiler knows to be global: made from an integer it is generic, and the store a flat_store.  A plain
 				// store: marked non-temporal it cost the kernel 0.03 ms more -- experiment builds, detector 0.924 against 0.897 ms)
-				typedef __attribute__((address_space(1))) unsigned long long *global_qword;
-				*(global_qword)(base + dst_lane_off) = *reinterpret_cast<const unsigned long long *>(&px);
+				if constexpr (C == 4) {
+					typedef __attribute__((address_space(1))) unsigned long long *global_qword;
+					*(global_qword)(base + dst_lane_off) = *reinterpret_cast<const unsigned long long *>(&px);
+				} else {
+					// the six bytes R0 G0 B0 R1 G1 B1 out of the aligned eight they were loaded in, at an even address: four + two
+					typedef __attribute__((address_space(1))) uint32_t global_u32_a2 __attribute__((aligned(2)));
+					typedef __attribute__((address_space(1))) uint16_t global_u16;
+					*(global_u32_a2 *)(base + dst_lane_off) = __builtin_amdgcn_alignbit(px.y, px.x, rgb_shift);
+					*(global_u16 *)(base + dst_lane_off + 4u) = (uint16_t)(px.y >> rgb_shift);
+				}
 			}
 		};
 		auto head = [&](bool valid, const uint2 &px) {
@@ -689,7 +699,7 @@ __global__ void __launch_bounds__(1024) oklab2_kernel(const ShrinkArgs a)
 				else head(src1 != nullptr && nb1 > 0u, q[0]);
 				// (after the head: the wait for its pixels is a wait for every load in flight)
 				request(k + 2u, src0, nb0, src1, nb1, q[k & 1u]);
-				copy_band(q[(k + 1u) & 1u], k + 1u < NB ? dst0 + (k + 1u) * (G * 512u) : dst1);
+				copy_band(q[(k + 1u) & 1u], k + 1u < NB ? dst0 + (k + 1u) * (G * kBandBytes) : dst1);
 				g3 = g3 == 2u ? 0u : g3 + 1u;
 				__syncthreads();
 			}
@@ -874,6 +884,7 @@ hipError_t launch_oklab(const ShrinkArgs &a, uint32_t n_cus, hipStream_t stream,
 			hipLaunchKernelGGL(kernel, dim3(blocks2), dim3(1024), 0, stream, a);
 			return hipGetLastError();
 		};
+		if (channels == 3 && a.clone_ahead) return a.bw == 16u ? go2(oklab2_kernel<16, 3, true>) : (a.bw == 32u ? go2(oklab2_kernel<32, 3, true>) : go2(oklab2_kernel<64, 3, true>));
 		if (channels == 3) return a.bw == 16u ? go2(oklab2_kernel<16, 3>) : (a.bw == 32u ? go2(oklab2_kernel<32, 3>) : go2(oklab2_kernel<64, 3>));
 		if (a.clone_ahead) return a.bw == 16u ? go2(oklab2_kernel<16, 4, true>) : (a.bw == 32u ? go2(oklab2_kernel<32, 4, true>) : go2(oklab2_kernel<64, 4, true>));
 		return a.bw == 16u ? go2(oklab2_kernel<16>) : (a.bw == 32u ? go2(oklab2_kernel<32>) : go2(oklab2_kernel<64>));

@@ -663,7 +663,7 @@ hipError_t launch_fast64(const ShrinkArgs &a, ShrinkArgs &ga, uint32_t channels,
 	f.finish_here = alpha_first ? 0u : 1u;
 	ga.finish_scan = alpha_first ? 1u : 0u;
 	f.clone_list = nullptr;
-	if (!alpha_first && f.clone_ahead != 0u && channels == 4 && a.clone_list != nullptr && a.out_w != nullptr && a.out_h != nullptr) {
+	if (!alpha_first && f.clone_ahead != 0u && a.clone_list != nullptr && a.out_w != nullptr && a.out_h != nullptr) {
 		f.clone_list = a.clone_list;
 		if ((e = hipMemsetAsync(a.clone_list, 0, 4, stream)) != hipSuccess) return e;
 		hipLaunchKernelGGL(clone_split64_kernel, dim3((a.n_tiles + 1023u) / 1024u), dim3(1024), 0, stream, f);

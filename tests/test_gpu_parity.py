@@ -331,9 +331,10 @@ def test_shrink_by_blocks_16_and_64(gpu, oracle, block, dist):
     assert len(seen) >= 3, seen
 
 
+@pytest.mark.parametrize("channels", [4, 3])
 @pytest.mark.parametrize("block", [16, 32, 64])
-def test_shrink_by_copies_ahead_of_the_value(product, oracle, block):
-    """shrink_by on the square RGBA tile sizes (round 4): the detector copies every tile into its slot while it converts it, and
+def test_shrink_by_copies_ahead_of_the_value(product, oracle, block, channels):
+    """shrink_by on the square tile sizes, RGBA and RGB (round 4): the detector copies every tile into its slot while it converts it, and
     the shrink kernel leaves the tiles that are stored at full size alone (32x32: skipped in the kernel; 64x64: finished by
     clone_split64_kernel, the rest listed; 16x16: a group of four such tiles is not read, single ones are not cloned again).
     A sequence on ONE handle and ONE set of output buffers: noise (every tile stored whole), flat frames (every tile small: the
@@ -347,7 +348,7 @@ def test_shrink_by_copies_ahead_of_the_value(product, oracle, block):
            (0, 1.0, 2, 8 * block + 3, 12 * block + 5), (0, 1.0, 1, 6 * block, 7 * block)]
     out, shape, seen = None, None, set()
     for k, (dist, factor, nf, fh, fw) in enumerate(seq):
-        frames = h.synth_frames_device(nf, fh, fw, 4, first_frame=11 + k, dist=dist)
+        frames = h.synth_frames_device(nf, fh, fw, channels, first_frame=11 + k, dist=dist)
         if shape != (nf, fh, fw):
             out, shape = None, (nf, fh, fw)
         out = h.shrink_frames_device(frames, block, block, 0, 4, factor, out=out)
@@ -356,7 +357,7 @@ def test_shrink_by_copies_ahead_of_the_value(product, oracle, block):
         for n in range(nf):
             exp = oracle.shrink_image(f[n], block, block, 0, 4, factor, nthreads=8)
             got = (out[0][n].cpu().numpy(), out[1][n].cpu().numpy().astype(np.uint32), out[2][n].cpu().numpy().astype(np.uint32), out[3][n].cpu().numpy())
-            assert_same_tiles(got, exp, 4, f"launch {k} (dist {dist}, k={factor}, {fw}x{fh}) frame {n}")
+            assert_same_tiles(got, exp, channels, f"launch {k} (dist {dist}, k={factor}, {fw}x{fh}) frame {n}")
             seen |= set(histogram(got[1], got[2]))
     assert (block, block) in seen and len(seen) >= 4, seen
 
