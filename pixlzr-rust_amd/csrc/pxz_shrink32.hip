@@ -729,6 +729,7 @@ __global__ void __launch_bounds__(1024) shrink16_kernel(const Fast32Args a)
 	// NEXT group's tiles are requested as soon as the group is known (the top of an iteration) and decide its prefetch in mid-iteration;
 	// they then are that group's `given` values.
 	bool pre_skipped = false;
+	uint32_t pre_mask = 0u;  // which tiles of the group in flight were left out of its loads
 	uint32_t gv[4] = {0, 0, 0, 0}, gvn[4] = {0, 0, 0, 0};
 	auto stored_whole = [&](uint32_t vb) -> bool {
 		return level_of(__float_as_uint(parse_value(__uint_as_float(__builtin_amdgcn_readfirstlane(vb))))) == 0u;
@@ -741,15 +742,21 @@ __global__ void __launch_bounds__(1024) shrink16_kernel(const Fast32Args a)
 			for (uint32_t k = 0; k < 4; ++k) v[k] = a.sums[2u * (t00 + (k & 1u) + (k >> 1) * a.cols)];
 		}
 	};
-	auto prefetch = [&](uint32_t grp, bool skip_loads = false) {
+	// whole_mask (MODE 0 with clone_ahead): bit k = tile k of the group is stored at full size and has the detector's copy in its
+	// slot -- its quarter of the region is not requested (a tile row is one 64-byte sector: what a lane leaves out is never
+	// fetched); the image then holds stale bytes there, which only reach outputs nobody stores.  All four: nothing is requested.
+	auto prefetch = [&](uint32_t grp, uint32_t whole_mask = 0u) {
 		const Place p = place_of(grp);
 		pre_valid = p.full;
-		if (pre_valid && !skip_loads) {
+		if (pre_valid && whole_mask != 15u) {
 			const uint8_t *q = p.src + (size_t)(tid >> 3) * a.pitch + (tid & 7u) * (4u * (uint32_t)C);
+			const bool right = (tid & 4u) != 0u;  // this lane's pixel quad lies in the right-hand tiles
+			const bool want_top = C == 3 || ((right ? whole_mask >> 1 : whole_mask) & 1u) == 0u;
+			const bool want_bottom = C == 3 || ((right ? whole_mask >> 3 : whole_mask >> 2) & 1u) == 0u;
 #pragma unroll
 			for (int k = 0; k < 4; ++k) {
 				if constexpr (C == 4) {
-					pre[k] = *reinterpret_cast<const uint4 *>(q + (size_t)(8 * k) * a.pitch);
+					if (k < 2 ? want_top : want_bottom) pre[k] = *reinterpret_cast<const uint4 *>(q + (size_t)(8 * k) * a.pitch);
 				} else {
 					const uint3 v = *reinterpret_cast<const uint3 *>(q + (size_t)(8 * k) * a.pitch);  // rows are 4-byte aligned
 					pre[k] = make_uint4(v.x, v.y, v.z, 0u);
@@ -757,19 +764,24 @@ __global__ void __launch_bounds__(1024) shrink16_kernel(const Fast32Args a)
 			}
 		}
 	};
+	auto whole_mask_of = [&](const uint32_t (&v)[4]) -> uint32_t {
+		return (stored_whole(v[0]) ? 1u : 0u) | (stored_whole(v[1]) ? 2u : 0u) | (stored_whole(v[2]) ? 4u : 0u) | (stored_whole(v[3]) ? 8u : 0u);
+	};
 	const uint32_t first = group_of_ticket(__builtin_amdgcn_readfirstlane(sub));
 	if constexpr (MODE == 0) {
 		request_values(first, gv);
-		pre_skipped = a.clone_ahead && place_of(first).full && stored_whole(gv[0]) && stored_whole(gv[1]) && stored_whole(gv[2]) && stored_whole(gv[3]);
+		if (a.clone_ahead && place_of(first).full) pre_mask = whole_mask_of(gv);
+		pre_skipped = pre_mask == 15u;
 	}
-	prefetch(first, pre_skipped);
+	prefetch(first, pre_mask);
 	for (uint32_t grp = first; grp < a.n_groups;) {
 		const uint32_t grp_next = next_ticket();
 		if constexpr (MODE == 0) request_values(grp_next, gvn);
 		auto prefetch_next = [&]() __attribute__((always_inline)) {
 			if constexpr (MODE == 0) {
-				pre_skipped = a.clone_ahead && place_of(grp_next).full && stored_whole(gvn[0]) && stored_whole(gvn[1]) && stored_whole(gvn[2]) && stored_whole(gvn[3]);
-				prefetch(grp_next, pre_skipped);
+				pre_mask = a.clone_ahead && place_of(grp_next).full ? whole_mask_of(gvn) : 0u;
+				pre_skipped = pre_mask == 15u;
+				prefetch(grp_next, pre_mask);
 			} else {
 				prefetch(grp_next);
 			}
@@ -782,6 +794,7 @@ __global__ void __launch_bounds__(1024) shrink16_kernel(const Fast32Args a)
 			}
 		};
 		const bool skipped = MODE == 0 && pre_skipped;  // (this group's loads were left out)
+		const uint32_t cur_mask = pre_mask;              // (and which of its tiles': prefetch_next() moves pre_mask on)
 		const Place pl = place_of(grp);
 		// tile ids of the group: t(dx, dy) = frame * tiles_per_frame + (2 gy + dy) * cols + 2 gx + dx
 		const uint32_t t00 = pl.frame * a.tiles_per_frame + (2u * pl.gy) * a.cols + 2u * pl.gx;
@@ -829,7 +842,16 @@ __global__ void __launch_bounds__(1024) shrink16_kernel(const Fast32Args a)
 		// every alpha byte is 255 iff the smallest of the 16 pixel dwords is >= 0xff000000 (alpha is the top byte): eight
 		// three-way minima instead of sixteen ANDs and a shift
 		uint32_t least = 0xffffffffu;
-		if constexpr (C == 4) {
+		if constexpr (C == 4 && MODE == 0) {
+			// (the quarters that were not requested hold an earlier group's pixels: they do not vote)
+			const bool right = (tid & 4u) != 0u;
+			const bool have_top = ((right ? cur_mask >> 1 : cur_mask) & 1u) == 0u, have_bottom = ((right ? cur_mask >> 3 : cur_mask >> 2) & 1u) == 0u;
+			const uint32_t t0 = min(min(pre[0].x, pre[0].y), pre[0].z), t1 = min(min(pre[0].w, pre[1].x), pre[1].y);
+			const uint32_t top = min(min(t0, t1), min(pre[1].z, pre[1].w));
+			const uint32_t b0 = min(min(pre[2].x, pre[2].y), pre[2].z), b1 = min(min(pre[2].w, pre[3].x), pre[3].y);
+			const uint32_t bottom = min(min(b0, b1), min(pre[3].z, pre[3].w));
+			least = min(have_top ? top : 0xffffffffu, have_bottom ? bottom : 0xffffffffu);
+		} else if constexpr (C == 4) {
 			const uint32_t m0 = min(min(pre[0].x, pre[0].y), pre[0].z), m1 = min(min(pre[0].w, pre[1].x), pre[1].y);
 			const uint32_t m2 = min(min(pre[1].z, pre[1].w), pre[2].x), m3 = min(min(pre[2].y, pre[2].z), pre[2].w);
 			const uint32_t m4 = min(min(pre[3].x, pre[3].y), pre[3].z);
