@@ -1190,7 +1190,7 @@ __global__ void __launch_bounds__(64 * kQoiWaves) qoi_decode_kernel(const Decode
 	global_qwords wp = (global_qwords)(first_addr & ~(uintptr_t)7);  // where w0 is from
 	const global_qwords w_last = (global_qwords)(last_addr & ~(uintptr_t)7);
 	auto window = [&](global_qwords p) __attribute__((always_inline)) { return *(p < w_last ? p : w_last); };
-	constexpr uint32_t kGroup = 8;                               // pixels between two refills
+	constexpr uint32_t kGroup = 8;                               // pixels between two refills (4, tried again with the global loads: 0.44 against 0.40 ms)
 	constexpr uint32_t kReq = (5u * kGroup + 7u) / 8u;           // windows they can use up (5 bytes a pixel)
 	constexpr uint32_t kWin = (7u + 5u * (kGroup - 1u) + 8u + 7u) / 8u + 1u;  // windows the last of them can reach into (+1: whole moves)
 	unsigned long long w[kWin];
