@@ -118,7 +118,9 @@ typedef struct pxz_params {
  *   block_value[t]  Some(value) of the shrunk tile = hypot(v0,v1) (operations.rs:154)
  *   out_w/out_h[t]  reduced tile dimensions
  *   out_pixels      fixed slots of block_w*block_h*channels bytes per tile, of
- *                   which out_w*out_h*channels are valid (tightly packed rows).
+ *                   which out_w*out_h*channels are valid (tightly packed rows);
+ *                   the rest of a slot is unspecified and may be written (shrink_by
+ *                   leaves the tile's own pixels there on its way).
  *                   May be NULL: LOD + dimensions only. */
 int pxz_shrink_image(pxz_handle *h, const uint8_t *pixels, uint32_t width, uint32_t height,
                      uint32_t channels, uint32_t pitch_bytes, uint32_t block_w, uint32_t block_h,
