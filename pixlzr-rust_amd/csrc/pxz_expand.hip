@@ -1086,6 +1086,35 @@ __global__ void __launch_bounds__(F32 ? 1024 : 256) expand_kernel(const ExpandAr
 					}
 				}
 			}
+		} else if (!F32 && C == 3 && !widen && tw == fw && th == fh && (fw & 3u) == 0u) {
+			// the same for RGB tiles in RGB frames (round 4): twelve bytes -- four pixels -- per lane and move, at whatever byte address
+			// the slot and the row have (through the image these tiles, an eighth of a frame, were a third of the RGB launch's time)
+			if constexpr (!F32 && C == 3) {
+				// (three dwords, not a three-element vector: that type is sixteen bytes wide, addresses are made in bytes)
+				const uint8_t *src = a.slots + (size_t)t * a.slot_bytes;
+				const uint32_t q4 = fw >> 2, total = q4 * fh;
+				for (uint32_t g0 = lane; g0 < total; g0 += 256u) {
+					uint32_t v[4][3];
+#pragma unroll
+					for (uint32_t k = 0; k < 4; ++k) {
+						const uint32_t g = g0 + 64u * k;
+						const uint32_t *q = reinterpret_cast<const uint32_t *>(src + 12u * (size_t)(g < total ? g : g0));
+						typedef uint32_t u32_a1 __attribute__((aligned(1)));
+						const u32_a1 *qa = reinterpret_cast<const u32_a1 *>(q);
+						v[k][0] = qa[0]; v[k][1] = qa[1]; v[k][2] = qa[2];
+					}
+#pragma unroll
+					for (uint32_t k = 0; k < 4; ++k) {
+						const uint32_t g = g0 + 64u * k;
+						if (g < total) {
+							const uint32_t oy = small_div(g, q4), q = g - oy * q4;
+							typedef uint32_t u32_a1 __attribute__((aligned(1)));
+							u32_a1 *o = reinterpret_cast<u32_a1 *>(dst + (size_t)oy * a.pitch + q * 12u);
+							o[0] = v[k][0]; o[1] = v[k][1]; o[2] = v[k][2];
+						}
+					}
+				}
+			}
 		} else {
 			// ---- stored pixels -> one dword per pixel
 			const uint8_t *src = a.slots + (size_t)t * a.slot_bytes;
