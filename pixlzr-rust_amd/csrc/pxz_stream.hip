@@ -1132,6 +1132,29 @@ __global__ void __launch_bounds__(256) pixlzr_index_kernel(const DecodeArgs a)
 #endif
 }
 
+// What an op's first byte says (qoi_decode_kernel's look-up table, one per channel count; built at compile time):
+//   bits 0-23   what a DIFF op adds to r, g, b (bytes, mod 256); for a LUMA op (vg - 8, vg, vg - 8), to which its second byte's
+//               nibbles are added; 0 otherwise
+//   bits 24-26  the bytes the op has (3 channels: 0 for 0xff -- see the kernel)
+//   bits 27-29  its kind
+struct QoiLut {
+	static constexpr uint32_t kIndex = 0, kDiff = 1, kLuma = 2, kRun = 3, kRgb = 4, kRgba = 5, kKeep = 6;
+	uint32_t v[256];
+	constexpr explicit QoiLut(int channels) : v()
+	{
+		for (uint32_t b = 0; b < 256u; ++b) {
+			uint32_t kind = kRun, used = 1u, d = 0u;
+			if (b == 0xfeu) { kind = kRgb; used = 4u; }
+			else if (b == 0xffu) { kind = channels == 4 ? kRgba : kKeep; used = channels == 4 ? 5u : 0u; }
+			else if (b < 0x40u) kind = kIndex;
+			else if (b < 0x80u) { kind = kDiff; d = ((((b >> 4) & 3u) - 2u) & 255u) | (((((b >> 2) & 3u) - 2u) & 255u) << 8) | ((((b & 3u) - 2u) & 255u) << 16); }
+			else if (b < 0xc0u) { kind = kLuma; used = 2u; const uint32_t vg = (b & 0x3fu) - 32u; d = ((vg - 8u) & 255u) | ((vg & 255u) << 8) | (((vg - 8u) & 255u) << 16); }
+			v[b] = d | (used << 24) | (kind << 27);
+		}
+	}
+};
+__device__ const QoiLut kQoiLut4(4), kQoiLut3(3);
+
 template <int C>
 __global__ void __launch_bounds__(64 * kQoiWaves) qoi_decode_kernel(const DecodeArgs a)
 {
@@ -1141,18 +1164,12 @@ __global__ void __launch_bounds__(64 * kQoiWaves) qoi_decode_kernel(const Decode
 	//               nibbles are added; 0 otherwise
 	//   bits 24-26  the bytes the op has (C = 3: 0 for 0xff -- see below)
 	//   bits 27-29  its kind
-	__shared__ uint32_t s_lut[256];
-	constexpr uint32_t kIndex = 0, kDiff = 1, kLuma = 2, kRun = 3, kRgb = 4, kRgba = 5, kKeep = 6;
-	for (uint32_t b = threadIdx.x; b < 256u; b += 64u * kQoiWaves) {
-		uint32_t kind, used = 1u, d = 0u;
-		if (b == 0xfeu) { kind = kRgb; used = 4u; }
-		else if (b == 0xffu) { kind = C == 4 ? kRgba : kKeep; used = C == 4 ? 5u : 0u; }
-		else if (b < 0x40u) kind = kIndex;
-		else if (b < 0x80u) { kind = kDiff; d = (((b >> 4) & 3u) - 2u) & 255u; d |= ((((b >> 2) & 3u) - 2u) & 255u) << 8; d |= (((b & 3u) - 2u) & 255u) << 16; }
-		else if (b < 0xc0u) { kind = kLuma; used = 2u; const uint32_t vg = (b & 0x3fu) - 32u; d = ((vg - 8u) & 255u) | ((vg & 255u) << 8) | (((vg - 8u) & 255u) << 16); }
-		else kind = kRun;
-		s_lut[b] = d | (used << 24) | (kind << 27);
-	}
+	__shared__ __attribute__((aligned(16))) uint32_t s_lut[256];
+	constexpr uint32_t kIndex = QoiLut::kIndex, kDiff = QoiLut::kDiff, kLuma = QoiLut::kLuma, kRun = QoiLut::kRun, kRgb = QoiLut::kRgb, kRgba = QoiLut::kRgba;
+	// (copied, not worked out: a wave of 2x2 tiles -- half the tiles of a 16x16 grid -- has less to do than the fifty instructions the
+	// table took to build; 8 x 8K at 16x16 tiles: 0.53 ms with the table built per block, 0.43 without a table at all)
+	for (uint32_t i = threadIdx.x; i < 64u; i += 64u * kQoiWaves)
+		reinterpret_cast<uint4 *>(s_lut)[i] = reinterpret_cast<const uint4 *>(C == 4 ? kQoiLut4.v : kQoiLut3.v)[i];
 	__syncthreads();
 	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
 	const uint32_t i0 = blockIdx.x * (64u * kQoiWaves) + threadIdx.x;
