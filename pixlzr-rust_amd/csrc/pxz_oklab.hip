@@ -545,10 +545,22 @@ __global__ void __launch_bounds__(1024) oklab2_kernel(const ShrinkArgs a)
 		// (the slots as SCALAR addresses -- a tile is a matter of the wave -- so that a copy is one store with a scalar base, the lane's
 		// offset and an immediate: as per-lane pointers every store cost a 64-bit add and two selects)
 		unsigned long long dst0 = 0, dst1 = 0;  // slot of the tile in conversion / the next one
+		// Which tiles are copied (T = 16 | 32): the ones whose first band looks busy -- two neighbouring pixels of it 24 or more apart
+		// (|dr| + |dg| + |db| + |da|).  Whether a tile is stored whole is not known before its second pass; on the bench frames this
+		// guess copies 45 % of the tiles instead of all (2-7 % of the tiles stored whole are missed, a tenth of the tiles copied in
+		// vain), which is what the copies cost in HBM traffic.  The guess never decides a result: sums[2 t + 1] says whether tile t
+		// was copied, and the shrink kernel leaves a tile alone only if it is stored whole AND was copied -- the others it reads, as
+		// before round 4.
+		constexpr uint32_t kCopyContrast = 24u;
+		bool copy0 = true, copy1 = true;  // the tile in conversion / the next one (T = 64: every tile, two thirds are stored whole)
+		unsigned long long flag1 = 0;     // where the next tile's flag goes
 		auto batch_src = [&](uint32_t j, uint32_t &bands) -> const uint8_t * {
 			const uint8_t *src;
 			bands = 0;
 			if constexpr (AHEAD) {
+				const unsigned long long fa = reinterpret_cast<unsigned long long>(a.sums) + 8ull * ((blockIdx.x + j * gridDim.x) * kTiles + pslot) + 4ull;
+				flag1 = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(fa >> 32)) << 32) |
+				        (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)fa);
 				// (in front of the conditions below, which the compiler takes to differ between lanes: set behind them the address
 				// would live in vector registers; the item number IS the tile's number in this launch, whether the tile is taken or not)
 				const unsigned long long d = reinterpret_cast<unsigned long long>(a.out_px) +
@@ -619,11 +631,12 @@ __global__ void __launch_bounds__(1024) oklab2_kernel(const ShrinkArgs a)
 		// (the copy of a band is issued BEHIND the request of the band after next: loads and stores share one in-order counter, a store
 		// takes longer than an interval to be acknowledged, and in front of that load it made every wait for the load a wait for the
 		// store -- detector 0.87 -> 1.04-1.10 ms; behind it the wait leaves one operation in flight: s_waitcnt vmcnt(1))
-		auto copy_band = [&](const uint2 &px, unsigned long long band_of_slot) {
+		auto copy_band = [&](const uint2 &px, unsigned long long band_of_slot, bool copied) {
 			if constexpr (AHEAD) {
-				// (a band that is not converted -- past the last batch, a tile the detector leaves to the generic kernel -- goes to spare bytes)
+				// (a band that is not converted -- past the last batch, a tile the detector leaves to the generic kernel -- and the bands of
+				// a tile that is not copied go to spare bytes: no branch around the store)
 				// (G = 4: the flag is a lane mask there -- one lane's copy of it)
-				const bool v = G == 1u ? st_valid : __builtin_amdgcn_readfirstlane((uint32_t)st_valid) != 0u;
+				const bool v = (G == 1u ? st_valid : __builtin_amdgcn_readfirstlane((uint32_t)st_valid) != 0u) && copied;
 				const unsigned long long base = v ? band_of_slot : reinterpret_cast<unsigned long long>(a.ahead_spare);
 				// (an address the compiler knows to be global: made from an integer it is generic, and the store a flat_store.  A plain
 				// store: marked non-temporal it cost the kernel 0.03 ms more -- experiment builds, detector 0.924 against 0.897 ms)
@@ -637,6 +650,29 @@ __global__ void __launch_bounds__(1024) oklab2_kernel(const ShrinkArgs a)
 					*(global_u32_a2 *)(base + dst_lane_off) = __builtin_amdgcn_alignbit(px.y, px.x, rgb_shift);
 					*(global_u16 *)(base + dst_lane_off + 4u) = (uint16_t)(px.y >> rgb_shift);
 				}
+			}
+		};
+		// band 0 of the next tile is in px: decide whether the tile is copied, say so in sums[2 t + 1] (every lane the same dword: no
+		// branch), copy the band
+		auto first_band = [&](const uint2 &px) {
+			if constexpr (AHEAD) {
+				if constexpr (G == 1u) {
+					// |dr| + |dg| + |db| (+ |da|) between the lane's two neighbouring pixels: one v_sad_u8
+					uint32_t d;
+					if constexpr (C == 4) {
+						d = __builtin_amdgcn_sad_u8(px.x, px.y, 0u);
+					} else {
+						const uint32_t w0 = __builtin_amdgcn_alignbit(px.y, px.x, rgb_shift);       // R0 G0 B0 R1
+						const uint32_t p1 = __builtin_amdgcn_alignbit(px.y >> rgb_shift, w0, 24);  // R1 G1 B1 .
+						d = __builtin_amdgcn_sad_u8(w0 & 0x00ffffffu, p1 & 0x00ffffffu, 0u);
+					}
+					copy1 = __builtin_amdgcn_ballot_w64(d >= kCopyContrast) != 0ull;
+				}
+				const bool v = G == 1u ? st_valid : __builtin_amdgcn_readfirstlane((uint32_t)st_valid) != 0u;
+				const unsigned long long fa = v ? flag1 : reinterpret_cast<unsigned long long>(a.ahead_spare);
+				typedef __attribute__((address_space(1))) uint32_t *global_dword;
+				*(global_dword)fa = copy1 ? 1u : 0u;
+				copy_band(px, dst1, copy1);
 			}
 		};
 		auto head = [&](bool valid, const uint2 &px) {
@@ -655,10 +691,11 @@ __global__ void __launch_bounds__(1024) oklab2_kernel(const ShrinkArgs a)
 			}
 		};
 		head(src1 != nullptr && nb1 > 0u, q[0]);
-		copy_band(q[0], dst1);
+		first_band(q[0]);
 		for (uint32_t p = 0; p < periods; ++p) {
 			src0 = src1;
 			dst0 = dst1;
+			copy0 = copy1;
 			nb_prev = nb0;
 			nb0 = nb1;
 			src1 = batch_src(p + 1u, nb1);
@@ -699,7 +736,8 @@ __global__ void __launch_bounds__(1024) oklab2_kernel(const ShrinkArgs a)
 				else head(src1 != nullptr && nb1 > 0u, q[0]);
 				// (after the head: the wait for its pixels is a wait for every load in flight)
 				request(k + 2u, src0, nb0, src1, nb1, q[k & 1u]);
-				copy_band(q[(k + 1u) & 1u], k + 1u < NB ? dst0 + (k + 1u) * (G * kBandBytes) : dst1);
+				if (k + 1u < NB) copy_band(q[(k + 1u) & 1u], dst0 + (k + 1u) * (G * kBandBytes), copy0);
+				else first_band(q[0]);
 				g3 = g3 == 2u ? 0u : g3 + 1u;
 				__syncthreads();
 			}
@@ -845,8 +883,11 @@ __global__ void __launch_bounds__(1024) oklab2_kernel(const ShrinkArgs a)
 						const float total = d0 + d1 + d2 + d3;  // :89
 						const float value = __fdiv_rn(total, (float)((uint32_t)T * h)) * a.factor * a.scale2;  // pixlzr.rs:162
 						const uint32_t tg = same ? gm1 : gm2;
-						if (live && cc == 0 && sub == 0u && h != 0u)
-							reinterpret_cast<uint2 *>(a.sums)[tg] = make_uint2(__float_as_uint(value), __float_as_uint(value));
+						if (live && cc == 0 && sub == 0u && h != 0u) {
+							// (AHEAD: sums[2 t + 1] is the producers' "this tile was copied" flag)
+							if constexpr (AHEAD) a.sums[2u * tg] = __float_as_uint(value);
+							else reinterpret_cast<uint2 *>(a.sums)[tg] = make_uint2(__float_as_uint(value), __float_as_uint(value));
+						}
 						acc = 0.0f;
 					}
 				}

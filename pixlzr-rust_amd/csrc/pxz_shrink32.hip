@@ -69,16 +69,19 @@ __global__ void __launch_bounds__(1024) shrink32_kernel(const Fast32Args a)
 	// anyway, and it runs under an idle memory system); a tile whose value says so is finished -- it is not read a second time.
 	bool pre_skipped = false;       // the current tile's loads were left out: it is one of those
 	uint32_t vb_cur = 0, vb_next = 0;  // value bits of the current / the next tile
-	auto value_bits_of = [&](uint32_t t) -> uint32_t { return t < a.n_tiles ? a.sums[2u * t] : 0u; };
-	auto stored_whole = [&](uint32_t vb) -> bool {
-		return a.clone_ahead && level_of(__float_as_uint(parse_value(__uint_as_float(vb)))) == 0u;
+	uint32_t fl_next = 0;              // and whether the detector copied the next tile (sums[2 t + 1] == 1: it copies the tiles it guesses to be stored whole)
+	auto value_pair_of = [&](uint32_t t) -> uint2 { return t < a.n_tiles ? reinterpret_cast<const uint2 *>(a.sums)[t] : make_uint2(0u, 0u); };
+	auto stored_whole = [&](uint32_t vb, uint32_t copied) -> bool {
+		return a.clone_ahead && copied == 1u && level_of(__float_as_uint(parse_value(__uint_as_float(vb)))) == 0u;
 	};
 	uint32_t second = 0xffffffffu;
 	if constexpr (MODE == 0) {
 		second = next_ticket();
-		vb_cur = __builtin_amdgcn_readfirstlane(value_bits_of(first));  // (scalars from here on)
-		vb_next = __builtin_amdgcn_readfirstlane(value_bits_of(second));
-		pre_skipped = stored_whole(vb_cur);
+		const uint2 p0 = value_pair_of(first), p1 = value_pair_of(second);
+		vb_cur = __builtin_amdgcn_readfirstlane(p0.x);  // (scalars from here on)
+		vb_next = __builtin_amdgcn_readfirstlane(p1.x);
+		fl_next = __builtin_amdgcn_readfirstlane(p1.y);
+		pre_skipped = stored_whole(vb_cur, __builtin_amdgcn_readfirstlane(p0.y));
 		fast32_prefetch<C>(a, first, tid, pre, pre_valid, pre_skipped);
 	} else {
 		fast32_prefetch<C>(a, first, tid, pre, pre_valid);
@@ -153,7 +156,7 @@ __global__ void __launch_bounds__(1024) shrink32_kernel(const Fast32Args a)
 	auto one_tile = [&](const uint32_t tile_g, const uint32_t tile_next) {
 		auto prefetch_next = [&]() __attribute__((always_inline)) {
 			if constexpr (MODE == 0) {
-				pre_skipped = stored_whole(vb_next);
+				pre_skipped = stored_whole(vb_next, fl_next);
 				fast32_prefetch<C>(a, tile_next, tid, pre, pre_valid, pre_skipped);
 			} else {
 				fast32_prefetch<C>(a, tile_next, tid, pre, pre_valid);
@@ -396,12 +399,13 @@ __global__ void __launch_bounds__(1024) shrink32_kernel(const Fast32Args a)
 #endif
 		if constexpr (MODE == 0) {
 			const uint32_t tile_after = next_ticket();
-			const uint32_t vb_after = value_bits_of(tile_after);  // needed at the next tile's prefetch: a whole tile's time away
+			const uint2 pair_after = value_pair_of(tile_after);  // needed at the next tile's prefetch: a whole tile's time away
 			one_tile(tile_g, tile_next);
 			tile_g = tile_next;
 			tile_next = tile_after;
 			vb_cur = vb_next;
-			vb_next = __builtin_amdgcn_readfirstlane(vb_after);
+			vb_next = __builtin_amdgcn_readfirstlane(pair_after.x);
+			fl_next = __builtin_amdgcn_readfirstlane(pair_after.y);
 		} else {
 			tile_next = next_ticket();
 			one_tile(tile_g, tile_next);
@@ -731,15 +735,20 @@ __global__ void __launch_bounds__(1024) shrink16_kernel(const Fast32Args a)
 	bool pre_skipped = false;
 	uint32_t pre_mask = 0u;  // which tiles of the group in flight were left out of its loads
 	uint32_t gv[4] = {0, 0, 0, 0}, gvn[4] = {0, 0, 0, 0};
-	auto stored_whole = [&](uint32_t vb) -> bool {
-		return level_of(__float_as_uint(parse_value(__uint_as_float(__builtin_amdgcn_readfirstlane(vb))))) == 0u;
+	uint32_t gf[4] = {0, 0, 0, 0}, gfn[4] = {0, 0, 0, 0};  // sums[2 t + 1] of the same tiles: 1 = the detector copied the tile
+	auto stored_whole = [&](uint32_t vb, uint32_t copied) -> bool {
+		return __builtin_amdgcn_readfirstlane(copied) == 1 && level_of(__float_as_uint(parse_value(__uint_as_float(__builtin_amdgcn_readfirstlane(vb))))) == 0u;
 	};
-	auto request_values = [&](uint32_t grp, uint32_t (&v)[4]) {
+	auto request_values = [&](uint32_t grp, uint32_t (&v)[4], uint32_t (&f)[4]) {
 		const Place p = place_of(grp);
 		if (p.full) {
 			const uint32_t t00 = p.frame * a.tiles_per_frame + (2u * p.gy) * a.cols + 2u * p.gx;
 #pragma unroll
-			for (uint32_t k = 0; k < 4; ++k) v[k] = a.sums[2u * (t00 + (k & 1u) + (k >> 1) * a.cols)];
+			for (uint32_t k = 0; k < 4; ++k) {
+				const uint2 pr = reinterpret_cast<const uint2 *>(a.sums)[t00 + (k & 1u) + (k >> 1) * a.cols];
+				v[k] = pr.x;
+				f[k] = pr.y;
+			}
 		}
 	};
 	// whole_mask (MODE 0 with clone_ahead): bit k = tile k of the group is stored at full size and has the detector's copy in its
@@ -764,22 +773,22 @@ __global__ void __launch_bounds__(1024) shrink16_kernel(const Fast32Args a)
 			}
 		}
 	};
-	auto whole_mask_of = [&](const uint32_t (&v)[4]) -> uint32_t {
-		return (stored_whole(v[0]) ? 1u : 0u) | (stored_whole(v[1]) ? 2u : 0u) | (stored_whole(v[2]) ? 4u : 0u) | (stored_whole(v[3]) ? 8u : 0u);
+	auto whole_mask_of = [&](const uint32_t (&v)[4], const uint32_t (&f)[4]) -> uint32_t {
+		return (stored_whole(v[0], f[0]) ? 1u : 0u) | (stored_whole(v[1], f[1]) ? 2u : 0u) | (stored_whole(v[2], f[2]) ? 4u : 0u) | (stored_whole(v[3], f[3]) ? 8u : 0u);
 	};
 	const uint32_t first = group_of_ticket(__builtin_amdgcn_readfirstlane(sub));
 	if constexpr (MODE == 0) {
-		request_values(first, gv);
-		if (a.clone_ahead && place_of(first).full) pre_mask = whole_mask_of(gv);
+		request_values(first, gv, gf);
+		if (a.clone_ahead && place_of(first).full) pre_mask = whole_mask_of(gv, gf);
 		pre_skipped = pre_mask == 15u;
 	}
 	prefetch(first, pre_mask);
 	for (uint32_t grp = first; grp < a.n_groups;) {
 		const uint32_t grp_next = next_ticket();
-		if constexpr (MODE == 0) request_values(grp_next, gvn);
+		if constexpr (MODE == 0) request_values(grp_next, gvn, gfn);
 		auto prefetch_next = [&]() __attribute__((always_inline)) {
 			if constexpr (MODE == 0) {
-				pre_mask = a.clone_ahead && place_of(grp_next).full ? whole_mask_of(gvn) : 0u;
+				pre_mask = a.clone_ahead && place_of(grp_next).full ? whole_mask_of(gvn, gfn) : 0u;
 				pre_skipped = pre_mask == 15u;
 				prefetch(grp_next, pre_mask);
 			} else {
@@ -792,7 +801,7 @@ __global__ void __launch_bounds__(1024) shrink16_kernel(const Fast32Args a)
 #pragma unroll
 				for (int k = 0; k < 4; ++k) gv[k] = gvn[k];
 			}
-		};
+		};  // (the flags are only looked at in prefetch_next(): gfn, then cur_mask)
 		const bool skipped = MODE == 0 && pre_skipped;  // (this group's loads were left out)
 		const uint32_t cur_mask = pre_mask;              // (and which of its tiles': prefetch_next() moves pre_mask on)
 		const Place pl = place_of(grp);
@@ -979,7 +988,7 @@ __global__ void __launch_bounds__(1024) shrink16_kernel(const Fast32Args a)
 			uint32_t *dst = reinterpret_cast<uint32_t *>(a.out_px + (size_t)t * (256u * (uint32_t)C));
 			const uint32_t *tile_pl = s_pl + (16u * (k >> 1)) * kRS32 + 8u * (k & 1u);  // first pixel pair of the tile
 			if (nw == 16u && nh == 16u) {
-				if (MODE == 0 && a.clone_ahead) continue;  // (the detector's copy is in the slot)
+				if (MODE == 0 && ((cur_mask >> k) & 1u)) continue;  // (the detector's copy is in the slot)
 				// clone (block.rs:279-281): 64 groups of 4 pixels, one per lane
 				const uint32_t row = tid >> 2, c4 = tid & 3u;
 				const uint32_t *p = tile_pl + row * kRS32 + c4 * 2u;

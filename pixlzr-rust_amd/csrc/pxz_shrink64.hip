@@ -90,9 +90,11 @@ __global__ void __launch_bounds__(256) shrink64_kernel(const Fast64Args a)
 	// tile after this one is requested as soon as that tile is known, an iteration before its pixels would be.
 	bool pre_skipped = false;          // the current tile's loads were left out (block-uniform)
 	uint32_t vb_cur = 0, vb_next = 0;  // value bits of the current tile / the next one
-	auto value_bits_of = [&](uint32_t t) -> uint32_t { return t < a.n_tiles ? a.sums[2u * t] : 0u; };
-	auto stored_whole = [&](uint32_t vb) -> bool {
-		return a.clone_ahead && level_of(__float_as_uint(parse_value(__uint_as_float(__builtin_amdgcn_readfirstlane(vb))))) == 0u;
+	uint32_t fl_cur = 0, fl_next = 0;  // and sums[2 t + 1]: 1 = the detector copied the tile (at this size it copies every tile it takes)
+	auto value_pair_of = [&](uint32_t t) -> uint2 { return t < a.n_tiles ? reinterpret_cast<const uint2 *>(a.sums)[t] : make_uint2(0u, 0u); };
+	auto stored_whole = [&](uint32_t vb, uint32_t copied) -> bool {
+		return a.clone_ahead && __builtin_amdgcn_readfirstlane(copied) == 1 &&
+		       level_of(__float_as_uint(parse_value(__uint_as_float(__builtin_amdgcn_readfirstlane(vb))))) == 0u;
 	};
 	auto prefetch = [&](uint32_t tile_g, bool skip_loads = false) {
 		const uint8_t *src;
@@ -137,9 +139,12 @@ __global__ void __launch_bounds__(256) shrink64_kernel(const Fast64Args a)
 	};
 	uint32_t tile_g = tile_of(blockIdx.x / n_ctr), tile_next = tile_of(blockIdx.x / n_ctr + nb_c);
 	if constexpr (MODE == 0 && !ALPHA) {
-		vb_cur = value_bits_of(tile_g);
-		vb_next = value_bits_of(tile_next);
-		pre_skipped = stored_whole(vb_cur);
+		const uint2 p0 = value_pair_of(tile_g), p1 = value_pair_of(tile_next);
+		vb_cur = p0.x;
+		fl_cur = p0.y;
+		vb_next = p1.x;
+		fl_next = p1.y;
+		pre_skipped = stored_whole(vb_cur, fl_cur);
 	}
 	prefetch(tile_g, pre_skipped);
 	// detector-only launches: equal cost per tile, and an iteration is shorter than an atomic's round trip:
@@ -160,12 +165,15 @@ __global__ void __launch_bounds__(256) shrink64_kernel(const Fast64Args a)
 			tile_next = tile_of(2u * nb_c + s_red[13]);
 			if constexpr (MODE == 0 && !ALPHA) {
 				vb_cur = vb_next;
-				vb_next = value_bits_of(tile_next);
+				fl_cur = fl_next;
+				const uint2 pn = value_pair_of(tile_next);
+				vb_next = pn.x;
+				fl_next = pn.y;
 			}
 		};
 		auto prefetch_next = [&]() {
 			if constexpr (MODE == 0 && !ALPHA) {
-				pre_skipped = stored_whole(vb_next);
+				pre_skipped = stored_whole(vb_next, fl_next);
 				prefetch(tile_next, pre_skipped);
 			} else {
 				prefetch(tile_next);
@@ -580,12 +588,13 @@ __global__ void __launch_bounds__(1024) clone_split64_kernel(const Fast64Args a)
 	if (t < a.n_tiles) {
 		const uint32_t r = t - fastdiv(t, a.div_tpf) * a.tiles_per_frame;
 		const uint32_t ty = fastdiv(r, a.div_cols), tx = r - ty * a.cols;
-		const uint32_t vb = a.sums[2u * t];
+		const uint2 pair = reinterpret_cast<const uint2 *>(a.sums)[t];  // (value bits, 1 = copied by the detector)
+		const uint32_t vb = pair.x;
 		const uint32_t key = __float_as_uint(parse_value(__uint_as_float(vb)));
 		uint32_t m = 0;  // the level, as the kernels' ballot form counts it
 #pragma unroll
 		for (int j = 0; j < kMaxLevel; ++j) m += ((key < a.breaks[j]) != (a.breaks_asc != 0u)) ? 1u : 0u;
-		if (tx < a.full_cols && ty < a.full_rows && m == 0u) {
+		if (tx < a.full_cols && ty < a.full_rows && m == 0u && pair.y == 1u) {
 			a.out_w[t] = 64u;
 			a.out_h[t] = 64u;
 			finish_tile(make_uint2(vb, vb), 64u, 64u, 0u, a.factor, a.value, a.lod0, a.lod1, t);

@@ -360,6 +360,38 @@ def test_shrink_by_copies_ahead_of_the_value(product, oracle, block, channels):
             assert_same_tiles(got, exp, channels, f"launch {k} (dist {dist}, k={factor}, {fw}x{fh}) frame {n}")
             seen |= set(histogram(got[1], got[2]))
     assert (block, block) in seen and len(seen) >= 4, seen
+    # the detector only copies the tiles it GUESSES to be stored whole (from their first band); the guess must never show: tiles whose
+    # first rows are flat and the rest noise (stored whole, not copied), the other way round (copied, not stored whole), plain noise
+    rng = np.random.default_rng(block + channels)
+    tiles_y, tiles_x = 6, 9
+    img = np.empty((2, tiles_y * block, tiles_x * block, channels), np.uint8)
+    img[...] = 90
+    if channels == 4:
+        img[..., 3] = 255
+    top = block // 2 if block == 16 else block // 4  # at least the first 128-px band of a tile
+    for n in range(2):
+        for ty in range(tiles_y):
+            for tx in range(tiles_x):
+                kind = (tx + 2 * ty + n) % 3
+                y0, x0 = ty * block, tx * block
+                noise = rng.integers(0, 256, size=(block, block, 3), dtype=np.uint8)
+                if kind == 0:
+                    img[n, y0:y0 + block, x0:x0 + block, :3] = noise
+                elif kind == 1:
+                    img[n, y0 + top:y0 + block, x0:x0 + block, :3] = noise[top:]
+                else:
+                    img[n, y0:y0 + 1, x0:x0 + block, :3] = noise[:1]  # (one busy row: copied, hardly stored whole)
+    frames = torch.from_numpy(img).cuda()
+    kinds = set()
+    for factor in (1.0, 0.2):
+        got_all = h.shrink_frames_device(frames, block, block, 0, 4, factor)
+        torch.cuda.synchronize()
+        for n in range(2):
+            exp = oracle.shrink_image(img[n], block, block, 0, 4, factor, nthreads=8)
+            got = (got_all[0][n].cpu().numpy(), got_all[1][n].cpu().numpy().astype(np.uint32), got_all[2][n].cpu().numpy().astype(np.uint32), got_all[3][n].cpu().numpy())
+            assert_same_tiles(got, exp, channels, f"guessed copies, k={factor} frame {n}")
+            kinds |= set(histogram(got[1], got[2]))
+    assert (block, block) in kinds and len(kinds) >= 2, kinds
 
 
 def test_block64_one_pass_classes_and_transparency(gpu, oracle):
